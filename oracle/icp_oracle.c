@@ -1,0 +1,762 @@
+/*
+ * icp_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the libpointmatcher ICP chain that pgslam's hot path
+ * resolves to.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (libpgicp.so) never
+ * links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference (Ellon/pgslam) holds no golden vectors and its
+ * arithmetic lives in un-vendored, un-pinned libpointmatcher / libnabo / Eigen
+ * (reference CMakeLists.txt:17-18), none of which exist in the build container
+ * (SURVEY.md F4/F5, §8(c)).  This file restates the *published* algorithm of
+ * those libraries and is pinned instead by
+ *   (i)  analytic known-answer tests and
+ *   (ii) an independent scipy.cKDTree / numpy-float64 cross-check
+ * (tests/test_oracle_*.py, fixtures under tests/golden/).
+ *
+ * Reference call sites each function stands in for (paths relative to
+ * /root/reference/src/pgslam/):
+ *   orc_icp              ICPSequence::operator() Localizer.hpp:126,
+ *                        ICP::operator()         LoopCloser.hpp:98      [A.2]
+ *   orc_knn_brute/_kd    matcher->init / findClosests
+ *                        Localizer.hpp:317,328  LoopCloser.hpp:356,358  [A.3]
+ *   orc_trim_weights     outlierFilters.compute Localizer.hpp:330,
+ *                        LoopCloser.hpp:360                             [A.4]
+ *   orc_error_stats      ErrorElements ctor     Localizer.hpp:332,347   [A.5]
+ *   orc_p2plane_system   errorMinimizer->compute (inside ICP)           [A.6]
+ *   orc_residual         getResidualError       LoopCloser.hpp:362      [A.7]
+ *   orc_covariance       getCovariance          Localizer.hpp:238,
+ *                        LoopCloser.hpp:108                             [A.8]
+ *   checkers             getMaxNumIterationsReached LoopCloser.hpp:317  [A.9]
+ *   orc_transform        rigid_transformation_->compute Localizer.hpp:106,323
+ *                        LocalMap.hpp:97,222  LoopCloser.hpp:352        [a9]
+ *   orc_build_local_map  LocalMap::BuildCloudFromData LocalMap.hpp:209-224 [a12]
+ *
+ * Arithmetic contract shared with the HIP path (DESIGN.md "Arithmetic contract"):
+ *   - points/normals are `real` (float or double, -DORC_DOUBLE); compiled with
+ *     -ffp-contract=off so no FMA is formed anywhere;
+ *   - rigid transform: x' = ((r00*x + r01*y) + r02*z) + tx in `real`;
+ *   - squared distance: d2 = ((dx*dx + dy*dy) + dz*dz) in `real`, dx = q - m;
+ *   - nearest neighbour = argmin over (d2, index) lexicographically, accepted
+ *     iff d2 <= maxDist*maxDist; otherwise id = -1, d2 = +inf;
+ *   - centroid: fixed-point (2^-24) integer sum => order independent;
+ *   - normal equations, residual, covariance: double accumulation;
+ *   - 6x6 solve, SE(3) composition and convergence checks: double.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#ifdef ORC_DOUBLE
+typedef double real;
+#define FN(name) name##_f64
+#else
+typedef float real;
+#define FN(name) name##_f32
+#endif
+
+#define ORC_OK 0
+#define ORC_ERR_NO_MATCH 1      /* "no outlier to filter" / "no point to minimize" (ConvergenceError) */
+#define ORC_ERR_NAN 2
+#define ORC_ERR_ARG 3
+
+typedef struct {
+    real max_dist;          /* KDTreeMatcher.maxDist (may be +inf) */
+    real trim_ratio;        /* TrimmedDistOutlierFilter.ratio */
+    int max_iters;          /* CounterTransformationChecker.maxIterationCount */
+    double min_diff_rot;    /* DifferentialTransformationChecker.minDiffRotErr */
+    double min_diff_trans;  /* ....minDiffTransErr */
+    int smooth_length;      /* ....smoothLength */
+    double sensor_std_dev;  /* PointToPlaneWithCovErrorMinimizer.sensorStdDev */
+    int use_kdtree;         /* 0: brute force (ground truth), 1: kd-tree (same results) */
+    int center_reference;   /* 1: subtract centroid as ICP::operator()/setMap do [A.2] */
+} FN(orc_params);
+
+typedef struct {
+    int status;
+    int iterations;
+    int converged;            /* Differential checker stopped the loop */
+    int max_iter_reached;     /* Counter checker stopped the loop */
+    double overlap;           /* weightedPointUsedRatio of the last iteration */
+    double residual;          /* sum w (n.(p-q))^2 of the last iteration (pre-update) */
+    double trim_limit;        /* last trim threshold (squared distance) */
+    int n_kept;
+    int n_finite;
+    double cov[36];           /* Censi covariance, order [x y z rx ry rz] */
+} orc_result;
+
+/* --------------------------------------------------------------------------
+ * small dense helpers (double, row-major 4x4 / 6x6)
+ * ------------------------------------------------------------------------ */
+static void mat4_mul(const double *a, const double *b, double *c)
+{
+    double t[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += a[i * 4 + k] * b[k * 4 + j];
+            t[i * 4 + j] = s;
+        }
+    memcpy(c, t, sizeof t);
+}
+
+static void mat4_identity(double *a)
+{
+    memset(a, 0, 16 * sizeof(double));
+    a[0] = a[5] = a[10] = a[15] = 1.0;
+}
+
+static void mat4_rigid_inverse(const double *t, double *o)
+{
+    double r[16];
+    mat4_identity(r);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r[i * 4 + j] = t[j * 4 + i];
+    for (int i = 0; i < 3; i++)
+        r[i * 4 + 3] = -(r[i * 4 + 0] * t[3] + r[i * 4 + 1] * t[7] + r[i * 4 + 2] * t[11]);
+    memcpy(o, r, sizeof r);
+}
+
+/* [a9] RigidTransformation::compute: features' = T*features; normals' = R*normals. */
+void FN(orc_transform)(const double *T, const real *in, real *out, int n, int rotate_only)
+{
+    const real r00 = (real)T[0], r01 = (real)T[1], r02 = (real)T[2], tx = (real)T[3];
+    const real r10 = (real)T[4], r11 = (real)T[5], r12 = (real)T[6], ty = (real)T[7];
+    const real r20 = (real)T[8], r21 = (real)T[9], r22 = (real)T[10], tz = (real)T[11];
+    for (int i = 0; i < n; i++) {
+        const real x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        real ox = (r00 * x + r01 * y) + r02 * z;
+        real oy = (r10 * x + r11 * y) + r12 * z;
+        real oz = (r20 * x + r21 * y) + r22 * z;
+        if (!rotate_only) { ox = ox + tx; oy = oy + ty; oz = oz + tz; }
+        out[3 * i] = ox; out[3 * i + 1] = oy; out[3 * i + 2] = oz;
+    }
+}
+
+/* [A.2] centroid of the reference, order-independent fixed-point definition. */
+void FN(orc_centroid)(const real *xyz, int n, real *mean)
+{
+    for (int a = 0; a < 3; a++) {
+        int64_t s = 0;
+        for (int i = 0; i < n; i++) s += llrint((double)xyz[3 * i + a] * 16777216.0);
+        mean[a] = (real)(((double)s / 16777216.0) / (double)n);
+    }
+}
+
+/* [a12] LocalMap::BuildCloudFromData: out = ref_kf cloud ++ T_k * cloud_k ... */
+void FN(orc_build_local_map)(int n_kf, const real *const *xyz, const real *const *nrm, const int *counts,
+                             const double *T_ref_kf /* n_kf x 16, entry 0 ignored (identity) */,
+                             real *out_xyz, real *out_nrm)
+{
+    int off = 0;
+    for (int k = 0; k < n_kf; k++) {
+        if (k == 0) {
+            memcpy(out_xyz + 3 * off, xyz[k], sizeof(real) * 3 * counts[k]);
+            memcpy(out_nrm + 3 * off, nrm[k], sizeof(real) * 3 * counts[k]);
+        } else {
+            FN(orc_transform)(T_ref_kf + 16 * k, xyz[k], out_xyz + 3 * off, counts[k], 0);
+            FN(orc_transform)(T_ref_kf + 16 * k, nrm[k], out_nrm + 3 * off, counts[k], 1);
+        }
+        off += counts[k];
+    }
+}
+
+/* --------------------------------------------------------------------------
+ * [A.3] matcher: brute force (ground truth) and kd-tree (identical results)
+ * ------------------------------------------------------------------------ */
+static inline real dist2(const real *q, const real *m)
+{
+    const real dx = q[0] - m[0], dy = q[1] - m[1], dz = q[2] - m[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+void FN(orc_knn_brute)(const real *q, int nq, const real *m, int nm, real max_dist, int *ids, real *d2)
+{
+    const real md2 = max_dist * max_dist;
+    for (int i = 0; i < nq; i++) {
+        real best = INFINITY;
+        int bi = -1;
+        for (int j = 0; j < nm; j++) {
+            const real d = dist2(q + 3 * i, m + 3 * j);
+            if (d < best) { best = d; bi = j; }      /* strict <: lowest index wins ties */
+        }
+        if (bi >= 0 && best <= md2) { ids[i] = bi; d2[i] = best; }
+        else { ids[i] = -1; d2[i] = INFINITY; }
+    }
+}
+
+typedef struct {
+    int n;
+    const real *pts;       /* borrowed */
+    int *perm;             /* point order inside the tree */
+    int n_nodes;
+    int *node_lo, *node_hi;    /* leaf: [lo,hi) into perm */
+    int *node_axis;            /* -1 for leaves */
+    real *node_split;
+    int *node_left, *node_right;
+} kdtree;
+
+#define KD_LEAF 12
+
+static int kd_build_rec(kdtree *t, int lo, int hi)
+{
+    const int id = t->n_nodes++;
+    t->node_lo[id] = lo; t->node_hi[id] = hi;
+    t->node_left[id] = t->node_right[id] = -1;
+    if (hi - lo <= KD_LEAF) { t->node_axis[id] = -1; t->node_split[id] = 0; return id; }
+    real mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = lo; i < hi; i++)
+        for (int a = 0; a < 3; a++) {
+            const real v = t->pts[3 * t->perm[i] + a];
+            if (v < mn[a]) mn[a] = v;
+            if (v > mx[a]) mx[a] = v;
+        }
+    int ax = 0;
+    if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+    if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+    if (!(mx[ax] > mn[ax])) { t->node_axis[id] = -1; t->node_split[id] = 0; return id; }
+    /* quickselect median on axis */
+    int l = lo, r = hi - 1;
+    const int k = lo + (hi - lo) / 2;
+    while (l < r) {
+        const real pv = t->pts[3 * t->perm[(l + r) / 2] + ax];
+        int i = l, j = r;
+        while (i <= j) {
+            while (t->pts[3 * t->perm[i] + ax] < pv) i++;
+            while (t->pts[3 * t->perm[j] + ax] > pv) j--;
+            if (i <= j) { int tmp = t->perm[i]; t->perm[i] = t->perm[j]; t->perm[j] = tmp; i++; j--; }
+        }
+        if (k <= j) r = j; else if (k >= i) l = i; else break;
+    }
+    /* split value: everything in [lo,k) <= split <= everything in [k,hi) */
+    real split = t->pts[3 * t->perm[k] + ax];
+    t->node_axis[id] = ax; t->node_split[id] = split;
+    const int left = kd_build_rec(t, lo, k);
+    const int right = kd_build_rec(t, k, hi);
+    t->node_left[id] = left; t->node_right[id] = right;
+    return id;
+}
+
+void *FN(orc_kdtree_build)(const real *m, int nm)
+{
+    kdtree *t = (kdtree *)calloc(1, sizeof *t);
+    t->n = nm; t->pts = m;
+    t->perm = (int *)malloc(sizeof(int) * (nm > 0 ? nm : 1));
+    for (int i = 0; i < nm; i++) t->perm[i] = i;
+    const int cap = 2 * (nm / (KD_LEAF / 2) + 2) + 64;   /* leaves hold >= KD_LEAF/2 points */
+    t->node_lo = (int *)malloc(sizeof(int) * cap); t->node_hi = (int *)malloc(sizeof(int) * cap);
+    t->node_axis = (int *)malloc(sizeof(int) * cap); t->node_split = (real *)malloc(sizeof(real) * cap);
+    t->node_left = (int *)malloc(sizeof(int) * cap); t->node_right = (int *)malloc(sizeof(int) * cap);
+    t->n_nodes = 0;
+    if (nm > 0) kd_build_rec(t, 0, nm);
+    return t;
+}
+
+void FN(orc_kdtree_free)(void *h)
+{
+    kdtree *t = (kdtree *)h;
+    if (!t) return;
+    free(t->perm); free(t->node_lo); free(t->node_hi); free(t->node_axis);
+    free(t->node_split); free(t->node_left); free(t->node_right); free(t);
+}
+
+static void kd_search(const kdtree *t, int node, const real *q, real *best, int *bi)
+{
+    const int ax = t->node_axis[node];
+    if (ax < 0) {
+        for (int i = t->node_lo[node]; i < t->node_hi[node]; i++) {
+            const int j = t->perm[i];
+            const real d = dist2(q, t->pts + 3 * j);
+            if (d < *best || (d == *best && j < *bi)) { *best = d; *bi = j; }
+        }
+        return;
+    }
+    const real diff = q[ax] - t->node_split[node];
+    const int near = diff < 0 ? t->node_left[node] : t->node_right[node];
+    const int far = diff < 0 ? t->node_right[node] : t->node_left[node];
+    kd_search(t, near, q, best, bi);
+    /* conservative prune: rounding is monotone, so every point beyond the
+     * plane has computed d2 >= fl(diff*diff); descend on equality (ties). */
+    if (!(diff * diff > *best)) kd_search(t, far, q, best, bi);
+}
+
+void FN(orc_kdtree_knn)(const void *h, const real *q, int nq, real max_dist, int *ids, real *d2)
+{
+    const kdtree *t = (const kdtree *)h;
+    const real md2 = max_dist * max_dist;
+    for (int i = 0; i < nq; i++) {
+        real best = INFINITY;
+        int bi = -1;
+        if (t->n > 0) {
+            /* seed with maxDist so far subtrees are pruned early; keep exactness:
+             * anything with d2 > md2 is rejected below anyway. */
+            best = md2; bi = INT32_MAX;
+            kd_search(t, 0, q + 3 * i, &best, &bi);
+            if (bi == INT32_MAX) bi = -1;
+        }
+        if (bi >= 0 && best <= md2) { ids[i] = bi; d2[i] = best; }
+        else { ids[i] = -1; d2[i] = INFINITY; }
+    }
+}
+
+/* --------------------------------------------------------------------------
+ * [A.4] TrimmedDistOutlierFilter
+ * ------------------------------------------------------------------------ */
+static int cmp_real(const void *a, const void *b)
+{
+    const real x = *(const real *)a, y = *(const real *)b;
+    return (x > y) - (x < y);
+}
+
+int FN(orc_trim_weights)(const real *d2, int n, real ratio, real *w, real *limit_out, int *n_finite_out)
+{
+    real *vals = (real *)malloc(sizeof(real) * (n > 0 ? n : 1));
+    int nf = 0;
+    for (int i = 0; i < n; i++)
+        if (d2[i] != INFINITY) vals[nf++] = d2[i];
+    if (n_finite_out) *n_finite_out = nf;
+    if (nf == 0) { free(vals); return ORC_ERR_NO_MATCH; }
+    if (ratio < 0 || ratio > 1) { free(vals); return ORC_ERR_ARG; }
+    qsort(vals, nf, sizeof(real), cmp_real);          /* nth_element == sorted[k] */
+    real limit;
+    if (ratio == (real)1) limit = vals[nf - 1];
+    else {
+        /* `values.size() * quantile` is evaluated in T (size_t * T -> T) */
+        size_t k = (size_t)((real)nf * ratio);
+        if (k >= (size_t)nf) k = nf - 1;
+        limit = vals[k];
+    }
+    free(vals);
+    for (int i = 0; i < n; i++) w[i] = (d2[i] <= limit) ? (real)1 : (real)0;
+    if (limit_out) *limit_out = limit;
+    return ORC_OK;
+}
+
+/* --------------------------------------------------------------------------
+ * [A.5]/[A.6]/[A.7] error elements -> point-to-plane normal equations
+ *   sys[0..20]  upper triangle of A (row-major: 00 01 .. 05 11 12 .. 55)
+ *   sys[21..26] b
+ *   sys[27] sum w, sys[28] kept count, sys[29] residual sum w e^2
+ * ------------------------------------------------------------------------ */
+int FN(orc_p2plane_system)(const real *p, int n, const real *ref_xyz, const real *ref_nrm,
+                           const int *ids, const real *w, double *sys)
+{
+    for (int i = 0; i < 30; i++) sys[i] = 0.0;
+    for (int i = 0; i < n; i++) {
+        if (w[i] == (real)0 || ids[i] < 0) continue;
+        const int j = ids[i];
+        const double wi = (double)w[i];
+        const double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+        const double nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
+        const double dx = px - (double)ref_xyz[3 * j], dy = py - (double)ref_xyz[3 * j + 1],
+                     dz = pz - (double)ref_xyz[3 * j + 2];
+        const double e = (nx * dx + ny * dy) + nz * dz;
+        double J[6];
+        J[0] = py * nz - pz * ny;           /* c = p x n */
+        J[1] = pz * nx - px * nz;
+        J[2] = px * ny - py * nx;
+        J[3] = nx; J[4] = ny; J[5] = nz;
+        int k = 0;
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) sys[k++] += wi * (J[a] * J[b]);
+        for (int a = 0; a < 6; a++) sys[21 + a] -= wi * (J[a] * e);
+        sys[27] += wi;
+        sys[28] += 1.0;
+        sys[29] += wi * (e * e);
+    }
+    return sys[28] > 0 ? ORC_OK : ORC_ERR_NO_MATCH;
+}
+
+/* cyclic Jacobi eigen-decomposition of a symmetric 6x6 (double) */
+static void jacobi6(double *a /* 36, destroyed */, double *v /* 36 */, double *ev)
+{
+    for (int i = 0; i < 36; i++) v[i] = 0.0;
+    for (int i = 0; i < 6; i++) v[i * 6 + i] = 1.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i + 1; j < 6; j++) off += a[i * 6 + j] * a[i * 6 + j];
+        if (off == 0.0) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = a[p * 6 + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * 6 + q] - a[p * 6 + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; k++) {
+                    const double akp = a[k * 6 + p], akq = a[k * 6 + q];
+                    a[k * 6 + p] = c * akp - s * akq;
+                    a[k * 6 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double apk = a[p * 6 + k], aqk = a[q * 6 + k];
+                    a[p * 6 + k] = c * apk - s * aqk;
+                    a[q * 6 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double vkp = v[k * 6 + p], vkq = v[k * 6 + q];
+                    v[k * 6 + p] = c * vkp - s * vkq;
+                    v[k * 6 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 6; i++) ev[i] = a[i * 6 + i];
+}
+
+/* [A.6] solvePossiblyUnderdeterminedLinearSystem: Cholesky when A is
+ * numerically full rank, else the minimal-norm solution (pseudo-inverse). */
+int FN(orc_solve6)(const double *sys, double *x, int *rank_out)
+{
+    double A[36], L[36];
+    int k = 0;
+    for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) { A[a * 6 + b] = sys[k]; A[b * 6 + a] = sys[k]; k++; }
+    const double *bv = sys + 21;
+    /* rank test on the eigenvalues, relative threshold 6*eps(real) */
+    double Aw[36], V[36], ev[6];
+    memcpy(Aw, A, sizeof A);
+    jacobi6(Aw, V, ev);
+    double emax = 0.0;
+    for (int i = 0; i < 6; i++) if (fabs(ev[i]) > emax) emax = fabs(ev[i]);
+#ifdef ORC_DOUBLE
+    const double tol = emax * 6.0 * DBL_EPSILON;
+#else
+    const double tol = emax * 6.0 * (double)FLT_EPSILON;
+#endif
+    int rank = 0;
+    for (int i = 0; i < 6; i++) if (ev[i] > tol) rank++;
+    if (rank_out) *rank_out = rank;
+    if (rank == 6) {
+        /* LL^T */
+        memset(L, 0, sizeof L);
+        int ok = 1;
+        for (int j = 0; j < 6 && ok; j++) {
+            double d = A[j * 6 + j];
+            for (int m = 0; m < j; m++) d -= L[j * 6 + m] * L[j * 6 + m];
+            if (!(d > 0.0)) { ok = 0; break; }
+            L[j * 6 + j] = sqrt(d);
+            for (int i = j + 1; i < 6; i++) {
+                double s = A[i * 6 + j];
+                for (int m = 0; m < j; m++) s -= L[i * 6 + m] * L[j * 6 + m];
+                L[i * 6 + j] = s / L[j * 6 + j];
+            }
+        }
+        if (ok) {
+            double y[6];
+            for (int i = 0; i < 6; i++) {
+                double s = bv[i];
+                for (int m = 0; m < i; m++) s -= L[i * 6 + m] * y[m];
+                y[i] = s / L[i * 6 + i];
+            }
+            for (int i = 5; i >= 0; i--) {
+                double s = y[i];
+                for (int m = i + 1; m < 6; m++) s -= L[m * 6 + i] * x[m];
+                x[i] = s / L[i * 6 + i];
+            }
+            return ORC_OK;
+        }
+    }
+    /* minimal-norm solution over the numerically non-null eigen-space */
+    for (int i = 0; i < 6; i++) x[i] = 0.0;
+    for (int e = 0; e < 6; e++) {
+        if (!(ev[e] > tol)) continue;
+        double dot = 0.0;
+        for (int i = 0; i < 6; i++) dot += V[i * 6 + e] * bv[i];
+        const double c = dot / ev[e];
+        for (int i = 0; i < 6; i++) x[i] += c * V[i * 6 + e];
+    }
+    return ORC_OK;
+}
+
+/* [A.6] x = [rx ry rz tx ty tz] -> 4x4; AngleAxis(|r|, r/|r|); NaN => R = I */
+void FN(orc_delta_T)(const double *x, double *T)
+{
+    mat4_identity(T);
+    const double th = sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+    if (th > 0.0 && isfinite(th)) {
+        const double ux = x[0] / th, uy = x[1] / th, uz = x[2] / th;
+        const double c = cos(th), s = sin(th), C = 1.0 - c;
+        T[0] = c + ux * ux * C;      T[1] = ux * uy * C - uz * s; T[2] = ux * uz * C + uy * s;
+        T[4] = uy * ux * C + uz * s; T[5] = c + uy * uy * C;      T[6] = uy * uz * C - ux * s;
+        T[8] = uz * ux * C - uy * s; T[9] = uz * uy * C + ux * s; T[10] = c + uz * uz * C;
+    }
+    T[3] = x[3]; T[7] = x[4]; T[11] = x[5];
+}
+
+/* rotation block -> unit quaternion (w,x,y,z), Shepperd's method */
+static void rot_to_quat(const double *T, double *q)
+{
+    const double m00 = T[0], m01 = T[1], m02 = T[2], m10 = T[4], m11 = T[5], m12 = T[6],
+                 m20 = T[8], m21 = T[9], m22 = T[10];
+    const double tr = m00 + m11 + m22;
+    if (tr > 0.0) {
+        double s = sqrt(tr + 1.0) * 2.0;
+        q[0] = 0.25 * s; q[1] = (m21 - m12) / s; q[2] = (m02 - m20) / s; q[3] = (m10 - m01) / s;
+    } else if (m00 > m11 && m00 > m22) {
+        double s = sqrt(1.0 + m00 - m11 - m22) * 2.0;
+        q[0] = (m21 - m12) / s; q[1] = 0.25 * s; q[2] = (m01 + m10) / s; q[3] = (m02 + m20) / s;
+    } else if (m11 > m22) {
+        double s = sqrt(1.0 + m11 - m00 - m22) * 2.0;
+        q[0] = (m02 - m20) / s; q[1] = (m01 + m10) / s; q[2] = 0.25 * s; q[3] = (m12 + m21) / s;
+    } else {
+        double s = sqrt(1.0 + m22 - m00 - m11) * 2.0;
+        q[0] = (m10 - m01) / s; q[1] = (m02 + m20) / s; q[2] = (m12 + m21) / s; q[3] = 0.25 * s;
+    }
+    const double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= nn;
+}
+
+/* Quaternion::angularDistance: d = a * conj(b); 2*atan2(|d.vec|, |d.w|) */
+static double quat_angdist(const double *a, const double *b)
+{
+    const double w = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    const double x = -a[0] * b[1] + a[1] * b[0] - a[2] * b[3] + a[3] * b[2];
+    const double y = -a[0] * b[2] + a[1] * b[3] + a[2] * b[0] - a[3] * b[1];
+    const double z = -a[0] * b[3] - a[1] * b[2] + a[2] * b[1] + a[3] * b[0];
+    return 2.0 * atan2(sqrt(x * x + y * y + z * z), fabs(w));
+}
+
+/* [A.9] checker state: Counter + Differential.  Exposed so that the scripted
+ * known-answer test can drive it directly. */
+#define ORC_HIST 64
+typedef struct {
+    int count, max_iters, smooth;
+    double min_rot, min_trans;
+    int n_hist;
+    double quat[ORC_HIST][4];
+    double trans[ORC_HIST][3];
+} orc_checker;
+
+void orc_checker_init(orc_checker *c, int max_iters, double min_rot, double min_trans, int smooth);
+int orc_checker_check(orc_checker *c, const double *T);
+#ifndef ORC_DOUBLE   /* type-independent: defined once, in the f32 object */
+void orc_checker_init(orc_checker *c, int max_iters, double min_rot, double min_trans, int smooth)
+{
+    memset(c, 0, sizeof *c);
+    c->max_iters = max_iters; c->min_rot = min_rot; c->min_trans = min_trans;
+    c->smooth = smooth < 1 ? 1 : (smooth > ORC_HIST - 2 ? ORC_HIST - 2 : smooth);
+    /* checkers.init(T_iter = I): history starts with the identity */
+    c->quat[0][0] = 1.0; c->n_hist = 1;
+}
+
+/* returns: bit0 = keep iterating, bit1 = differential stop, bit2 = counter stop, bit3 = NaN */
+int orc_checker_check(orc_checker *c, const double *T)
+{
+    int iterate = 1, flags = 0;
+    /* Counter */
+    c->count++;
+    if (c->count >= c->max_iters) { iterate = 0; flags |= 4; }
+    /* Differential */
+    if (c->n_hist == ORC_HIST) {
+        memmove(c->quat[0], c->quat[1], sizeof(double) * 4 * (ORC_HIST - 1));
+        memmove(c->trans[0], c->trans[1], sizeof(double) * 3 * (ORC_HIST - 1));
+        c->n_hist--;
+    }
+    rot_to_quat(T, c->quat[c->n_hist]);
+    c->trans[c->n_hist][0] = T[3]; c->trans[c->n_hist][1] = T[7]; c->trans[c->n_hist][2] = T[11];
+    c->n_hist++;
+    if (c->n_hist > c->smooth) {
+        double rsum = 0.0, tsum = 0.0;
+        for (int i = c->n_hist - 1; i >= c->n_hist - c->smooth; i--) {
+            rsum += fabs(quat_angdist(c->quat[i], c->quat[i - 1]));
+            const double dx = c->trans[i][0] - c->trans[i - 1][0], dy = c->trans[i][1] - c->trans[i - 1][1],
+                         dz = c->trans[i][2] - c->trans[i - 1][2];
+            tsum += fabs(sqrt(dx * dx + dy * dy + dz * dz));
+        }
+        rsum /= (double)c->smooth; tsum /= (double)c->smooth;
+        if (isnan(rsum) || isnan(tsum)) return 8;
+        if (rsum < c->min_rot && tsum < c->min_trans) { iterate = 0; flags |= 2; }
+    }
+    return flags | iterate;
+}
+#endif
+
+/* [A.8] PointToPlaneWithCov: Censi closed form on the kept pairs of the last
+ * iteration (p = reading moved by the previous T_iter), dT = last increment. */
+void FN(orc_covariance)(const real *p, int n, const real *ref_xyz, const real *ref_nrm, const int *ids,
+                        const real *w, const double *dT, double sensor_std_dev, double *cov)
+{
+    double H[36], G[36];
+    memset(H, 0, sizeof H); memset(G, 0, sizeof G);
+    const double beta = -asin(dT[8]);
+    const double alpha = atan2(dT[9], dT[10]);
+    const double gamma = atan2(dT[4] / cos(beta), dT[0] / cos(beta));
+    const double t_x = dT[3], t_y = dT[7], t_z = dT[11];
+    for (int i = 0; i < n; i++) {
+        if (w[i] == (real)0 || ids[i] < 0) continue;
+        const int j = ids[i];
+        const double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+        const double qx = ref_xyz[3 * j], qy = ref_xyz[3 * j + 1], qz = ref_xyz[3 * j + 2];
+        const double nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
+        const double rr = sqrt((px * px + py * py) + pz * pz);
+        const double rdx = px / rr, rdy = py / rr, rdz = pz / rr;
+        const double qr = sqrt((qx * qx + qy * qy) + qz * qz);
+        const double qdx = qx / qr, qdy = qy / qr, qdz = qz / qr;
+        const double n_alpha = nz * rdy - ny * rdz;
+        const double n_beta = nx * rdz - nz * rdx;
+        const double n_gamma = ny * rdx - nx * rdy;
+        double E = nx * (px - gamma * py + beta * pz + t_x - qx);
+        E += ny * (gamma * px + py - alpha * pz + t_y - qy);
+        E += nz * (-beta * px + alpha * py + pz + t_z - qz);
+        double Nr = nx * (rdx - gamma * rdy + beta * rdz);
+        Nr += ny * (gamma * rdx + rdy - alpha * rdz);
+        Nr += nz * (-beta * rdx + alpha * rdy + rdz);
+        const double Nq = -((nx * qdx + ny * qdy) + nz * qdz);
+        const double h[6] = {nx, ny, nz, rr * n_alpha, rr * n_beta, rr * n_gamma};
+        const double er = E + rr * Nr;
+        const double gr[6] = {nx * Nr, ny * Nr, nz * Nr, n_alpha * er, n_beta * er, n_gamma * er};
+        const double gq[6] = {nx * Nq, ny * Nq, nz * Nq, qr * n_alpha * Nq, qr * n_beta * Nq, qr * n_gamma * Nq};
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) {
+                H[a * 6 + b] += h[a] * h[b];
+                G[a * 6 + b] += gr[a] * gr[b] + gq[a] * gq[b];
+            }
+    }
+    /* inv(H) by Gauss-Jordan with partial pivoting */
+    double M[6][12];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) { M[i][j] = H[i * 6 + j]; M[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++) if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+        if (piv != c) for (int j = 0; j < 12; j++) { double t = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = t; }
+        const double d = M[c][c];
+        for (int j = 0; j < 12; j++) M[c][j] /= d;
+        for (int r = 0; r < 6; r++) {
+            if (r == c) continue;
+            const double f = M[r][c];
+            for (int j = 0; j < 12; j++) M[r][j] -= f * M[c][j];
+        }
+    }
+    double Hi[36], tmp[36];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Hi[i * 6 + j] = M[i][6 + j];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 6; k++) s += Hi[i * 6 + k] * G[k * 6 + j];
+            tmp[i * 6 + j] = s;
+        }
+    const double s2 = sensor_std_dev * sensor_std_dev;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 6; k++) s += tmp[i * 6 + k] * Hi[k * 6 + j];
+            cov[i * 6 + j] = s2 * s;
+        }
+}
+
+/* partial chain used by Localizer::ComputeOverlapWith (Localizer.hpp:309-347)
+ * and LoopCloser::ComputeResidualError (LoopCloser.hpp:346-364): reading is
+ * moved by T, matched against the RAW (un-centred) reference, weighted, and
+ * both weightedPointUsedRatio and the residual are returned. */
+int FN(orc_partial_chain)(const FN(orc_params) *prm, const real *reading, int n, const real *ref_xyz,
+                          const real *ref_nrm, int m, const double *T, double *overlap, double *residual,
+                          int *ids_out, real *d2_out)
+{
+    real *p = (real *)malloc(sizeof(real) * 3 * (n > 0 ? n : 1));
+    int *ids = ids_out ? ids_out : (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    real *d2 = d2_out ? d2_out : (real *)malloc(sizeof(real) * (n > 0 ? n : 1));
+    real *w = (real *)malloc(sizeof(real) * (n > 0 ? n : 1));
+    FN(orc_transform)(T, reading, p, n, 0);
+    if (prm->use_kdtree) {
+        void *t = FN(orc_kdtree_build)(ref_xyz, m);
+        FN(orc_kdtree_knn)(t, p, n, prm->max_dist, ids, d2);
+        FN(orc_kdtree_free)(t);
+    } else FN(orc_knn_brute)(p, n, ref_xyz, m, prm->max_dist, ids, d2);
+    real limit; int nf;
+    int st = FN(orc_trim_weights)(d2, n, prm->trim_ratio, w, &limit, &nf);
+    if (st == ORC_OK) {
+        double sys[30];
+        st = FN(orc_p2plane_system)(p, n, ref_xyz, ref_nrm, ids, w, sys);
+        if (overlap) *overlap = sys[27] / (double)n;
+        if (residual) *residual = sys[29];
+    }
+    free(p); free(w);
+    if (!ids_out) free(ids);
+    if (!d2_out) free(d2);
+    return st;
+}
+
+/* --------------------------------------------------------------------------
+ * [A.2] the ICP loop.  `trace` (optional) receives per iteration 16 doubles of
+ * T_iter (so tests can compare trajectories); trace_cap = max iterations stored.
+ * ------------------------------------------------------------------------ */
+int FN(orc_icp)(const FN(orc_params) *prm, const real *reading, int n, const real *ref_xyz_in,
+                const real *ref_nrm, int m, const double *T_init, double *T_out, orc_result *res,
+                double *trace, int trace_cap, int *last_ids, real *last_d2)
+{
+    memset(res, 0, sizeof *res);
+    if (n <= 0 || m <= 0) { res->status = ORC_ERR_ARG; return ORC_ERR_ARG; }
+    real *ref = (real *)malloc(sizeof(real) * 3 * m);
+    real mean[3] = {0, 0, 0};
+    if (prm->center_reference) {
+        FN(orc_centroid)(ref_xyz_in, m, mean);
+        for (int i = 0; i < m; i++)
+            for (int a = 0; a < 3; a++) ref[3 * i + a] = ref_xyz_in[3 * i + a] - mean[a];
+    } else memcpy(ref, ref_xyz_in, sizeof(real) * 3 * m);
+    double T_ref_mean[16], T_ref_mean_inv[16], T_pre[16];
+    mat4_identity(T_ref_mean);
+    T_ref_mean[3] = mean[0]; T_ref_mean[7] = mean[1]; T_ref_mean[11] = mean[2];
+    mat4_rigid_inverse(T_ref_mean, T_ref_mean_inv);
+    mat4_mul(T_ref_mean_inv, T_init, T_pre);
+
+    real *rd = (real *)malloc(sizeof(real) * 3 * n);       /* reading in centred-map frame */
+    real *step = (real *)malloc(sizeof(real) * 3 * n);
+    int *ids = (int *)malloc(sizeof(int) * n);
+    real *d2 = (real *)malloc(sizeof(real) * n);
+    real *w = (real *)malloc(sizeof(real) * n);
+    FN(orc_transform)(T_pre, reading, rd, n, 0);
+
+    void *tree = prm->use_kdtree ? FN(orc_kdtree_build)(ref, m) : NULL;
+    double T_iter[16], dT[16], T_prev[16];
+    mat4_identity(T_iter); mat4_identity(dT); mat4_identity(T_prev);
+    orc_checker chk;
+    orc_checker_init(&chk, prm->max_iters, prm->min_diff_rot, prm->min_diff_trans, prm->smooth_length);
+    int status = ORC_OK, iterate = 1, it = 0;
+    double sys[30];
+    while (iterate) {
+        FN(orc_transform)(T_iter, rd, step, n, 0);
+        if (tree) FN(orc_kdtree_knn)(tree, step, n, prm->max_dist, ids, d2);
+        else FN(orc_knn_brute)(step, n, ref, m, prm->max_dist, ids, d2);
+        real limit; int nf;
+        status = FN(orc_trim_weights)(d2, n, prm->trim_ratio, w, &limit, &nf);
+        if (status != ORC_OK) break;
+        status = FN(orc_p2plane_system)(step, n, ref, ref_nrm, ids, w, sys);
+        if (status != ORC_OK) break;
+        double x[6]; int rank;
+        FN(orc_solve6)(sys, x, &rank);
+        FN(orc_delta_T)(x, dT);
+        memcpy(T_prev, T_iter, sizeof T_iter);
+        mat4_mul(dT, T_iter, T_iter);
+        res->overlap = sys[27] / (double)n;
+        res->residual = sys[29];
+        res->trim_limit = (double)limit;
+        res->n_kept = (int)sys[28];
+        res->n_finite = nf;
+        if (trace && it < trace_cap) memcpy(trace + 16 * it, T_iter, sizeof T_iter);
+        it++;
+        const int f = orc_checker_check(&chk, T_iter);
+        if (f & 8) { status = ORC_ERR_NAN; break; }
+        iterate = f & 1;
+        if (f & 2) res->converged = 1;
+        if (f & 4) res->max_iter_reached = 1;
+    }
+    res->iterations = it;
+    res->status = status;
+    if (status == ORC_OK) {
+        /* covariance on the last iteration's error elements (step = T_prev*rd) */
+        FN(orc_covariance)(step, n, ref, ref_nrm, ids, w, dT, prm->sensor_std_dev, res->cov);
+        double t1[16];
+        mat4_mul(T_iter, T_pre, t1);
+        mat4_mul(T_ref_mean, t1, T_out);
+    } else mat4_identity(T_out);
+    if (last_ids) memcpy(last_ids, ids, sizeof(int) * n);
+    if (last_d2) memcpy(last_d2, d2, sizeof(real) * n);
+    if (tree) FN(orc_kdtree_free)(tree);
+    free(ref); free(rd); free(step); free(ids); free(d2); free(w);
+    return status;
+}

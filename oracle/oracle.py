@@ -1,0 +1,211 @@
+"""ctypes binding of the CPU oracle (liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; nothing under pgslam_amd/ does.  See icp_oracle.c for the citations
+of the reference call sites each function restates, and for the "parity
+unpinned" statement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "icp_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return _LIB_PATH
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("converged", C.c_int),
+                ("max_iter_reached", C.c_int), ("overlap", C.c_double), ("residual", C.c_double),
+                ("trim_limit", C.c_double), ("n_kept", C.c_int), ("n_finite", C.c_int),
+                ("cov", C.c_double * 36)]
+
+
+def _params_type(real):
+    class Params(C.Structure):
+        _fields_ = [("max_dist", real), ("trim_ratio", real), ("max_iters", C.c_int),
+                    ("min_diff_rot", C.c_double), ("min_diff_trans", C.c_double),
+                    ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double),
+                    ("use_kdtree", C.c_int), ("center_reference", C.c_int)]
+    return Params
+
+
+class Checker(C.Structure):
+    _fields_ = [("count", C.c_int), ("max_iters", C.c_int), ("smooth", C.c_int),
+                ("min_rot", C.c_double), ("min_trans", C.c_double), ("n_hist", C.c_int),
+                ("quat", C.c_double * (64 * 4)), ("trans", C.c_double * (64 * 3))]
+
+
+DEFAULT_CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001,
+                     min_diff_trans=0.01, smooth_length=3, sensor_std_dev=0.01)
+
+
+class Oracle:
+    """dtype = np.float32 (PointMatcher<float>) or np.float64 (PointMatcher<double>)."""
+
+    def __init__(self, dtype=np.float32):
+        self.lib = C.CDLL(build())
+        self.dtype = np.dtype(dtype)
+        self.sfx = "_f32" if self.dtype == np.float32 else "_f64"
+        self.real = C.c_float if self.dtype == np.float32 else C.c_double
+        self.Params = _params_type(self.real)
+
+    def _f(self, name):
+        return getattr(self.lib, name + self.sfx)
+
+    def _a(self, x, shape_last=3):
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        return x
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def params(self, use_kdtree=True, center_reference=True, **kw):
+        d = dict(DEFAULT_CHAIN)
+        d.update(kw)
+        return self.Params(d["max_dist"], d["trim_ratio"], d["max_iters"], d["min_diff_rot"],
+                           d["min_diff_trans"], d["smooth_length"], d["sensor_std_dev"],
+                           int(use_kdtree), int(center_reference))
+
+    # -- stages -----------------------------------------------------------
+    def transform(self, T, pts, rotate_only=False):
+        pts = self._a(pts)
+        out = np.empty_like(pts)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        self._f("orc_transform")(self._p(T), self._p(pts), self._p(out), C.c_int(pts.shape[0]), C.c_int(int(rotate_only)))
+        return out
+
+    def centroid(self, pts):
+        pts = self._a(pts)
+        mean = np.zeros(3, dtype=self.dtype)
+        self._f("orc_centroid")(self._p(pts), C.c_int(pts.shape[0]), self._p(mean))
+        return mean
+
+    def knn_brute(self, q, m, max_dist=np.inf):
+        q, m = self._a(q), self._a(m)
+        ids = np.empty(q.shape[0], dtype=np.int32)
+        d2 = np.empty(q.shape[0], dtype=self.dtype)
+        self._f("orc_knn_brute")(self._p(q), C.c_int(q.shape[0]), self._p(m), C.c_int(m.shape[0]),
+                                 self.real(max_dist), self._p(ids), self._p(d2))
+        return ids, d2
+
+    def knn_kdtree(self, q, m, max_dist=np.inf):
+        q, m = self._a(q), self._a(m)
+        ids = np.empty(q.shape[0], dtype=np.int32)
+        d2 = np.empty(q.shape[0], dtype=self.dtype)
+        b = self._f("orc_kdtree_build"); b.restype = C.c_void_p
+        t = b(self._p(m), C.c_int(m.shape[0]))
+        self._f("orc_kdtree_knn")(C.c_void_p(t), self._p(q), C.c_int(q.shape[0]), self.real(max_dist),
+                                  self._p(ids), self._p(d2))
+        self._f("orc_kdtree_free")(C.c_void_p(t))
+        return ids, d2
+
+    def trim_weights(self, d2, ratio):
+        d2 = np.ascontiguousarray(d2, dtype=self.dtype)
+        w = np.empty_like(d2)
+        limit = self.real(0)
+        nf = C.c_int(0)
+        st = self._f("orc_trim_weights")(self._p(d2), C.c_int(d2.shape[0]), self.real(ratio), self._p(w),
+                                         C.byref(limit), C.byref(nf))
+        return st, w, limit.value, nf.value
+
+    def p2plane_system(self, p, ref_xyz, ref_nrm, ids, w):
+        p, ref_xyz, ref_nrm = self._a(p), self._a(ref_xyz), self._a(ref_nrm)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        w = np.ascontiguousarray(w, dtype=self.dtype)
+        sys_ = np.zeros(30, dtype=np.float64)
+        st = self._f("orc_p2plane_system")(self._p(p), C.c_int(p.shape[0]), self._p(ref_xyz), self._p(ref_nrm),
+                                           self._p(ids), self._p(w), self._p(sys_))
+        return st, sys_
+
+    def solve6(self, sys_):
+        sys_ = np.ascontiguousarray(sys_, dtype=np.float64)
+        x = np.zeros(6)
+        rank = C.c_int(0)
+        self._f("orc_solve6")(self._p(sys_), self._p(x), C.byref(rank))
+        return x, rank.value
+
+    def delta_T(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        T = np.zeros((4, 4))
+        self._f("orc_delta_T")(self._p(x), self._p(T))
+        return T
+
+    def covariance(self, p, ref_xyz, ref_nrm, ids, w, dT, sensor_std_dev):
+        p, ref_xyz, ref_nrm = self._a(p), self._a(ref_xyz), self._a(ref_nrm)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        w = np.ascontiguousarray(w, dtype=self.dtype)
+        dT = np.ascontiguousarray(dT, dtype=np.float64)
+        cov = np.zeros((6, 6))
+        self._f("orc_covariance")(self._p(p), C.c_int(p.shape[0]), self._p(ref_xyz), self._p(ref_nrm), self._p(ids),
+                                  self._p(w), self._p(dT), C.c_double(sensor_std_dev), self._p(cov))
+        return cov
+
+    def build_local_map(self, clouds_xyz, clouds_nrm, T_ref_kf):
+        """clouds[0] is the reference keyframe; T_ref_kf[k] moves cloud k into its frame."""
+        k = len(clouds_xyz)
+        xs = [self._a(c) for c in clouds_xyz]
+        ns = [self._a(c) for c in clouds_nrm]
+        counts = np.array([c.shape[0] for c in xs], dtype=np.int32)
+        Ts = np.ascontiguousarray(np.stack(T_ref_kf), dtype=np.float64)
+        out_x = np.empty((int(counts.sum()), 3), dtype=self.dtype)
+        out_n = np.empty_like(out_x)
+        PP = C.c_void_p * k
+        self._f("orc_build_local_map")(C.c_int(k), PP(*[c.ctypes.data for c in xs]), PP(*[c.ctypes.data for c in ns]),
+                                       self._p(counts), self._p(Ts), self._p(out_x), self._p(out_n))
+        return out_x, out_n
+
+    def partial_chain(self, reading, ref_xyz, ref_nrm, T, **kw):
+        """Localizer::ComputeOverlapWith / LoopCloser::ComputeResidualError."""
+        reading, ref_xyz, ref_nrm = self._a(reading), self._a(ref_xyz), self._a(ref_nrm)
+        prm = self.params(**kw)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        ov, rs = C.c_double(0), C.c_double(0)
+        ids = np.empty(reading.shape[0], dtype=np.int32)
+        d2 = np.empty(reading.shape[0], dtype=self.dtype)
+        st = self._f("orc_partial_chain")(C.byref(prm), self._p(reading), C.c_int(reading.shape[0]), self._p(ref_xyz),
+                                          self._p(ref_nrm), C.c_int(ref_xyz.shape[0]), self._p(T), C.byref(ov),
+                                          C.byref(rs), self._p(ids), self._p(d2))
+        return dict(status=st, overlap=ov.value, residual=rs.value, ids=ids, d2=d2)
+
+    def icp(self, reading, ref_xyz, ref_nrm, T_init, trace=False, **kw):
+        reading, ref_xyz, ref_nrm = self._a(reading), self._a(ref_xyz), self._a(ref_nrm)
+        prm = self.params(**kw)
+        T_init = np.ascontiguousarray(T_init, dtype=np.float64)
+        T_out = np.zeros((4, 4))
+        res = Result()
+        cap = prm.max_iters if trace else 0
+        tr = np.zeros((max(cap, 1), 4, 4))
+        ids = np.empty(reading.shape[0], dtype=np.int32)
+        d2 = np.empty(reading.shape[0], dtype=self.dtype)
+        st = self._f("orc_icp")(C.byref(prm), self._p(reading), C.c_int(reading.shape[0]), self._p(ref_xyz),
+                                self._p(ref_nrm), C.c_int(ref_xyz.shape[0]), self._p(T_init), self._p(T_out),
+                                C.byref(res), self._p(tr) if trace else None, C.c_int(cap), self._p(ids), self._p(d2))
+        out = dict(status=st, T=T_out, iterations=res.iterations, converged=bool(res.converged),
+                   max_iter_reached=bool(res.max_iter_reached), overlap=res.overlap, residual=res.residual,
+                   trim_limit=res.trim_limit, n_kept=res.n_kept, n_finite=res.n_finite,
+                   cov=np.array(res.cov[:]).reshape(6, 6), last_ids=ids, last_d2=d2)
+        if trace:
+            out["trace"] = tr[: res.iterations]
+        return out
+
+    # -- checker (type independent) ---------------------------------------
+    def checker(self, max_iters, min_rot, min_trans, smooth):
+        c = Checker()
+        self.lib.orc_checker_init(C.byref(c), C.c_int(max_iters), C.c_double(min_rot), C.c_double(min_trans), C.c_int(smooth))
+        return c
+
+    def checker_check(self, c, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        return self.lib.orc_checker_check(C.byref(c), self._p(T))
