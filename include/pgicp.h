@@ -1,0 +1,250 @@
+/*
+ * pgicp.h -- C ABI of the MI355X-native ICP hot path of pgslam.
+ *
+ * This is the drop-in boundary: every entry point replaces a
+ * call pgslam makes into libpointmatcher's ICP chain.  Paths below are relative
+ * to /root/reference/src/pgslam/.  All entry points are `extern "C"`, take plain
+ * pointers and sizes, return an int status (0 = PGICP_OK) and never throw.
+ *
+ * Conventions
+ *   - Point buffers are `float` (PointMatcher<float>) or `double`
+ *     (PointMatcher<double>): `_f32` / `_f64` suffix.
+ *   - A point buffer is (pointer, stride, count): element a of point i is
+ *     ptr[i*stride + a], a in {0,1,2}.  libpointmatcher's `features` matrix
+ *     (4 x N, column-major, homogeneous) is (features.data(), 4, N); a `normals`
+ *     descriptor view inside a D-row descriptor matrix is (&desc(row0,0), D, N);
+ *     a packed xyz array is (ptr, 3, N).
+ *   - `mem` says where a buffer lives: PGICP_HOST (caller-owned host memory,
+ *     read only during the call) or PGICP_DEVICE (HIP device memory on the
+ *     context's GPU, e.g. a torch tensor's data_ptr()).
+ *   - 4x4 transforms cross the ABI as 16 doubles, ROW-major.  (The C++ shim
+ *     converts from the column-major PM::Matrix.)
+ *   - A context is thread-compatible (one thread at a time); different contexts
+ *     are fully concurrent, each owns its HIP stream (SURVEY.md §8(b) threading).
+ *   - There is NO CPU fallback: without a usable gfx950 device
+ *     pgicp_ctx_create() fails with PGICP_ERR_NO_DEVICE.
+ */
+#ifndef PGICP_H
+#define PGICP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGICP_ABI_VERSION 1
+
+/* status codes (pgslam sees PM::ConvergenceError for 1..2 through the C++ shim) */
+#define PGICP_OK 0
+#define PGICP_ERR_NO_MATCH 1    /* "no outlier to filter" / "no point to minimize" */
+#define PGICP_ERR_NAN 2         /* NaN in the transformation checkers */
+#define PGICP_ERR_ARG 3
+#define PGICP_ERR_HIP 4
+#define PGICP_ERR_NO_DEVICE 5
+#define PGICP_ERR_NOT_RIGID 6   /* RigidTransformation::checkParameters failed */
+
+#define PGICP_HOST 0
+#define PGICP_DEVICE 1
+
+#define PGICP_MATCHER_GRID 0    /* grid-hashed exact kNN (performance path) */
+#define PGICP_MATCHER_BRUTE 1   /* LDS-tiled brute force (parity path) */
+
+typedef struct pgicp_ctx pgicp_ctx;
+
+/* The ICP chain configuration: what pgslam loads from YAML through
+ * icp_sequence_.loadFromYaml (Localizer.hpp:70) / icp_.loadFromYaml
+ * (LoopCloser.hpp:73).  Field <- libpointmatcher module.parameter. */
+typedef struct pgicp_params {
+    int knn;                 /* KDTreeMatcher.knn; only 1 is supported */
+    double epsilon;          /* KDTreeMatcher.epsilon; only 0 (exact) is supported */
+    double max_dist;         /* KDTreeMatcher.maxDist, metres; +inf allowed */
+    double trim_ratio;       /* TrimmedDistOutlierFilter.ratio */
+    int max_iters;           /* CounterTransformationChecker.maxIterationCount */
+    double min_diff_rot;     /* DifferentialTransformationChecker.minDiffRotErr */
+    double min_diff_trans;   /* DifferentialTransformationChecker.minDiffTransErr */
+    int smooth_length;       /* DifferentialTransformationChecker.smoothLength (<= 15) */
+    double sensor_std_dev;   /* PointToPlaneWithCovErrorMinimizer.sensorStdDev */
+    int matcher;             /* PGICP_MATCHER_GRID | PGICP_MATCHER_BRUTE */
+    double grid_cell;        /* grid cell edge in metres; 0 = automatic */
+    int check_every;         /* host polls the device-side "all done" flag every this many iterations (>=1) */
+} pgicp_params;
+
+/* What pgslam reads back after an ICP: errorMinimizer->getOverlap()
+ * (Localizer.hpp:278, LoopCloser.hpp:331), getCovariance() (Localizer.hpp:238,
+ * LoopCloser.hpp:108), icp_.getMaxNumIterationsReached() (LoopCloser.hpp:317). */
+typedef struct pgicp_stats {
+    int status;              /* PGICP_OK or PGICP_ERR_NO_MATCH / PGICP_ERR_NAN for this problem */
+    int iterations;
+    int converged;           /* DifferentialTransformationChecker stopped the loop */
+    int max_iter_reached;    /* CounterTransformationChecker stopped the loop */
+    double overlap;          /* weightedPointUsedRatio of the last ErrorElements */
+    double residual;         /* sum w (n.(p-q))^2 of the last ErrorElements */
+    double trim_limit;       /* last TrimmedDist threshold (squared distance) */
+    int n_kept;              /* pairs with non-zero weight in the last iteration */
+    int n_finite;            /* pairs with a neighbour within maxDist */
+    double cov[36];          /* 6x6 row-major, order [x y z rx ry rz] (Optimizer.hpp:32-42) */
+} pgicp_stats;
+
+/* One ICP problem of a batch (scan-to-map: many readings, one map;
+ * loop closure: one map per pair -- LoopCloser.hpp:98). */
+typedef struct pgicp_problem {
+    int map_id;
+    const void *reading;     /* float* or double* according to the entry point */
+    int stride;
+    int n;
+    int mem;
+    double T_init[16];
+} pgicp_problem;
+
+/* Loop-closure edge record exchanged between GPUs: the payload of
+ * Optimizer<T>::InputData = tuple<Vertex,Vertex,Matrix,CovMatrix>
+ * (Optimizer.h:22) plus the acceptance evidence of LoopCloser::CheckIcpResult
+ * (LoopCloser.hpp:308-340).  Exactly 512 bytes so a rank's edges all-gather as
+ * one contiguous buffer. */
+typedef struct pgicp_edge {
+    int64_t from_id;
+    int64_t to_id;
+    int32_t accepted;        /* CheckIcpResult() */
+    int32_t status;
+    int32_t iterations;
+    int32_t max_iter_reached;
+    double overlap;
+    double residual;
+    double T_from_to[16];
+    double cov[36];
+    double reserved[6];
+} pgicp_edge;
+
+/* ---- context --------------------------------------------------------- */
+int pgicp_abi_version(void);
+int pgicp_device_count(void);
+int pgicp_ctx_create(int device, pgicp_ctx **out);
+void pgicp_ctx_destroy(pgicp_ctx *ctx);
+const char *pgicp_last_error(const pgicp_ctx *ctx);
+/* The HIP stream (hipStream_t) every kernel of this context is launched on. */
+void *pgicp_ctx_stream(pgicp_ctx *ctx);
+int pgicp_ctx_synchronize(pgicp_ctx *ctx);
+
+void pgicp_default_params(pgicp_params *p);
+/* replaces ICP::loadFromYaml / setDefault for the supported chain */
+int pgicp_set_params(pgicp_ctx *ctx, const pgicp_params *p);
+int pgicp_get_params(const pgicp_ctx *ctx, pgicp_params *p);
+
+/* ---- reference cloud / matcher index ---------------------------------
+ * pgicp_map_create = ICPSequence::setMap (Localizer.hpp:148,168,254) when
+ * center != 0 (the reference is mean-centred) and
+ * matcher->init(reference) (Localizer.hpp:317, LoopCloser.hpp:356) when
+ * center == 0.  Copies the cloud to the device, builds the grid index; the map
+ * stays resident until pgicp_map_destroy. `nrm` may be NULL for match-only maps. */
+int pgicp_map_create_f32(pgicp_ctx *ctx, const float *xyz, int xyz_stride, const float *nrm, int nrm_stride,
+                         int m, int mem, int center, int *map_id);
+int pgicp_map_create_f64(pgicp_ctx *ctx, const double *xyz, int xyz_stride, const double *nrm, int nrm_stride,
+                         int m, int mem, int center, int *map_id);
+int pgicp_map_destroy(pgicp_ctx *ctx, int map_id);
+int pgicp_map_size(pgicp_ctx *ctx, int map_id, int *m);
+
+/* ---- full ICP --------------------------------------------------------
+ * pgicp_align = ICPSequence::operator()(reading, T_init) (Localizer.hpp:126).
+ * pgicp_align_batch runs independent problems concurrently on the device
+ * (LoopCloserMT's queue, LoopCloserMT.hpp:26-67, is where batches form).
+ * pgicp_icp_pair = ICP::operator()(reading, reference, T_init)
+ * (LoopCloser.hpp:98): builds the centred index, aligns, frees the index. */
+int pgicp_align_f32(pgicp_ctx *ctx, int map_id, const float *reading, int stride, int n, int mem,
+                    const double T_init[16], double T_out[16], pgicp_stats *stats);
+int pgicp_align_f64(pgicp_ctx *ctx, int map_id, const double *reading, int stride, int n, int mem,
+                    const double T_init[16], double T_out[16], pgicp_stats *stats);
+int pgicp_align_batch_f32(pgicp_ctx *ctx, int n_problems, const pgicp_problem *problems, double *T_out,
+                          pgicp_stats *stats);
+int pgicp_align_batch_f64(pgicp_ctx *ctx, int n_problems, const pgicp_problem *problems, double *T_out,
+                          pgicp_stats *stats);
+int pgicp_icp_pair_f32(pgicp_ctx *ctx, const float *reading, int rd_stride, int n, const float *ref_xyz,
+                       int ref_stride, const float *ref_nrm, int nrm_stride, int m, int mem,
+                       const double T_init[16], double T_out[16], pgicp_stats *stats);
+int pgicp_icp_pair_f64(pgicp_ctx *ctx, const double *reading, int rd_stride, int n, const double *ref_xyz,
+                       int ref_stride, const double *ref_nrm, int nrm_stride, int m, int mem,
+                       const double T_init[16], double T_out[16], pgicp_stats *stats);
+
+/* ---- chain stages (the partial-chain callers) ------------------------
+ * pgicp_match = matcher->findClosests (Localizer.hpp:328, LoopCloser.hpp:358):
+ * the reading is first moved by T (NULL = identity), then matched.  ids are
+ * indices into the cloud given to pgicp_map_create (-1 = no neighbour within
+ * maxDist), dist2 are SQUARED distances (+inf when id == -1).
+ * pgicp_outlier_weights = outlierFilters.compute (Localizer.hpp:330,
+ * LoopCloser.hpp:360) for TrimmedDistOutlierFilter.
+ * pgicp_error_stats = ErrorElements(...) + weightedPointUsedRatio
+ * (Localizer.hpp:332,347) and getResidualError (LoopCloser.hpp:362);
+ * `reading` must already be in the map's frame (as pgslam passes it).
+ * pgicp_partial_chain fuses the three for Localizer::ComputeOverlapWith
+ * (Localizer.hpp:282-348) and LoopCloser::ComputeResidualError
+ * (LoopCloser.hpp:343-365): one device pass, no host round trip. */
+int pgicp_match_f32(pgicp_ctx *ctx, int map_id, const float *reading, int stride, int n, int mem,
+                    const double *T, int32_t *ids, float *dist2);
+int pgicp_match_f64(pgicp_ctx *ctx, int map_id, const double *reading, int stride, int n, int mem,
+                    const double *T, int32_t *ids, double *dist2);
+int pgicp_outlier_weights_f32(pgicp_ctx *ctx, const float *dist2, int n, int mem, float *weights,
+                              float *limit, int *n_finite);
+int pgicp_outlier_weights_f64(pgicp_ctx *ctx, const double *dist2, int n, int mem, double *weights,
+                              double *limit, int *n_finite);
+int pgicp_error_stats_f32(pgicp_ctx *ctx, int map_id, const float *reading, int stride, int n, int mem,
+                          const int32_t *ids, const float *weights, double *weighted_point_used_ratio,
+                          double *residual, double sys[30]);
+int pgicp_error_stats_f64(pgicp_ctx *ctx, int map_id, const double *reading, int stride, int n, int mem,
+                          const int32_t *ids, const double *weights, double *weighted_point_used_ratio,
+                          double *residual, double sys[30]);
+int pgicp_partial_chain_f32(pgicp_ctx *ctx, int map_id, const float *reading, int stride, int n, int mem,
+                            const double *T, double *weighted_point_used_ratio, double *residual);
+int pgicp_partial_chain_f64(pgicp_ctx *ctx, int map_id, const double *reading, int stride, int n, int mem,
+                            const double *T, double *weighted_point_used_ratio, double *residual);
+
+/* ---- rigid transform and local-map assembly ---------------------------
+ * pgicp_transform = rigid_transformation_->compute (Localizer.hpp:106,323,
+ * LocalMap.hpp:97,222) / transformations.apply (LoopCloser.hpp:352): points get
+ * R*p + t, normals (rotate_only) get R*n.  In-place (out == in) is allowed.
+ * pgicp_build_local_map = LocalMap::BuildCloudFromData (LocalMap.hpp:209-224):
+ * cloud 0 is copied, cloud k>0 is moved by T_ref_kf[k] and appended. */
+int pgicp_transform_f32(pgicp_ctx *ctx, const double T[16], const float *in, int in_stride, float *out,
+                        int out_stride, int n, int rotate_only, int mem);
+int pgicp_transform_f64(pgicp_ctx *ctx, const double T[16], const double *in, int in_stride, double *out,
+                        int out_stride, int n, int rotate_only, int mem);
+int pgicp_build_local_map_f32(pgicp_ctx *ctx, int n_kf, const float *const *xyz, const float *const *nrm,
+                              const int *strides_xyz, const int *strides_nrm, const int *counts,
+                              const double *T_ref_kf, float *out_xyz, float *out_nrm, int out_stride, int mem);
+int pgicp_build_local_map_f64(pgicp_ctx *ctx, int n_kf, const double *const *xyz, const double *const *nrm,
+                              const int *strides_xyz, const int *strides_nrm, const int *counts,
+                              const double *T_ref_kf, double *out_xyz, double *out_nrm, int out_stride, int mem);
+
+/* ---- loop-closure dispatcher helpers (host logic, no GPU needed) -------
+ * pgicp_shard_pairs: deterministic longest-processing-time split of n_pairs
+ * candidate ICPs (cost[i] ~ N_i + M_i) over world_size ranks; writes the pair
+ * indices of `rank` (at most cap) and returns their count through n_out.
+ * pgicp_check_icp_result = LoopCloser::CheckIcpResult (LoopCloser.hpp:308-340). */
+int pgicp_shard_pairs(int n_pairs, const int64_t *cost, int world_size, int rank, int *out_idx, int cap,
+                      int *n_out);
+int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double overlap_threshold,
+                           double residual_error_threshold);
+
+/* ---- measurement -------------------------------------------------------
+ * With profiling on, every launch of the named kernels is bracketed by HIP
+ * events on the context stream; pgicp_profile_get returns launch count and
+ * summed device milliseconds.  Kernel ids: 0 knn_grid, 1 knn_brute, 2 trim_select,
+ * 3 p2plane_reduce, 4 solve_update, 5 pretransform, 6 covariance, 7 grid_build. */
+#define PGICP_PROF_KNN_GRID 0
+#define PGICP_PROF_KNN_BRUTE 1
+#define PGICP_PROF_TRIM 2
+#define PGICP_PROF_REDUCE 3
+#define PGICP_PROF_SOLVE 4
+#define PGICP_PROF_PRETRANSFORM 5
+#define PGICP_PROF_COV 6
+#define PGICP_PROF_GRID_BUILD 7
+#define PGICP_PROF_COUNT 8
+int pgicp_profile_enable(pgicp_ctx *ctx, int on);
+int pgicp_profile_reset(pgicp_ctx *ctx);
+int pgicp_profile_get(pgicp_ctx *ctx, int kernel_id, long long *launches, double *total_ms,
+                      long long *units /* queries processed by those launches */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGICP_H */

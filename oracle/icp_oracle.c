@@ -23,9 +23,12 @@
  *                        Localizer.hpp:317,328  LoopCloser.hpp:356,358  [A.3]
  *   orc_trim_weights     outlierFilters.compute Localizer.hpp:330,
  *                        LoopCloser.hpp:360                             [A.4]
- *   orc_error_stats      ErrorElements ctor     Localizer.hpp:332,347   [A.5]
- *   orc_p2plane_system   errorMinimizer->compute (inside ICP)           [A.6]
- *   orc_residual         getResidualError       LoopCloser.hpp:362      [A.7]
+ *   orc_p2plane_system   ErrorElements ctor + weightedPointUsedRatio
+ *                        Localizer.hpp:332,347 (sys[27]/N)              [A.5]
+ *                        errorMinimizer->compute (inside ICP)           [A.6]
+ *                        getResidualError LoopCloser.hpp:362 (sys[29])  [A.7]
+ *   orc_partial_chain    Localizer::ComputeOverlapWith Localizer.hpp:282-348,
+ *                        LoopCloser::ComputeResidualError LoopCloser.hpp:343-365
  *   orc_covariance       getCovariance          Localizer.hpp:238,
  *                        LoopCloser.hpp:108                             [A.8]
  *   checkers             getMaxNumIterationsReached LoopCloser.hpp:317  [A.9]
@@ -407,8 +410,12 @@ static void jacobi6(double *a /* 36, destroyed */, double *v /* 36 */, double *e
     for (int i = 0; i < 6; i++) ev[i] = a[i * 6 + i];
 }
 
-/* [A.6] solvePossiblyUnderdeterminedLinearSystem: Cholesky when A is
- * numerically full rank, else the minimal-norm solution (pseudo-inverse). */
+/* [A.6] solvePossiblyUnderdeterminedLinearSystem.  libpointmatcher tests
+ * invertibility with a rank-revealing QR and then uses A.llt(); rank-deficient
+ * systems get the minimal-norm solution.  Restated as: Cholesky whose pivots
+ * must all exceed 6*eps(T)*max|A_ii| (numerically full rank), otherwise the
+ * pseudo-inverse solution over the eigen-directions with
+ * lambda > 6*eps(T)*lambda_max.  (Assumption-ledger item: rank threshold.) */
 int FN(orc_solve6)(const double *sys, double *x, int *rank_out)
 {
     double A[36], L[36];
@@ -416,59 +423,59 @@ int FN(orc_solve6)(const double *sys, double *x, int *rank_out)
     for (int a = 0; a < 6; a++)
         for (int b = a; b < 6; b++) { A[a * 6 + b] = sys[k]; A[b * 6 + a] = sys[k]; k++; }
     const double *bv = sys + 21;
-    /* rank test on the eigenvalues, relative threshold 6*eps(real) */
+#ifdef ORC_DOUBLE
+    const double rel = 6.0 * DBL_EPSILON;
+#else
+    const double rel = 6.0 * (double)FLT_EPSILON;
+#endif
+    double dmax = 0.0;
+    for (int i = 0; i < 6; i++) if (fabs(A[i * 6 + i]) > dmax) dmax = fabs(A[i * 6 + i]);
+    memset(L, 0, sizeof L);
+    int ok = 1;
+    for (int j = 0; j < 6 && ok; j++) {
+        double d = A[j * 6 + j];
+        for (int m = 0; m < j; m++) d -= L[j * 6 + m] * L[j * 6 + m];
+        if (!(d > dmax * rel)) { ok = 0; break; }
+        L[j * 6 + j] = sqrt(d);
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i * 6 + j];
+            for (int m = 0; m < j; m++) s -= L[i * 6 + m] * L[j * 6 + m];
+            L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    }
+    if (ok) {
+        double y[6];
+        for (int i = 0; i < 6; i++) {
+            double s = bv[i];
+            for (int m = 0; m < i; m++) s -= L[i * 6 + m] * y[m];
+            y[i] = s / L[i * 6 + i];
+        }
+        for (int i = 5; i >= 0; i--) {
+            double s = y[i];
+            for (int m = i + 1; m < 6; m++) s -= L[m * 6 + i] * x[m];
+            x[i] = s / L[i * 6 + i];
+        }
+        if (rank_out) *rank_out = 6;
+        return ORC_OK;
+    }
+    /* minimal-norm solution over the numerically non-null eigen-space */
     double Aw[36], V[36], ev[6];
     memcpy(Aw, A, sizeof A);
     jacobi6(Aw, V, ev);
     double emax = 0.0;
     for (int i = 0; i < 6; i++) if (fabs(ev[i]) > emax) emax = fabs(ev[i]);
-#ifdef ORC_DOUBLE
-    const double tol = emax * 6.0 * DBL_EPSILON;
-#else
-    const double tol = emax * 6.0 * (double)FLT_EPSILON;
-#endif
+    const double tol = emax * rel;
     int rank = 0;
-    for (int i = 0; i < 6; i++) if (ev[i] > tol) rank++;
-    if (rank_out) *rank_out = rank;
-    if (rank == 6) {
-        /* LL^T */
-        memset(L, 0, sizeof L);
-        int ok = 1;
-        for (int j = 0; j < 6 && ok; j++) {
-            double d = A[j * 6 + j];
-            for (int m = 0; m < j; m++) d -= L[j * 6 + m] * L[j * 6 + m];
-            if (!(d > 0.0)) { ok = 0; break; }
-            L[j * 6 + j] = sqrt(d);
-            for (int i = j + 1; i < 6; i++) {
-                double s = A[i * 6 + j];
-                for (int m = 0; m < j; m++) s -= L[i * 6 + m] * L[j * 6 + m];
-                L[i * 6 + j] = s / L[j * 6 + j];
-            }
-        }
-        if (ok) {
-            double y[6];
-            for (int i = 0; i < 6; i++) {
-                double s = bv[i];
-                for (int m = 0; m < i; m++) s -= L[i * 6 + m] * y[m];
-                y[i] = s / L[i * 6 + i];
-            }
-            for (int i = 5; i >= 0; i--) {
-                double s = y[i];
-                for (int m = i + 1; m < 6; m++) s -= L[m * 6 + i] * x[m];
-                x[i] = s / L[i * 6 + i];
-            }
-            return ORC_OK;
-        }
-    }
-    /* minimal-norm solution over the numerically non-null eigen-space */
     for (int i = 0; i < 6; i++) x[i] = 0.0;
     for (int e = 0; e < 6; e++) {
         if (!(ev[e] > tol)) continue;
+        rank++;
         double dot = 0.0;
         for (int i = 0; i < 6; i++) dot += V[i * 6 + e] * bv[i];
         const double c = dot / ev[e];
         for (int i = 0; i < 6; i++) x[i] += c * V[i * 6 + e];
     }
+    if (rank_out) *rank_out = rank;
     return ORC_OK;
 }
 

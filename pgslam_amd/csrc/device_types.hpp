@@ -1,0 +1,81 @@
+// device_types.hpp -- structures shared by the HIP kernels and the host side of
+// libpgicp.  Everything that lives in HBM is described here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "icp_math.hpp"
+
+namespace pgicp {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+// Uniform grid over the (centred) reference cloud.  Cell id = x + nx*(y + ny*z),
+// x fastest, so the cells of one x-row are contiguous in the cell-sorted point
+// array and a whole row segment is one contiguous range.
+template <typename T>
+struct GridDesc {
+    T ox, oy, oz;        // lower corner
+    T h, inv_h;          // cell edge and its reciprocal
+    T margin;            // conservative slack for rounding in cell assignment (0.02 h)
+    int nx, ny, nz;
+};
+
+// A resident reference cloud ("map"): cell-sorted AoS records, 16/32 B each so
+// a neighbour candidate is ONE aligned vector load.
+template <typename T>
+struct MapDev {
+    const typename Vec4<T>::type *pts;   // (x, y, z, bit-cast original index) cell-sorted, centred
+    const typename Vec4<T>::type *nrm;   // (nx, ny, nz, 0) same order; may be null
+    const int *cell_start;               // ncells + 1 exclusive prefix sums
+    GridDesc<T> g;
+    int m;
+    int pad_;
+};
+
+// Chain parameters as the kernels need them.
+template <typename T>
+struct ChainDev {
+    T max_dist;          // may be +inf
+    T max_dist2;         // max_dist * max_dist in T
+    T trim_ratio;
+    int max_iters;
+    int smooth;
+    double min_rot, min_trans;
+    double rank_rel_tol; // 6 * eps(T)
+};
+
+// One ICP problem of a batch.  Lives in device memory; written by the solve
+// kernel, read by every other kernel; copied back to the host once at the end.
+struct ProblemDev {
+    int map;                 // slot in the MapDev table
+    int n;                   // reading points
+    long long off;           // offset (in points) of this problem in the packed per-point arrays
+    double Tpre[16];         // T_refMean^-1 * T_init (applied once per scan, cast to T)
+    double T_iter[16];       // accumulated correction in the centred map frame
+    double T_prev[16];       // T_iter used for the last matching
+    double dT[16];           // last increment
+    double Tcur[12];         // T_iter as 3x4 for the kernels (cast to T when applied)
+    int done, status, iters, converged, max_iter_reached;
+    int n_finite, n_kept, rank;
+    double limit;            // last trim threshold (squared distance)
+    double sys[kSys];        // final sums of the last iteration
+    Checker chk;
+};
+
+// status codes inside ProblemDev (mirror PGICP_OK / PGICP_ERR_NO_MATCH / PGICP_ERR_NAN)
+#define PGICP_ST_OK 0
+#define PGICP_ST_NO_MATCH 1
+#define PGICP_ST_NAN 2
+
+struct Mat34 { double v[12]; };                    // row-major 3x4, kernel argument
+struct SrcDesc { const void *ptr; int stride; int pad_; };   // where a problem's reading lives (device)
+
+constexpr int kKnnBlock = 256;
+constexpr int kReduceBlock = 256;
+constexpr int kReduceItems = 2;      // queries per thread in the reduce kernels
+constexpr int kSelectBlock = 1024;
+constexpr int kCovTerms = 42;        // 21 (H upper) + 21 (G upper)
+
+}  // namespace pgicp

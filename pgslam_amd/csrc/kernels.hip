@@ -1,0 +1,958 @@
+// kernels.hip -- hand-written gfx950 kernels of the ICP hot path.
+//
+// Arithmetic contract (shared with oracle/icp_oracle.c, compiled with
+// -ffp-contract=off so hipcc never fuses a multiply-add):
+//   transform   x' = ((r00*x + r01*y) + r02*z) + tx            in T
+//   distance    d2 = ((dx*dx + dy*dy) + dz*dz), dx = q - m     in T
+//   neighbour   argmin over (d2, original index), accepted iff d2 <= maxDist^2
+//   sums        double, fixed reduction tree (lane -> wave -> block -> block order)
+//
+// wave = 64 lanes everywhere; no warp-size-32 idiom is used.
+#include "kernels.hpp"
+
+namespace pgicp {
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+template <typename T> struct Bits;
+template <> struct Bits<float> {
+    using U = unsigned int;
+    static constexpr int kBits = 32;
+    __device__ static U key(float v) { return __float_as_uint(v); }
+    __device__ static float val(U k) { return __uint_as_float(k); }
+    __device__ static float pack_idx(int i) { return __int_as_float(i); }
+    __device__ static int unpack_idx(float w) { return __float_as_int(w); }
+    __device__ static float inf() { return __uint_as_float(0x7F800000u); }
+};
+template <> struct Bits<double> {
+    using U = unsigned long long;
+    static constexpr int kBits = 64;
+    __device__ static U key(double v) { return (U)__double_as_longlong(v); }
+    __device__ static double val(U k) { return __longlong_as_double((long long)k); }
+    __device__ static double pack_idx(int i) { return __longlong_as_double((long long)i); }
+    __device__ static int unpack_idx(double w) { return (int)__double_as_longlong(w); }
+    __device__ static double inf() { return __longlong_as_double(0x7FF0000000000000LL); }
+};
+
+__device__ __forceinline__ float4 make_v4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+__device__ __forceinline__ double4 make_v4(double x, double y, double z, double w) { return make_double4(x, y, z, w); }
+
+// Blocks b and b+8 share an XCD (round-robin dispatch, observed; used for L2
+// locality only).  Give every XCD one contiguous span of tiles so that the map
+// cells a span touches stay in that XCD's 4 MiB L2.  Bijective for any nb.
+__device__ __forceinline__ int xcd_tile(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, j = b >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void apply_T(const double *Tc, T x, T y, T z, T &ox, T &oy, T &oz)
+{
+    const T r00 = (T)Tc[0], r01 = (T)Tc[1], r02 = (T)Tc[2], tx = (T)Tc[3];
+    const T r10 = (T)Tc[4], r11 = (T)Tc[5], r12 = (T)Tc[6], ty = (T)Tc[7];
+    const T r20 = (T)Tc[8], r21 = (T)Tc[9], r22 = (T)Tc[10], tz = (T)Tc[11];
+    ox = ((r00 * x + r01 * y) + r02 * z) + tx;
+    oy = ((r10 * x + r11 * y) + r12 * z) + ty;
+    oz = ((r20 * x + r21 * y) + r22 * z) + tz;
+}
+
+// ---------------------------------------------------------------------------
+// map build: centroid (order-independent fixed point), bbox, cell sort
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ordered_key(double v)
+{
+    const long long i = __double_as_longlong(v);
+    return (unsigned long long)(i >= 0 ? (i ^ (long long)0x8000000000000000LL) : ~i);
+}
+
+// stats[0..2] = fixed-point sums (int64), stats[3..5] = min keys, stats[6..8] = max keys
+template <typename T>
+__global__ __launch_bounds__(256) void k_centroid_bbox(const T *__restrict__ xyz, int stride, int m,
+                                                        unsigned long long *__restrict__ stats)
+{
+    long long s[3] = {0, 0, 0};
+    double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double v = (double)xyz[i * stride + a];
+            s[a] += __double2ll_rn(v * 16777216.0);
+            mn[a] = fmin(mn[a], v);
+            mx[a] = fmax(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        long long sv = s[a];
+        double lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sv += __shfl_down(sv, o, 64);
+            lo = fmin(lo, __shfl_down(lo, o, 64));
+            hi = fmax(hi, __shfl_down(hi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&stats[a], (unsigned long long)sv);
+            atomicMin(&stats[3 + a], ordered_key(lo));
+            atomicMax(&stats[6 + a], ordered_key(hi));
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ int build_cell(const GridDesc<T> &g, T x, T y, T z)
+{
+    int cx = (int)floor((x - g.ox) * g.inv_h);
+    int cy = (int)floor((y - g.oy) * g.inv_h);
+    int cz = (int)floor((z - g.oz) * g.inv_h);
+    cx = min(max(cx, 0), g.nx - 1);
+    cy = min(max(cy, 0), g.ny - 1);
+    cz = min(max(cz, 0), g.nz - 1);
+    return cx + g.nx * (cy + g.ny * cz);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_cell_count(const T *__restrict__ xyz, int stride, int m, T mx, T my, T mz,
+                                                     GridDesc<T> g, int *__restrict__ cell_of, int *__restrict__ counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const T x = xyz[(long long)i * stride] - mx, y = xyz[(long long)i * stride + 1] - my,
+            z = xyz[(long long)i * stride + 2] - mz;
+    const int c = build_cell(g, x, y, z);
+    cell_of[i] = c;
+    atomicAdd(&counts[c], 1);
+}
+
+// three-phase exclusive scan over `n` ints (n up to 2^27)
+constexpr int kScanChunk = 4096;   // elements per block (1024 threads x 4)
+
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *lds /*>=17 ints*/, int &total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        int w = (lane < (int)(blockDim.x >> 6)) ? lds[lane] : 0;
+        int winc = w;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int t = __shfl_up(winc, o, 64);
+            if (lane >= o) winc += t;
+        }
+        if (lane < 16) lds[lane] = winc - w;      // exclusive wave offsets
+        if (lane == 15) lds[16] = winc;
+    }
+    __syncthreads();
+    total = lds[16];
+    const int res = lds[wid] + inc - v;
+    __syncthreads();
+    return res;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_block_sums(const int *__restrict__ in, int n, int *__restrict__ block_sums)
+{
+    __shared__ int lds[32];
+    const long long base = (long long)blockIdx.x * kScanChunk + threadIdx.x * 4;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (base + k < n) s += in[base + k];
+    int total;
+    block_exclusive_scan_1024(s, lds, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums_inplace(int *__restrict__ block_sums, int nb)
+{
+    __shared__ int lds[32];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? block_sums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan_1024(v, lds, total);
+        if (i < nb) block_sums[i] = ex + carry;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_final(const int *__restrict__ in, int n, const int *__restrict__ block_offs,
+                                                      int *__restrict__ out /* n+1 */, int *__restrict__ cursor)
+{
+    __shared__ int lds[32];
+    const long long base = (long long)blockIdx.x * kScanChunk + threadIdx.x * 4;
+    int v[4];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    int total;
+    int ex = block_exclusive_scan_1024(s, lds, total) + block_offs[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (base + k < n) { out[base + k] = ex; cursor[base + k] = ex; }
+        ex += v[k];
+    }
+    if (base <= n - 1 && n - 1 < base + 4) out[n] = ex;    // the thread holding the last element
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ xyz, int stride, const T *__restrict__ nrm,
+                                                  int nstride, int m, T mx, T my, T mz, const int *__restrict__ cell_of,
+                                                  int *__restrict__ cursor, typename Vec4<T>::type *__restrict__ pts,
+                                                  typename Vec4<T>::type *__restrict__ nrm_out, int *__restrict__ slot_of)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const T x = xyz[(long long)i * stride] - mx, y = xyz[(long long)i * stride + 1] - my,
+            z = xyz[(long long)i * stride + 2] - mz;
+    const int pos = atomicAdd(&cursor[cell_of[i]], 1);
+    pts[pos] = make_v4(x, y, z, Bits<T>::pack_idx(i));
+    if (nrm) nrm_out[pos] = make_v4(nrm[(long long)i * nstride], nrm[(long long)i * nstride + 1],
+                                    nrm[(long long)i * nstride + 2], (T)0);
+    slot_of[i] = pos;
+}
+
+// Cells are filled through an atomic cursor, so the order inside a cell is
+// arbitrary.  Re-sort every cell by original index (cells are small) so that
+// the resident layout -- and with it every later sum order -- is reproducible.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell_start, int ncells,
+                                                     typename Vec4<T>::type *__restrict__ pts,
+                                                     typename Vec4<T>::type *__restrict__ nrm, int *__restrict__ slot_of)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const int a = cell_start[c], b = cell_start[c + 1];
+    for (int i = a + 1; i < b; i++) {           // insertion sort by original index
+        const auto p = pts[i];
+        const int key = Bits<T>::unpack_idx(p.w);
+        typename Vec4<T>::type nn = p;
+        if (nrm) nn = nrm[i];
+        int j = i - 1;
+        while (j >= a && Bits<T>::unpack_idx(pts[j].w) > key) {
+            pts[j + 1] = pts[j];
+            if (nrm) nrm[j + 1] = nrm[j];
+            j--;
+        }
+        pts[j + 1] = p;
+        if (nrm) nrm[j + 1] = nn;
+    }
+    for (int i = a; i < b; i++) slot_of[Bits<T>::unpack_idx(pts[i].w)] = i;
+}
+
+// ---------------------------------------------------------------------------
+// rigid transform (a9) -- also the per-scan pre-transform of the ICP prologue
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_transform(const T *__restrict__ in, int in_stride, T *__restrict__ out,
+                                                    int out_stride, int n, Mat34 M, int rotate_only)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T x = in[(long long)i * in_stride], y = in[(long long)i * in_stride + 1], z = in[(long long)i * in_stride + 2];
+    const T r00 = (T)M.v[0], r01 = (T)M.v[1], r02 = (T)M.v[2], r10 = (T)M.v[4], r11 = (T)M.v[5], r12 = (T)M.v[6],
+            r20 = (T)M.v[8], r21 = (T)M.v[9], r22 = (T)M.v[10];
+    T ox = (r00 * x + r01 * y) + r02 * z;
+    T oy = (r10 * x + r11 * y) + r12 * z;
+    T oz = (r20 * x + r21 * y) + r22 * z;
+    if (!rotate_only) { ox = ox + (T)M.v[3]; oy = oy + (T)M.v[7]; oz = oz + (T)M.v[11]; }
+    out[(long long)i * out_stride] = ox;
+    out[(long long)i * out_stride + 1] = oy;
+    out[(long long)i * out_stride + 2] = oz;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pretransform(const ProblemDev *__restrict__ probs, const SrcDesc *__restrict__ src,
+                                                       T *__restrict__ rd_pre)
+{
+    const ProblemDev &P = probs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const SrcDesc s = src[blockIdx.y];
+    const T *in = (const T *)s.ptr;
+    const T x = in[(long long)i * s.stride], y = in[(long long)i * s.stride + 1], z = in[(long long)i * s.stride + 2];
+    T ox, oy, oz;
+    apply_T<T>(P.Tpre, x, y, z, ox, oy, oz);
+    T *o = rd_pre + 3 * (P.off + i);
+    o[0] = ox; o[1] = oy; o[2] = oz;
+}
+
+// ---------------------------------------------------------------------------
+// matcher: exact nearest neighbour on the cell-sorted map
+// ---------------------------------------------------------------------------
+template <typename T>
+struct Best {
+    T d2;
+    int idx;
+    int slot;
+};
+
+template <typename T>
+__device__ __forceinline__ void scan_range(const typename Vec4<T>::type *__restrict__ pts, int a, int b, T qx, T qy,
+                                           T qz, Best<T> &best)
+{
+    for (int s = a; s < b; ++s) {
+        const auto v = pts[s];
+        const T dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+        const T d = (dx * dx + dy * dy) + dz * dz;
+        const int idx = Bits<T>::unpack_idx(v.w);
+        if (d < best.d2 || (d == best.d2 && idx < best.idx)) { best.d2 = d; best.idx = idx; best.slot = s; }
+    }
+}
+
+// distance from coordinate offset u (= x - origin) to the slab of cell c
+template <typename T>
+__device__ __forceinline__ T slab_dist(T u, int c, T h)
+{
+    const T lo = (T)c * h - u;          // > 0 when the query is below the slab
+    const T hi = u - (T)(c + 1) * h;    // > 0 when above
+    return fmax((T)0, fmax(lo, hi));
+}
+
+// Exact NN by expanding Chebyshev rings of cells around the query's (clamped)
+// cell.  Rows (fixed y,z) are contiguous in memory, so a ring costs one or two
+// range look-ups per row.  A row is skipped when its slab distance already
+// exceeds the best candidate; the search stops when every unexamined cell is
+// provably farther than the best candidate, or farther than maxDist.
+template <typename T>
+__device__ __forceinline__ Best<T> grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T max_dist, T max_dist2)
+{
+    const GridDesc<T> g = M.g;
+    const int *__restrict__ cs = M.cell_start;
+    const auto *__restrict__ pts = M.pts;
+    Best<T> best;
+    best.d2 = max_dist2;            // seed: anything farther than maxDist is useless
+    best.idx = 0x7FFFFFFF;
+    best.slot = -1;
+    const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+    const T lim = (T)16777216.0;
+    const int c0x = min(max((int)fmin(fmax(floor(ux * g.inv_h), -lim), lim), 0), g.nx - 1);
+    const int c0y = min(max((int)fmin(fmax(floor(uy * g.inv_h), -lim), lim), 0), g.ny - 1);
+    const int c0z = min(max((int)fmin(fmax(floor(uz * g.inv_h), -lim), lim), 0), g.nz - 1);
+    for (int r = 0;; ++r) {
+        const int z0 = max(c0z - r, 0), z1 = min(c0z + r, g.nz - 1);
+        const int y0 = max(c0y - r, 0), y1 = min(c0y + r, g.ny - 1);
+        const int xa = max(c0x - r, 0), xb = min(c0x + r, g.nx - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
+            const bool zo = (z - c0z == r) || (c0z - z == r);
+            for (int y = y0; y <= y1; ++y) {
+                const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
+                if (ly * ly + lz * lz > best.d2) continue;
+                const int row = g.nx * (y + g.ny * z);
+                if (zo || (y - c0y == r) || (c0y - y == r)) {
+                    scan_range<T>(pts, cs[row + xa], cs[row + xb + 1], qx, qy, qz, best);
+                } else {
+                    if (c0x - r >= 0) scan_range<T>(pts, cs[row + c0x - r], cs[row + c0x - r + 1], qx, qy, qz, best);
+                    if (c0x + r <= g.nx - 1) scan_range<T>(pts, cs[row + c0x + r], cs[row + c0x + r + 1], qx, qy, qz, best);
+                }
+            }
+        }
+        // guaranteed radius: every cell outside ring r is at least this far away
+        T gr = Bits<T>::inf();
+        if (c0x - r - 1 >= 0) gr = fmin(gr, slab_dist(ux, c0x - r - 1, g.h));
+        if (c0x + r + 1 <= g.nx - 1) gr = fmin(gr, slab_dist(ux, c0x + r + 1, g.h));
+        if (c0y - r - 1 >= 0) gr = fmin(gr, slab_dist(uy, c0y - r - 1, g.h));
+        if (c0y + r + 1 <= g.ny - 1) gr = fmin(gr, slab_dist(uy, c0y + r + 1, g.h));
+        if (c0z - r - 1 >= 0) gr = fmin(gr, slab_dist(uz, c0z - r - 1, g.h));
+        if (c0z + r + 1 <= g.nz - 1) gr = fmin(gr, slab_dist(uz, c0z + r + 1, g.h));
+        if (!(gr < Bits<T>::inf())) break;                              // grid exhausted
+        gr = gr - g.margin;
+        if (gr > (T)0 && (best.d2 < gr * gr || gr > max_dist)) break;
+    }
+    if (best.slot < 0) { best.d2 = Bits<T>::inf(); best.idx = -1; }
+    return best;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kKnnBlock) void k_knn_grid(const ProblemDev *__restrict__ probs,
+                                                         const MapDev<T> *__restrict__ maps, const T *__restrict__ rd_pre,
+                                                         int *__restrict__ slot_out, T *__restrict__ d2_out,
+                                                         ChainDev<T> ch)
+{
+    const ProblemDev &P = probs[blockIdx.y];
+    if (P.done) return;
+    const int i = xcd_tile(blockIdx.x, gridDim.x) * kKnnBlock + threadIdx.x;
+    if (i >= P.n) return;
+    const T *q = rd_pre + 3 * (P.off + i);
+    T qx, qy, qz;
+    apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
+    const Best<T> b = grid_nn<T>(maps[P.map], qx, qy, qz, ch.max_dist, ch.max_dist2);
+    slot_out[P.off + i] = b.slot;
+    d2_out[P.off + i] = b.d2;
+}
+
+// Brute force (parity path): a block owns 256 queries; the map streams through
+// LDS in tiles, every lane reads the same LDS address (broadcast, conflict free).
+constexpr int kBruteTile = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kKnnBlock) void k_knn_brute(const ProblemDev *__restrict__ probs,
+                                                          const MapDev<T> *__restrict__ maps, const T *__restrict__ rd_pre,
+                                                          int *__restrict__ slot_out, T *__restrict__ d2_out,
+                                                          ChainDev<T> ch)
+{
+    using V4 = typename Vec4<T>::type;
+    __shared__ V4 tile[kBruteTile];
+    const ProblemDev &P = probs[blockIdx.y];
+    if (P.done) return;
+    if (blockIdx.x * kKnnBlock >= P.n) return;
+    const MapDev<T> M = maps[P.map];
+    const int i = blockIdx.x * kKnnBlock + threadIdx.x;
+    const bool live = i < P.n;
+    T qx = 0, qy = 0, qz = 0;
+    if (live) {
+        const T *q = rd_pre + 3 * (P.off + i);
+        apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
+    }
+    Best<T> best;
+    best.d2 = ch.max_dist2; best.idx = 0x7FFFFFFF; best.slot = -1;
+    for (int base = 0; base < M.m; base += kBruteTile) {
+        const int cnt = min(kBruteTile, M.m - base);
+        for (int k = threadIdx.x; k < cnt; k += kKnnBlock) tile[k] = M.pts[base + k];
+        __syncthreads();
+        for (int k = 0; k < cnt; ++k) {
+            const V4 v = tile[k];
+            const T dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+            const T d = (dx * dx + dy * dy) + dz * dz;
+            const int idx = Bits<T>::unpack_idx(v.w);
+            if (d < best.d2 || (d == best.d2 && idx < best.idx)) { best.d2 = d; best.idx = idx; best.slot = base + k; }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        if (best.slot < 0) best.d2 = Bits<T>::inf();
+        slot_out[P.off + i] = best.slot;
+        d2_out[P.off + i] = best.d2;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// outlier filter: exact order statistic of the finite squared distances
+// (radix select on the IEEE bit pattern, 11 bits per level; one block/problem)
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ void trim_select_block(const T *__restrict__ d2, int n, T ratio, T &limit_out, int &nf_out)
+{
+    using U = typename Bits<T>::U;
+    constexpr int KB = Bits<T>::kBits;
+    __shared__ int hist[2048];
+    __shared__ int lds_scan[32];
+    __shared__ U s_prefix;
+    __shared__ long long s_k;
+    __shared__ int s_nf;
+    U prefix = 0;
+    int done_bits = 0;
+    long long k = 0;
+    const U inf_key = Bits<T>::key(Bits<T>::inf());
+    while (done_bits < KB) {
+        const int width = (KB - done_bits) >= 11 ? 11 : (KB - done_bits);
+        const int shift = KB - done_bits - width;
+        for (int b = threadIdx.x; b < 2048; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const U key = Bits<T>::key(d2[i]);
+            if (key >= inf_key) continue;                         // +inf (no neighbour) is not a value
+            if (done_bits == 0 || (key >> (KB - done_bits)) == prefix)
+                atomicAdd(&hist[(int)((key >> shift) & (U)((1u << width) - 1u))], 1);
+        }
+        __syncthreads();
+        // block scan over 2048 bins: 2 bins per thread (blockDim = 1024)
+        const int b0 = 2 * threadIdx.x;
+        const int h0 = hist[b0], h1 = hist[b0 + 1];
+        int total;
+        const int ex = block_exclusive_scan_1024(h0 + h1, lds_scan, total);
+        if (done_bits == 0) {
+            if (threadIdx.x == 0) {
+                s_nf = total;
+                long long kk;
+                if (ratio == (T)1) kk = (long long)total - 1;
+                else {
+                    kk = (long long)((T)total * ratio);           // `values.size() * quantile` evaluated in T
+                    if (kk > (long long)total - 1) kk = (long long)total - 1;
+                }
+                s_k = kk < 0 ? 0 : kk;
+            }
+            __syncthreads();
+            k = s_k;
+            const int nf0 = s_nf;
+            __syncthreads();                       // everyone has read s_k before the owner rewrites it
+            if (nf0 == 0) { limit_out = Bits<T>::inf(); nf_out = 0; return; }
+        }
+        if (k >= ex && k < ex + h0) { s_prefix = (prefix << width) | (U)b0; s_k = k - ex; }
+        else if (k >= ex + h0 && k < ex + h0 + h1) { s_prefix = (prefix << width) | (U)(b0 + 1); s_k = k - ex - h0; }
+        __syncthreads();
+        prefix = s_prefix;
+        k = s_k;
+        done_bits += width;
+        __syncthreads();
+    }
+    limit_out = Bits<T>::val(prefix);
+    nf_out = s_nf;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSelectBlock) void k_trim_select(ProblemDev *__restrict__ probs, const T *__restrict__ d2,
+                                                               ChainDev<T> ch)
+{
+    ProblemDev &P = probs[blockIdx.x];
+    if (P.done) return;
+    T limit;
+    int nf;
+    trim_select_block<T>(d2 + P.off, P.n, ch.trim_ratio, limit, nf);
+    if (threadIdx.x == 0) {
+        P.limit = (double)limit;
+        P.n_finite = nf;
+    }
+}
+
+// stand-alone outlier weights for the stage-level API (one problem)
+template <typename T>
+__global__ __launch_bounds__(kSelectBlock) void k_trim_select_raw(const T *__restrict__ d2, int n, T ratio,
+                                                                   T *__restrict__ limit_nf /* [0]=limit, [1]=nf */)
+{
+    T limit;
+    int nf;
+    trim_select_block<T>(d2, n, ratio, limit, nf);
+    if (threadIdx.x == 0) { limit_nf[0] = limit; limit_nf[1] = (T)nf; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_weights(const T *__restrict__ d2, int n, const T *__restrict__ limit_nf,
+                                                  T *__restrict__ w)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    w[i] = (d2[i] <= limit_nf[0]) ? (T)1 : (T)0;
+}
+
+// ---------------------------------------------------------------------------
+// error minimiser: per-pair 6-DoF Jacobian, 30 sums, wave __shfl reduction
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void accumulate_pair(double *acc, double w, double px, double py, double pz, double qx,
+                                                double qy, double qz, double nx, double ny, double nz)
+{
+    const double dx = px - qx, dy = py - qy, dz = pz - qz;
+    const double e = (nx * dx + ny * dy) + nz * dz;
+    double J[6];
+    J[0] = py * nz - pz * ny;
+    J[1] = pz * nx - px * nz;
+    J[2] = px * ny - py * nx;
+    J[3] = nx; J[4] = ny; J[5] = nz;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = a; b < 6; b++) acc[k++] += w * (J[a] * J[b]);
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[21 + a] -= w * (J[a] * e);
+    acc[27] += w;
+    acc[28] += 1.0;
+    acc[29] += w * (e * e);
+}
+
+template <int NT>
+__device__ __forceinline__ void block_reduce_store(double *acc, double *__restrict__ out)
+{
+    __shared__ double red[kReduceBlock / 64][NT];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wid][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NT) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kReduceBlock / 64; w++) s += red[w][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kReduceBlock) void k_p2plane_reduce(const ProblemDev *__restrict__ probs,
+                                                                  const MapDev<T> *__restrict__ maps,
+                                                                  const T *__restrict__ rd_pre, const int *__restrict__ slot,
+                                                                  const T *__restrict__ d2, double *__restrict__ partials,
+                                                                  int max_blocks)
+{
+    const ProblemDev &P = probs[blockIdx.y];
+    if (P.done) return;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    if (tile * (kReduceBlock * kReduceItems) >= P.n) return;      // whole block past the end: partial stays unused
+    const MapDev<T> M = maps[P.map];
+    const T limit = (T)P.limit;
+    double acc[kSys];
+#pragma unroll
+    for (int k = 0; k < kSys; k++) acc[k] = 0.0;
+#pragma unroll
+    for (int it = 0; it < kReduceItems; it++) {
+        const int i = tile * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
+        if (i < P.n) {
+            const T dd = d2[P.off + i];
+            const int s = slot[P.off + i];
+            if (s >= 0 && dd <= limit) {
+                const T *q = rd_pre + 3 * (P.off + i);
+                T px, py, pz;
+                apply_T<T>(P.Tcur, q[0], q[1], q[2], px, py, pz);
+                const auto mp = M.pts[s];
+                const auto mn = M.nrm[s];
+                accumulate_pair(acc, 1.0, (double)px, (double)py, (double)pz, (double)mp.x, (double)mp.y, (double)mp.z,
+                                (double)mn.x, (double)mn.y, (double)mn.z);
+            }
+        }
+    }
+    block_reduce_store<kSys>(acc, partials + ((long long)blockIdx.y * max_blocks + tile) * kSys);
+}
+
+// stage-level ErrorElements/residual with caller-provided ids (original
+// indices) and weights; reading is already in the map frame.
+template <typename T>
+__global__ __launch_bounds__(kReduceBlock) void k_error_stats(const MapDev<T> *__restrict__ maps, int map,
+                                                               const int *__restrict__ slot_of, const T *__restrict__ rd,
+                                                               int stride, const int *__restrict__ ids,
+                                                               const T *__restrict__ w, int n, T mx, T my, T mz,
+                                                               double *__restrict__ partials)
+{
+    const MapDev<T> M = maps[map];
+    double acc[kSys];
+#pragma unroll
+    for (int k = 0; k < kSys; k++) acc[k] = 0.0;
+    for (int it = 0; it < kReduceItems; it++) {
+        const int i = blockIdx.x * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
+        if (i < n) {
+            const T wi = w[i];
+            const int id = ids[i];
+            if (id >= 0 && wi != (T)0) {
+                // the map is stored centred; express the reading in the same frame
+                const T px = rd[(long long)i * stride] - mx, py = rd[(long long)i * stride + 1] - my,
+                        pz = rd[(long long)i * stride + 2] - mz;
+                const int s = slot_of[id];
+                const auto mp = M.pts[s];
+                const auto mn = M.nrm[s];
+                accumulate_pair(acc, (double)wi, (double)px, (double)py, (double)pz, (double)mp.x, (double)mp.y,
+                                (double)mp.z, (double)mn.x, (double)mn.y, (double)mn.z);
+            }
+        }
+    }
+    block_reduce_store<kSys>(acc, partials + (long long)blockIdx.x * kSys);
+}
+
+// sums `nb` block partials of `nt` doubles each, per problem, in block order
+__global__ __launch_bounds__(64) void k_sum_partials(const double *__restrict__ partials, int max_blocks, int nt,
+                                                      const ProblemDev *__restrict__ probs /* or null */,
+                                                      int nb_uniform, double *__restrict__ out)
+{
+    const int p = blockIdx.x;
+    int nb = nb_uniform;
+    if (probs) {
+        nb = (probs[p].n + kReduceBlock * kReduceItems - 1) / (kReduceBlock * kReduceItems);
+        if (probs[p].status != PGICP_ST_OK) nb = 0;       // partials were never written
+    }
+    if ((int)threadIdx.x < nt) {
+        double s = 0.0;
+        for (int b = 0; b < nb; b++) s += partials[((long long)p * max_blocks + b) * nt + threadIdx.x];
+        out[(long long)p * nt + threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// solve + update + convergence check: one wave per problem, lane 0 does the
+// (tiny, serial) double-precision algebra; no host round trip per iteration
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_solve_update(ProblemDev *__restrict__ probs, const double *__restrict__ partials,
+                                                      int max_blocks, ChainDev<T> ch, int *__restrict__ n_done)
+{
+    ProblemDev &P = probs[blockIdx.x];
+    if (P.done) return;
+    __shared__ double sys[kSys];
+    const int nb = (P.n + kReduceBlock * kReduceItems - 1) / (kReduceBlock * kReduceItems);
+    if (threadIdx.x < kSys) {
+        double s = 0.0;
+        for (int b = 0; b < nb; b++) s += partials[((long long)blockIdx.x * max_blocks + b) * kSys + threadIdx.x];
+        sys[threadIdx.x] = s;
+        P.sys[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int status = PGICP_ST_OK;
+    if (P.n_finite == 0 || !(sys[28] > 0.0)) status = PGICP_ST_NO_MATCH;
+    if (status == PGICP_ST_OK) {
+        double x[6], dT[16], Tn[16];
+        P.rank = solve6(sys, ch.rank_rel_tol, x);
+        delta_T(x, dT);
+        for (int i = 0; i < 16; i++) { P.T_prev[i] = P.T_iter[i]; P.dT[i] = dT[i]; }
+        mat4_mul(dT, P.T_iter, Tn);
+        for (int i = 0; i < 16; i++) P.T_iter[i] = Tn[i];
+        for (int i = 0; i < 12; i++) P.Tcur[i] = Tn[i];
+        P.n_kept = (int)sys[28];
+        P.iters += 1;
+        const int f = checker_check(P.chk, Tn, ch.max_iters, ch.min_rot, ch.min_trans, ch.smooth);
+        if (f & 8) status = PGICP_ST_NAN;
+        else {
+            if (f & 2) P.converged = 1;
+            if (f & 4) P.max_iter_reached = 1;
+            if (!(f & 1)) { P.done = 1; atomicAdd(n_done, 1); }
+        }
+    }
+    if (status != PGICP_ST_OK) {
+        P.status = status;
+        P.done = 1;
+        atomicAdd(n_done, 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Censi covariance sums over the last iteration's kept pairs:
+// 21 terms of H (upper) + 21 terms of G (upper); the host inverts H.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kReduceBlock) void k_cov_reduce(const ProblemDev *__restrict__ probs,
+                                                              const MapDev<T> *__restrict__ maps,
+                                                              const T *__restrict__ rd_pre, const int *__restrict__ slot,
+                                                              const T *__restrict__ d2, double *__restrict__ partials,
+                                                              int max_blocks)
+{
+    const ProblemDev &P = probs[blockIdx.y];
+    if (P.status != PGICP_ST_OK) return;
+    if (blockIdx.x * (kReduceBlock * kReduceItems) >= P.n) return;
+    const MapDev<T> M = maps[P.map];
+    const T limit = (T)P.limit;
+    // small-angle parameters of the last increment
+    const double beta = -asin(P.dT[8]);
+    const double alpha = atan2(P.dT[9], P.dT[10]);
+    const double gamma = atan2(P.dT[4] / cos(beta), P.dT[0] / cos(beta));
+    const double t_x = P.dT[3], t_y = P.dT[7], t_z = P.dT[11];
+    double Tp[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) Tp[k] = P.T_prev[k];
+    double acc[kCovTerms];
+#pragma unroll
+    for (int k = 0; k < kCovTerms; k++) acc[k] = 0.0;
+    for (int it = 0; it < kReduceItems; it++) {
+        const int i = blockIdx.x * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
+        if (i >= P.n) continue;
+        const T dd = d2[P.off + i];
+        const int s = slot[P.off + i];
+        if (s < 0 || !(dd <= limit)) continue;
+        const T *q = rd_pre + 3 * (P.off + i);
+        T pxt, pyt, pzt;
+        apply_T<T>(Tp, q[0], q[1], q[2], pxt, pyt, pzt);
+        const auto mp = M.pts[s];
+        const auto mn = M.nrm[s];
+        const double px = pxt, py = pyt, pz = pzt, qx = mp.x, qy = mp.y, qz = mp.z, nx = mn.x, ny = mn.y, nz = mn.z;
+        const double rr = sqrt((px * px + py * py) + pz * pz);
+        const double rdx = px / rr, rdy = py / rr, rdz = pz / rr;
+        const double qr = sqrt((qx * qx + qy * qy) + qz * qz);
+        const double qdx = qx / qr, qdy = qy / qr, qdz = qz / qr;
+        const double n_alpha = nz * rdy - ny * rdz;
+        const double n_beta = nx * rdz - nz * rdx;
+        const double n_gamma = ny * rdx - nx * rdy;
+        double E = nx * (px - gamma * py + beta * pz + t_x - qx);
+        E += ny * (gamma * px + py - alpha * pz + t_y - qy);
+        E += nz * (-beta * px + alpha * py + pz + t_z - qz);
+        double Nr = nx * (rdx - gamma * rdy + beta * rdz);
+        Nr += ny * (gamma * rdx + rdy - alpha * rdz);
+        Nr += nz * (-beta * rdx + alpha * rdy + rdz);
+        const double Nq = -((nx * qdx + ny * qdy) + nz * qdz);
+        const double er = E + rr * Nr;
+        const double h[6] = {nx, ny, nz, rr * n_alpha, rr * n_beta, rr * n_gamma};
+        const double gr[6] = {nx * Nr, ny * Nr, nz * Nr, n_alpha * er, n_beta * er, n_gamma * er};
+        const double gq[6] = {nx * Nq, ny * Nq, nz * Nq, qr * n_alpha * Nq, qr * n_beta * Nq, qr * n_gamma * Nq};
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) {
+                acc[k] += h[a] * h[b];
+                acc[21 + k] += gr[a] * gr[b] + gq[a] * gq[b];
+                k++;
+            }
+    }
+    block_reduce_store<kCovTerms>(acc, partials + ((long long)blockIdx.y * max_blocks + blockIdx.x) * kCovTerms);
+}
+
+// slots -> original indices for the public matcher output
+template <typename T>
+__global__ __launch_bounds__(256) void k_slots_to_ids(const MapDev<T> *__restrict__ maps, int map,
+                                                       const int *__restrict__ slot, int n, int *__restrict__ ids)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = slot[i];
+    ids[i] = s < 0 ? -1 : Bits<T>::unpack_idx(maps[map].pts[s].w);
+}
+
+// ---------------------------------------------------------------------------
+// launchers (host side, called from pgicp_api.cpp)
+// ---------------------------------------------------------------------------
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int round8(int x) { return (x + 7) & ~7; }
+
+template <typename T>
+void launch_centroid_bbox(hipStream_t st, const T *xyz, int stride, int m, unsigned long long *stats)
+{
+    int nb = cdiv(m, 256 * 8);
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_centroid_bbox<T>, dim3(nb), dim3(256), 0, st, xyz, stride, m, stats);
+}
+
+template <typename T>
+void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, int nstride, int m, const T mean[3],
+                       const GridDesc<T> &g, int *cell_of, int *counts, int *block_sums, int *cell_start, int *cursor,
+                       typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of)
+{
+    const long long ncells = (long long)g.nx * g.ny * g.nz;
+    (void)hipMemsetAsync(counts, 0, sizeof(int) * ncells, st);
+    hipLaunchKernelGGL(k_cell_count<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, m, mean[0], mean[1], mean[2], g,
+                       cell_of, counts);
+    const int nb = cdiv(ncells, kScanChunk);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)ncells, block_sums);
+    hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)ncells, (const int *)block_sums,
+                       cell_start, cursor);
+    hipLaunchKernelGGL(k_scatter<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, nrm, nstride, m, mean[0], mean[1],
+                       mean[2], (const int *)cell_of, cursor, pts, nrm_out, slot_of);
+    hipLaunchKernelGGL(k_sort_cells<T>, dim3(cdiv(ncells, 256)), dim3(256), 0, st, (const int *)cell_start, (int)ncells, pts,
+                       nrm ? nrm_out : (typename Vec4<T>::type *)nullptr, slot_of);
+}
+
+template <typename T>
+void launch_transform(hipStream_t st, const T *in, int in_stride, T *out, int out_stride, int n, const double *T16,
+                      int rotate_only)
+{
+    Mat34 M;
+    for (int i = 0; i < 12; i++) M.v[i] = T16[i];
+    if (n > 0)
+        hipLaunchKernelGGL(k_transform<T>, dim3(cdiv(n, 256)), dim3(256), 0, st, in, in_stride, out, out_stride, n, M,
+                           rotate_only);
+}
+
+template <typename T>
+void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, T *rd_pre, int P, int max_n)
+{
+    hipLaunchKernelGGL(k_pretransform<T>, dim3(cdiv(max_n, 256), P), dim3(256), 0, st, probs, src, rd_pre);
+}
+
+template <typename T>
+void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, int *slot,
+                T *d2, const ChainDev<T> &ch, int P, int max_n)
+{
+    if (matcher == 1)
+        hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd_pre, slot,
+                           d2, ch);
+    else
+        hipLaunchKernelGGL(k_knn_grid<T>, dim3(round8(cdiv(max_n, kKnnBlock)), P), dim3(kKnnBlock), 0, st, probs, maps,
+                           rd_pre, slot, d2, ch);
+}
+
+template <typename T>
+void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P)
+{
+    hipLaunchKernelGGL(k_trim_select<T>, dim3(P), dim3(kSelectBlock), 0, st, probs, d2, ch);
+}
+
+int reduce_blocks(int max_n) { return round8(cdiv(max_n, kReduceBlock * kReduceItems)); }
+
+template <typename T>
+void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
+                   const T *d2, double *partials, int P, int max_n)
+{
+    const int nb = reduce_blocks(max_n);
+    hipLaunchKernelGGL(k_p2plane_reduce<T>, dim3(nb, P), dim3(kReduceBlock), 0, st, probs, maps, rd_pre, slot, d2, partials,
+                       nb);
+}
+
+template <typename T>
+void launch_solve(hipStream_t st, ProblemDev *probs, const double *partials, const ChainDev<T> &ch, int *n_done, int P,
+                  int max_n)
+{
+    hipLaunchKernelGGL(k_solve_update<T>, dim3(P), dim3(64), 0, st, probs, partials, reduce_blocks(max_n), ch, n_done);
+}
+
+template <typename T>
+void launch_cov(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
+                const T *d2, double *partials, double *out, int P, int max_n)
+{
+    const int nb = reduce_blocks(max_n);
+    hipLaunchKernelGGL(k_cov_reduce<T>, dim3(nb, P), dim3(kReduceBlock), 0, st, probs, maps, rd_pre, slot, d2, partials, nb);
+    hipLaunchKernelGGL(k_sum_partials, dim3(P), dim3(64), 0, st, (const double *)partials, nb, kCovTerms, probs, 0, out);
+}
+
+void launch_sum_partials(hipStream_t st, const double *partials, int max_blocks, int nt, const ProblemDev *probs,
+                         int nb_uniform, double *out, int P)
+{
+    hipLaunchKernelGGL(k_sum_partials, dim3(P), dim3(64), 0, st, partials, max_blocks, nt, probs, nb_uniform, out);
+}
+
+template <typename T>
+void launch_trim_raw(hipStream_t st, const T *d2, int n, T ratio, T *limit_nf, T *w)
+{
+    hipLaunchKernelGGL(k_trim_select_raw<T>, dim3(1), dim3(kSelectBlock), 0, st, d2, n, ratio, limit_nf);
+    if (w) hipLaunchKernelGGL(k_weights<T>, dim3(cdiv(n, 256)), dim3(256), 0, st, d2, n, (const T *)limit_nf, w);
+}
+
+template <typename T>
+void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const int *slot_of, const T *rd, int stride,
+                        const int *ids, const T *w, int n, const T mean[3], double *partials, double *out)
+{
+    const int nb = cdiv(n, kReduceBlock * kReduceItems);
+    hipLaunchKernelGGL(k_error_stats<T>, dim3(nb), dim3(kReduceBlock), 0, st, maps, map, slot_of, rd, stride, ids, w, n,
+                       mean[0], mean[1], mean[2], partials);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, (const double *)partials, nb, kSys,
+                       (const ProblemDev *)nullptr, nb, out);
+}
+
+template <typename T>
+void launch_slots_to_ids(hipStream_t st, const MapDev<T> *maps, int map, const int *slot, int n, int *ids)
+{
+    hipLaunchKernelGGL(k_slots_to_ids<T>, dim3(cdiv(n, 256)), dim3(256), 0, st, maps, map, slot, n, ids);
+}
+
+#define INSTANTIATE(T)                                                                                                   \
+    template void launch_centroid_bbox<T>(hipStream_t, const T *, int, int, unsigned long long *);                        \
+    template void launch_grid_build<T>(hipStream_t, const T *, int, const T *, int, int, const T[3], const GridDesc<T> &, \
+                                       int *, int *, int *, int *, int *, typename Vec4<T>::type *,                       \
+                                       typename Vec4<T>::type *, int *);                                                  \
+    template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
+    template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
+    template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
+                                const ChainDev<T> &, int, int);                                                           \
+    template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int);                  \
+    template void launch_reduce<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, const int *, const T *, \
+                                   double *, int, int);                                                                   \
+    template void launch_solve<T>(hipStream_t, ProblemDev *, const double *, const ChainDev<T> &, int *, int, int);       \
+    template void launch_cov<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, const int *, const T *,    \
+                                double *, double *, int, int);                                                            \
+    template void launch_trim_raw<T>(hipStream_t, const T *, int, T, T *, T *);                                           \
+    template void launch_error_stats<T>(hipStream_t, const MapDev<T> *, int, const int *, const T *, int, const int *,    \
+                                        const T *, int, const T[3], double *, double *);                                  \
+    template void launch_slots_to_ids<T>(hipStream_t, const MapDev<T> *, int, const int *, int, int *);
+
+INSTANTIATE(float)
+INSTANTIATE(double)
+
+}  // namespace pgicp

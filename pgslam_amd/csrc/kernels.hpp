@@ -1,0 +1,45 @@
+// kernels.hpp -- launch entry points of kernels.hip (host callable).
+#pragma once
+#include "device_types.hpp"
+
+namespace pgicp {
+
+template <typename T>
+void launch_centroid_bbox(hipStream_t st, const T *xyz, int stride, int m, unsigned long long *stats);
+template <typename T>
+void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, int nstride, int m, const T mean[3],
+                       const GridDesc<T> &g, int *cell_of, int *counts, int *block_sums, int *cell_start, int *cursor,
+                       typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of);
+template <typename T>
+void launch_transform(hipStream_t st, const T *in, int in_stride, T *out, int out_stride, int n, const double *T16,
+                      int rotate_only);
+template <typename T>
+void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, T *rd_pre, int P, int max_n);
+template <typename T>
+void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, int *slot,
+                T *d2, const ChainDev<T> &ch, int P, int max_n);
+template <typename T>
+void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P);
+int reduce_blocks(int max_n);
+template <typename T>
+void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
+                   const T *d2, double *partials, int P, int max_n);
+template <typename T>
+void launch_solve(hipStream_t st, ProblemDev *probs, const double *partials, const ChainDev<T> &ch, int *n_done, int P,
+                  int max_n);
+template <typename T>
+void launch_cov(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
+                const T *d2, double *partials, double *out, int P, int max_n);
+void launch_sum_partials(hipStream_t st, const double *partials, int max_blocks, int nt, const ProblemDev *probs,
+                         int nb_uniform, double *out, int P);
+template <typename T>
+void launch_trim_raw(hipStream_t st, const T *d2, int n, T ratio, T *limit_nf, T *w);
+template <typename T>
+void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const int *slot_of, const T *rd, int stride,
+                        const int *ids, const T *w, int n, const T mean[3], double *partials, double *out);
+template <typename T>
+void launch_slots_to_ids(hipStream_t st, const MapDev<T> *maps, int map, const int *slot, int n, int *ids);
+
+constexpr int kScanChunkHost = 4096;
+
+}  // namespace pgicp

@@ -1,0 +1,1047 @@
+// pgicp_api.cpp -- host side of libpgicp: the extern "C" ABI of include/pgicp.h.
+//
+// Owns device memory (maps stay resident in HBM), sequences the kernels of
+// kernels.hip on the context's HIP stream, and finishes the few host-side
+// steps (un-centring the result, inverting the 6x6 covariance Hessian).
+// There is no CPU compute path here: every stage runs on the GPU.
+#include "pgicp.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace pgicp;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename U> U *as() const { return (U *)p; }
+};
+
+template <typename T>
+struct MapHost {
+    bool used = false;
+    int m = 0;
+    T mean[3] = {0, 0, 0};
+    bool has_nrm = false;
+    typename Vec4<T>::type *pts = nullptr;
+    typename Vec4<T>::type *nrm = nullptr;
+    int *cell_start = nullptr;
+    int *slot_of = nullptr;
+    GridDesc<T> g{};
+};
+
+template <typename T>
+struct State {
+    std::vector<MapHost<T>> maps;
+    DevBuf d_maps;                  // MapDev<T>[capacity]
+    int d_maps_cap = 0;
+    DevBuf rd_pre, slot, d2, staging, stage_aux;
+};
+
+struct ProfEvent {
+    hipEvent_t a, b;
+    int kid;
+    long long units;
+};
+
+}  // namespace
+
+struct pgicp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    pgicp_params prm{};
+    State<float> f32;
+    State<double> f64;
+    DevBuf probs, src, partials, sums, small, tmp_a, tmp_b, tmp_c, tmp_d;
+    int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
+    bool prof_on = false;
+    std::vector<ProfEvent> prof_events;
+    long long prof_launches[PGICP_PROF_COUNT] = {0};
+    double prof_ms[PGICP_PROF_COUNT] = {0};
+    long long prof_units[PGICP_PROF_COUNT] = {0};
+};
+
+namespace {
+
+template <typename T> State<T> &state(pgicp_ctx *c);
+template <> State<float> &state<float>(pgicp_ctx *c) { return c->f32; }
+template <> State<double> &state<double>(pgicp_ctx *c) { return c->f64; }
+
+// public map ids carry the precision in bit 30 so f32 and f64 maps never alias
+template <typename T> constexpr int id_tag();
+template <> constexpr int id_tag<float>() { return 0; }
+template <> constexpr int id_tag<double>() { return 0x40000000; }
+
+template <typename T>
+int map_index(pgicp_ctx *c, int id)
+{
+    State<T> &S = state<T>(c);
+    if (id < 0 || (id & 0x40000000) != id_tag<T>()) return -1;
+    const int idx = id & 0x3FFFFFFF;
+    if (idx >= (int)S.maps.size() || !S.maps[idx].used) return -1;
+    return idx;
+}
+
+template <typename T>
+MapHost<T> *get_map(pgicp_ctx *c, int id)
+{
+    const int idx = map_index<T>(c, id);
+    return idx < 0 ? nullptr : &state<T>(c).maps[idx];
+}
+
+int fail(pgicp_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPC(ctx, call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(ctx, PGICP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct ProfScope {
+    pgicp_ctx *c;
+    int kid;
+    ProfEvent ev{};
+    bool on;
+    ProfScope(pgicp_ctx *c_, int kid_, long long units) : c(c_), kid(kid_), on(c_->prof_on)
+    {
+        if (!on) return;
+        ev.kid = kid;
+        ev.units = units;
+        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(ev.a, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, c->stream);
+        c->prof_events.push_back(ev);
+    }
+};
+
+void prof_collect(pgicp_ctx *c)
+{
+    if (c->prof_events.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &e : c->prof_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_launches[e.kid] += 1;
+            c->prof_ms[e.kid] += ms;
+            c->prof_units[e.kid] += e.units;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    c->prof_events.clear();
+}
+
+template <typename T>
+ChainDev<T> make_chain(const pgicp_params &p)
+{
+    ChainDev<T> ch;
+    ch.max_dist = (T)p.max_dist;
+    ch.max_dist2 = ch.max_dist * ch.max_dist;
+    ch.trim_ratio = (T)p.trim_ratio;
+    ch.max_iters = p.max_iters;
+    ch.smooth = p.smooth_length;
+    ch.min_rot = p.min_diff_rot;
+    ch.min_trans = p.min_diff_trans;
+    ch.rank_rel_tol = 6.0 * (double)std::numeric_limits<T>::epsilon();
+    return ch;
+}
+
+double key_to_double(unsigned long long k)
+{
+    long long i = (k & 0x8000000000000000ULL) ? (long long)(k ^ 0x8000000000000000ULL) : (long long)~k;
+    double d;
+    std::memcpy(&d, &i, sizeof d);
+    return d;
+}
+
+// Bring a strided point buffer onto the device if it is host memory.
+// Returns the device pointer to use (either the caller's or the staging copy).
+template <typename T>
+int to_device(pgicp_ctx *c, const T *p, int stride, int n, int mem, DevBuf &stage, size_t stage_off_bytes, const T **out)
+{
+    if (mem == PGICP_DEVICE) { *out = p; return PGICP_OK; }
+    const size_t bytes = sizeof(T) * ((size_t)(n - 1) * stride + 3);
+    HIPC(c, hipMemcpyAsync((char *)stage.p + stage_off_bytes, p, bytes, hipMemcpyHostToDevice, c->stream));
+    *out = (const T *)((char *)stage.p + stage_off_bytes);
+    return PGICP_OK;
+}
+
+size_t staged_bytes(size_t elt, int stride, int n)
+{
+    size_t b = elt * ((size_t)(n - 1) * stride + 3);
+    return (b + 255) & ~(size_t)255;
+}
+
+template <typename T>
+int sync_maps_table(pgicp_ctx *c)
+{
+    State<T> &S = state<T>(c);
+    const int n = (int)S.maps.size();
+    if (n == 0) return PGICP_OK;
+    if (n > S.d_maps_cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, S.d_maps.ensure(sizeof(MapDev<T>) * (size_t)(n + 16)));
+        S.d_maps_cap = n + 16;
+    }
+    std::vector<MapDev<T>> h(n);
+    for (int i = 0; i < n; i++) {
+        const MapHost<T> &m = S.maps[i];
+        h[i].pts = m.pts; h[i].nrm = m.nrm; h[i].cell_start = m.cell_start; h[i].g = m.g; h[i].m = m.used ? m.m : 0;
+        h[i].pad_ = 0;
+    }
+    HIPC(c, hipMemcpyAsync(S.d_maps.p, h.data(), sizeof(MapDev<T>) * n, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));   // h goes out of scope
+    return PGICP_OK;
+}
+
+template <typename T>
+void free_map(MapHost<T> &m)
+{
+    if (m.pts) (void)hipFree(m.pts);
+    if (m.nrm) (void)hipFree(m.nrm);
+    if (m.cell_start) (void)hipFree(m.cell_start);
+    if (m.slot_of) (void)hipFree(m.slot_of);
+    m = MapHost<T>();
+}
+
+template <typename T>
+int map_create(pgicp_ctx *c, const T *xyz, int xyz_stride, const T *nrm, int nrm_stride, int m, int mem, int center,
+               int *map_id)
+{
+    if (!c || !xyz || m <= 0 || xyz_stride < 3 || (nrm && nrm_stride < 3) || !map_id)
+        return fail(c, PGICP_ERR_ARG, "pgicp_map_create: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    State<T> &S = state<T>(c);
+    const T *d_xyz = nullptr, *d_nrm = nullptr;
+    const size_t b_xyz = staged_bytes(sizeof(T), xyz_stride, m), b_nrm = nrm ? staged_bytes(sizeof(T), nrm_stride, m) : 0;
+    if (mem == PGICP_HOST) HIPC(c, S.staging.ensure(b_xyz + b_nrm));
+    int st = to_device<T>(c, xyz, xyz_stride, m, mem, S.staging, 0, &d_xyz);
+    if (st) return st;
+    if (nrm) { st = to_device<T>(c, nrm, nrm_stride, m, mem, S.staging, b_xyz, &d_nrm); if (st) return st; }
+
+    // centroid + bbox
+    HIPC(c, c->small.ensure(256));
+    unsigned long long h_stats[9] = {0, 0, 0, ~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
+    HIPC(c, hipMemcpyAsync(c->small.p, h_stats, sizeof h_stats, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
+        launch_centroid_bbox<T>(c->stream, d_xyz, xyz_stride, m, c->small.as<unsigned long long>());
+    }
+    HIPC(c, hipMemcpyAsync(h_stats, c->small.p, sizeof h_stats, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+
+    MapHost<T> M;
+    M.used = true; M.m = m; M.has_nrm = nrm != nullptr;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; a++) {
+        const double mean_d = ((double)(long long)h_stats[a] / 16777216.0) / (double)m;
+        M.mean[a] = center ? (T)mean_d : (T)0;
+        // rounding is monotone: min/max of fl(x - mean) are fl(min - mean), fl(max - mean)
+        lo[a] = (double)((T)key_to_double(h_stats[3 + a]) - M.mean[a]);
+        hi[a] = (double)((T)key_to_double(h_stats[6 + a]) - M.mean[a]);
+        if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a]))
+            return fail(c, PGICP_ERR_ARG, "pgicp_map_create: non-finite coordinates");
+    }
+    const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    double h = c->prm.grid_cell;
+    if (!(h > 0)) {
+        // surface-like clouds: aim at ~8 points per occupied cell of the projected area
+        const double area = ex * ey + ey * ez + ex * ez;
+        h = std::sqrt(8.0 * std::max(area, 1e-12) / (double)m);
+        const double diag = std::sqrt(ex * ex + ey * ey + ez * ez);
+        if (!(h > diag * 1e-4)) h = std::max(diag * 1e-4, 1e-6);
+    }
+    for (;;) {   // bound the dense cell table
+        const double nx = std::floor(ex / h) + 1, ny = std::floor(ey / h) + 1, nz = std::floor(ez / h) + 1;
+        if (nx <= 65535 && ny <= 65535 && nz <= 65535 && nx * ny * nz <= 67108864.0) break;
+        h *= 1.26;
+    }
+    GridDesc<T> &g = M.g;
+    g.h = (T)h; g.inv_h = (T)1 / g.h; g.margin = (T)0.02 * g.h;
+    g.ox = (T)lo[0]; g.oy = (T)lo[1]; g.oz = (T)lo[2];
+    g.nx = (int)std::floor(ex / (double)g.h) + 1; g.ny = (int)std::floor(ey / (double)g.h) + 1;
+    g.nz = (int)std::floor(ez / (double)g.h) + 1;
+    const long long ncells = (long long)g.nx * g.ny * g.nz;
+
+    using V4 = typename Vec4<T>::type;
+    HIPC(c, hipMalloc((void **)&M.pts, sizeof(V4) * (size_t)m));
+    if (nrm) HIPC(c, hipMalloc((void **)&M.nrm, sizeof(V4) * (size_t)m));
+    HIPC(c, hipMalloc((void **)&M.cell_start, sizeof(int) * (size_t)(ncells + 1)));
+    HIPC(c, hipMalloc((void **)&M.slot_of, sizeof(int) * (size_t)m));
+    const int nb = (int)((ncells + kScanChunkHost - 1) / kScanChunkHost);
+    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)m));             // cell_of
+    HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)ncells));        // counts
+    HIPC(c, c->tmp_c.ensure(sizeof(int) * (size_t)(nb + 1)));      // block sums
+    HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)ncells));        // cursor
+    {
+        ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
+        launch_grid_build<T>(c->stream, d_xyz, xyz_stride, d_nrm, nrm_stride, m, M.mean, g, c->tmp_a.as<int>(),
+                             c->tmp_b.as<int>(), c->tmp_c.as<int>(), M.cell_start, c->tmp_d.as<int>(), M.pts, M.nrm,
+                             M.slot_of);
+    }
+    HIPC(c, hipGetLastError());
+    int id = -1;
+    for (size_t i = 0; i < S.maps.size(); i++) if (!S.maps[i].used) { id = (int)i; break; }
+    if (id < 0) { S.maps.push_back(MapHost<T>()); id = (int)S.maps.size() - 1; }
+    S.maps[id] = M;
+    st = sync_maps_table<T>(c);
+    if (st) return st;
+    *map_id = id | id_tag<T>();
+    return PGICP_OK;
+}
+
+void translation(const double *t3, double sign, double *T)
+{
+    mat4_identity(T);
+    T[3] = sign * t3[0]; T[7] = sign * t3[1]; T[11] = sign * t3[2];
+}
+
+struct BatchLayout {
+    int P = 0;
+    int max_n = 0;
+    long long total = 0;
+};
+
+// Prepare a batch: stage readings, fill + upload ProblemDev, run the prologue
+// transform.  `Tpre_of(p, out16)` provides each problem's pre-transform.
+template <typename T, typename F>
+int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLayout &L, std::vector<ProblemDev> &hp)
+{
+    State<T> &S = state<T>(c);
+    L.P = P; L.max_n = 0; L.total = 0;
+    size_t stage_total = 0;
+    for (int p = 0; p < P; p++) {
+        if (pr[p].n <= 0 || !pr[p].reading || pr[p].stride < 3)
+            return fail(c, PGICP_ERR_ARG, "pgicp: bad reading in problem " + std::to_string(p));
+        MapHost<T> *M = get_map<T>(c, pr[p].map_id);
+        if (!M) return fail(c, PGICP_ERR_ARG, "pgicp: unknown map id " + std::to_string(pr[p].map_id));
+        L.max_n = std::max(L.max_n, pr[p].n);
+        L.total += pr[p].n;
+        if (pr[p].mem == PGICP_HOST) stage_total += staged_bytes(sizeof(T), pr[p].stride, pr[p].n);
+    }
+    HIPC(c, S.rd_pre.ensure(sizeof(T) * 3 * (size_t)L.total));
+    HIPC(c, S.slot.ensure(sizeof(int) * (size_t)L.total));
+    HIPC(c, S.d2.ensure(sizeof(T) * (size_t)L.total));
+    HIPC(c, c->probs.ensure(sizeof(ProblemDev) * (size_t)P));
+    HIPC(c, c->src.ensure(sizeof(SrcDesc) * (size_t)P));
+    HIPC(c, c->partials.ensure(sizeof(double) * (size_t)P * reduce_blocks(L.max_n) * kCovTerms));
+    HIPC(c, c->sums.ensure(sizeof(double) * (size_t)P * kCovTerms));
+    HIPC(c, c->small.ensure(256));
+    if (stage_total) HIPC(c, S.staging.ensure(stage_total));
+
+    hp.assign(P, ProblemDev());
+    std::vector<SrcDesc> hs(P);
+    size_t soff = 0;
+    long long off = 0;
+    for (int p = 0; p < P; p++) {
+        const T *d_rd = nullptr;
+        int st = to_device<T>(c, (const T *)pr[p].reading, pr[p].stride, pr[p].n, pr[p].mem, S.staging, soff, &d_rd);
+        if (st) return st;
+        if (pr[p].mem == PGICP_HOST) soff += staged_bytes(sizeof(T), pr[p].stride, pr[p].n);
+        hs[p].ptr = d_rd; hs[p].stride = pr[p].stride; hs[p].pad_ = 0;
+        ProblemDev &D = hp[p];
+        std::memset(&D, 0, sizeof D);
+        D.map = map_index<T>(c, pr[p].map_id); D.n = pr[p].n; D.off = off;
+        off += pr[p].n;
+        Tpre_of(p, D.Tpre);
+        mat4_identity(D.T_iter); mat4_identity(D.T_prev); mat4_identity(D.dT);
+        for (int i = 0; i < 12; i++) D.Tcur[i] = D.T_iter[i];
+        checker_init(D.chk);
+    }
+    HIPC(c, hipMemcpyAsync(c->probs.p, hp.data(), sizeof(ProblemDev) * P, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->src.p, hs.data(), sizeof(SrcDesc) * P, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
+    {
+        ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total);
+        launch_pretransform<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.rd_pre.template as<T>(), P, L.max_n);
+    }
+    // hs/hp must outlive the async copies
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return PGICP_OK;
+}
+
+template <typename T>
+void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bool with_solve)
+{
+    State<T> &S = state<T>(c);
+    const MapDev<T> *maps = S.d_maps.template as<MapDev<T>>();
+    ProblemDev *probs = c->probs.as<ProblemDev>();
+    {
+        ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, L.total);
+        launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(),
+                      S.d2.template as<T>(), ch, L.P, L.max_n);
+    }
+    {
+        ProfScope ps(c, PGICP_PROF_TRIM, L.total);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, L.P);
+    }
+    {
+        ProfScope ps(c, PGICP_PROF_REDUCE, L.total);
+        launch_reduce<T>(c->stream, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
+                         c->partials.as<double>(), L.P, L.max_n);
+    }
+    if (with_solve) {
+        ProfScope ps(c, PGICP_PROF_SOLVE, L.P);
+        launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), L.P, L.max_n);
+    }
+}
+
+template <typename T>
+int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgicp_stats *stats)
+{
+    if (!c || P <= 0 || !pr || !T_out) return fail(c, PGICP_ERR_ARG, "pgicp_align_batch: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    State<T> &S = state<T>(c);
+    const pgicp_params &prm = c->prm;
+    std::vector<std::vector<double>> Tref(P, std::vector<double>(16));
+    BatchLayout L;
+    std::vector<ProblemDev> hp;
+    for (int p = 0; p < P; p++) {
+        MapHost<T> *M = get_map<T>(c, pr[p].map_id);
+        if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_align: unknown map id");
+        if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp_align: reference has no normals descriptor");
+    }
+    int st = batch_begin<T>(c, P, pr, [&](int p, double *Tpre) {
+        MapHost<T> *M = get_map<T>(c, pr[p].map_id);
+        double mean[3] = {(double)M->mean[0], (double)M->mean[1], (double)M->mean[2]};
+        double Tm_inv[16];
+        translation(mean, -1.0, Tm_inv);
+        translation(mean, +1.0, Tref[p].data());
+        mat4_mul(Tm_inv, pr[p].T_init, Tpre);
+    }, L, hp);
+    if (st) return st;
+    const ChainDev<T> ch = make_chain<T>(prm);
+    const int every = std::max(1, prm.check_every);
+    for (int it = 0; it < prm.max_iters; it++) {
+        one_iteration<T>(c, L, ch, true);
+        if ((it + 1) % every == 0 || it + 1 == prm.max_iters) {
+            HIPC(c, hipMemcpyAsync(c->h_pinned, c->small.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (c->h_pinned[0] >= P) break;
+        }
+    }
+    {
+        ProfScope ps(c, PGICP_PROF_COV, L.total);
+        launch_cov<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(), S.rd_pre.template as<T>(),
+                      S.slot.template as<int>(), S.d2.template as<T>(), c->partials.as<double>(), c->sums.as<double>(), P,
+                      L.max_n);
+    }
+    std::vector<double> cs((size_t)P * kCovTerms);
+    HIPC(c, hipMemcpyAsync(hp.data(), c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(cs.data(), c->sums.p, sizeof(double) * cs.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    int worst = PGICP_OK;
+    for (int p = 0; p < P; p++) {
+        const ProblemDev &D = hp[p];
+        double *To = T_out + 16 * p;
+        pgicp_stats s;
+        std::memset(&s, 0, sizeof s);
+        s.status = D.status;
+        s.iterations = D.iters; s.converged = D.converged; s.max_iter_reached = D.max_iter_reached;
+        s.overlap = D.sys[27] / (double)D.n; s.residual = D.sys[29]; s.trim_limit = D.limit;
+        s.n_kept = D.n_kept; s.n_finite = D.n_finite;
+        if (D.status == PGICP_ST_OK) {
+            double t1[16];
+            mat4_mul(D.T_iter, D.Tpre, t1);
+            mat4_mul(Tref[p].data(), t1, To);
+            double H[36], G[36], Hi[36], tmp[36];
+            sys_to_full(cs.data() + (size_t)p * kCovTerms, H);
+            sys_to_full(cs.data() + (size_t)p * kCovTerms + 21, G);
+            if (inverse6(H, Hi)) {
+                const double s2 = prm.sensor_std_dev * prm.sensor_std_dev;
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 6; j++) {
+                        double a = 0.0;
+                        for (int k = 0; k < 6; k++) a += Hi[i * 6 + k] * G[k * 6 + j];
+                        tmp[i * 6 + j] = a;
+                    }
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 6; j++) {
+                        double a = 0.0;
+                        for (int k = 0; k < 6; k++) a += tmp[i * 6 + k] * Hi[k * 6 + j];
+                        s.cov[i * 6 + j] = s2 * a;
+                    }
+            } else
+                for (int i = 0; i < 6; i++) s.cov[i * 6 + i] = std::numeric_limits<double>::max();
+        } else {
+            mat4_identity(To);
+            if (worst == PGICP_OK) worst = D.status;
+        }
+        if (stats) stats[p] = s;
+    }
+    if (worst != PGICP_OK)
+        return fail(c, worst, worst == PGICP_ST_NO_MATCH ? "ICP: no point to minimize (ConvergenceError)"
+                                                         : "ICP: NaN in transformation checker (ConvergenceError)");
+    return PGICP_OK;
+}
+
+template <typename T>
+int icp_pair(pgicp_ctx *c, const T *reading, int rd_stride, int n, const T *ref_xyz, int ref_stride, const T *ref_nrm,
+             int nrm_stride, int m, int mem, const double *T_init, double *T_out, pgicp_stats *stats)
+{
+    int id = -1;
+    int st = map_create<T>(c, ref_xyz, ref_stride, ref_nrm, nrm_stride, m, mem, 1, &id);
+    if (st) return st;
+    pgicp_problem pr;
+    pr.map_id = id; pr.reading = reading; pr.stride = rd_stride; pr.n = n; pr.mem = mem;
+    std::memcpy(pr.T_init, T_init, sizeof pr.T_init);
+    st = align_batch<T>(c, 1, &pr, T_out, stats);
+    (void)hipStreamSynchronize(c->stream);
+    if (MapHost<T> *mh = get_map<T>(c, id)) free_map(*mh);
+    return st;
+}
+
+// matcher-only / partial chain on one problem
+template <typename T>
+int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem, const double *Tmove, bool do_trim,
+                BatchLayout &L, std::vector<ProblemDev> &hp)
+{
+    MapHost<T> *M = get_map<T>(c, map_id);
+    if (!M) return fail(c, PGICP_ERR_ARG, "pgicp: unknown map id");
+    pgicp_problem pr;
+    pr.map_id = map_id; pr.reading = reading; pr.stride = stride; pr.n = n; pr.mem = mem;
+    mat4_identity(pr.T_init);
+    if (Tmove) std::memcpy(pr.T_init, Tmove, sizeof pr.T_init);
+    int st = batch_begin<T>(c, 1, &pr, [&](int, double *Tpre) {
+        double mean[3] = {(double)M->mean[0], (double)M->mean[1], (double)M->mean[2]};
+        double Tm_inv[16];
+        translation(mean, -1.0, Tm_inv);
+        mat4_mul(Tm_inv, pr.T_init, Tpre);
+    }, L, hp);
+    if (st) return st;
+    State<T> &S = state<T>(c);
+    const ChainDev<T> ch = make_chain<T>(c->prm);
+    const MapDev<T> *maps = S.d_maps.template as<MapDev<T>>();
+    ProblemDev *probs = c->probs.as<ProblemDev>();
+    {
+        ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
+        launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(),
+                      S.d2.template as<T>(), ch, 1, n);
+    }
+    if (do_trim) {
+        if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
+        {
+            ProfScope ps(c, PGICP_PROF_TRIM, n);
+            launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, 1);
+        }
+        {
+            ProfScope ps(c, PGICP_PROF_REDUCE, n);
+            launch_reduce<T>(c->stream, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(),
+                             S.d2.template as<T>(), c->partials.as<double>(), 1, n);
+        }
+        launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(n), kSys, probs, 0, c->sums.as<double>(), 1);
+    }
+    return PGICP_OK;
+}
+
+template <typename T>
+int match(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem, const double *Tm, int32_t *ids, T *dist2)
+{
+    if (!c || !reading || n <= 0 || !ids || !dist2) return fail(c, PGICP_ERR_ARG, "pgicp_match: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    BatchLayout L;
+    std::vector<ProblemDev> hp;
+    int st = run_partial<T>(c, map_id, reading, stride, n, mem, Tm, false, L, hp);
+    if (st) return st;
+    State<T> &S = state<T>(c);
+    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)n));
+    launch_slots_to_ids<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), S.slot.template as<int>(), n,
+                           c->tmp_a.as<int>());
+    const hipMemcpyKind k = mem == PGICP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * (size_t)n, k, c->stream));
+    HIPC(c, hipMemcpyAsync(dist2, S.d2.p, sizeof(T) * (size_t)n, k, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    return PGICP_OK;
+}
+
+template <typename T>
+int partial_chain(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem, const double *Tm, double *ratio,
+                  double *residual)
+{
+    if (!c || !reading || n <= 0) return fail(c, PGICP_ERR_ARG, "pgicp_partial_chain: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    BatchLayout L;
+    std::vector<ProblemDev> hp;
+    int st = run_partial<T>(c, map_id, reading, stride, n, mem, Tm, true, L, hp);
+    if (st) return st;
+    double sys[kSys];
+    ProblemDev D;
+    HIPC(c, hipMemcpyAsync(sys, c->sums.p, sizeof sys, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(&D, c->probs.p, sizeof D, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    if (D.n_finite == 0 || !(sys[28] > 0.0)) return fail(c, PGICP_ERR_NO_MATCH, "no point to minimize (ConvergenceError)");
+    if (ratio) *ratio = sys[27] / (double)n;
+    if (residual) *residual = sys[29];
+    return PGICP_OK;
+}
+
+template <typename T>
+int outlier_weights(pgicp_ctx *c, const T *dist2, int n, int mem, T *weights, T *limit, int *n_finite)
+{
+    if (!c || !dist2 || n <= 0) return fail(c, PGICP_ERR_ARG, "pgicp_outlier_weights: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    const T *d_d2 = dist2;
+    T *d_w = weights;
+    if (mem == PGICP_HOST) {
+        HIPC(c, c->tmp_a.ensure(sizeof(T) * (size_t)n));
+        HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)n));
+        HIPC(c, hipMemcpyAsync(c->tmp_a.p, dist2, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        d_d2 = c->tmp_a.as<T>();
+        d_w = weights ? c->tmp_b.as<T>() : nullptr;
+    }
+    HIPC(c, c->small.ensure(256));
+    {
+        ProfScope ps(c, PGICP_PROF_TRIM, n);
+        launch_trim_raw<T>(c->stream, d_d2, n, (T)c->prm.trim_ratio, c->small.as<T>(), d_w);
+    }
+    T h[2];
+    HIPC(c, hipMemcpyAsync(h, c->small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    if (mem == PGICP_HOST && weights)
+        HIPC(c, hipMemcpyAsync(weights, d_w, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    if (limit) *limit = h[0];
+    if (n_finite) *n_finite = (int)h[1];
+    if ((int)h[1] == 0) return fail(c, PGICP_ERR_NO_MATCH, "no outlier to filter (ConvergenceError)");
+    return PGICP_OK;
+}
+
+template <typename T>
+int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem, const int32_t *ids, const T *w,
+                double *ratio, double *residual, double *sys_out)
+{
+    if (!c || !reading || !ids || !w || n <= 0 || stride < 3) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    MapHost<T> *M = get_map<T>(c, map_id);
+    if (!M || !M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: unknown map or no normals");
+    State<T> &S = state<T>(c);
+    const T *d_rd = reading, *d_w = w;
+    const int *d_ids = ids;
+    if (mem == PGICP_HOST) {
+        HIPC(c, S.staging.ensure(staged_bytes(sizeof(T), stride, n)));
+        int st = to_device<T>(c, reading, stride, n, mem, S.staging, 0, &d_rd);
+        if (st) return st;
+        HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)n));
+        HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)n));
+        HIPC(c, hipMemcpyAsync(c->tmp_a.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->tmp_b.p, w, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        d_ids = c->tmp_a.as<int>();
+        d_w = c->tmp_b.as<T>();
+    }
+    const int nb = (n + kReduceBlock * kReduceItems - 1) / (kReduceBlock * kReduceItems);
+    HIPC(c, c->partials.ensure(sizeof(double) * (size_t)nb * kSys));
+    HIPC(c, c->sums.ensure(sizeof(double) * kCovTerms));
+    {
+        ProfScope ps(c, PGICP_PROF_REDUCE, n);
+        launch_error_stats<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), M->slot_of, d_rd, stride, d_ids, d_w, n,
+                              M->mean, c->partials.as<double>(), c->sums.as<double>());
+    }
+    double sys[kSys];
+    HIPC(c, hipMemcpyAsync(sys, c->sums.p, sizeof sys, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    if (sys_out) std::memcpy(sys_out, sys, sizeof sys);
+    if (!(sys[28] > 0.0)) return fail(c, PGICP_ERR_NO_MATCH, "no point to minimize (ConvergenceError)");
+    if (ratio) *ratio = sys[27] / (double)n;
+    if (residual) *residual = sys[29];
+    return PGICP_OK;
+}
+
+bool is_rigid(const double *T)
+{
+    // RigidTransformation::checkParameters: R^T R ~ I and det(R) ~ +1
+    double err = 0.0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 3; k++) s += T[k * 4 + i] * T[k * 4 + j];
+            err = std::max(err, std::fabs(s - (i == j ? 1.0 : 0.0)));
+        }
+    const double det = T[0] * (T[5] * T[10] - T[6] * T[9]) - T[1] * (T[4] * T[10] - T[6] * T[8]) +
+                       T[2] * (T[4] * T[9] - T[5] * T[8]);
+    return err < 1e-3 && std::fabs(det - 1.0) < 1e-3;
+}
+
+template <typename T>
+int transform(pgicp_ctx *c, const double *T16, const T *in, int in_stride, T *out, int out_stride, int n, int rotate_only,
+              int mem)
+{
+    if (!c || !T16 || !in || !out || n < 0 || in_stride < 3 || out_stride < 3)
+        return fail(c, PGICP_ERR_ARG, "pgicp_transform: bad argument");
+    if (!is_rigid(T16)) return fail(c, PGICP_ERR_NOT_RIGID, "pgicp_transform: transformation is not rigid");
+    if (n == 0) return PGICP_OK;
+    HIPC(c, hipSetDevice(c->device));
+    State<T> &S = state<T>(c);
+    if (mem == PGICP_DEVICE) {
+        launch_transform<T>(c->stream, in, in_stride, out, out_stride, n, T16, rotate_only);
+        HIPC(c, hipStreamSynchronize(c->stream));
+        return PGICP_OK;
+    }
+    const size_t bi = staged_bytes(sizeof(T), in_stride, n), bo = staged_bytes(sizeof(T), out_stride, n);
+    HIPC(c, S.staging.ensure(bi));
+    HIPC(c, S.stage_aux.ensure(bo));
+    const T *d_in = nullptr;
+    int st = to_device<T>(c, in, in_stride, n, mem, S.staging, 0, &d_in);
+    if (st) return st;
+    // keep the caller's other rows (e.g. the homogeneous 1) when out is strided
+    HIPC(c, hipMemcpyAsync(S.stage_aux.p, out, sizeof(T) * ((size_t)(n - 1) * out_stride + 3), hipMemcpyHostToDevice, c->stream));
+    launch_transform<T>(c->stream, d_in, in_stride, S.stage_aux.template as<T>(), out_stride, n, T16, rotate_only);
+    HIPC(c, hipMemcpyAsync(out, S.stage_aux.p, sizeof(T) * ((size_t)(n - 1) * out_stride + 3), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    return PGICP_OK;
+}
+
+template <typename T>
+int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const *nrm, const int *sx, const int *sn,
+                    const int *counts, const double *T_ref_kf, T *out_xyz, T *out_nrm, int out_stride, int mem)
+{
+    if (!c || n_kf <= 0 || !xyz || !counts || !T_ref_kf || !out_xyz || out_stride < 3)
+        return fail(c, PGICP_ERR_ARG, "pgicp_build_local_map: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    State<T> &S = state<T>(c);
+    long long total = 0;
+    size_t stage = 0;
+    for (int k = 0; k < n_kf; k++) {
+        if (counts[k] <= 0 || sx[k] < 3) return fail(c, PGICP_ERR_ARG, "pgicp_build_local_map: bad keyframe");
+        total += counts[k];
+        if (mem == PGICP_HOST) stage += staged_bytes(sizeof(T), sx[k], counts[k]) + (nrm ? staged_bytes(sizeof(T), sn[k], counts[k]) : 0);
+    }
+    T *d_ox = out_xyz, *d_on = out_nrm;
+    const size_t ob = sizeof(T) * ((size_t)(total - 1) * out_stride + 3);
+    if (mem == PGICP_HOST) {
+        HIPC(c, S.staging.ensure(stage));
+        HIPC(c, S.stage_aux.ensure(2 * ((ob + 255) & ~(size_t)255)));
+        d_ox = S.stage_aux.template as<T>();
+        d_on = out_nrm ? (T *)((char *)S.stage_aux.p + ((ob + 255) & ~(size_t)255)) : nullptr;
+        HIPC(c, hipMemcpyAsync(d_ox, out_xyz, ob, hipMemcpyHostToDevice, c->stream));
+        if (out_nrm) HIPC(c, hipMemcpyAsync(d_on, out_nrm, ob, hipMemcpyHostToDevice, c->stream));
+    }
+    size_t soff = 0;
+    long long off = 0;
+    double I[16];
+    mat4_identity(I);
+    for (int k = 0; k < n_kf; k++) {
+        const double *Tk = k == 0 ? I : T_ref_kf + 16 * k;     // LocalMap.hpp:214: the reference cloud is copied as is
+        if (k > 0 && !is_rigid(Tk)) return fail(c, PGICP_ERR_NOT_RIGID, "pgicp_build_local_map: transformation is not rigid");
+        const T *d_x = nullptr, *d_n = nullptr;
+        int st = to_device<T>(c, xyz[k], sx[k], counts[k], mem, S.staging, soff, &d_x);
+        if (st) return st;
+        if (mem == PGICP_HOST) soff += staged_bytes(sizeof(T), sx[k], counts[k]);
+        launch_transform<T>(c->stream, d_x, sx[k], d_ox + off * out_stride, out_stride, counts[k], Tk, 0);
+        if (nrm && out_nrm) {
+            st = to_device<T>(c, nrm[k], sn[k], counts[k], mem, S.staging, soff, &d_n);
+            if (st) return st;
+            if (mem == PGICP_HOST) soff += staged_bytes(sizeof(T), sn[k], counts[k]);
+            launch_transform<T>(c->stream, d_n, sn[k], d_on + off * out_stride, out_stride, counts[k], Tk, 1);
+        }
+        off += counts[k];
+    }
+    if (mem == PGICP_HOST) {
+        HIPC(c, hipMemcpyAsync(out_xyz, d_ox, ob, hipMemcpyDeviceToHost, c->stream));
+        if (out_nrm) HIPC(c, hipMemcpyAsync(out_nrm, d_on, ob, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    return PGICP_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// extern "C" surface
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int pgicp_abi_version(void) { return PGICP_ABI_VERSION; }
+
+int pgicp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void pgicp_default_params(pgicp_params *p)
+{
+    if (!p) return;
+    // libpointmatcher defaults for the chain pgslam instantiates
+    p->knn = 1;
+    p->epsilon = 0.0;
+    p->max_dist = std::numeric_limits<double>::infinity();
+    p->trim_ratio = 0.85;
+    p->max_iters = 40;
+    p->min_diff_rot = 0.001;
+    p->min_diff_trans = 0.001;
+    p->smooth_length = 3;
+    p->sensor_std_dev = 0.01;
+    p->matcher = PGICP_MATCHER_GRID;
+    p->grid_cell = 0.0;
+    p->check_every = 1;
+}
+
+int pgicp_ctx_create(int device, pgicp_ctx **out)
+{
+    if (!out) return PGICP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PGICP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PGICP_ERR_NO_DEVICE;
+    pgicp_ctx *c = new pgicp_ctx();
+    c->device = device;
+    pgicp_default_params(&c->prm);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return PGICP_ERR_HIP;
+    }
+    *out = c;
+    return PGICP_OK;
+}
+
+void pgicp_ctx_destroy(pgicp_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto &m : c->f32.maps) free_map(m);
+    for (auto &m : c->f64.maps) free_map(m);
+    for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
+                      &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
+                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d})
+        b->release();
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *pgicp_last_error(const pgicp_ctx *c) { return c ? c->err.c_str() : "null context"; }
+void *pgicp_ctx_stream(pgicp_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int pgicp_ctx_synchronize(pgicp_ctx *c)
+{
+    if (!c) return PGICP_ERR_ARG;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return PGICP_OK;
+}
+
+int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
+{
+    if (!c || !p) return PGICP_ERR_ARG;
+    if (p->knn != 1) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.knn: only 1 is supported");
+    if (p->epsilon != 0.0) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.epsilon: only 0 (exact search) is supported");
+    if (!(p->max_dist > 0.0)) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.maxDist must be > 0");
+    if (!(p->trim_ratio > 0.0 && p->trim_ratio <= 1.0)) return fail(c, PGICP_ERR_ARG, "TrimmedDistOutlierFilter.ratio must be in (0,1]");
+    if (p->max_iters < 1) return fail(c, PGICP_ERR_ARG, "CounterTransformationChecker.maxIterationCount must be >= 1");
+    if (p->smooth_length < 1 || p->smooth_length > kHist - 1)
+        return fail(c, PGICP_ERR_ARG, "DifferentialTransformationChecker.smoothLength must be in [1,15]");
+    if (p->matcher != PGICP_MATCHER_GRID && p->matcher != PGICP_MATCHER_BRUTE) return fail(c, PGICP_ERR_ARG, "unknown matcher");
+    if (p->grid_cell < 0.0) return fail(c, PGICP_ERR_ARG, "grid_cell must be >= 0");
+    c->prm = *p;
+    if (c->prm.check_every < 1) c->prm.check_every = 1;
+    return PGICP_OK;
+}
+
+int pgicp_get_params(const pgicp_ctx *c, pgicp_params *p)
+{
+    if (!c || !p) return PGICP_ERR_ARG;
+    *p = c->prm;
+    return PGICP_OK;
+}
+
+int pgicp_map_create_f32(pgicp_ctx *c, const float *xyz, int xs, const float *nrm, int ns, int m, int mem, int center, int *id)
+{ return map_create<float>(c, xyz, xs, nrm, ns, m, mem, center, id); }
+int pgicp_map_create_f64(pgicp_ctx *c, const double *xyz, int xs, const double *nrm, int ns, int m, int mem, int center, int *id)
+{ return map_create<double>(c, xyz, xs, nrm, ns, m, mem, center, id); }
+
+int pgicp_map_destroy(pgicp_ctx *c, int id)
+{
+    if (!c) return PGICP_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    // a map id is unique across precisions only per State; try both, f32 first
+    (void)hipStreamSynchronize(c->stream);
+    if (MapHost<float> *m = get_map<float>(c, id)) { free_map(*m); return PGICP_OK; }
+    if (MapHost<double> *m = get_map<double>(c, id)) { free_map(*m); return PGICP_OK; }
+    return fail(c, PGICP_ERR_ARG, "pgicp_map_destroy: unknown map id");
+}
+
+int pgicp_map_size(pgicp_ctx *c, int id, int *m)
+{
+    if (!c || !m) return PGICP_ERR_ARG;
+    if (MapHost<float> *h = get_map<float>(c, id)) { *m = h->m; return PGICP_OK; }
+    if (MapHost<double> *h = get_map<double>(c, id)) { *m = h->m; return PGICP_OK; }
+    return fail(c, PGICP_ERR_ARG, "pgicp_map_size: unknown map id");
+}
+
+static pgicp_problem one_problem(int map_id, const void *rd, int stride, int n, int mem, const double *T)
+{
+    pgicp_problem p;
+    p.map_id = map_id; p.reading = rd; p.stride = stride; p.n = n; p.mem = mem;
+    if (T) std::memcpy(p.T_init, T, sizeof p.T_init); else mat4_identity(p.T_init);
+    return p;
+}
+
+int pgicp_align_f32(pgicp_ctx *c, int map_id, const float *rd, int stride, int n, int mem, const double T_init[16],
+                    double T_out[16], pgicp_stats *stats)
+{
+    if (!T_init) return fail(c, PGICP_ERR_ARG, "pgicp_align: T_init is null");
+    pgicp_problem p = one_problem(map_id, rd, stride, n, mem, T_init);
+    return align_batch<float>(c, 1, &p, T_out, stats);
+}
+int pgicp_align_f64(pgicp_ctx *c, int map_id, const double *rd, int stride, int n, int mem, const double T_init[16],
+                    double T_out[16], pgicp_stats *stats)
+{
+    if (!T_init) return fail(c, PGICP_ERR_ARG, "pgicp_align: T_init is null");
+    pgicp_problem p = one_problem(map_id, rd, stride, n, mem, T_init);
+    return align_batch<double>(c, 1, &p, T_out, stats);
+}
+int pgicp_align_batch_f32(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgicp_stats *stats)
+{ return align_batch<float>(c, P, pr, T_out, stats); }
+int pgicp_align_batch_f64(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgicp_stats *stats)
+{ return align_batch<double>(c, P, pr, T_out, stats); }
+
+int pgicp_icp_pair_f32(pgicp_ctx *c, const float *rd, int rs, int n, const float *rx, int xs, const float *rn, int ns, int m,
+                       int mem, const double T_init[16], double T_out[16], pgicp_stats *stats)
+{ return icp_pair<float>(c, rd, rs, n, rx, xs, rn, ns, m, mem, T_init, T_out, stats); }
+int pgicp_icp_pair_f64(pgicp_ctx *c, const double *rd, int rs, int n, const double *rx, int xs, const double *rn, int ns,
+                       int m, int mem, const double T_init[16], double T_out[16], pgicp_stats *stats)
+{ return icp_pair<double>(c, rd, rs, n, rx, xs, rn, ns, m, mem, T_init, T_out, stats); }
+
+int pgicp_match_f32(pgicp_ctx *c, int map_id, const float *rd, int stride, int n, int mem, const double *T, int32_t *ids, float *d2)
+{ return match<float>(c, map_id, rd, stride, n, mem, T, ids, d2); }
+int pgicp_match_f64(pgicp_ctx *c, int map_id, const double *rd, int stride, int n, int mem, const double *T, int32_t *ids, double *d2)
+{ return match<double>(c, map_id, rd, stride, n, mem, T, ids, d2); }
+
+int pgicp_outlier_weights_f32(pgicp_ctx *c, const float *d2, int n, int mem, float *w, float *limit, int *nf)
+{ return outlier_weights<float>(c, d2, n, mem, w, limit, nf); }
+int pgicp_outlier_weights_f64(pgicp_ctx *c, const double *d2, int n, int mem, double *w, double *limit, int *nf)
+{ return outlier_weights<double>(c, d2, n, mem, w, limit, nf); }
+
+int pgicp_error_stats_f32(pgicp_ctx *c, int map_id, const float *rd, int stride, int n, int mem, const int32_t *ids,
+                          const float *w, double *ratio, double *residual, double sys[30])
+{ return error_stats<float>(c, map_id, rd, stride, n, mem, ids, w, ratio, residual, sys); }
+int pgicp_error_stats_f64(pgicp_ctx *c, int map_id, const double *rd, int stride, int n, int mem, const int32_t *ids,
+                          const double *w, double *ratio, double *residual, double sys[30])
+{ return error_stats<double>(c, map_id, rd, stride, n, mem, ids, w, ratio, residual, sys); }
+
+int pgicp_partial_chain_f32(pgicp_ctx *c, int map_id, const float *rd, int stride, int n, int mem, const double *T,
+                            double *ratio, double *residual)
+{ return partial_chain<float>(c, map_id, rd, stride, n, mem, T, ratio, residual); }
+int pgicp_partial_chain_f64(pgicp_ctx *c, int map_id, const double *rd, int stride, int n, int mem, const double *T,
+                            double *ratio, double *residual)
+{ return partial_chain<double>(c, map_id, rd, stride, n, mem, T, ratio, residual); }
+
+int pgicp_transform_f32(pgicp_ctx *c, const double T[16], const float *in, int is, float *out, int os, int n, int ro, int mem)
+{ return transform<float>(c, T, in, is, out, os, n, ro, mem); }
+int pgicp_transform_f64(pgicp_ctx *c, const double T[16], const double *in, int is, double *out, int os, int n, int ro, int mem)
+{ return transform<double>(c, T, in, is, out, os, n, ro, mem); }
+
+int pgicp_build_local_map_f32(pgicp_ctx *c, int n_kf, const float *const *xyz, const float *const *nrm, const int *sx,
+                              const int *sn, const int *counts, const double *T_ref_kf, float *ox, float *on, int os, int mem)
+{ return build_local_map<float>(c, n_kf, xyz, nrm, sx, sn, counts, T_ref_kf, ox, on, os, mem); }
+int pgicp_build_local_map_f64(pgicp_ctx *c, int n_kf, const double *const *xyz, const double *const *nrm, const int *sx,
+                              const int *sn, const int *counts, const double *T_ref_kf, double *ox, double *on, int os, int mem)
+{ return build_local_map<double>(c, n_kf, xyz, nrm, sx, sn, counts, T_ref_kf, ox, on, os, mem); }
+
+int pgicp_shard_pairs(int n_pairs, const int64_t *cost, int world, int rank, int *out_idx, int cap, int *n_out)
+{
+    if (n_pairs < 0 || world <= 0 || rank < 0 || rank >= world || !n_out) return PGICP_ERR_ARG;
+    // longest-processing-time first: sort by cost descending (index ascending on
+    // ties), give each pair to the currently least loaded rank (lowest rank on ties)
+    std::vector<int> order(n_pairs);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const int64_t ca = cost ? cost[a] : 1, cb = cost ? cost[b] : 1;
+        return ca > cb;
+    });
+    std::vector<int64_t> load(world, 0);
+    std::vector<int> count(world, 0);
+    int n = 0;
+    for (int i : order) {
+        int best = 0;
+        for (int r = 1; r < world; r++)
+            if (load[r] < load[best] || (load[r] == load[best] && count[r] < count[best])) best = r;
+        load[best] += cost ? cost[i] : 1;
+        count[best]++;
+        if (best == rank) {
+            if (out_idx && n < cap) out_idx[n] = i;
+            n++;
+        }
+    }
+    *n_out = n;
+    if (out_idx && n > cap) return PGICP_ERR_ARG;
+    if (out_idx) std::sort(out_idx, out_idx + n);
+    return PGICP_OK;
+}
+
+int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double overlap_threshold,
+                           double residual_error_threshold)
+{
+    if (!icp) return 0;
+    if (icp->status != PGICP_OK) return 0;
+    if (icp->max_iter_reached) return 0;                       // LoopCloser.hpp:317
+    if (icp->overlap < overlap_threshold) return 0;            // LoopCloser.hpp:331
+    if (residual_error > residual_error_threshold) return 0;   // LoopCloser.hpp:335
+    return 1;
+}
+
+int pgicp_profile_enable(pgicp_ctx *c, int on)
+{
+    if (!c) return PGICP_ERR_ARG;
+    if (!on) prof_collect(c);
+    c->prof_on = on != 0;
+    return PGICP_OK;
+}
+
+int pgicp_profile_reset(pgicp_ctx *c)
+{
+    if (!c) return PGICP_ERR_ARG;
+    prof_collect(c);
+    for (int i = 0; i < PGICP_PROF_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_units[i] = 0; }
+    return PGICP_OK;
+}
+
+int pgicp_profile_get(pgicp_ctx *c, int kid, long long *launches, double *total_ms, long long *units)
+{
+    if (!c || kid < 0 || kid >= PGICP_PROF_COUNT) return PGICP_ERR_ARG;
+    prof_collect(c);
+    if (launches) *launches = c->prof_launches[kid];
+    if (total_ms) *total_ms = c->prof_ms[kid];
+    if (units) *units = c->prof_units[kid];
+    return PGICP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,376 @@
+"""Python binding of the C ABI in include/pgicp.h (ctypes, no torch types cross it).
+
+This is plumbing for tests and bench.py; the C++ drop-in host layer lives in
+include/pgslam_amd/.  The names mirror the libpointmatcher objects pgslam drives
+(reference src/pgslam/Localizer.hpp:126,148,309-347, LoopCloser.hpp:98,343-365):
+
+    ICPSequence.setMap(cloud)            -> Context.set_map(xyz, normals)
+    ICPSequence.__call__(reading, T)     -> Context.align(map, reading, T_init)
+    ICP.__call__(reading, reference, T)  -> Context.icp_pair(...)
+    matcher.findClosests                 -> Context.match(...)
+    outlierFilters.compute               -> Context.outlier_weights(...)
+    ErrorElements / getResidualError     -> Context.error_stats(...)
+
+There is no CPU fallback: if libpgicp.so is missing, or no GPU is present,
+construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpgicp.so")
+
+OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID = range(7)
+HOST, DEVICE = 0, 1
+MATCHER_GRID, MATCHER_BRUTE = 0, 1
+PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_update", "pretransform",
+              "covariance", "grid_build"]
+
+# every symbol include/pgicp.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "pgicp_abi_version", "pgicp_device_count", "pgicp_ctx_create", "pgicp_ctx_destroy", "pgicp_last_error",
+    "pgicp_ctx_stream", "pgicp_ctx_synchronize", "pgicp_default_params", "pgicp_set_params", "pgicp_get_params",
+    "pgicp_map_create_f32", "pgicp_map_create_f64", "pgicp_map_destroy", "pgicp_map_size",
+    "pgicp_align_f32", "pgicp_align_f64", "pgicp_align_batch_f32", "pgicp_align_batch_f64",
+    "pgicp_icp_pair_f32", "pgicp_icp_pair_f64", "pgicp_match_f32", "pgicp_match_f64",
+    "pgicp_outlier_weights_f32", "pgicp_outlier_weights_f64", "pgicp_error_stats_f32", "pgicp_error_stats_f64",
+    "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_transform_f32", "pgicp_transform_f64",
+    "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
+    "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("knn", C.c_int), ("epsilon", C.c_double), ("max_dist", C.c_double), ("trim_ratio", C.c_double),
+                ("max_iters", C.c_int), ("min_diff_rot", C.c_double), ("min_diff_trans", C.c_double),
+                ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double), ("matcher", C.c_int),
+                ("grid_cell", C.c_double), ("check_every", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("converged", C.c_int), ("max_iter_reached", C.c_int),
+                ("overlap", C.c_double), ("residual", C.c_double), ("trim_limit", C.c_double), ("n_kept", C.c_int),
+                ("n_finite", C.c_int), ("cov", C.c_double * 36)]
+
+    def as_dict(self):
+        return dict(status=self.status, iterations=self.iterations, converged=bool(self.converged),
+                    max_iter_reached=bool(self.max_iter_reached), overlap=self.overlap, residual=self.residual,
+                    trim_limit=self.trim_limit, n_kept=self.n_kept, n_finite=self.n_finite,
+                    cov=np.array(self.cov[:]).reshape(6, 6))
+
+
+class Problem(C.Structure):
+    _fields_ = [("map_id", C.c_int), ("reading", C.c_void_p), ("stride", C.c_int), ("n", C.c_int), ("mem", C.c_int),
+                ("T_init", C.c_double * 16)]
+
+
+class Edge(C.Structure):
+    _fields_ = [("from_id", C.c_int64), ("to_id", C.c_int64), ("accepted", C.c_int32), ("status", C.c_int32),
+                ("iterations", C.c_int32), ("max_iter_reached", C.c_int32), ("overlap", C.c_double),
+                ("residual", C.c_double), ("T_from_to", C.c_double * 16), ("cov", C.c_double * 36),
+                ("reserved", C.c_double * 6)]
+
+
+assert C.sizeof(Edge) == 512
+
+
+class PgicpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pgicp error {code}: {msg}")
+        self.code = code
+
+
+class ConvergenceError(PgicpError):
+    """PM::ConvergenceError: 'no point to minimize' / NaN in the checkers."""
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libpgicp.so.  Raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
+                              "pgslam_amd has no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.pgicp_last_error.restype = C.c_char_p
+        _lib.pgicp_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class _Buf:
+    """(pointer, stride, n, mem, dtype) view of a numpy array or a torch CUDA tensor.
+    Accepts (N,3) packed xyz or (N,4) homogeneous rows (= libpointmatcher's 4xN
+    column-major `features`)."""
+
+    def __init__(self, x, dtype=None):
+        if _is_torch(x):
+            if not x.is_cuda:
+                x = x.numpy()
+            else:
+                assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] >= 3
+                self.keep = x
+                self.ptr = x.data_ptr()
+                self.stride = x.stride(0)
+                self.n = x.shape[0]
+                self.mem = DEVICE
+                self.dtype = np.dtype(str(x.dtype).replace("torch.", ""))
+                return
+        x = np.asarray(x)
+        if dtype is not None:
+            x = x.astype(dtype, copy=False)
+        assert x.ndim == 2 and x.shape[1] >= 3 and x.strides[1] == x.itemsize
+        self.keep = x
+        self.ptr = x.ctypes.data
+        self.stride = x.strides[0] // x.itemsize
+        self.n = x.shape[0]
+        self.mem = HOST
+        self.dtype = x.dtype
+
+
+def _T16(T):
+    T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4))
+    return (C.c_double * 16)(*T.ravel())
+
+
+class Context:
+    def __init__(self, device: int = 0, **params):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.pgicp_ctx_create(C.c_int(device), C.byref(h))
+        if st != OK:
+            raise PgicpError(st, "pgicp_ctx_create failed (no usable gfx950 device?)")
+        self.h = h
+        self.device = device
+        self.params = Params()
+        self.lib.pgicp_default_params(C.byref(self.params))
+        if params:
+            self.set_params(**params)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pgicp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st == OK:
+            return
+        msg = self.lib.pgicp_last_error(self.h).decode()
+        if st in (ERR_NO_MATCH, ERR_NAN):
+            raise ConvergenceError(st, msg)
+        raise PgicpError(st, msg)
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise KeyError(k)
+            setattr(self.params, k, v)
+        self._check(self.lib.pgicp_set_params(self.h, C.byref(self.params)))
+
+    @property
+    def stream(self):
+        return self.lib.pgicp_ctx_stream(self.h)
+
+    def synchronize(self):
+        self._check(self.lib.pgicp_ctx_synchronize(self.h))
+
+    @staticmethod
+    def _sfx(dtype):
+        return "_f32" if np.dtype(dtype) == np.float32 else "_f64"
+
+    # ---- map -------------------------------------------------------------
+    def set_map(self, xyz, normals=None, center=True, dtype=None) -> int:
+        x = _Buf(xyz, dtype)
+        nb = _Buf(normals, x.dtype) if normals is not None else None
+        assert nb is None or (nb.n == x.n and nb.mem == x.mem)
+        mid = C.c_int(-1)
+        fn = getattr(self.lib, "pgicp_map_create" + self._sfx(x.dtype))
+        self._check(fn(self.h, C.c_void_p(x.ptr), C.c_int(x.stride), C.c_void_p(nb.ptr if nb else None),
+                       C.c_int(nb.stride if nb else 0), C.c_int(x.n), C.c_int(x.mem), C.c_int(int(center)), C.byref(mid)))
+        return mid.value
+
+    def destroy_map(self, map_id):
+        self._check(self.lib.pgicp_map_destroy(self.h, C.c_int(map_id)))
+
+    def map_size(self, map_id):
+        m = C.c_int(0)
+        self._check(self.lib.pgicp_map_size(self.h, C.c_int(map_id), C.byref(m)))
+        return m.value
+
+    # ---- full ICP -----------------------------------------------------------
+    def align(self, map_id, reading, T_init, dtype=None):
+        r = _Buf(reading, dtype)
+        T_out = (C.c_double * 16)()
+        st = Stats()
+        fn = getattr(self.lib, "pgicp_align" + self._sfx(r.dtype))
+        self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem),
+                       _T16(T_init), T_out, C.byref(st)))
+        return np.array(T_out[:]).reshape(4, 4), st.as_dict()
+
+    def align_batch(self, map_ids, readings, T_inits, dtype=None, raise_on_error=True):
+        P = len(readings)
+        if isinstance(map_ids, int):
+            map_ids = [map_ids] * P
+        bufs = [_Buf(r, dtype) for r in readings]
+        probs = (Problem * P)()
+        for p in range(P):
+            probs[p].map_id = map_ids[p]
+            probs[p].reading = bufs[p].ptr
+            probs[p].stride = bufs[p].stride
+            probs[p].n = bufs[p].n
+            probs[p].mem = bufs[p].mem
+            probs[p].T_init = _T16(T_inits[p])
+        T_out = (C.c_double * (16 * P))()
+        stats = (Stats * P)()
+        fn = getattr(self.lib, "pgicp_align_batch" + self._sfx(bufs[0].dtype))
+        rc = fn(self.h, C.c_int(P), probs, T_out, stats)
+        if raise_on_error:
+            self._check(rc)
+        elif rc not in (OK, ERR_NO_MATCH, ERR_NAN):
+            self._check(rc)
+        return np.array(T_out[:]).reshape(P, 4, 4), [s.as_dict() for s in stats]
+
+    def icp_pair(self, reading, ref_xyz, ref_nrm, T_init, dtype=None):
+        r = _Buf(reading, dtype)
+        x = _Buf(ref_xyz, r.dtype)
+        nb = _Buf(ref_nrm, r.dtype)
+        assert r.mem == x.mem == nb.mem
+        T_out = (C.c_double * 16)()
+        st = Stats()
+        fn = getattr(self.lib, "pgicp_icp_pair" + self._sfx(r.dtype))
+        self._check(fn(self.h, C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_void_p(x.ptr), C.c_int(x.stride),
+                       C.c_void_p(nb.ptr), C.c_int(nb.stride), C.c_int(x.n), C.c_int(r.mem), _T16(T_init), T_out,
+                       C.byref(st)))
+        return np.array(T_out[:]).reshape(4, 4), st.as_dict()
+
+    # ---- stages -----------------------------------------------------------
+    def match(self, map_id, reading, T=None, dtype=None):
+        r = _Buf(reading, dtype)
+        fn = getattr(self.lib, "pgicp_match" + self._sfx(r.dtype))
+        Tp = _T16(T) if T is not None else None
+        if r.mem == DEVICE:
+            import torch
+            ids = torch.empty(r.n, dtype=torch.int32, device=r.keep.device)
+            d2 = torch.empty(r.n, dtype=r.keep.dtype, device=r.keep.device)
+            self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem),
+                           Tp, C.c_void_p(ids.data_ptr()), C.c_void_p(d2.data_ptr())))
+            return ids, d2
+        ids = np.empty(r.n, dtype=np.int32)
+        d2 = np.empty(r.n, dtype=r.dtype)
+        self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem), Tp,
+                       C.c_void_p(ids.ctypes.data), C.c_void_p(d2.ctypes.data)))
+        return ids, d2
+
+    def outlier_weights(self, d2):
+        d2 = np.ascontiguousarray(d2)
+        assert d2.dtype in (np.float32, np.float64)
+        w = np.empty_like(d2)
+        real = C.c_float if d2.dtype == np.float32 else C.c_double
+        limit = real(0)
+        nf = C.c_int(0)
+        fn = getattr(self.lib, "pgicp_outlier_weights" + self._sfx(d2.dtype))
+        self._check(fn(self.h, C.c_void_p(d2.ctypes.data), C.c_int(d2.shape[0]), C.c_int(HOST), C.c_void_p(w.ctypes.data),
+                       C.byref(limit), C.byref(nf)))
+        return w, limit.value, nf.value
+
+    def error_stats(self, map_id, reading, ids, weights, dtype=None):
+        r = _Buf(reading, dtype)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=r.dtype)
+        ratio, resid = C.c_double(0), C.c_double(0)
+        sys_ = (C.c_double * 30)()
+        fn = getattr(self.lib, "pgicp_error_stats" + self._sfx(r.dtype))
+        self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem),
+                       C.c_void_p(ids.ctypes.data), C.c_void_p(w.ctypes.data), C.byref(ratio), C.byref(resid), sys_))
+        return ratio.value, resid.value, np.array(sys_[:])
+
+    def partial_chain(self, map_id, reading, T=None, dtype=None):
+        r = _Buf(reading, dtype)
+        ratio, resid = C.c_double(0), C.c_double(0)
+        fn = getattr(self.lib, "pgicp_partial_chain" + self._sfx(r.dtype))
+        self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem),
+                       _T16(T) if T is not None else None, C.byref(ratio), C.byref(resid)))
+        return ratio.value, resid.value
+
+    def transform(self, T, pts, rotate_only=False, dtype=None):
+        r = _Buf(pts, dtype)
+        assert r.mem == HOST
+        out = np.array(r.keep, copy=True)
+        fn = getattr(self.lib, "pgicp_transform" + self._sfx(r.dtype))
+        self._check(fn(self.h, _T16(T), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_void_p(out.ctypes.data),
+                       C.c_int(out.strides[0] // out.itemsize), C.c_int(r.n), C.c_int(int(rotate_only)), C.c_int(HOST)))
+        return out
+
+    def build_local_map(self, clouds_xyz, clouds_nrm, T_ref_kf, dtype=np.float32):
+        k = len(clouds_xyz)
+        xs = [_Buf(c, dtype) for c in clouds_xyz]
+        ns = [_Buf(c, dtype) for c in clouds_nrm]
+        counts = (C.c_int * k)(*[b.n for b in xs])
+        sx = (C.c_int * k)(*[b.stride for b in xs])
+        sn = (C.c_int * k)(*[b.stride for b in ns])
+        Ts = np.ascontiguousarray(np.stack([np.asarray(t, dtype=np.float64).reshape(4, 4) for t in T_ref_kf]))
+        total = sum(b.n for b in xs)
+        out_x = np.zeros((total, 3), dtype=dtype)
+        out_n = np.zeros((total, 3), dtype=dtype)
+        PP = C.c_void_p * k
+        fn = getattr(self.lib, "pgicp_build_local_map" + self._sfx(dtype))
+        self._check(fn(self.h, C.c_int(k), PP(*[b.ptr for b in xs]), PP(*[b.ptr for b in ns]), sx, sn, counts,
+                       C.c_void_p(Ts.ctypes.data), C.c_void_p(out_x.ctypes.data), C.c_void_p(out_n.ctypes.data),
+                       C.c_int(3), C.c_int(HOST)))
+        return out_x, out_n
+
+    # ---- measurement --------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.pgicp_profile_enable(self.h, C.c_int(int(on))))
+
+    def profile_reset(self):
+        self._check(self.lib.pgicp_profile_reset(self.h))
+
+    def profile(self):
+        out = {}
+        for kid, name in enumerate(PROF_NAMES):
+            n, ms, u = C.c_longlong(0), C.c_double(0), C.c_longlong(0)
+            self._check(self.lib.pgicp_profile_get(self.h, C.c_int(kid), C.byref(n), C.byref(ms), C.byref(u)))
+            out[name] = dict(launches=n.value, total_ms=ms.value, units=u.value)
+        return out
+
+
+def shard_pairs(costs, world_size, rank):
+    """pgicp_shard_pairs: host-only LPT split of candidate ICPs over ranks."""
+    lib = load_library()
+    costs = np.ascontiguousarray(costs, dtype=np.int64)
+    n = costs.shape[0]
+    out = np.empty(max(n, 1), dtype=np.int32)
+    cnt = C.c_int(0)
+    st = lib.pgicp_shard_pairs(C.c_int(n), C.c_void_p(costs.ctypes.data), C.c_int(world_size), C.c_int(rank),
+                               C.c_void_p(out.ctypes.data), C.c_int(n), C.byref(cnt))
+    if st != OK:
+        raise PgicpError(st, "pgicp_shard_pairs")
+    return out[: cnt.value].copy()
+
+
+def check_icp_result(stats: dict, residual_error, overlap_threshold=0.8, residual_error_threshold=5000.0) -> bool:
+    """LoopCloser::CheckIcpResult (LoopCloser.hpp:308-340) through the C ABI."""
+    lib = load_library()
+    s = Stats()
+    s.status = stats["status"]
+    s.max_iter_reached = int(stats["max_iter_reached"])
+    s.overlap = stats["overlap"]
+    return bool(lib.pgicp_check_icp_result(C.byref(s), C.c_double(residual_error), C.c_double(overlap_threshold),
+                                           C.c_double(residual_error_threshold)))

@@ -1,0 +1,72 @@
+"""CPU-side checks of the drop-in boundary: libpgicp.so loads and exports every
+symbol include/pgicp.h declares; no compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pgslam_amd import icp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pgicp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgicp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(icp.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = icp.load_library()
+    for name in _declared():
+        assert hasattr(lib, name), name
+
+
+def test_abi_version_and_struct_sizes():
+    lib = icp.load_library()
+    assert lib.pgicp_abi_version() == 1
+    assert ctypes.sizeof(icp.Edge) == 512
+    p = icp.Params()
+    lib.pgicp_default_params(ctypes.byref(p))
+    # libpointmatcher defaults of the chain pgslam instantiates
+    assert (p.knn, p.epsilon, p.trim_ratio, p.max_iters, p.smooth_length) == (1, 0.0, 0.85, 40, 3)
+    assert p.max_dist == float("inf") and p.min_diff_rot == 0.001 and p.min_diff_trans == 0.001
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = icp.load_library()
+    if lib.pgicp_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(icp.PgicpError) as e:
+        icp.Context(0)
+    assert e.value.code == icp.ERR_NO_DEVICE
+
+
+def test_shard_pairs_lpt_is_a_partition():
+    costs = np.array([9, 1, 8, 2, 7, 3, 6, 4, 5, 5], dtype=np.int64)
+    parts = [icp.shard_pairs(costs, 4, r) for r in range(4)]
+    allidx = np.sort(np.concatenate(parts))
+    assert np.array_equal(allidx, np.arange(10))
+    loads = [int(costs[p].sum()) for p in parts]
+    assert max(loads) - min(loads) <= int(costs.max())
+    # deterministic
+    assert all(np.array_equal(icp.shard_pairs(costs, 4, r), parts[r]) for r in range(4))
+    # uniform costs deal evenly
+    sizes = [len(icp.shard_pairs(np.ones(512, dtype=np.int64), 8, r)) for r in range(8)]
+    assert sizes == [64] * 8
+
+
+def test_check_icp_result_follows_loop_closer():
+    ok = dict(status=0, max_iter_reached=False, overlap=0.9)
+    assert icp.check_icp_result(ok, 100.0)
+    assert not icp.check_icp_result(dict(ok, max_iter_reached=True), 100.0)      # LoopCloser.hpp:317
+    assert not icp.check_icp_result(dict(ok, overlap=0.79), 100.0)               # LoopCloser.hpp:331
+    assert not icp.check_icp_result(ok, 5000.1)                                  # LoopCloser.hpp:335
+    assert icp.check_icp_result(ok, 5000.0)
+    assert not icp.check_icp_result(dict(ok, status=1), 1.0)

@@ -1,0 +1,262 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Bit-exact for indices / squared distances / trim
+thresholds / transforms; final ICP transform within 1e-5 m and 1e-5 rad
+(BASELINE.json north_star tolerance)."""
+import math
+
+import numpy as np
+import pytest
+
+from pgslam_amd import icp, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_TRANS = 1e-5   # metres
+TOL_ROT = 1e-5     # radians
+
+CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01,
+             smooth_length=3, sensor_std_dev=0.01)
+
+
+def pose_error(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    tr = np.linalg.norm(d[:3, 3])
+    c = min(1.0, max(-1.0, (np.trace(d[:3, :3]) - 1.0) / 2.0))
+    return tr, math.acos(c)
+
+
+@pytest.fixture(scope="module")
+def small():
+    return synth.make_scan_to_map(n_scan=6000, n_map=50_000, n_queries=3, n_map_poses=4, rings=16)
+
+
+@pytest.fixture(scope="module")
+def two_scans():
+    return synth.make_two_scans(10_000, rings=16)
+
+
+def rng_cloud(seed, n, scale=1.0):
+    u = synth.uniform01(seed, 3 * n).reshape(n, 3)
+    return ((u - 0.5) * scale).astype(np.float32)
+
+
+# ---------------------------------------------------------------- matcher
+@pytest.mark.parametrize("matcher", [icp.MATCHER_BRUTE, icp.MATCHER_GRID])
+@pytest.mark.parametrize("max_dist", [2.0, 0.3, float("inf")])
+def test_match_bit_exact_two_scans(ctx, oracle32, two_scans, matcher, max_dist):
+    """BASELINE configs[0]: 10k vs 10k, ids and squared distances bit-exact."""
+    w = two_scans
+    ctx.set_params(**dict(CHAIN, max_dist=max_dist, matcher=matcher))
+    mid = ctx.set_map(w["ref_xyz"], w["ref_nrm"], center=False)
+    ids, d2 = ctx.match(mid, w["reading_xyz"], T=w["T_init"])
+    q = oracle32.transform(w["T_init"], w["reading_xyz"])
+    oid, od2 = oracle32.knn_brute(q, w["ref_xyz"], max_dist)
+    ctx.destroy_map(mid)
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+
+
+@pytest.mark.parametrize("matcher", [icp.MATCHER_BRUTE, icp.MATCHER_GRID])
+def test_match_ties_lowest_index_and_duplicates(ctx, oracle32, matcher):
+    """Duplicate map points and exact ties across cell borders: lowest index wins."""
+    base = rng_cloud(11, 500)
+    m = np.concatenate([base, base[::-1], base[100:200]])              # many exact duplicates
+    # lattice points: queries at cell-centre midpoints tie between neighbours
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(4), indexing="ij"), -1).reshape(-1, 3)
+    m = np.concatenate([m, (g * 0.125 - 0.5).astype(np.float32)])
+    q = np.concatenate([base[:300], (g[:200] * 0.125 - 0.5 + 0.0625).astype(np.float32), rng_cloud(12, 500, 1.5)])
+    ctx.set_params(**dict(CHAIN, max_dist=float("inf"), matcher=matcher))
+    mid = ctx.set_map(m, None, center=False)
+    ids, d2 = ctx.match(mid, q)
+    oid, od2 = oracle32.knn_brute(q, m, np.inf)
+    ctx.destroy_map(mid)
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+
+
+def test_match_max_dist_sentinels(ctx, oracle32):
+    """Queries farther than maxDist from everything: id -1, dist +inf (Appendix B.5)."""
+    m = rng_cloud(21, 2000)
+    q = np.concatenate([rng_cloud(22, 100), rng_cloud(23, 100) + np.float32(10.0)])
+    for matcher in (icp.MATCHER_BRUTE, icp.MATCHER_GRID):
+        ctx.set_params(**dict(CHAIN, max_dist=0.5, matcher=matcher))
+        mid = ctx.set_map(m, None, center=False)
+        ids, d2 = ctx.match(mid, q)
+        ctx.destroy_map(mid)
+        oid, od2 = oracle32.knn_brute(q, m, 0.5)
+        assert np.array_equal(ids, oid) and np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+        assert np.all(ids[100:] == -1) and np.all(np.isinf(d2[100:]))
+
+
+def test_match_grid_equals_brute_on_scan_vs_map(ctx, oracle32, small):
+    w = small
+    q = w.scans_xyz[0]
+    out = {}
+    for matcher in (icp.MATCHER_BRUTE, icp.MATCHER_GRID):
+        ctx.set_params(**dict(CHAIN, matcher=matcher))
+        mid = ctx.set_map(w.map_xyz, w.map_nrm, center=False)
+        out[matcher] = ctx.match(mid, q, T=w.T_init[0])
+        ctx.destroy_map(mid)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    oid, od2 = oracle32.knn_kdtree(oracle32.transform(w.T_init[0], q), w.map_xyz, 2.0)
+    assert np.array_equal(out[0][0], oid)
+    assert np.array_equal(out[0][1].view(np.uint32), od2.view(np.uint32))
+
+
+# ---------------------------------------------------------------- outlier filter
+@pytest.mark.parametrize("ratio", [0.85, 0.5, 1.0, 0.999])
+def test_trim_threshold_exact(ctx, oracle32, ratio):
+    d2 = (synth.uniform01(31, 20_000) ** 2).astype(np.float32)
+    d2[::97] = np.inf
+    d2[5] = d2[6] = d2[7]                                        # ties
+    ctx.set_params(**dict(CHAIN, trim_ratio=ratio))
+    w, limit, nf = ctx.outlier_weights(d2)
+    st, ow, olimit, onf = oracle32.trim_weights(d2, ratio)
+    assert st == 0 and nf == onf
+    assert np.float32(limit).view(np.uint32) == np.float32(olimit).view(np.uint32)
+    assert np.array_equal(w, ow)
+
+
+def test_trim_known_answer(ctx):
+    """Appendix B.3: dists 0..9, ratio .85 -> index 8 -> limit 8 -> 9 kept; inf excluded from n."""
+    ctx.set_params(**dict(CHAIN, trim_ratio=0.85))
+    w, limit, nf = ctx.outlier_weights(np.arange(10, dtype=np.float32))
+    assert limit == 8.0 and nf == 10 and w.sum() == 9
+    d = np.concatenate([np.arange(10, dtype=np.float32), np.full(5, np.inf, np.float32)])
+    w, limit, nf = ctx.outlier_weights(d)
+    assert limit == 8.0 and nf == 10 and w.sum() == 9 and np.all(w[10:] == 0)
+    with pytest.raises(icp.ConvergenceError):
+        ctx.outlier_weights(np.full(8, np.inf, np.float32))
+
+
+# ---------------------------------------------------------------- transform / map assembly
+def test_transform_bit_exact(ctx, oracle32, small):
+    T = synth.se3(0.3, -1.2, 0.05, 0.2, -0.03, 0.01)
+    p = small.scans_xyz[1]
+    assert np.array_equal(ctx.transform(T, p), oracle32.transform(T, p))
+    n = small.scans_nrm[1]
+    assert np.array_equal(ctx.transform(T, n, rotate_only=True), oracle32.transform(T, n, rotate_only=True))
+    bad = T.copy()
+    bad[0, 0] *= 1.5
+    with pytest.raises(icp.PgicpError) as e:
+        ctx.transform(bad, p)
+    assert e.value.code == icp.ERR_NOT_RIGID
+
+
+def test_build_local_map_bit_exact(ctx, oracle32, small):
+    """LocalMap::BuildCloudFromData: reference cloud, then T_k * cloud_k appended (Appendix B.9)."""
+    Ts = [np.eye(4), synth.se3(1.5, 0.1, 0, 0.02), synth.se3(-3.0, 0.2, 0, -0.03)]
+    xs, ns = small.scans_xyz[:3], small.scans_nrm[:3]
+    gx, gn = ctx.build_local_map(xs, ns, Ts)
+    ox, on = oracle32.build_local_map(xs, ns, Ts)
+    assert np.array_equal(gx, ox) and np.array_equal(gn, on)
+    assert np.array_equal(gx[: xs[0].shape[0]], xs[0])
+
+
+# ---------------------------------------------------------------- error elements
+def test_error_stats_and_partial_chain(ctx, oracle32, small):
+    w = small
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=False)
+    T = w.T_init[1]
+    moved = oracle32.transform(T, w.scans_xyz[1])
+    ids, d2 = ctx.match(mid, moved)
+    wts, limit, nf = ctx.outlier_weights(d2)
+    ratio, resid, sys_ = ctx.error_stats(mid, moved, ids, wts)
+    st, osys = oracle32.p2plane_system(moved, w.map_xyz, w.map_nrm, ids, wts)
+    assert st == 0
+    np.testing.assert_allclose(sys_, osys, rtol=1e-12, atol=1e-12)
+    assert ratio == pytest.approx(osys[27] / moved.shape[0], rel=1e-14)
+    # fused partial chain = Localizer::ComputeOverlapWith / LoopCloser::ComputeResidualError
+    r2, e2 = ctx.partial_chain(mid, w.scans_xyz[1], T=T)
+    o = oracle32.partial_chain(w.scans_xyz[1], w.map_xyz, w.map_nrm, T, **CHAIN)
+    ctx.destroy_map(mid)
+    assert o["status"] == 0
+    assert r2 == pytest.approx(o["overlap"], rel=1e-14)
+    assert e2 == pytest.approx(o["residual"], rel=1e-11)
+
+
+# ---------------------------------------------------------------- full ICP
+@pytest.mark.parametrize("matcher", [icp.MATCHER_GRID, icp.MATCHER_BRUTE])
+def test_icp_scan_to_map_parity(ctx, oracle32, small, matcher):
+    w = small
+    ctx.set_params(**dict(CHAIN, matcher=matcher))
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=True)
+    for b in range(len(w.scans_xyz)):
+        T, st = ctx.align(mid, w.scans_xyz[b], w.T_init[b])
+        o = oracle32.icp(w.scans_xyz[b], w.map_xyz, w.map_nrm, w.T_init[b], **CHAIN)
+        assert o["status"] == 0 and st["status"] == 0
+        dt, dr = pose_error(o["T"], T)
+        assert dt < TOL_TRANS and dr < TOL_ROT, (dt, dr)
+        assert st["iterations"] == o["iterations"]
+        assert st["converged"] == o["converged"] and st["max_iter_reached"] == o["max_iter_reached"]
+        assert st["n_finite"] == o["n_finite"] and st["n_kept"] == o["n_kept"]
+        assert st["overlap"] == pytest.approx(o["overlap"], rel=1e-12)
+        assert st["residual"] == pytest.approx(o["residual"], rel=1e-6)
+        assert np.float32(st["trim_limit"]) == np.float32(o["trim_limit"])
+        np.testing.assert_allclose(st["cov"], o["cov"], rtol=1e-5, atol=1e-14)
+        # and the answer is the right one
+        gt, gr = pose_error(w.T_truth[b], T)
+        assert gt < 0.02 and gr < 0.002
+    ctx.destroy_map(mid)
+
+
+def test_icp_batch_equals_single(ctx, small):
+    w = small
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=True)
+    singles = [ctx.align(mid, w.scans_xyz[b], w.T_init[b]) for b in range(3)]
+    Tb, sb = ctx.align_batch(mid, w.scans_xyz, w.T_init)
+    ctx.destroy_map(mid)
+    for b in range(3):
+        assert np.array_equal(Tb[b], singles[b][0])               # same kernels, same order: bit-identical
+        assert sb[b]["iterations"] == singles[b][1]["iterations"]
+
+
+def test_icp_pair_two_scans(ctx, oracle32, two_scans):
+    """BASELINE configs[0] through ICP::operator()(reading, reference, T) (LoopCloser.hpp:98)."""
+    w = two_scans
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    T, st = ctx.icp_pair(w["reading_xyz"], w["ref_xyz"], w["ref_nrm"], w["T_init"])
+    o = oracle32.icp(w["reading_xyz"], w["ref_xyz"], w["ref_nrm"], w["T_init"], **CHAIN)
+    dt, dr = pose_error(o["T"], T)
+    assert dt < TOL_TRANS and dr < TOL_ROT
+    assert st["iterations"] == o["iterations"]
+
+
+def test_icp_fixed_iterations_counter_stop(ctx, oracle32, small):
+    """Differential checker disabled -> the Counter stops the loop and raises the flag."""
+    w = small
+    prm = dict(CHAIN, max_iters=7, min_diff_rot=0.0, min_diff_trans=0.0)
+    ctx.set_params(**dict(prm, matcher=icp.MATCHER_GRID))
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=True)
+    T, st = ctx.align(mid, w.scans_xyz[0], w.T_init[0])
+    ctx.destroy_map(mid)
+    o = oracle32.icp(w.scans_xyz[0], w.map_xyz, w.map_nrm, w.T_init[0], **prm)
+    assert st["iterations"] == 7 and st["max_iter_reached"] and not st["converged"]
+    assert o["iterations"] == 7 and o["max_iter_reached"]
+    dt, dr = pose_error(o["T"], T)
+    assert dt < TOL_TRANS and dr < TOL_ROT
+
+
+def test_icp_no_match_is_convergence_error(ctx, small):
+    w = small
+    ctx.set_params(**dict(CHAIN, max_dist=0.5, matcher=icp.MATCHER_GRID))
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=True)
+    far = synth.se3(z=500.0)
+    with pytest.raises(icp.ConvergenceError):
+        ctx.align(mid, w.scans_xyz[0], far)
+    ctx.destroy_map(mid)
+
+
+def test_icp_double_precision(ctx, oracle64, small):
+    w = small
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    mx, mn, rd = (a.astype(np.float64) for a in (w.map_xyz, w.map_nrm, w.scans_xyz[0]))
+    mid = ctx.set_map(mx, mn, center=True)
+    T, st = ctx.align(mid, rd, w.T_init[0])
+    ids, d2 = ctx.match(mid, rd, T=w.T_init[0])
+    ctx.destroy_map(mid)
+    o = oracle64.icp(rd, mx, mn, w.T_init[0], **CHAIN)
+    dt, dr = pose_error(o["T"], T)
+    assert dt < TOL_TRANS and dr < TOL_ROT and st["iterations"] == o["iterations"]
