@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""bench.py -- ICP-converged scans/sec at a 100k-pt scan vs a 1M-pt local map.
+
+Workload = BASELINE.json configs[1]: "Scan-to-map ICP: 100k-pt Velodyne-style
+scan vs 1M-pt local map, 30 iters, 1xMI355X" (synthetic).
+A "step" is one batch of `--batch` independent scan-to-map ICPs (distinct query
+scans, each with its own perturbed initial guess) against the resident map;
+`value` = scans whose Differential checker stopped the loop (converged, status
+OK) per second, whole job.  Inputs are in HBM before the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds a
+full copy of the map and aligns its own batch -- independent replicas, weak
+scaling, no data-path collective (scan-to-map ICPs of one trajectory are
+sequential).  The barrier and the max-over-ranks timing use
+torch.distributed (RCCL).
+
+The JSON line also carries
+  roofline     kNN kernel (dominant): algorithmic bytes per launch
+               ((20 N + 12 M) per active problem) / the kernel's
+               mean duration measured with HIP events on the context's stream,
+               against the 8 TB/s HBM peak.
+  cpu_baseline the CPU oracle (kd-tree restatement of the reference chain, kind
+               "port") timed on this box's host cores on a bounded sample of the
+               same scans.  Baseline, not target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01,
+             smooth_length=3, sensor_std_dev=0.01)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def _gen_scan(args):
+    from pgslam_amd import synth
+    kind, i, n_pts, rings, pose = args
+    world = synth.make_world()
+    return synth.make_scan(world, pose, n_pts, i, rings=rings)
+
+
+def build_workload(n_scan, n_map, n_queries, cache_dir="/tmp"):
+    """Same construction as synth.make_scan_to_map, but with the ray casting of
+    the individual scans spread over host cores, and cached on disk."""
+    from pgslam_amd import synth
+    key = f"pgslam_amd_s2m_{n_scan}_{n_map}_{n_queries}.npz"
+    path = os.path.join(cache_dir, key)
+    if os.path.exists(path):
+        z = np.load(path)
+        return synth.ScanToMap(z["map_xyz"], z["map_nrm"], list(z["scans_xyz"]), [None] * n_queries,
+                               list(z["T_truth"]), list(z["T_init"]))
+    import multiprocessing as mp
+    import math
+    n_map_poses = 12 if n_map <= 1_500_000 else 24
+    rings = 64 if n_scan >= 50_000 else 16
+    jitter = np.deg2rad(synth.uniform(synth.WORLD_SEED + 17, n_map_poses, -2.0, 2.0))
+    poses = [synth.se3(x=1.5 * i, yaw=float(jitter[i])) for i in range(n_map_poses)]
+    T_ref, T_ref_inv = poses[-1], synth.se3_inv(poses[-1])
+    per_scan = max(n_scan, -(-n_map // n_map_poses))
+    order = [n_map_poses - 1] + list(range(n_map_poses - 2, -1, -1))
+    qu = synth.uniform01(synth.WORLD_SEED + 33, 3 * n_queries).reshape(n_queries, 3)
+    T_q = []
+    for b in range(n_queries):
+        dx = 0.75 + (-0.5 + 1.0 * qu[b, 0])
+        dy = -0.3 + 0.6 * qu[b, 1]
+        dyaw = math.radians(-3.0 + 6.0 * qu[b, 2])
+        T_q.append(T_ref @ synth.se3(x=dx, y=dy, yaw=dyaw))
+    jobs = [("map", 1000 + i, per_scan, rings, poses[i]) for i in order] + \
+           [("query", b, n_scan, rings, T_q[b]) for b in range(n_queries)]
+    nproc = max(1, min(len(jobs), (os.cpu_count() or 1), 32))
+    with mp.get_context("fork").Pool(nproc) as pool:
+        res = pool.map(_gen_scan, jobs)
+    parts_p, parts_n = [], []
+    for k, i in enumerate(order):
+        p, n = synth.transform_cloud(T_ref_inv @ poses[i], res[k][0].astype(np.float64), res[k][1].astype(np.float64))
+        parts_p.append(p)
+        parts_n.append(n)
+    mp_, mn_ = np.concatenate(parts_p), np.concatenate(parts_n)
+    sel = (np.arange(n_map, dtype=np.int64) * mp_.shape[0]) // n_map
+    map_xyz, map_nrm = mp_[sel].astype(np.float32), mn_[sel].astype(np.float32)
+    scans = [res[len(order) + b][0] for b in range(n_queries)]
+    truth = [T_ref_inv @ T_q[b] for b in range(n_queries)]
+    init = [truth[b] @ synth.perturbation(b) for b in range(n_queries)]
+    try:
+        np.savez(path + ".tmp.npz", map_xyz=map_xyz, map_nrm=map_nrm, scans_xyz=np.stack(scans),
+                 T_truth=np.stack(truth), T_init=np.stack(init))
+        os.replace(path + ".tmp.npz", path)
+    except OSError:
+        pass
+    return synth.ScanToMap(map_xyz, map_nrm, scans, [None] * n_queries, truth, init)
+
+
+def cpu_baseline(w, sample_scans, max_threads):
+    """Time the oracle (kd-tree port of the reference chain) on host cores: one
+    independent ICP per thread (pgslam gives each ICP object one thread,
+    LocalizerMT.hpp:43-48).  The kd-tree build is timed separately (setMap)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle
+    o = Oracle(np.float32)
+    t0 = time.perf_counter()
+    m = o.map_create(w.map_xyz, w.map_nrm, center=True, use_kdtree=True)
+    t_build = time.perf_counter() - t0
+    n_thr = max(1, min(max_threads, sample_scans))
+    results = [None] * sample_scans
+
+    def work(tid):
+        for b in range(tid, sample_scans, n_thr):
+            q = b % len(w.scans_xyz)
+            results[b] = o.icp_map(m, w.scans_xyz[q], w.T_init[q], **CHAIN)
+
+    # single-core figure on one scan
+    t0 = time.perf_counter()
+    r0 = o.icp_map(m, w.scans_xyz[0], w.T_init[0], **CHAIN)
+    t_one = time.perf_counter() - t0
+    th = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    o.map_free(m)
+    conv = sum(1 for r in results if r["status"] == 0 and r["converged"])
+    iters = float(np.mean([r["iterations"] for r in results]))
+    return dict(value=conv / dt, unit="scans/s", cores=n_thr, kind="port",
+                sample=f"{sample_scans} of the benchmark's 100k-pt scans vs the 1M-pt map, kd-tree oracle, "
+                       f"one ICP per thread, {n_thr} threads; index build excluded",
+                single_core_scans_per_s=(1.0 / t_one if r0["status"] == 0 else 0.0),
+                mean_iterations=iters, index_build_s=t_build)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="independent scans aligned per step")
+    ap.add_argument("--queries", type=int, default=16, help="distinct query scans generated (cycled to fill the batch)")
+    ap.add_argument("--n-scan", type=int, default=100_000)
+    ap.add_argument("--n-map", type=int, default=1_000_000)
+    ap.add_argument("--fixed-iters", action="store_true", help="disable the Differential checker: exactly 30 iterations")
+    ap.add_argument("--matcher", choices=["grid", "brute"], default="grid")
+    ap.add_argument("--grid-cell", type=float, default=0.0)
+    ap.add_argument("--check-every", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pgslam_amd import icp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    # ---- inputs (rank 0 generates + caches, the others load the cache) ----
+    if rank == 0:
+        w = build_workload(args.n_scan, args.n_map, args.queries)
+    if distributed:
+        dist.barrier()
+    if rank != 0:
+        w = build_workload(args.n_scan, args.n_map, args.queries)
+
+    chain = dict(CHAIN)
+    if args.fixed_iters:
+        chain.update(min_diff_rot=0.0, min_diff_trans=0.0)
+    ctx = icp.Context(local_rank, **chain, matcher=icp.MATCHER_GRID if args.matcher == "grid" else icp.MATCHER_BRUTE,
+                      grid_cell=args.grid_cell, check_every=args.check_every)
+    d_map_xyz = torch.from_numpy(w.map_xyz).to(dev)
+    d_map_nrm = torch.from_numpy(w.map_nrm).to(dev)
+    d_scans = [torch.from_numpy(s).to(dev) for s in w.scans_xyz]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    map_id = ctx.set_map(d_map_xyz, d_map_nrm, center=True)
+    t_setmap = time.perf_counter() - t0
+
+    B = args.batch
+    readings = [d_scans[b % len(d_scans)] for b in range(B)]
+    # distinct problems even when scans are cycled: each slot has its own initial guess
+    from pgslam_amd import synth
+    T_inits = [w.T_truth[b % len(d_scans)] @ synth.perturbation(1000 * rank + b) for b in range(B)]
+
+    def step():
+        T, st = ctx.align_batch(map_id, readings, T_inits, raise_on_error=False)
+        return T, st
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    converged = 0
+    iters = []
+    last = None
+    for _ in range(args.steps):
+        T, st = step()
+        converged += sum(1 for s in st if s["status"] == 0 and s["converged"])
+        iters += [s["iterations"] for s in st]
+        last = (T, st)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_max = float(t.item())
+        cnt = torch.tensor([converged, args.steps * B, int(np.sum(iters))], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        converged_all, scans_all, iters_all = (int(x) for x in cnt.tolist())
+    else:
+        elapsed_max, converged_all, scans_all, iters_all = elapsed, converged, args.steps * B, int(np.sum(iters))
+
+    # accuracy of what was timed (not part of the metric, guards against a fast wrong answer)
+    T, st = last
+    err_t = [float(np.linalg.norm((np.linalg.inv(w.T_truth[b % len(d_scans)]) @ T[b])[:3, 3])) for b in range(B)
+             if st[b]["status"] == 0]
+
+    # ---- roofline: kNN kernel timed with HIP events on the context's stream ----
+    roofline = None
+    kern = {}
+    if not args.no_profile:
+        ctx.set_params(check_every=1)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        step()
+        ctx.profile_enable(False)
+        prof = ctx.profile()
+        kname = "knn_grid" if args.matcher == "grid" else "knn_brute"
+        k = prof[kname]
+        if k["launches"]:
+            alg_bytes = 20.0 * k["units"] + 12.0 * args.n_map * k["problems"]      # sum over launches
+            avg_s = k["total_ms"] * 1e-3 / k["launches"]
+            achieved = alg_bytes / k["launches"] / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("n_scan") == args.n_scan and tj.get("n_map") == args.n_map and tj.get("batch") == B:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except (OSError, ValueError):
+                    pass
+            roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                            avg_launch_us=avg_s * 1e6, launches=k["launches"],
+                            algorithmic_bytes_per_launch=alg_bytes / k["launches"],
+                            active_problems_per_launch=k["problems"] / k["launches"])
+        for name, v in prof.items():
+            if v["launches"]:
+                kern[name] = dict(launches=v["launches"], total_ms=round(v["total_ms"], 4),
+                                  avg_us=round(v["total_ms"] * 1e3 / v["launches"], 2))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w, args.cpu_sample, os.cpu_count() or 1)
+
+    if rank == 0:
+        value = converged_all / elapsed_max
+        out = {
+            "metric": "ICP-converged scans/sec at 100k-pt scan vs 1M-pt local map",
+            "value": value,
+            "unit": "scans/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"scan-to-map ICP, {args.n_scan}-pt Velodyne-shaped scan vs {args.n_map}-pt local map, "
+                                   f"<=30 iterations (BASELINE.json configs[1])",
+                       "batch_scans_per_step": B, "distinct_scans": len(d_scans), "matcher": args.matcher,
+                       "chain": chain, "fixed_iterations": bool(args.fixed_iters),
+                       "parallelism": f"{world} independent replica(s), one process per GPU"},
+            "scans_total": scans_all,
+            "scans_converged": converged_all,
+            "mean_iterations": iters_all / max(1, scans_all),
+            "set_map_ms": t_setmap * 1e3,
+            "median_translation_error_m": float(np.median(err_t)) if err_t else None,
+            "roofline": roofline,
+            "kernels": kern,
+            "cpu_baseline": cpu,
+        }
+        if cpu and cpu["value"] > 0:
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        print(json.dumps(out))
+    ctx.destroy_map(map_id)
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -242,7 +242,8 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
 int pgicp_profile_enable(pgicp_ctx *ctx, int on);
 int pgicp_profile_reset(pgicp_ctx *ctx);
 int pgicp_profile_get(pgicp_ctx *ctx, int kernel_id, long long *launches, double *total_ms,
-                      long long *units /* queries processed by those launches */);
+                      long long *units /* reading points of the ACTIVE problems of those launches */,
+                      long long *problems /* ACTIVE (not yet converged) problems of those launches */);
 
 #ifdef __cplusplus
 }

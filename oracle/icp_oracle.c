@@ -495,7 +495,7 @@ void FN(orc_delta_T)(const double *x, double *T)
 }
 
 /* rotation block -> unit quaternion (w,x,y,z), Shepperd's method */
-static void rot_to_quat(const double *T, double *q)
+__attribute__((unused)) static void rot_to_quat(const double *T, double *q)
 {
     const double m00 = T[0], m01 = T[1], m02 = T[2], m10 = T[4], m11 = T[5], m12 = T[6],
                  m20 = T[8], m21 = T[9], m22 = T[10];
@@ -518,7 +518,7 @@ static void rot_to_quat(const double *T, double *q)
 }
 
 /* Quaternion::angularDistance: d = a * conj(b); 2*atan2(|d.vec|, |d.w|) */
-static double quat_angdist(const double *a, const double *b)
+__attribute__((unused)) static double quat_angdist(const double *a, const double *b)
 {
     const double w = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
     const double x = -a[0] * b[1] + a[1] * b[0] - a[2] * b[3] + a[3] * b[2];
@@ -689,25 +689,53 @@ int FN(orc_partial_chain)(const FN(orc_params) *prm, const real *reading, int n,
 }
 
 /* --------------------------------------------------------------------------
- * [A.2] the ICP loop.  `trace` (optional) receives per iteration 16 doubles of
- * T_iter (so tests can compare trajectories); trace_cap = max iterations stored.
+ * [A.2] the ICP loop.  The reference side (copy, centre, index) is what
+ * ICPSequence::setMap / ICP::operator() do once per map; it is split off so the
+ * CPU baseline can time the per-scan loop separately from the index build
+ * (mirrors setMap's amortisation, Localizer.hpp:148,168,254).
+ * `trace` (optional) receives per iteration 16 doubles of T_iter.
  * ------------------------------------------------------------------------ */
-int FN(orc_icp)(const FN(orc_params) *prm, const real *reading, int n, const real *ref_xyz_in,
-                const real *ref_nrm, int m, const double *T_init, double *T_out, orc_result *res,
-                double *trace, int trace_cap, int *last_ids, real *last_d2)
+typedef struct {
+    real *ref;              /* centred copy of the reference xyz */
+    const real *nrm;        /* borrowed */
+    real mean[3];
+    int m;
+    void *tree;             /* kd-tree over ref, or NULL (brute force) */
+} FN(orc_map);
+
+void *FN(orc_map_create)(const real *ref_xyz, const real *ref_nrm, int m, int center, int use_kdtree)
 {
-    memset(res, 0, sizeof *res);
-    if (n <= 0 || m <= 0) { res->status = ORC_ERR_ARG; return ORC_ERR_ARG; }
-    real *ref = (real *)malloc(sizeof(real) * 3 * m);
-    real mean[3] = {0, 0, 0};
-    if (prm->center_reference) {
-        FN(orc_centroid)(ref_xyz_in, m, mean);
+    FN(orc_map) *M = (FN(orc_map) *)calloc(1, sizeof *M);
+    M->m = m; M->nrm = ref_nrm;
+    M->ref = (real *)malloc(sizeof(real) * 3 * (m > 0 ? m : 1));
+    if (center) {
+        FN(orc_centroid)(ref_xyz, m, M->mean);
         for (int i = 0; i < m; i++)
-            for (int a = 0; a < 3; a++) ref[3 * i + a] = ref_xyz_in[3 * i + a] - mean[a];
-    } else memcpy(ref, ref_xyz_in, sizeof(real) * 3 * m);
+            for (int a = 0; a < 3; a++) M->ref[3 * i + a] = ref_xyz[3 * i + a] - M->mean[a];
+    } else memcpy(M->ref, ref_xyz, sizeof(real) * 3 * m);
+    M->tree = use_kdtree ? FN(orc_kdtree_build)(M->ref, m) : NULL;
+    return M;
+}
+
+void FN(orc_map_free)(void *h)
+{
+    FN(orc_map) *M = (FN(orc_map) *)h;
+    if (!M) return;
+    if (M->tree) FN(orc_kdtree_free)(M->tree);
+    free(M->ref); free(M);
+}
+
+int FN(orc_icp_map)(const FN(orc_params) *prm, const void *map, const real *reading, int n, const double *T_init,
+                    double *T_out, orc_result *res, double *trace, int trace_cap, int *last_ids, real *last_d2)
+{
+    const FN(orc_map) *M = (const FN(orc_map) *)map;
+    memset(res, 0, sizeof *res);
+    if (n <= 0 || M->m <= 0) { res->status = ORC_ERR_ARG; return ORC_ERR_ARG; }
+    const real *ref = M->ref, *ref_nrm = M->nrm;
+    const int m = M->m;
     double T_ref_mean[16], T_ref_mean_inv[16], T_pre[16];
     mat4_identity(T_ref_mean);
-    T_ref_mean[3] = mean[0]; T_ref_mean[7] = mean[1]; T_ref_mean[11] = mean[2];
+    T_ref_mean[3] = M->mean[0]; T_ref_mean[7] = M->mean[1]; T_ref_mean[11] = M->mean[2];
     mat4_rigid_inverse(T_ref_mean, T_ref_mean_inv);
     mat4_mul(T_ref_mean_inv, T_init, T_pre);
 
@@ -718,7 +746,7 @@ int FN(orc_icp)(const FN(orc_params) *prm, const real *reading, int n, const rea
     real *w = (real *)malloc(sizeof(real) * n);
     FN(orc_transform)(T_pre, reading, rd, n, 0);
 
-    void *tree = prm->use_kdtree ? FN(orc_kdtree_build)(ref, m) : NULL;
+    void *tree = M->tree;
     double T_iter[16], dT[16], T_prev[16];
     mat4_identity(T_iter); mat4_identity(dT); mat4_identity(T_prev);
     orc_checker chk;
@@ -763,7 +791,17 @@ int FN(orc_icp)(const FN(orc_params) *prm, const real *reading, int n, const rea
     } else mat4_identity(T_out);
     if (last_ids) memcpy(last_ids, ids, sizeof(int) * n);
     if (last_d2) memcpy(last_d2, d2, sizeof(real) * n);
-    if (tree) FN(orc_kdtree_free)(tree);
-    free(ref); free(rd); free(step); free(ids); free(d2); free(w);
+    free(rd); free(step); free(ids); free(d2); free(w);
     return status;
+}
+
+int FN(orc_icp)(const FN(orc_params) *prm, const real *reading, int n, const real *ref_xyz_in,
+                const real *ref_nrm, int m, const double *T_init, double *T_out, orc_result *res,
+                double *trace, int trace_cap, int *last_ids, real *last_d2)
+{
+    if (n <= 0 || m <= 0) { memset(res, 0, sizeof *res); res->status = ORC_ERR_ARG; return ORC_ERR_ARG; }
+    void *M = FN(orc_map_create)(ref_xyz_in, ref_nrm, m, prm->center_reference, prm->use_kdtree);
+    const int st = FN(orc_icp_map)(prm, M, reading, n, T_init, T_out, res, trace, trace_cap, last_ids, last_d2);
+    FN(orc_map_free)(M);
+    return st;
 }

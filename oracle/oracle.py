@@ -200,6 +200,27 @@ class Oracle:
             out["trace"] = tr[: res.iterations]
         return out
 
+    # -- prebuilt reference (setMap amortisation) ---------------------------
+    def map_create(self, ref_xyz, ref_nrm, center=True, use_kdtree=True):
+        ref_xyz, ref_nrm = self._a(ref_xyz), self._a(ref_nrm)
+        f = self._f("orc_map_create"); f.restype = C.c_void_p
+        h = f(self._p(ref_xyz), self._p(ref_nrm), C.c_int(ref_xyz.shape[0]), C.c_int(int(center)), C.c_int(int(use_kdtree)))
+        return (C.c_void_p(h), ref_xyz, ref_nrm)            # keep the borrowed arrays alive
+
+    def map_free(self, m):
+        self._f("orc_map_free")(m[0])
+
+    def icp_map(self, m, reading, T_init, **kw):
+        reading = self._a(reading)
+        prm = self.params(**kw)
+        T_init = np.ascontiguousarray(T_init, dtype=np.float64)
+        T_out = np.zeros((4, 4))
+        res = Result()
+        st = self._f("orc_icp_map")(C.byref(prm), m[0], self._p(reading), C.c_int(reading.shape[0]), self._p(T_init),
+                                    self._p(T_out), C.byref(res), None, C.c_int(0), None, None)
+        return dict(status=st, T=T_out, iterations=res.iterations, converged=bool(res.converged),
+                    max_iter_reached=bool(res.max_iter_reached), overlap=res.overlap, residual=res.residual)
+
     # -- checker (type independent) ---------------------------------------
     def checker(self, max_iters, min_rot, min_trans, smooth):
         c = Checker()

@@ -61,6 +61,7 @@ struct ProfEvent {
     hipEvent_t a, b;
     int kid;
     long long units;
+    long long problems;
 };
 
 }  // namespace
@@ -79,6 +80,7 @@ struct pgicp_ctx {
     long long prof_launches[PGICP_PROF_COUNT] = {0};
     double prof_ms[PGICP_PROF_COUNT] = {0};
     long long prof_units[PGICP_PROF_COUNT] = {0};
+    long long prof_problems[PGICP_PROF_COUNT] = {0};
 };
 
 namespace {
@@ -127,11 +129,12 @@ struct ProfScope {
     int kid;
     ProfEvent ev{};
     bool on;
-    ProfScope(pgicp_ctx *c_, int kid_, long long units) : c(c_), kid(kid_), on(c_->prof_on)
+    ProfScope(pgicp_ctx *c_, int kid_, long long units, long long problems = 1) : c(c_), kid(kid_), on(c_->prof_on)
     {
         if (!on) return;
         ev.kid = kid;
         ev.units = units;
+        ev.problems = problems;
         if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(ev.a, c->stream);
     }
@@ -153,6 +156,7 @@ void prof_collect(pgicp_ctx *c)
             c->prof_launches[e.kid] += 1;
             c->prof_ms[e.kid] += ms;
             c->prof_units[e.kid] += e.units;
+            c->prof_problems[e.kid] += e.problems;
         }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -381,7 +385,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     HIPC(c, hipMemcpyAsync(c->src.p, hs.data(), sizeof(SrcDesc) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
     {
-        ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total);
+        ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
         launch_pretransform<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.rd_pre.template as<T>(), P, L.max_n);
     }
     // hs/hp must outlive the async copies
@@ -390,27 +394,28 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
 }
 
 template <typename T>
-void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bool with_solve)
+void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bool with_solve, long long act_units,
+                   long long act_probs)
 {
     State<T> &S = state<T>(c);
     const MapDev<T> *maps = S.d_maps.template as<MapDev<T>>();
     ProblemDev *probs = c->probs.as<ProblemDev>();
     {
-        ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, L.total);
+        ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, L.P, L.max_n);
     }
     {
-        ProfScope ps(c, PGICP_PROF_TRIM, L.total);
+        ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
         launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, L.P);
     }
     {
-        ProfScope ps(c, PGICP_PROF_REDUCE, L.total);
+        ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
         launch_reduce<T>(c->stream, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
                          c->partials.as<double>(), L.P, L.max_n);
     }
     if (with_solve) {
-        ProfScope ps(c, PGICP_PROF_SOLVE, L.P);
+        ProfScope ps(c, PGICP_PROF_SOLVE, act_units, act_probs);
         launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), L.P, L.max_n);
     }
 }
@@ -441,16 +446,21 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     if (st) return st;
     const ChainDev<T> ch = make_chain<T>(prm);
     const int every = std::max(1, prm.check_every);
+    // active-problem accounting for the profile: exact when check_every == 1 and all
+    // readings have the same size (the benchmark's case), an upper bound otherwise
+    int n_done = 0;
     for (int it = 0; it < prm.max_iters; it++) {
-        one_iteration<T>(c, L, ch, true);
+        const long long act_p = P - n_done;
+        one_iteration<T>(c, L, ch, true, L.total * act_p / P, act_p);
         if ((it + 1) % every == 0 || it + 1 == prm.max_iters) {
             HIPC(c, hipMemcpyAsync(c->h_pinned, c->small.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPC(c, hipStreamSynchronize(c->stream));
-            if (c->h_pinned[0] >= P) break;
+            n_done = c->h_pinned[0];
+            if (n_done >= P) break;
         }
     }
     {
-        ProfScope ps(c, PGICP_PROF_COV, L.total);
+        ProfScope ps(c, PGICP_PROF_COV, L.total, P);
         launch_cov<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(), S.rd_pre.template as<T>(),
                       S.slot.template as<int>(), S.d2.template as<T>(), c->partials.as<double>(), c->sums.as<double>(), P,
                       L.max_n);
@@ -1030,17 +1040,18 @@ int pgicp_profile_reset(pgicp_ctx *c)
 {
     if (!c) return PGICP_ERR_ARG;
     prof_collect(c);
-    for (int i = 0; i < PGICP_PROF_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_units[i] = 0; }
+    for (int i = 0; i < PGICP_PROF_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_units[i] = 0; c->prof_problems[i] = 0; }
     return PGICP_OK;
 }
 
-int pgicp_profile_get(pgicp_ctx *c, int kid, long long *launches, double *total_ms, long long *units)
+int pgicp_profile_get(pgicp_ctx *c, int kid, long long *launches, double *total_ms, long long *units, long long *problems)
 {
     if (!c || kid < 0 || kid >= PGICP_PROF_COUNT) return PGICP_ERR_ARG;
     prof_collect(c);
     if (launches) *launches = c->prof_launches[kid];
     if (total_ms) *total_ms = c->prof_ms[kid];
     if (units) *units = c->prof_units[kid];
+    if (problems) *problems = c->prof_problems[kid];
     return PGICP_OK;
 }
 

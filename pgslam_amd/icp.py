@@ -345,9 +345,9 @@ class Context:
     def profile(self):
         out = {}
         for kid, name in enumerate(PROF_NAMES):
-            n, ms, u = C.c_longlong(0), C.c_double(0), C.c_longlong(0)
-            self._check(self.lib.pgicp_profile_get(self.h, C.c_int(kid), C.byref(n), C.byref(ms), C.byref(u)))
-            out[name] = dict(launches=n.value, total_ms=ms.value, units=u.value)
+            n, ms, u, pr = C.c_longlong(0), C.c_double(0), C.c_longlong(0), C.c_longlong(0)
+            self._check(self.lib.pgicp_profile_get(self.h, C.c_int(kid), C.byref(n), C.byref(ms), C.byref(u), C.byref(pr)))
+            out[name] = dict(launches=n.value, total_ms=ms.value, units=u.value, problems=pr.value)
         return out
 
 
