@@ -29,9 +29,10 @@ struct MapDev {
     const typename Vec4<T>::type *pts;   // (x, y, z, bit-cast original index) cell-sorted, centred
     const typename Vec4<T>::type *nrm;   // (nx, ny, nz, 0) same order; may be null
     const int *cell_start;               // ncells + 1 exclusive prefix sums
+    const int *sc_count;                 // points per 8x8x8 super-cell (coarse occupancy)
     GridDesc<T> g;
     int m;
-    int pad_;
+    int nsx, nsy, nsz;                   // super-cell grid dims
 };
 
 // Chain parameters as the kernels need them.

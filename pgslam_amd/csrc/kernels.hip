@@ -123,7 +123,8 @@ __device__ __forceinline__ int build_cell(const GridDesc<T> &g, T x, T y, T z)
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_cell_count(const T *__restrict__ xyz, int stride, int m, T mx, T my, T mz,
-                                                     GridDesc<T> g, int *__restrict__ cell_of, int *__restrict__ counts)
+                                                     GridDesc<T> g, int *__restrict__ cell_of, int *__restrict__ counts,
+                                                     int *__restrict__ sc_count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
@@ -132,6 +133,10 @@ __global__ __launch_bounds__(256) void k_cell_count(const T *__restrict__ xyz, i
     const int c = build_cell(g, x, y, z);
     cell_of[i] = c;
     atomicAdd(&counts[c], 1);
+    // occupancy of the 8x8x8 super-cell (used by the wave-cooperative slow path)
+    const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+    const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3;
+    atomicAdd(&sc_count[(cx >> 3) + nsx * ((cy >> 3) + nsy * (cz >> 3))], 1);
 }
 
 // three-phase exclusive scan over `n` ints (n up to 2^27)
@@ -215,49 +220,39 @@ __global__ __launch_bounds__(1024) void k_scan_final(const int *__restrict__ in,
     if (base <= n - 1 && n - 1 < base + 4) out[n] = ex;    // the thread holding the last element
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_scatter(const T *__restrict__ xyz, int stride, const T *__restrict__ nrm,
-                                                  int nstride, int m, T mx, T my, T mz, const int *__restrict__ cell_of,
-                                                  int *__restrict__ cursor, typename Vec4<T>::type *__restrict__ pts,
-                                                  typename Vec4<T>::type *__restrict__ nrm_out, int *__restrict__ slot_of)
+// Cells are filled through an atomic cursor (arbitrary order inside a cell); the
+// rank kernel then places every point at cell_start + (number of points of the
+// same cell with a smaller original index), so the resident layout -- and with
+// it every later sum order -- is reproducible run to run.
+__global__ __launch_bounds__(256) void k_scatter_idx(int m, const int *__restrict__ cell_of, int *__restrict__ cursor,
+                                                      int *__restrict__ order_tmp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
+    order_tmp[atomicAdd(&cursor[cell_of[i]], 1)] = i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_rank_place(const T *__restrict__ xyz, int stride, const T *__restrict__ nrm,
+                                                     int nstride, int m, T mx, T my, T mz, const int *__restrict__ cell_of,
+                                                     const int *__restrict__ cell_start, const int *__restrict__ order_tmp,
+                                                     typename Vec4<T>::type *__restrict__ pts,
+                                                     typename Vec4<T>::type *__restrict__ nrm_out, int *__restrict__ slot_of)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int i = order_tmp[j];
+    const int c = cell_of[i];
+    const int a = cell_start[c], b = cell_start[c + 1];
+    int rank = 0;
+    for (int k = a; k < b; ++k) rank += (order_tmp[k] < i) ? 1 : 0;
+    const int pos = a + rank;
     const T x = xyz[(long long)i * stride] - mx, y = xyz[(long long)i * stride + 1] - my,
             z = xyz[(long long)i * stride + 2] - mz;
-    const int pos = atomicAdd(&cursor[cell_of[i]], 1);
     pts[pos] = make_v4(x, y, z, Bits<T>::pack_idx(i));
     if (nrm) nrm_out[pos] = make_v4(nrm[(long long)i * nstride], nrm[(long long)i * nstride + 1],
                                     nrm[(long long)i * nstride + 2], (T)0);
     slot_of[i] = pos;
-}
-
-// Cells are filled through an atomic cursor, so the order inside a cell is
-// arbitrary.  Re-sort every cell by original index (cells are small) so that
-// the resident layout -- and with it every later sum order -- is reproducible.
-template <typename T>
-__global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell_start, int ncells,
-                                                     typename Vec4<T>::type *__restrict__ pts,
-                                                     typename Vec4<T>::type *__restrict__ nrm, int *__restrict__ slot_of)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells) return;
-    const int a = cell_start[c], b = cell_start[c + 1];
-    for (int i = a + 1; i < b; i++) {           // insertion sort by original index
-        const auto p = pts[i];
-        const int key = Bits<T>::unpack_idx(p.w);
-        typename Vec4<T>::type nn = p;
-        if (nrm) nn = nrm[i];
-        int j = i - 1;
-        while (j >= a && Bits<T>::unpack_idx(pts[j].w) > key) {
-            pts[j + 1] = pts[j];
-            if (nrm) nrm[j + 1] = nrm[j];
-            j--;
-        }
-        pts[j + 1] = p;
-        if (nrm) nrm[j + 1] = nn;
-    }
-    for (int i = a; i < b; i++) slot_of[Bits<T>::unpack_idx(pts[i].w)] = i;
 }
 
 // ---------------------------------------------------------------------------
@@ -298,6 +293,87 @@ __global__ __launch_bounds__(256) void k_pretransform(const ProblemDev *__restri
 }
 
 // ---------------------------------------------------------------------------
+// reading sort: once per scan the (pre-transformed) reading is ordered by the
+// (y,z) row of the map grid it falls in, then by x.  A rigid correction keeps
+// neighbours neighbours, so for every later iteration the 64 queries of a wave
+// walk the same few rows of the cell-sorted map: their candidate loads hit the
+// same cache lines instead of 64 different ones.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ int clamp_cell(T u, T inv_h, int n)
+{
+    const T lim = (T)16777216.0;
+    return min(max((int)fmin(fmax(floor(u * inv_h), -lim), lim), 0), n - 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_qbin(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
+                                               const T *__restrict__ rd_pre, int max_rows, int *__restrict__ qrow,
+                                               int *__restrict__ counts)
+{
+    const ProblemDev &P = probs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const GridDesc<T> g = maps[P.map].g;
+    const T *q = rd_pre + 3 * (P.off + i);
+    const int cy = clamp_cell<T>(q[1] - g.oy, g.inv_h, g.ny), cz = clamp_cell<T>(q[2] - g.oz, g.inv_h, g.nz);
+    int row = cy + g.ny * cz;
+    if (row >= max_rows) row = max_rows - 1;
+    qrow[P.off + i] = row;
+    atomicAdd(&counts[(long long)blockIdx.y * max_rows + row], 1);
+}
+
+__global__ __launch_bounds__(256) void k_qscatter(const ProblemDev *__restrict__ probs, int max_rows,
+                                                   const int *__restrict__ qrow, int *__restrict__ cursor,
+                                                   int *__restrict__ qtmp)
+{
+    const ProblemDev &P = probs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    qtmp[atomicAdd(&cursor[(long long)blockIdx.y * max_rows + qrow[P.off + i]], 1)] = i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_qrank(const ProblemDev *__restrict__ probs, int max_rows,
+                                                const int *__restrict__ qrow, const int *__restrict__ qstart,
+                                                const int *__restrict__ qtmp, const T *__restrict__ rd_pre,
+                                                T *__restrict__ rd_sorted, int *__restrict__ order)
+{
+    const ProblemDev &P = probs[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n) return;
+    const int i = qtmp[P.off + j];
+    const long long bin = (long long)blockIdx.y * max_rows + qrow[P.off + i];
+    const int a = qstart[bin], b = qstart[bin + 1];
+    const T xi = rd_pre[3 * (P.off + i)];
+    int rank = 0;
+    for (int k = a; k < b; ++k) {
+        const int ik = qtmp[k];
+        const T xk = rd_pre[3 * (P.off + ik)];
+        rank += (xk < xi || (xk == xi && ik < i)) ? 1 : 0;
+    }
+    const int f = a + rank;                       // global position (scan runs over all problems)
+    order[f] = i;
+    const T *src = rd_pre + 3 * (P.off + i);
+    T *dst = rd_sorted + 3 * (long long)f;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+// results in reading order for the public matcher output
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpermute(const MapDev<T> *__restrict__ maps, int map, const int *__restrict__ order,
+                                                    const int *__restrict__ slot, const T *__restrict__ d2, int n,
+                                                    int *__restrict__ ids_out, T *__restrict__ d2_out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int i = order[j];
+    const int s = slot[j];
+    ids_out[i] = s < 0 ? -1 : Bits<T>::unpack_idx(maps[map].pts[s].w);
+    d2_out[i] = d2[j];
+}
+
+// ---------------------------------------------------------------------------
 // matcher: exact nearest neighbour on the cell-sorted map
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -308,16 +384,27 @@ struct Best {
 };
 
 template <typename T>
+__device__ __forceinline__ void eval_point(const typename Vec4<T>::type v, int s, T qx, T qy, T qz, Best<T> &best)
+{
+    const T dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+    const T d = (dx * dx + dy * dy) + dz * dz;
+    const int idx = Bits<T>::unpack_idx(v.w);
+    if (d < best.d2 || (d == best.d2 && idx < best.idx)) { best.d2 = d; best.idx = idx; best.slot = s; }
+}
+
+template <typename T>
 __device__ __forceinline__ void scan_range(const typename Vec4<T>::type *__restrict__ pts, int a, int b, T qx, T qy,
                                            T qz, Best<T> &best)
 {
-    for (int s = a; s < b; ++s) {
-        const auto v = pts[s];
-        const T dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
-        const T d = (dx * dx + dy * dy) + dz * dz;
-        const int idx = Bits<T>::unpack_idx(v.w);
-        if (d < best.d2 || (d == best.d2 && idx < best.idx)) { best.d2 = d; best.idx = idx; best.slot = s; }
+    int s = a;
+    for (; s + 4 <= b; s += 4) {                 // four independent loads in flight
+        const auto v0 = pts[s], v1 = pts[s + 1], v2 = pts[s + 2], v3 = pts[s + 3];
+        eval_point<T>(v0, s, qx, qy, qz, best);
+        eval_point<T>(v1, s + 1, qx, qy, qz, best);
+        eval_point<T>(v2, s + 2, qx, qy, qz, best);
+        eval_point<T>(v3, s + 3, qx, qy, qz, best);
     }
+    for (; s < b; ++s) eval_point<T>(pts[s], s, qx, qy, qz, best);
 }
 
 // distance from coordinate offset u (= x - origin) to the slab of cell c
@@ -329,27 +416,35 @@ __device__ __forceinline__ T slab_dist(T u, int c, T h)
     return fmax((T)0, fmax(lo, hi));
 }
 
-// Exact NN by expanding Chebyshev rings of cells around the query's (clamped)
-// cell.  Rows (fixed y,z) are contiguous in memory, so a ring costs one or two
-// range look-ups per row.  A row is skipped when its slab distance already
-// exceeds the best candidate; the search stops when every unexamined cell is
-// provably farther than the best candidate, or farther than maxDist.
+// One (y,z) row of cells, restricted to cells [xa,xb]: the cells of a row are
+// contiguous in memory, and only those within sqrt(best - rowdist^2) of the
+// query in x can hold a better point.
 template <typename T>
-__device__ __forceinline__ Best<T> grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T max_dist, T max_dist2)
+__device__ __forceinline__ void scan_row(const MapDev<T> &M, int row_base, int xa, int xb, T ux, T lb2, T qx, T qy, T qz,
+                                         Best<T> &best)
+{
+    if (best.d2 < Bits<T>::inf()) {
+        const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + M.g.margin;
+        xa = max(xa, clamp_cell<T>(ux - rad, M.g.inv_h, M.g.nx));
+        xb = min(xb, clamp_cell<T>(ux + rad, M.g.inv_h, M.g.nx));
+        if (xa > xb) return;
+    }
+    scan_range<T>(M.pts, M.cell_start[row_base + xa], M.cell_start[row_base + xb + 1], qx, qy, qz, best);
+}
+
+// Exact NN by expanding Chebyshev rings of cells around the query's (clamped)
+// cell.  A row is skipped when its slab distance already exceeds the best
+// candidate; the search is RESOLVED when every unexamined cell is provably
+// farther than the best candidate or than maxDist.  At most `max_rings` rings
+// are walked here (the per-lane fast path); returns false if unresolved.
+template <typename T>
+__device__ __forceinline__ bool grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T max_dist, int max_rings, Best<T> &best)
 {
     const GridDesc<T> g = M.g;
-    const int *__restrict__ cs = M.cell_start;
-    const auto *__restrict__ pts = M.pts;
-    Best<T> best;
-    best.d2 = max_dist2;            // seed: anything farther than maxDist is useless
-    best.idx = 0x7FFFFFFF;
-    best.slot = -1;
     const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
-    const T lim = (T)16777216.0;
-    const int c0x = min(max((int)fmin(fmax(floor(ux * g.inv_h), -lim), lim), 0), g.nx - 1);
-    const int c0y = min(max((int)fmin(fmax(floor(uy * g.inv_h), -lim), lim), 0), g.ny - 1);
-    const int c0z = min(max((int)fmin(fmax(floor(uz * g.inv_h), -lim), lim), 0), g.nz - 1);
-    for (int r = 0;; ++r) {
+    const int c0x = clamp_cell<T>(ux, g.inv_h, g.nx), c0y = clamp_cell<T>(uy, g.inv_h, g.ny),
+              c0z = clamp_cell<T>(uz, g.inv_h, g.nz);
+    for (int r = 0; r <= max_rings; ++r) {
         const int z0 = max(c0z - r, 0), z1 = min(c0z + r, g.nz - 1);
         const int y0 = max(c0y - r, 0), y1 = min(c0y + r, g.ny - 1);
         const int xa = max(c0x - r, 0), xb = min(c0x + r, g.nx - 1);
@@ -358,13 +453,14 @@ __device__ __forceinline__ Best<T> grid_nn(const MapDev<T> &M, T qx, T qy, T qz,
             const bool zo = (z - c0z == r) || (c0z - z == r);
             for (int y = y0; y <= y1; ++y) {
                 const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
-                if (ly * ly + lz * lz > best.d2) continue;
+                const T lb2 = ly * ly + lz * lz;
+                if (lb2 > best.d2) continue;
                 const int row = g.nx * (y + g.ny * z);
                 if (zo || (y - c0y == r) || (c0y - y == r)) {
-                    scan_range<T>(pts, cs[row + xa], cs[row + xb + 1], qx, qy, qz, best);
-                } else {
-                    if (c0x - r >= 0) scan_range<T>(pts, cs[row + c0x - r], cs[row + c0x - r + 1], qx, qy, qz, best);
-                    if (c0x + r <= g.nx - 1) scan_range<T>(pts, cs[row + c0x + r], cs[row + c0x + r + 1], qx, qy, qz, best);
+                    scan_row<T>(M, row, xa, xb, ux, lb2, qx, qy, qz, best);
+                } else {                         // inner row of the shell: only its two end cells are new
+                    if (c0x - r >= 0) scan_row<T>(M, row, c0x - r, c0x - r, ux, lb2, qx, qy, qz, best);
+                    if (c0x + r <= g.nx - 1) scan_row<T>(M, row, c0x + r, c0x + r, ux, lb2, qx, qy, qz, best);
                 }
             }
         }
@@ -376,30 +472,149 @@ __device__ __forceinline__ Best<T> grid_nn(const MapDev<T> &M, T qx, T qy, T qz,
         if (c0y + r + 1 <= g.ny - 1) gr = fmin(gr, slab_dist(uy, c0y + r + 1, g.h));
         if (c0z - r - 1 >= 0) gr = fmin(gr, slab_dist(uz, c0z - r - 1, g.h));
         if (c0z + r + 1 <= g.nz - 1) gr = fmin(gr, slab_dist(uz, c0z + r + 1, g.h));
-        if (!(gr < Bits<T>::inf())) break;                              // grid exhausted
+        if (!(gr < Bits<T>::inf())) return true;                        // grid exhausted
         gr = gr - g.margin;
-        if (gr > (T)0 && (best.d2 < gr * gr || gr > max_dist)) break;
+        if (gr > (T)0 && (best.d2 < gr * gr || gr > max_dist)) return true;
     }
-    if (best.slot < 0) { best.d2 = Bits<T>::inf(); best.idx = -1; }
-    return best;
+    return false;
 }
 
+constexpr int kFastRings = 3;       // rings walked per lane before a query is handed to the wave-cooperative path
+
+// Fast path: one query per lane.  The previous iteration's match (if any) seeds
+// the bound, so from the second iteration on almost every query is resolved
+// inside its own cell and the few touching rows.  Unresolved queries (no
+// neighbour within kFastRings cells) are queued for k_knn_slow.
 template <typename T>
 __global__ __launch_bounds__(kKnnBlock) void k_knn_grid(const ProblemDev *__restrict__ probs,
-                                                         const MapDev<T> *__restrict__ maps, const T *__restrict__ rd_pre,
-                                                         int *__restrict__ slot_out, T *__restrict__ d2_out,
-                                                         ChainDev<T> ch)
+                                                         const MapDev<T> *__restrict__ maps, const T *__restrict__ rd,
+                                                         int *__restrict__ slot_io, T *__restrict__ d2_out,
+                                                         ChainDev<T> ch, int use_seed, int *__restrict__ slow_count,
+                                                         int2 *__restrict__ slow_list)
 {
     const ProblemDev &P = probs[blockIdx.y];
     if (P.done) return;
     const int i = xcd_tile(blockIdx.x, gridDim.x) * kKnnBlock + threadIdx.x;
     if (i >= P.n) return;
-    const T *q = rd_pre + 3 * (P.off + i);
+    const T *q = rd + 3 * (P.off + i);
     T qx, qy, qz;
     apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
-    const Best<T> b = grid_nn<T>(maps[P.map], qx, qy, qz, ch.max_dist, ch.max_dist2);
-    slot_out[P.off + i] = b.slot;
-    d2_out[P.off + i] = b.d2;
+    const MapDev<T> M = maps[P.map];
+    Best<T> best;
+    best.d2 = ch.max_dist2;            // anything farther than maxDist is useless
+    best.idx = 0x7FFFFFFF;
+    best.slot = -1;
+    if (use_seed) {
+        const int prev = slot_io[P.off + i];
+        if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
+    }
+    const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, kFastRings, best);
+    if (!resolved) {
+        const int k = atomicAdd(slow_count, 1);
+        slow_list[k] = make_int2((int)blockIdx.y, i);
+    }
+    if (best.slot < 0) best.d2 = Bits<T>::inf();
+    slot_io[P.off + i] = best.slot;    // doubles as the slow path's seed
+    d2_out[P.off + i] = best.d2;
+}
+
+// Slow path: one WAVE per queued query (no neighbour proven within kFastRings
+// cells).  Rings of 8x8x8 SUPER-cells are walked around the query: the lanes
+// first test one super-cell of the shell each (occupancy count, box distance
+// against the wave's bound), then every surviving super-cell is scanned by the
+// whole wave, one lane per (y,z) row of it.  Empty space costs one table look-up
+// per super-cell, so proving "nothing within maxDist" stays cheap.  A
+// lexicographic (d2, index) wave reduction picks the winner.
+template <typename T>
+__global__ __launch_bounds__(256) void k_knn_slow(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
+                                                   const T *__restrict__ rd, int *__restrict__ slot_io,
+                                                   T *__restrict__ d2_out, ChainDev<T> ch,
+                                                   const int *__restrict__ slow_count, const int2 *__restrict__ slow_list)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int count = *slow_count;
+    for (int k = wave; k < count; k += nwaves) {
+        const int2 e = slow_list[k];
+        const ProblemDev &P = probs[e.x];
+        const int i = e.y;
+        const T *q = rd + 3 * (P.off + i);
+        T qx, qy, qz;
+        apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
+        const MapDev<T> M = maps[P.map];
+        const GridDesc<T> g = M.g;
+        const T H = g.h * (T)8;
+        Best<T> best;
+        best.d2 = ch.max_dist2; best.idx = 0x7FFFFFFF; best.slot = -1;
+        const int prev = slot_io[P.off + i];
+        if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
+        const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+        const int Cx = clamp_cell<T>(ux, g.inv_h, g.nx) >> 3, Cy = clamp_cell<T>(uy, g.inv_h, g.ny) >> 3,
+                  Cz = clamp_cell<T>(uz, g.inv_h, g.nz) >> 3;
+        for (int R = 0;; ++R) {
+            const int side = 2 * R + 1, total = side * side * side;
+            for (int base = 0; base < total; base += 64) {
+                const int t = base + lane;
+                const int dx = t % side - R, dy = (t / side) % side - R, dz = t / (side * side) - R;
+                const int X = Cx + dx, Y = Cy + dy, Z = Cz + dz;
+                bool need = t < total && (abs(dx) == R || abs(dy) == R || abs(dz) == R) && X >= 0 && X < M.nsx &&
+                            Y >= 0 && Y < M.nsy && Z >= 0 && Z < M.nsz;
+                if (need) need = M.sc_count[X + M.nsx * (Y + M.nsy * Z)] > 0;
+                if (need) {
+                    const T bx = fmax(slab_dist(ux, X, H) - g.margin, (T)0), by = fmax(slab_dist(uy, Y, H) - g.margin, (T)0),
+                            bz = fmax(slab_dist(uz, Z, H) - g.margin, (T)0);
+                    need = !((bx * bx + by * by) + bz * bz > best.d2);
+                }
+                unsigned long long mask = __ballot(need);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int SX = __shfl(X, src, 64), SY = __shfl(Y, src, 64), SZ = __shfl(Z, src, 64);
+                    const int y = 8 * SY + (lane & 7), z = 8 * SZ + (lane >> 3);
+                    if (y < g.ny && z < g.nz) {
+                        const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
+                        const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
+                        const T lb2 = ly * ly + lz * lz;
+                        if (!(lb2 > best.d2))
+                            scan_row<T>(M, g.nx * (y + g.ny * z), 8 * SX, min(8 * SX + 7, g.nx - 1), ux, lb2, qx, qy, qz, best);
+                    }
+                    // share the tightest bound (pruning only; the winner is reduced at the end)
+                    T wmin = best.d2;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) wmin = fmin(wmin, __shfl_xor(wmin, o, 64));
+                    if (wmin < best.d2) { best.d2 = wmin; best.idx = 0x7FFFFFFF; best.slot = -1; }
+                }
+            }
+            // every super-cell outside ring R is at least this far away (wave-uniform)
+            T gr = Bits<T>::inf();
+            if (Cx - R - 1 >= 0) gr = fmin(gr, slab_dist(ux, Cx - R - 1, H));
+            if (Cx + R + 1 <= M.nsx - 1) gr = fmin(gr, slab_dist(ux, Cx + R + 1, H));
+            if (Cy - R - 1 >= 0) gr = fmin(gr, slab_dist(uy, Cy - R - 1, H));
+            if (Cy + R + 1 <= M.nsy - 1) gr = fmin(gr, slab_dist(uy, Cy + R + 1, H));
+            if (Cz - R - 1 >= 0) gr = fmin(gr, slab_dist(uz, Cz - R - 1, H));
+            if (Cz + R + 1 <= M.nsz - 1) gr = fmin(gr, slab_dist(uz, Cz + R + 1, H));
+            if (!(gr < Bits<T>::inf())) break;
+            gr = gr - g.margin;
+            T wbest = best.d2;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wbest = fmin(wbest, __shfl_xor(wbest, o, 64));
+            if (gr > (T)0 && (wbest < gr * gr || gr > ch.max_dist)) break;
+        }
+        // lexicographic (d2, idx) minimum over the wave; lanes whose bound was only borrowed hold slot -1
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const T od = __shfl_xor(best.d2, o, 64);
+            const int oi = __shfl_xor(best.idx, o, 64);
+            const int os = __shfl_xor(best.slot, o, 64);
+            if (od < best.d2 || (od == best.d2 && oi < best.idx)) { best.d2 = od; best.idx = oi; best.slot = os; }
+        }
+        if (lane == 0) {
+            if (best.slot < 0) best.d2 = Bits<T>::inf();
+            slot_io[P.off + i] = best.slot;
+            d2_out[P.off + i] = best.d2;
+        }
+    }
 }
 
 // Brute force (parity path): a block owns 256 queries; the map streams through
@@ -681,19 +896,38 @@ __global__ __launch_bounds__(64) void k_sum_partials(const double *__restrict__ 
 // solve + update + convergence check: one wave per problem, lane 0 does the
 // (tiny, serial) double-precision algebra; no host round trip per iteration
 // ---------------------------------------------------------------------------
+// fixed-shape two-level sum of `nb` block partials (nt <= 32 doubles each): 8 groups
+// of threads each add a strided subset of the blocks, then the 8 subtotals are
+// added in group order.  Deterministic, and ~8x shorter than one serial chain.
+__device__ __forceinline__ double sum_partials_256(const double *__restrict__ part, int nb, int nt, double (*lds)[32])
+{
+    const int v = threadIdx.x & 31, grp = threadIdx.x >> 5;      // 256 threads: 8 groups x 32 values
+    double s = 0.0;
+    if (v < nt)
+        for (int b = grp; b < nb; b += 8) s += part[(long long)b * nt + v];
+    lds[grp][v] = s;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < 32) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) tot += lds[k][threadIdx.x];
+    }
+    return tot;                                                   // valid for threadIdx.x < nt
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void k_solve_update(ProblemDev *__restrict__ probs, const double *__restrict__ partials,
-                                                      int max_blocks, ChainDev<T> ch, int *__restrict__ n_done)
+__global__ __launch_bounds__(256) void k_solve_update(ProblemDev *__restrict__ probs, const double *__restrict__ partials,
+                                                       int max_blocks, ChainDev<T> ch, int *__restrict__ n_done)
 {
     ProblemDev &P = probs[blockIdx.x];
     if (P.done) return;
     __shared__ double sys[kSys];
+    __shared__ double red[8][32];
     const int nb = (P.n + kReduceBlock * kReduceItems - 1) / (kReduceBlock * kReduceItems);
+    const double tot = sum_partials_256(partials + (long long)blockIdx.x * max_blocks * kSys, nb, kSys, red);
     if (threadIdx.x < kSys) {
-        double s = 0.0;
-        for (int b = 0; b < nb; b++) s += partials[((long long)blockIdx.x * max_blocks + b) * kSys + threadIdx.x];
-        sys[threadIdx.x] = s;
-        P.sys[threadIdx.x] = s;
+        sys[threadIdx.x] = tot;
+        P.sys[threadIdx.x] = tot;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -794,17 +1028,6 @@ __global__ __launch_bounds__(kReduceBlock) void k_cov_reduce(const ProblemDev *_
     block_reduce_store<kCovTerms>(acc, partials + ((long long)blockIdx.y * max_blocks + blockIdx.x) * kCovTerms);
 }
 
-// slots -> original indices for the public matcher output
-template <typename T>
-__global__ __launch_bounds__(256) void k_slots_to_ids(const MapDev<T> *__restrict__ maps, int map,
-                                                       const int *__restrict__ slot, int n, int *__restrict__ ids)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int s = slot[i];
-    ids[i] = s < 0 ? -1 : Bits<T>::unpack_idx(maps[map].pts[s].w);
-}
-
 // ---------------------------------------------------------------------------
 // launchers (host side, called from pgicp_api.cpp)
 // ---------------------------------------------------------------------------
@@ -823,21 +1046,43 @@ void launch_centroid_bbox(hipStream_t st, const T *xyz, int stride, int m, unsig
 template <typename T>
 void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, int nstride, int m, const T mean[3],
                        const GridDesc<T> &g, int *cell_of, int *counts, int *block_sums, int *cell_start, int *cursor,
-                       typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of)
+                       int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of,
+                       int *sc_count)
 {
     const long long ncells = (long long)g.nx * g.ny * g.nz;
+    const long long nsc = (long long)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
     (void)hipMemsetAsync(counts, 0, sizeof(int) * ncells, st);
+    (void)hipMemsetAsync(sc_count, 0, sizeof(int) * nsc, st);
     hipLaunchKernelGGL(k_cell_count<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, m, mean[0], mean[1], mean[2], g,
-                       cell_of, counts);
+                       cell_of, counts, sc_count);
     const int nb = cdiv(ncells, kScanChunk);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)ncells, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)ncells, (const int *)block_sums,
                        cell_start, cursor);
-    hipLaunchKernelGGL(k_scatter<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, nrm, nstride, m, mean[0], mean[1],
-                       mean[2], (const int *)cell_of, cursor, pts, nrm_out, slot_of);
-    hipLaunchKernelGGL(k_sort_cells<T>, dim3(cdiv(ncells, 256)), dim3(256), 0, st, (const int *)cell_start, (int)ncells, pts,
-                       nrm ? nrm_out : (typename Vec4<T>::type *)nullptr, slot_of);
+    hipLaunchKernelGGL(k_scatter_idx, dim3(cdiv(m, 256)), dim3(256), 0, st, m, (const int *)cell_of, cursor, order_tmp);
+    hipLaunchKernelGGL(k_rank_place<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, nrm, nstride, m, mean[0], mean[1],
+                       mean[2], (const int *)cell_of, (const int *)cell_start, (const int *)order_tmp, pts, nrm_out, slot_of);
+}
+
+// once per scan: order every problem's pre-transformed reading by (map row, x)
+template <typename T>
+void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
+                       int *qrow, int *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
+                       int max_n, int max_rows)
+{
+    const long long nbins = (long long)P * max_rows;
+    (void)hipMemsetAsync(counts, 0, sizeof(int) * nbins, st);
+    const dim3 grid(cdiv(max_n, 256), P);
+    hipLaunchKernelGGL(k_qbin<T>, grid, dim3(256), 0, st, probs, maps, rd_pre, max_rows, qrow, counts);
+    const int nb = cdiv(nbins, kScanChunk);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, block_sums);
+    hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, (const int *)block_sums,
+                       qstart, cursor);
+    hipLaunchKernelGGL(k_qscatter, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, cursor, qtmp);
+    hipLaunchKernelGGL(k_qrank<T>, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, (const int *)qstart,
+                       (const int *)qtmp, rd_pre, rd_sorted, order);
 }
 
 template <typename T>
@@ -858,15 +1103,19 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 }
 
 template <typename T>
-void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, int *slot,
-                T *d2, const ChainDev<T> &ch, int P, int max_n)
+void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
+                T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list)
 {
-    if (matcher == 1)
-        hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd_pre, slot,
-                           d2, ch);
-    else
-        hipLaunchKernelGGL(k_knn_grid<T>, dim3(round8(cdiv(max_n, kKnnBlock)), P), dim3(kKnnBlock), 0, st, probs, maps,
-                           rd_pre, slot, d2, ch);
+    if (matcher == 1) {
+        hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot, d2,
+                           ch);
+        return;
+    }
+    (void)hipMemsetAsync(slow_count, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_knn_grid<T>, dim3(round8(cdiv(max_n, kKnnBlock)), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot,
+                       d2, ch, use_seed, slow_count, slow_list);
+    hipLaunchKernelGGL(k_knn_slow<T>, dim3(1024), dim3(256), 0, st, probs, maps, rd, slot, d2, ch, (const int *)slow_count,
+                       (const int2 *)slow_list);
 }
 
 template <typename T>
@@ -890,7 +1139,7 @@ template <typename T>
 void launch_solve(hipStream_t st, ProblemDev *probs, const double *partials, const ChainDev<T> &ch, int *n_done, int P,
                   int max_n)
 {
-    hipLaunchKernelGGL(k_solve_update<T>, dim3(P), dim3(64), 0, st, probs, partials, reduce_blocks(max_n), ch, n_done);
+    hipLaunchKernelGGL(k_solve_update<T>, dim3(P), dim3(256), 0, st, probs, partials, reduce_blocks(max_n), ch, n_done);
 }
 
 template <typename T>
@@ -927,20 +1176,23 @@ void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const in
 }
 
 template <typename T>
-void launch_slots_to_ids(hipStream_t st, const MapDev<T> *maps, int map, const int *slot, int n, int *ids)
+void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int *order, const int *slot, const T *d2, int n,
+                      int *ids_out, T *d2_out)
 {
-    hipLaunchKernelGGL(k_slots_to_ids<T>, dim3(cdiv(n, 256)), dim3(256), 0, st, maps, map, slot, n, ids);
+    hipLaunchKernelGGL(k_unpermute<T>, dim3(cdiv(n, 256)), dim3(256), 0, st, maps, map, order, slot, d2, n, ids_out, d2_out);
 }
 
 #define INSTANTIATE(T)                                                                                                   \
     template void launch_centroid_bbox<T>(hipStream_t, const T *, int, int, unsigned long long *);                        \
     template void launch_grid_build<T>(hipStream_t, const T *, int, const T *, int, int, const T[3], const GridDesc<T> &, \
-                                       int *, int *, int *, int *, int *, typename Vec4<T>::type *,                       \
-                                       typename Vec4<T>::type *, int *);                                                  \
+                                       int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,                \
+                                       typename Vec4<T>::type *, int *, int *);                                           \
+    template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *, int *,  \
+                                       int *, int *, int *, int *, int *, int, int, int);                                 \
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
-                                const ChainDev<T> &, int, int);                                                           \
+                                const ChainDev<T> &, int, int, int, int *, int2 *);                                       \
     template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int);                  \
     template void launch_reduce<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, const int *, const T *, \
                                    double *, int, int);                                                                   \
@@ -950,7 +1202,8 @@ void launch_slots_to_ids(hipStream_t st, const MapDev<T> *maps, int map, const i
     template void launch_trim_raw<T>(hipStream_t, const T *, int, T, T *, T *);                                           \
     template void launch_error_stats<T>(hipStream_t, const MapDev<T> *, int, const int *, const T *, int, const int *,    \
                                         const T *, int, const T[3], double *, double *);                                  \
-    template void launch_slots_to_ids<T>(hipStream_t, const MapDev<T> *, int, const int *, int, int *);
+    template void launch_unpermute<T>(hipStream_t, const MapDev<T> *, int, const int *, const int *, const T *, int,      \
+                                      int *, T *);
 
 INSTANTIATE(float)
 INSTANTIATE(double)

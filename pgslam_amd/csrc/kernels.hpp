@@ -9,15 +9,20 @@ void launch_centroid_bbox(hipStream_t st, const T *xyz, int stride, int m, unsig
 template <typename T>
 void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, int nstride, int m, const T mean[3],
                        const GridDesc<T> &g, int *cell_of, int *counts, int *block_sums, int *cell_start, int *cursor,
-                       typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of);
+                       int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of,
+                       int *sc_count);
+template <typename T>
+void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
+                       int *qrow, int *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
+                       int max_n, int max_rows);
 template <typename T>
 void launch_transform(hipStream_t st, const T *in, int in_stride, T *out, int out_stride, int n, const double *T16,
                       int rotate_only);
 template <typename T>
 void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, T *rd_pre, int P, int max_n);
 template <typename T>
-void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, int *slot,
-                T *d2, const ChainDev<T> &ch, int P, int max_n);
+void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
+                T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list);
 template <typename T>
 void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P);
 int reduce_blocks(int max_n);
@@ -38,7 +43,8 @@ template <typename T>
 void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const int *slot_of, const T *rd, int stride,
                         const int *ids, const T *w, int n, const T mean[3], double *partials, double *out);
 template <typename T>
-void launch_slots_to_ids(hipStream_t st, const MapDev<T> *maps, int map, const int *slot, int n, int *ids);
+void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int *order, const int *slot, const T *d2, int n,
+                      int *ids_out, T *d2_out);
 
 constexpr int kScanChunkHost = 4096;
 

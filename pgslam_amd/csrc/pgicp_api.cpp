@@ -46,6 +46,7 @@ struct MapHost {
     typename Vec4<T>::type *nrm = nullptr;
     int *cell_start = nullptr;
     int *slot_of = nullptr;
+    int *sc_count = nullptr;
     GridDesc<T> g{};
 };
 
@@ -54,7 +55,7 @@ struct State {
     std::vector<MapHost<T>> maps;
     DevBuf d_maps;                  // MapDev<T>[capacity]
     int d_maps_cap = 0;
-    DevBuf rd_pre, slot, d2, staging, stage_aux;
+    DevBuf rd_pre, rd_sorted, slot, d2, staging, stage_aux;
 };
 
 struct ProfEvent {
@@ -73,7 +74,8 @@ struct pgicp_ctx {
     pgicp_params prm{};
     State<float> f32;
     State<double> f64;
-    DevBuf probs, src, partials, sums, small, tmp_a, tmp_b, tmp_c, tmp_d;
+    DevBuf probs, src, partials, sums, small, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
+    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     bool prof_on = false;
     std::vector<ProfEvent> prof_events;
@@ -220,7 +222,8 @@ int sync_maps_table(pgicp_ctx *c)
     for (int i = 0; i < n; i++) {
         const MapHost<T> &m = S.maps[i];
         h[i].pts = m.pts; h[i].nrm = m.nrm; h[i].cell_start = m.cell_start; h[i].g = m.g; h[i].m = m.used ? m.m : 0;
-        h[i].pad_ = 0;
+        h[i].sc_count = m.sc_count;
+        h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
     }
     HIPC(c, hipMemcpyAsync(S.d_maps.p, h.data(), sizeof(MapDev<T>) * n, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));   // h goes out of scope
@@ -234,6 +237,7 @@ void free_map(MapHost<T> &m)
     if (m.nrm) (void)hipFree(m.nrm);
     if (m.cell_start) (void)hipFree(m.cell_start);
     if (m.slot_of) (void)hipFree(m.slot_of);
+    if (m.sc_count) (void)hipFree(m.sc_count);
     m = MapHost<T>();
 }
 
@@ -278,9 +282,11 @@ int map_create(pgicp_ctx *c, const T *xyz, int xyz_stride, const T *nrm, int nrm
     const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
     double h = c->prm.grid_cell;
     if (!(h > 0)) {
-        // surface-like clouds: aim at ~8 points per occupied cell of the projected area
+        // Range-scan clouds sit on surfaces (and, ring by ring, on curves): cells sized for ~2
+        // points per cell of the projected bounding-box area end up holding ~15-20 points where
+        // the data actually is (measured on the Velodyne-shaped benchmark map).
         const double area = ex * ey + ey * ez + ex * ez;
-        h = std::sqrt(8.0 * std::max(area, 1e-12) / (double)m);
+        h = std::sqrt(2.0 * std::max(area, 1e-12) / (double)m);
         const double diag = std::sqrt(ex * ex + ey * ey + ez * ez);
         if (!(h > diag * 1e-4)) h = std::max(diag * 1e-4, 1e-6);
     }
@@ -301,16 +307,21 @@ int map_create(pgicp_ctx *c, const T *xyz, int xyz_stride, const T *nrm, int nrm
     if (nrm) HIPC(c, hipMalloc((void **)&M.nrm, sizeof(V4) * (size_t)m));
     HIPC(c, hipMalloc((void **)&M.cell_start, sizeof(int) * (size_t)(ncells + 1)));
     HIPC(c, hipMalloc((void **)&M.slot_of, sizeof(int) * (size_t)m));
+    {
+        const size_t nsc = (size_t)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
+        HIPC(c, hipMalloc((void **)&M.sc_count, sizeof(int) * nsc));
+    }
     const int nb = (int)((ncells + kScanChunkHost - 1) / kScanChunkHost);
     HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)m));             // cell_of
     HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)ncells));        // counts
     HIPC(c, c->tmp_c.ensure(sizeof(int) * (size_t)(nb + 1)));      // block sums
     HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)ncells));        // cursor
+    HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)m));             // order_tmp
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
         launch_grid_build<T>(c->stream, d_xyz, xyz_stride, d_nrm, nrm_stride, m, M.mean, g, c->tmp_a.as<int>(),
-                             c->tmp_b.as<int>(), c->tmp_c.as<int>(), M.cell_start, c->tmp_d.as<int>(), M.pts, M.nrm,
-                             M.slot_of);
+                             c->tmp_b.as<int>(), c->tmp_c.as<int>(), M.cell_start, c->tmp_d.as<int>(), c->tmp_e.as<int>(), M.pts, M.nrm,
+                             M.slot_of, M.sc_count);
     }
     HIPC(c, hipGetLastError());
     int id = -1;
@@ -332,6 +343,7 @@ void translation(const double *t3, double sign, double *T)
 struct BatchLayout {
     int P = 0;
     int max_n = 0;
+    int max_rows = 1;
     long long total = 0;
 };
 
@@ -341,7 +353,7 @@ template <typename T, typename F>
 int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLayout &L, std::vector<ProblemDev> &hp)
 {
     State<T> &S = state<T>(c);
-    L.P = P; L.max_n = 0; L.total = 0;
+    L.P = P; L.max_n = 0; L.max_rows = 1; L.total = 0;
     size_t stage_total = 0;
     for (int p = 0; p < P; p++) {
         if (pr[p].n <= 0 || !pr[p].reading || pr[p].stride < 3)
@@ -349,10 +361,23 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp: unknown map id " + std::to_string(pr[p].map_id));
         L.max_n = std::max(L.max_n, pr[p].n);
+        L.max_rows = std::max(L.max_rows, M->g.ny * M->g.nz);
         L.total += pr[p].n;
         if (pr[p].mem == PGICP_HOST) stage_total += staged_bytes(sizeof(T), pr[p].stride, pr[p].n);
     }
     HIPC(c, S.rd_pre.ensure(sizeof(T) * 3 * (size_t)L.total));
+    HIPC(c, S.rd_sorted.ensure(sizeof(T) * 3 * (size_t)L.total));
+    {
+        const size_t nbins = (size_t)P * L.max_rows;
+        HIPC(c, c->qrow.ensure(sizeof(int) * (size_t)L.total));
+        HIPC(c, c->qtmp.ensure(sizeof(int) * (size_t)L.total));
+        HIPC(c, c->order.ensure(sizeof(int) * (size_t)L.total));
+        HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
+        HIPC(c, c->qcounts.ensure(sizeof(int) * nbins));
+        HIPC(c, c->qcursor.ensure(sizeof(int) * nbins));
+        HIPC(c, c->qstart.ensure(sizeof(int) * (nbins + 1)));
+        HIPC(c, c->qblock.ensure(sizeof(int) * (nbins / kScanChunkHost + 2)));
+    }
     HIPC(c, S.slot.ensure(sizeof(int) * (size_t)L.total));
     HIPC(c, S.d2.ensure(sizeof(T) * (size_t)L.total));
     HIPC(c, c->probs.ensure(sizeof(ProblemDev) * (size_t)P));
@@ -387,6 +412,11 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     {
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
         launch_pretransform<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.rd_pre.template as<T>(), P, L.max_n);
+        // order each reading by (map row, x) once: waves stay spatially coherent for every iteration
+        launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(),
+                             S.rd_pre.template as<T>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<int>(),
+                             c->order.as<int>(), c->qcounts.as<int>(), c->qblock.as<int>(), c->qstart.as<int>(),
+                             c->qcursor.as<int>(), P, L.max_n, L.max_rows);
     }
     // hs/hp must outlive the async copies
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -395,15 +425,15 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
 
 template <typename T>
 void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bool with_solve, long long act_units,
-                   long long act_probs)
+                   long long act_probs, int use_seed)
 {
     State<T> &S = state<T>(c);
     const MapDev<T> *maps = S.d_maps.template as<MapDev<T>>();
     ProblemDev *probs = c->probs.as<ProblemDev>();
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
-        launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(),
-                      S.d2.template as<T>(), ch, L.P, L.max_n);
+        launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
+                      S.d2.template as<T>(), ch, L.P, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>());
     }
     {
         ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
@@ -411,7 +441,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
     }
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
-        launch_reduce<T>(c->stream, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
+        launch_reduce<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
                          c->partials.as<double>(), L.P, L.max_n);
     }
     if (with_solve) {
@@ -451,7 +481,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     int n_done = 0;
     for (int it = 0; it < prm.max_iters; it++) {
         const long long act_p = P - n_done;
-        one_iteration<T>(c, L, ch, true, L.total * act_p / P, act_p);
+        one_iteration<T>(c, L, ch, true, L.total * act_p / P, act_p, it > 0 ? 1 : 0);
         if ((it + 1) % every == 0 || it + 1 == prm.max_iters) {
             HIPC(c, hipMemcpyAsync(c->h_pinned, c->small.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPC(c, hipStreamSynchronize(c->stream));
@@ -461,7 +491,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     }
     {
         ProfScope ps(c, PGICP_PROF_COV, L.total, P);
-        launch_cov<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(), S.rd_pre.template as<T>(),
+        launch_cov<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(), S.rd_sorted.template as<T>(),
                       S.slot.template as<int>(), S.d2.template as<T>(), c->partials.as<double>(), c->sums.as<double>(), P,
                       L.max_n);
     }
@@ -555,8 +585,8 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     ProblemDev *probs = c->probs.as<ProblemDev>();
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
-        launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(),
-                      S.d2.template as<T>(), ch, 1, n);
+        launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
+                      S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>());
     }
     if (do_trim) {
         if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
@@ -566,7 +596,7 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         }
         {
             ProfScope ps(c, PGICP_PROF_REDUCE, n);
-            launch_reduce<T>(c->stream, probs, maps, S.rd_pre.template as<T>(), S.slot.template as<int>(),
+            launch_reduce<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                              S.d2.template as<T>(), c->partials.as<double>(), 1, n);
         }
         launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(n), kSys, probs, 0, c->sums.as<double>(), 1);
@@ -585,11 +615,12 @@ int match(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem
     if (st) return st;
     State<T> &S = state<T>(c);
     HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)n));
-    launch_slots_to_ids<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), S.slot.template as<int>(), n,
-                           c->tmp_a.as<int>());
+    HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)n));
+    launch_unpermute<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), c->order.as<int>(),
+                        S.slot.template as<int>(), S.d2.template as<T>(), n, c->tmp_a.as<int>(), c->tmp_b.as<T>());
     const hipMemcpyKind k = mem == PGICP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * (size_t)n, k, c->stream));
-    HIPC(c, hipMemcpyAsync(dist2, S.d2.p, sizeof(T) * (size_t)n, k, c->stream));
+    HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * (size_t)n, k, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
     return PGICP_OK;
@@ -851,7 +882,9 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     for (auto &m : c->f64.maps) free_map(m);
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
-                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d})
+                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
+                      &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
+                      &c->qcursor, &c->slow_list})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
