@@ -155,7 +155,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--prepare-only", action="store_true",
+                    help="generate + cache the synthetic workload and exit (run this before a rocprofv3 --pmc pass: the "
+                         "generator forks worker processes, which must not happen under the counter profiler)")
     args = ap.parse_args()
+
+    if args.prepare_only:
+        build_workload(args.n_scan, args.n_map, args.queries)
+        return
 
     import torch
     import torch.distributed as dist

@@ -239,6 +239,10 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
 #define PGICP_PROF_COV 6
 #define PGICP_PROF_GRID_BUILD 7
 #define PGICP_PROF_COUNT 8
+/* diagnostics of the last kNN launch: [0] queries queued by the fast path, [1] queued queries
+ * resolved because their existence was unknown, [2] resolved because their lower bound was
+ * within the trim threshold, [3] reserved. */
+int pgicp_debug_counters(pgicp_ctx *ctx, int out[4]);
 int pgicp_profile_enable(pgicp_ctx *ctx, int on);
 int pgicp_profile_reset(pgicp_ctx *ctx);
 int pgicp_profile_get(pgicp_ctx *ctx, int kernel_id, long long *launches, double *total_ms,

@@ -60,6 +60,7 @@ struct ProblemDev {
     double Tcur[12];         // T_iter as 3x4 for the kernels (cast to T when applied)
     int done, status, iters, converged, max_iter_reached;
     int n_finite, n_kept, rank;
+    int n_refined;           // queued queries the slow path resolved since the last threshold selection
     double limit;            // last trim threshold (squared distance)
     double sys[kSys];        // final sums of the last iteration
     Checker chk;

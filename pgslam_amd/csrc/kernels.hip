@@ -9,6 +9,9 @@
 //
 // wave = 64 lanes everywhere; no warp-size-32 idiom is used.
 #include "kernels.hpp"
+#ifndef PGICP_TILE_ENABLE
+#define PGICP_TILE_ENABLE 0
+#endif
 
 namespace pgicp {
 
@@ -293,11 +296,13 @@ __global__ __launch_bounds__(256) void k_pretransform(const ProblemDev *__restri
 }
 
 // ---------------------------------------------------------------------------
-// reading sort: once per scan the (pre-transformed) reading is ordered by the
-// (y,z) row of the map grid it falls in, then by x.  A rigid correction keeps
-// neighbours neighbours, so for every later iteration the 64 queries of a wave
-// walk the same few rows of the cell-sorted map: their candidate loads hit the
-// same cache lines instead of 64 different ones.
+// reading sort: once per scan the (pre-transformed) reading is put in a
+// 3-D-compact order: by 4x4x4-cell block of the map grid (blocks x-fastest),
+// then by cell inside the block, then by original index.  A rigid correction
+// keeps neighbours neighbours, so for every later iteration the 64 queries of a
+// wave share one small neighbourhood of the cell-sorted map: the wave can stage
+// that neighbourhood in LDS once instead of every lane pulling its own cache
+// lines.
 // ---------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ int clamp_cell(T u, T inv_h, int n)
@@ -308,7 +313,7 @@ __device__ __forceinline__ int clamp_cell(T u, T inv_h, int n)
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_qbin(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
-                                               const T *__restrict__ rd_pre, int max_rows, int *__restrict__ qrow,
+                                               const T *__restrict__ rd_pre, int max_bins, int *__restrict__ qbin,
                                                int *__restrict__ counts)
 {
     const ProblemDev &P = probs[blockIdx.y];
@@ -316,26 +321,29 @@ __global__ __launch_bounds__(256) void k_qbin(const ProblemDev *__restrict__ pro
     if (i >= P.n) return;
     const GridDesc<T> g = maps[P.map].g;
     const T *q = rd_pre + 3 * (P.off + i);
-    const int cy = clamp_cell<T>(q[1] - g.oy, g.inv_h, g.ny), cz = clamp_cell<T>(q[2] - g.oz, g.inv_h, g.nz);
-    int row = cy + g.ny * cz;
-    if (row >= max_rows) row = max_rows - 1;
-    qrow[P.off + i] = row;
-    atomicAdd(&counts[(long long)blockIdx.y * max_rows + row], 1);
+    const int cx = clamp_cell<T>(q[0] - g.ox, g.inv_h, g.nx), cy = clamp_cell<T>(q[1] - g.oy, g.inv_h, g.ny),
+              cz = clamp_cell<T>(q[2] - g.oz, g.inv_h, g.nz);
+    const int nbx = (g.nx + 3) >> 2, nby = (g.ny + 3) >> 2;
+    int bin = (cx >> 2) + nbx * ((cy >> 2) + nby * (cz >> 2));
+    if (bin >= max_bins) bin = max_bins - 1;
+    const int local = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
+    qbin[P.off + i] = (bin << 6) | local;                  // bin < 2^25 (<= 2^26 cells / 64 + slack)
+    atomicAdd(&counts[(long long)blockIdx.y * max_bins + bin], 1);
 }
 
-__global__ __launch_bounds__(256) void k_qscatter(const ProblemDev *__restrict__ probs, int max_rows,
-                                                   const int *__restrict__ qrow, int *__restrict__ cursor,
+__global__ __launch_bounds__(256) void k_qscatter(const ProblemDev *__restrict__ probs, int max_bins,
+                                                   const int *__restrict__ qbin, int *__restrict__ cursor,
                                                    int *__restrict__ qtmp)
 {
     const ProblemDev &P = probs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
-    qtmp[atomicAdd(&cursor[(long long)blockIdx.y * max_rows + qrow[P.off + i]], 1)] = i;
+    qtmp[atomicAdd(&cursor[(long long)blockIdx.y * max_bins + (qbin[P.off + i] >> 6)], 1)] = i;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_qrank(const ProblemDev *__restrict__ probs, int max_rows,
-                                                const int *__restrict__ qrow, const int *__restrict__ qstart,
+__global__ __launch_bounds__(256) void k_qrank(const ProblemDev *__restrict__ probs, int max_bins,
+                                                const int *__restrict__ qbin, const int *__restrict__ qstart,
                                                 const int *__restrict__ qtmp, const T *__restrict__ rd_pre,
                                                 T *__restrict__ rd_sorted, int *__restrict__ order)
 {
@@ -343,16 +351,16 @@ __global__ __launch_bounds__(256) void k_qrank(const ProblemDev *__restrict__ pr
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n) return;
     const int i = qtmp[P.off + j];
-    const long long bin = (long long)blockIdx.y * max_rows + qrow[P.off + i];
+    const int key = qbin[P.off + i];
+    const long long bin = (long long)blockIdx.y * max_bins + (key >> 6);
     const int a = qstart[bin], b = qstart[bin + 1];
-    const T xi = rd_pre[3 * (P.off + i)];
     int rank = 0;
     for (int k = a; k < b; ++k) {
         const int ik = qtmp[k];
-        const T xk = rd_pre[3 * (P.off + ik)];
-        rank += (xk < xi || (xk == xi && ik < i)) ? 1 : 0;
+        const int kk = qbin[P.off + ik];                    // same bin: compares the cell-in-block bits
+        rank += (kk < key || (kk == key && ik < i)) ? 1 : 0;
     }
-    const int f = a + rank;                       // global position (scan runs over all problems)
+    const int f = a + rank;                                 // global position (the scan runs over all problems)
     order[f] = i;
     const T *src = rd_pre + 3 * (P.off + i);
     T *dst = rd_sorted + 3 * (long long)f;
@@ -432,19 +440,44 @@ __device__ __forceinline__ void scan_row(const MapDev<T> &M, int row_base, int x
     scan_range<T>(M.pts, M.cell_start[row_base + xa], M.cell_start[row_base + xb + 1], qx, qy, qz, best);
 }
 
-// Exact NN by expanding Chebyshev rings of cells around the query's (clamped)
-// cell.  A row is skipped when its slab distance already exceeds the best
-// candidate; the search is RESOLVED when every unexamined cell is provably
-// farther than the best candidate or than maxDist.  At most `max_rings` rings
-// are walked here (the per-lane fast path); returns false if unresolved.
+// guaranteed radius after ring r: every cell outside Chebyshev ring r around c0 is at
+// least this far from the query (+inf when the grid is exhausted); margin NOT yet removed
 template <typename T>
-__device__ __forceinline__ bool grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T max_dist, int max_rings, Best<T> &best)
+__device__ __forceinline__ T ring_guarantee(const GridDesc<T> &g, T ux, T uy, T uz, int c0x, int c0y, int c0z, int r)
+{
+    T gr = Bits<T>::inf();
+    if (c0x - r - 1 >= 0) gr = fmin(gr, slab_dist(ux, c0x - r - 1, g.h));
+    if (c0x + r + 1 <= g.nx - 1) gr = fmin(gr, slab_dist(ux, c0x + r + 1, g.h));
+    if (c0y - r - 1 >= 0) gr = fmin(gr, slab_dist(uy, c0y - r - 1, g.h));
+    if (c0y + r + 1 <= g.ny - 1) gr = fmin(gr, slab_dist(uy, c0y + r + 1, g.h));
+    if (c0z - r - 1 >= 0) gr = fmin(gr, slab_dist(uz, c0z - r - 1, g.h));
+    if (c0z + r + 1 <= g.nz - 1) gr = fmin(gr, slab_dist(uz, c0z + r + 1, g.h));
+    return gr;
+}
+
+// Exact NN by expanding Chebyshev rings of cells around the query's (clamped)
+// cell, starting at ring r_start (rings below it were already examined).  A row
+// is skipped when its slab distance already exceeds the best candidate; the
+// search is RESOLVED when every unexamined cell is provably farther than the
+// best candidate or than maxDist.  At most ring max_rings is walked here (the
+// per-lane path); returns false if unresolved, with the last guaranteed radius.
+template <typename T>
+__device__ __forceinline__ bool grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T max_dist, int r_start, int max_rings,
+                                        Best<T> &best, T &gr_out)
 {
     const GridDesc<T> g = M.g;
     const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
     const int c0x = clamp_cell<T>(ux, g.inv_h, g.nx), c0y = clamp_cell<T>(uy, g.inv_h, g.ny),
               c0z = clamp_cell<T>(uz, g.inv_h, g.nz);
-    for (int r = 0; r <= max_rings; ++r) {
+    gr_out = (T)0;
+    if (r_start > 0) {
+        T gr = ring_guarantee<T>(g, ux, uy, uz, c0x, c0y, c0z, r_start - 1);
+        if (!(gr < Bits<T>::inf())) return true;
+        gr = gr - g.margin;
+        gr_out = gr;
+        if (gr > (T)0 && (best.d2 < gr * gr || gr > max_dist)) return true;
+    }
+    for (int r = r_start; r <= max_rings; ++r) {
         const int z0 = max(c0z - r, 0), z1 = min(c0z + r, g.nz - 1);
         const int y0 = max(c0y - r, 0), y1 = min(c0y + r, g.ny - 1);
         const int xa = max(c0x - r, 0), xb = min(c0x + r, g.nx - 1);
@@ -464,57 +497,234 @@ __device__ __forceinline__ bool grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T 
                 }
             }
         }
-        // guaranteed radius: every cell outside ring r is at least this far away
-        T gr = Bits<T>::inf();
-        if (c0x - r - 1 >= 0) gr = fmin(gr, slab_dist(ux, c0x - r - 1, g.h));
-        if (c0x + r + 1 <= g.nx - 1) gr = fmin(gr, slab_dist(ux, c0x + r + 1, g.h));
-        if (c0y - r - 1 >= 0) gr = fmin(gr, slab_dist(uy, c0y - r - 1, g.h));
-        if (c0y + r + 1 <= g.ny - 1) gr = fmin(gr, slab_dist(uy, c0y + r + 1, g.h));
-        if (c0z - r - 1 >= 0) gr = fmin(gr, slab_dist(uz, c0z - r - 1, g.h));
-        if (c0z + r + 1 <= g.nz - 1) gr = fmin(gr, slab_dist(uz, c0z + r + 1, g.h));
+        T gr = ring_guarantee<T>(g, ux, uy, uz, c0x, c0y, c0z, r);
         if (!(gr < Bits<T>::inf())) return true;                        // grid exhausted
         gr = gr - g.margin;
+        gr_out = gr;
         if (gr > (T)0 && (best.d2 < gr * gr || gr > max_dist)) return true;
     }
     return false;
 }
 
-constexpr int kFastRings = 3;       // rings walked per lane before a query is handed to the wave-cooperative path
-
-// Fast path: one query per lane.  The previous iteration's match (if any) seeds
-// the bound, so from the second iteration on almost every query is resolved
-// inside its own cell and the few touching rows.  Unresolved queries (no
-// neighbour within kFastRings cells) are queued for k_knn_slow.
+// farthest-corner distance from coordinate offset u to the slab [lo, hi]
 template <typename T>
-__global__ __launch_bounds__(kKnnBlock) void k_knn_grid(const ProblemDev *__restrict__ probs,
-                                                         const MapDev<T> *__restrict__ maps, const T *__restrict__ rd,
-                                                         int *__restrict__ slot_io, T *__restrict__ d2_out,
-                                                         ChainDev<T> ch, int use_seed, int *__restrict__ slow_count,
-                                                         int2 *__restrict__ slow_list)
+__device__ __forceinline__ T slab_far(T u, T lo, T hi)
 {
+    return fmax(fabs(u - lo), fabs(hi - u));
+}
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+constexpr int kFastRings = 3;       // rings walked per lane before a query is handed to the wave-cooperative path
+constexpr int kFastRingsUnseeded = 8;
+constexpr int kTileRows = 64;       // most (y,z) rows of a tile's neighbourhood box (one lane loads one row's offsets)
+constexpr int kTileWx = 20;         // widest x extent (cells) of that box
+template <typename T> struct TileChunk { static constexpr int value = 512 * 4 / (int)sizeof(T); };   // 8 KiB of points
+
+// Fast path: one WAVE owns a tile of 64 consecutive queries of the sorted
+// reading (one workgroup = one wave, so __syncthreads() is a wave-local fence).
+//
+// Phase A -- LDS-staged neighbourhood.  The tile's queries occupy a small box of
+// cells; the box grown by R cells holds every cell within Chebyshev radius R of
+// every query.  The wave loads the cell-offset table of that box (rows x
+// x-extent) and then its points -- contiguous per row in the cell-sorted map --
+// into LDS with coalesced loads; each lane then scans only its own cells out of
+// LDS, nearest row first, pruning rows and x-ranges with its current bound.
+// Every map point is fetched once per tile instead of once per lane cache line,
+// which is what bounded the per-lane version.
+// Phase B -- lanes not resolved within radius R (and tiles whose box is too big:
+// sparse far-field points) continue ring by ring on their own up to kFastRings.
+// Phase C -- what is still unresolved is queued with a lower bound LB on its true
+// squared distance while d2 keeps an UPPER bound (partial best, or a certificate
+// that a non-empty super-cell lies wholly within maxDist).  The trimmed-distance
+// filter only needs exact values up to its threshold, so k_knn_slow resolves
+// just the queued queries with LB <= threshold (normally none): kept pairs,
+// threshold and n_finite stay exact.
+template <typename T>
+__global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
+                                                  const T *__restrict__ rd, int *__restrict__ slot_io,
+                                                  T *__restrict__ d2_out, ChainDev<T> ch, int use_seed, int R,
+                                                  int *__restrict__ slow_count, int2 *__restrict__ slow_list,
+                                                  T *__restrict__ slow_lb)
+{
+    using V4 = typename Vec4<T>::type;
+    constexpr int CH = TileChunk<T>::value;
+    __shared__ V4 pts_l[CH];
+    __shared__ int cs_l[kTileRows][kTileWx + 1];
+    __shared__ int row_off[kTileRows + 1];
     const ProblemDev &P = probs[blockIdx.y];
     if (P.done) return;
-    const int i = xcd_tile(blockIdx.x, gridDim.x) * kKnnBlock + threadIdx.x;
-    if (i >= P.n) return;
-    const T *q = rd + 3 * (P.off + i);
-    T qx, qy, qz;
-    apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    if (tile * 64 >= P.n) return;
+    const int lane = threadIdx.x;
+    const int i = tile * 64 + lane;
+    const bool live = i < P.n;
     const MapDev<T> M = maps[P.map];
+    const GridDesc<T> g = M.g;
+    T qx = 0, qy = 0, qz = 0;
     Best<T> best;
     best.d2 = ch.max_dist2;            // anything farther than maxDist is useless
     best.idx = 0x7FFFFFFF;
     best.slot = -1;
-    if (use_seed) {
-        const int prev = slot_io[P.off + i];
-        if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
+    if (live) {
+        const T *q = rd + 3 * (P.off + i);
+        apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
+        if (use_seed) {
+            const int prev = slot_io[P.off + i];
+            if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
+        }
     }
-    const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, kFastRings, best);
-    if (!resolved) {
+    const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+    const int cx = clamp_cell<T>(ux, g.inv_h, g.nx), cy = clamp_cell<T>(uy, g.inv_h, g.ny), cz = clamp_cell<T>(uz, g.inv_h, g.nz);
+
+    // ---- phase A: LDS-staged neighbourhood box ----
+    const int xa = max(wave_min_i(live ? cx : 0x7FFFFFFF) - R, 0), xb = min(wave_max_i(live ? cx : -1) + R, g.nx - 1);
+    const int ya = max(wave_min_i(live ? cy : 0x7FFFFFFF) - R, 0), yb = min(wave_max_i(live ? cy : -1) + R, g.ny - 1);
+    const int za = max(wave_min_i(live ? cz : 0x7FFFFFFF) - R, 0), zb = min(wave_max_i(live ? cz : -1) + R, g.nz - 1);
+    const int wx = xb - xa + 1, wy = yb - ya + 1, nrows = wy * (zb - za + 1);
+    int r_start = 0;
+    if (nrows <= kTileRows && wx <= kTileWx && PGICP_TILE_ENABLE) {
+        // cell offsets of the box: cs_l[r][k] = cell_start[row(r) + xa + k], k = 0..wx
+        for (int t = lane; t < nrows * (wx + 1); t += 64) {
+            const int r = t / (wx + 1), k = t - r * (wx + 1);
+            cs_l[r][k] = M.cell_start[g.nx * ((ya + r % wy) + g.ny * (za + r / wy)) + xa + k];
+        }
+        __syncthreads();
+        // exclusive prefix of the row lengths (lane r <-> row r)
+        int len = 0;
+        if (lane < nrows) len = cs_l[lane][wx] - cs_l[lane][0];
+        int inc = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        row_off[lane + 1 <= kTileRows ? lane + 1 : kTileRows] = inc;   // lane 63 -> slot 64
+        if (lane == 0) row_off[0] = 0;
+        __syncthreads();
+        int r0 = 0;
+        while (r0 < nrows) {
+            // rows [r0, r1) whose points fit the LDS chunk together (at least one row)
+            const int base = row_off[r0];
+            const bool fits = lane >= r0 && lane < nrows && (row_off[lane + 1] - base) <= CH;
+            const unsigned long long fm = __ballot(fits) >> r0;
+            const unsigned long long nfm = ~fm;
+            int r1 = r0 + (nfm ? (int)__builtin_ctzll(nfm) : 64);
+            int c_lo = 0, c_hi = 0;                                   // sub-range of a single over-long row
+            const bool long_row = (r1 == r0);
+            const int long_len = row_off[r0 + 1] - base;
+            if (long_row) r1 = r0 + 1;
+            for (;;) {
+                if (long_row) { c_hi = min(c_lo + CH, long_len); }
+                // stage: 4 rows at a time, 16 lanes each
+                if (long_row) {
+                    const int seg = cs_l[r0][0];
+                    for (int k = lane; k < c_hi - c_lo; k += 64) pts_l[k] = M.pts[seg + c_lo + k];
+                } else {
+                    for (int rr = r0 + (lane >> 4); rr < r1; rr += 4) {
+                        const int seg = cs_l[rr][0], n = cs_l[rr][wx] - seg, dst = row_off[rr] - base;
+                        for (int k = lane & 15; k < n; k += 16) pts_l[dst + k] = M.pts[seg + k];
+                    }
+                }
+                __syncthreads();
+                if (live) {
+                    // own row first, then the rest of the (2R+1)^2 neighbourhood
+                    for (int t = 0; t < (2 * R + 1) * (2 * R + 1); ++t) {
+                        int dy, dz;
+                        if (t == 0) { dy = 0; dz = 0; }
+                        else {
+                            const int tt = (t - 1 < 2 * R * (R + 1)) ? t - 1 : t;   // skip the centre entry
+                            dy = tt % (2 * R + 1) - R; dz = tt / (2 * R + 1) - R;
+                        }
+                        const int y = cy + dy, z = cz + dz;
+                        if (y < ya || y > yb || z < za || z > zb) continue;
+                        const int r = (y - ya) + wy * (z - za);
+                        if (r < r0 || r >= r1) continue;
+                        const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
+                        const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
+                        const T lb2 = ly * ly + lz * lz;
+                        if (lb2 > best.d2) continue;
+                        int xlo = max(cx - R, xa), xhi = min(cx + R, xb);
+                        if (best.d2 < Bits<T>::inf()) {
+                            const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + g.margin;
+                            xlo = max(xlo, clamp_cell<T>(ux - rad, g.inv_h, g.nx));
+                            xhi = min(xhi, clamp_cell<T>(ux + rad, g.inv_h, g.nx));
+                        }
+                        if (xlo > xhi) continue;
+                        const int seg = cs_l[r][0];
+                        int a = cs_l[r][xlo - xa], b = cs_l[r][xhi + 1 - xa];       // global point indices
+                        int off = row_off[r] - base - seg;                        // LDS position = global index + off
+                        if (long_row) { a = max(a, seg + c_lo); b = min(b, seg + c_hi); off = -(seg + c_lo); }
+                        int j = a;
+                        for (; j + 2 <= b; j += 2) {
+                            const V4 v0 = pts_l[j + off], v1 = pts_l[j + 1 + off];
+                            eval_point<T>(v0, j, qx, qy, qz, best);
+                            eval_point<T>(v1, j + 1, qx, qy, qz, best);
+                        }
+                        if (j < b) eval_point<T>(pts_l[j + off], j, qx, qy, qz, best);
+                    }
+                }
+                __syncthreads();
+                if (!long_row) break;
+                c_lo = c_hi;
+                if (c_lo >= long_len) break;
+            }
+            r0 = r1;
+        }
+        r_start = R + 1;
+    }
+    if (!live) return;
+
+    // ---- phase B: per-lane continuation ----
+    T gr;
+    // without a seed (first iteration) distances are larger: walk more rings per lane before queueing
+    const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, r_start, use_seed ? kFastRings : kFastRingsUnseeded, best, gr);
+
+    // ---- phase C: bookkeeping for the lazy slow path ----
+    if (resolved) {
+        if (best.slot < 0) best.d2 = Bits<T>::inf();
+    } else {
+        T lb = gr > (T)0 ? gr * gr : (T)0;
+        if (best.slot < 0) {
+            // no candidate yet: look for a certificate that a neighbour within maxDist exists
+            const T H = g.h * (T)8;
+            const int Cx = cx >> 3, Cy = cy >> 3, Cz = cz >> 3;
+            T ub = Bits<T>::inf();
+            for (int t = 0; t < 27 && !(ub < Bits<T>::inf()); ++t) {
+                const int order = (t + 13) % 27;               // own super-cell first
+                const int X = Cx + order % 3 - 1, Y = Cy + (order / 3) % 3 - 1, Z = Cz + order / 9 - 1;
+                if (X < 0 || X >= M.nsx || Y < 0 || Y >= M.nsy || Z < 0 || Z >= M.nsz) continue;
+                if (M.sc_count[X + M.nsx * (Y + M.nsy * Z)] <= 0) continue;
+                const T fx = slab_far(ux, (T)X * H, (T)(X + 1) * H) + g.margin, fy = slab_far(uy, (T)Y * H, (T)(Y + 1) * H) + g.margin,
+                        fz = slab_far(uz, (T)Z * H, (T)(Z + 1) * H) + g.margin;
+                const T far2 = (fx * fx + fy * fy) + fz * fz;
+                if (far2 <= ch.max_dist2) ub = far2;
+            }
+            if (!(ub < Bits<T>::inf()) && M.m > 0 && !(ch.max_dist2 < Bits<T>::inf())) {
+                // maxDist = inf: the whole (non-empty) grid is a certificate
+                const T fx = slab_far(ux, (T)0, (T)g.nx * g.h) + g.margin, fy = slab_far(uy, (T)0, (T)g.ny * g.h) + g.margin,
+                        fz = slab_far(uz, (T)0, (T)g.nz * g.h) + g.margin;
+                ub = (fx * fx + fy * fy) + fz * fz;
+            }
+            if (ub < Bits<T>::inf()) { best.d2 = ub; best.slot = -2; }   // exists, not located
+            else { best.d2 = ch.max_dist2; best.slot = -2; lb = (T)-1; } // existence unknown: always resolved later
+        }
         const int k = atomicAdd(slow_count, 1);
         slow_list[k] = make_int2((int)blockIdx.y, i);
+        slow_lb[k] = lb;
     }
-    if (best.slot < 0) best.d2 = Bits<T>::inf();
-    slot_io[P.off + i] = best.slot;    // doubles as the slow path's seed
+    slot_io[P.off + i] = best.slot;
     d2_out[P.off + i] = best.d2;
 }
 
@@ -526,10 +736,11 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_grid(const ProblemDev *__rest
 // per super-cell, so proving "nothing within maxDist" stays cheap.  A
 // lexicographic (d2, index) wave reduction picks the winner.
 template <typename T>
-__global__ __launch_bounds__(256) void k_knn_slow(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
+__global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                    const T *__restrict__ rd, int *__restrict__ slot_io,
                                                    T *__restrict__ d2_out, ChainDev<T> ch,
-                                                   const int *__restrict__ slow_count, const int2 *__restrict__ slow_list)
+                                                   const int *__restrict__ slow_count, const int2 *__restrict__ slow_list,
+                                                   const T *__restrict__ slow_lb, int exact_all)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -537,8 +748,18 @@ __global__ __launch_bounds__(256) void k_knn_slow(const ProblemDev *__restrict__
     const int count = *slow_count;
     for (int k = wave; k < count; k += nwaves) {
         const int2 e = slow_list[k];
-        const ProblemDev &P = probs[e.x];
+        ProblemDev &P = probs[e.x];
         const int i = e.y;
+        if (!exact_all) {
+            // lazy: only queries whose lower bound does not already exceed the (upper bound of the)
+            // trim threshold can influence the result
+            const T lb = slow_lb[k];
+            if (lb >= (T)0 && lb > (T)P.limit) continue;
+            if (lane == 0) {
+                atomicAdd(&P.n_refined, 1);
+                atomicAdd(const_cast<int *>(slow_count) + (lb < (T)0 ? 1 : 2), 1);     // diagnostics: forced / bound-hit
+            }
+        }
         const T *q = rd + 3 * (P.off + i);
         T qx, qy, qz;
         apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
@@ -728,10 +949,15 @@ __device__ void trim_select_block(const T *__restrict__ d2, int n, T ratio, T &l
 
 template <typename T>
 __global__ __launch_bounds__(kSelectBlock) void k_trim_select(ProblemDev *__restrict__ probs, const T *__restrict__ d2,
-                                                               ChainDev<T> ch)
+                                                               ChainDev<T> ch, int second)
 {
     ProblemDev &P = probs[blockIdx.x];
     if (P.done) return;
+    if (second) {                      // re-select only if the slow path refined something
+        if (P.n_refined == 0) return;
+        __syncthreads();
+        if (threadIdx.x == 0) P.n_refined = 0;
+    }
     T limit;
     int nf;
     trim_select_block<T>(d2 + P.off, P.n, ch.trim_ratio, limit, nf);
@@ -1104,24 +1330,33 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
-                T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list)
+                T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb)
 {
     if (matcher == 1) {
         hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot, d2,
                            ch);
+        (void)hipMemsetAsync(slow_count, 0, sizeof(int), st);
         return;
     }
     (void)hipMemsetAsync(slow_count, 0, sizeof(int), st);
-    hipLaunchKernelGGL(k_knn_grid<T>, dim3(round8(cdiv(max_n, kKnnBlock)), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot,
-                       d2, ch, use_seed, slow_count, slow_list);
-    hipLaunchKernelGGL(k_knn_slow<T>, dim3(1024), dim3(256), 0, st, probs, maps, rd, slot, d2, ch, (const int *)slow_count,
-                       (const int2 *)slow_list);
+    hipLaunchKernelGGL(k_knn_grid<T>, dim3(round8(cdiv(max_n, 64)), P), dim3(64), 0, st, probs, maps, rd, slot, d2, ch, use_seed,
+                       use_seed ? 1 : 2, slow_count, slow_list, slow_lb);
+}
+
+// resolves the queries the fast path queued: all of them (exact_all, public matcher
+// output) or only those that can still matter for the trimmed filter (lazy)
+template <typename T>
+void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
+                     const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb, int exact_all)
+{
+    hipLaunchKernelGGL(k_knn_slow<T>, dim3(1024), dim3(256), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list,
+                       slow_lb, exact_all);
 }
 
 template <typename T>
-void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P)
+void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second)
 {
-    hipLaunchKernelGGL(k_trim_select<T>, dim3(P), dim3(kSelectBlock), 0, st, probs, d2, ch);
+    hipLaunchKernelGGL(k_trim_select<T>, dim3(P), dim3(kSelectBlock), 0, st, probs, d2, ch, second);
 }
 
 int reduce_blocks(int max_n) { return round8(cdiv(max_n, kReduceBlock * kReduceItems)); }
@@ -1192,8 +1427,10 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
-                                const ChainDev<T> &, int, int, int, int *, int2 *);                                       \
-    template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int);                  \
+                                const ChainDev<T> &, int, int, int, int *, int2 *, T *);                                  \
+    template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \
+                                     const ChainDev<T> &, const int *, const int2 *, const T *, int);                     \
+    template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int, int);             \
     template void launch_reduce<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, const int *, const T *, \
                                    double *, int, int);                                                                   \
     template void launch_solve<T>(hipStream_t, ProblemDev *, const double *, const ChainDev<T> &, int *, int, int);       \

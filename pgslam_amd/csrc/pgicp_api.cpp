@@ -75,7 +75,7 @@ struct pgicp_ctx {
     State<float> f32;
     State<double> f64;
     DevBuf probs, src, partials, sums, small, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
-    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list;
+    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     bool prof_on = false;
     std::vector<ProfEvent> prof_events;
@@ -361,7 +361,8 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp: unknown map id " + std::to_string(pr[p].map_id));
         L.max_n = std::max(L.max_n, pr[p].n);
-        L.max_rows = std::max(L.max_rows, M->g.ny * M->g.nz);
+        // bins of the reading sort: 4x4x4-cell blocks of the map grid
+        L.max_rows = std::max(L.max_rows, ((M->g.nx + 3) >> 2) * ((M->g.ny + 3) >> 2) * ((M->g.nz + 3) >> 2));
         L.total += pr[p].n;
         if (pr[p].mem == PGICP_HOST) stage_total += staged_bytes(sizeof(T), pr[p].stride, pr[p].n);
     }
@@ -373,6 +374,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         HIPC(c, c->qtmp.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->order.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
+        HIPC(c, c->slow_lb.ensure(sizeof(T) * (size_t)L.total));
         HIPC(c, c->qcounts.ensure(sizeof(int) * nbins));
         HIPC(c, c->qcursor.ensure(sizeof(int) * nbins));
         HIPC(c, c->qstart.ensure(sizeof(int) * (nbins + 1)));
@@ -433,11 +435,24 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
-                      S.d2.template as<T>(), ch, L.P, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>());
+                      S.d2.template as<T>(), ch, L.P, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
+                      c->slow_lb.as<T>());
     }
     {
         ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, L.P);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, L.P, 0);
+    }
+    if (c->prm.matcher == PGICP_MATCHER_GRID) {
+        // lazy resolution: only queued queries whose lower bound is within the threshold just
+        // selected (an upper bound of the final one) are searched exactly; then the threshold
+        // is re-selected if anything changed.  Kept pairs / threshold / n_finite stay exact.
+        {
+            ProfScope ps(c, PGICP_PROF_KNN_GRID, 0, 0);
+            launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
+                               S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), 0);
+        }
+        ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, L.P, 1);
     }
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
@@ -586,13 +601,17 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
-                      S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>());
+                      S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>());
+        // public matcher output / partial chain: resolve every queued query exactly
+        if (c->prm.matcher == PGICP_MATCHER_GRID)
+            launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
+                               S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), 1);
     }
     if (do_trim) {
         if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
         {
             ProfScope ps(c, PGICP_PROF_TRIM, n);
-            launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, 1);
+            launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, 1, 0);
         }
         {
             ProfScope ps(c, PGICP_PROF_REDUCE, n);
@@ -884,7 +903,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
-                      &c->qcursor, &c->slow_list})
+                      &c->qcursor, &c->slow_list, &c->slow_lb})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1059,6 +1078,13 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
     if (icp->overlap < overlap_threshold) return 0;            // LoopCloser.hpp:331
     if (residual_error > residual_error_threshold) return 0;   // LoopCloser.hpp:335
     return 1;
+}
+
+int pgicp_debug_counters(pgicp_ctx *c, int out[4])
+{
+    if (!c || !out) return PGICP_ERR_ARG;
+    HIPC(c, hipMemcpy(out, c->small.as<int>() + 16, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    return PGICP_OK;
 }
 
 int pgicp_profile_enable(pgicp_ctx *c, int on)

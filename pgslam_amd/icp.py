@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "pgicp_outlier_weights_f32", "pgicp_outlier_weights_f64", "pgicp_error_stats_f32", "pgicp_error_stats_f64",
     "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_transform_f32", "pgicp_transform_f64",
     "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
-    "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get",
+    "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters",
 ]
 
 
@@ -338,6 +338,11 @@ class Context:
     # ---- measurement --------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.lib.pgicp_profile_enable(self.h, C.c_int(int(on))))
+
+    def debug_counters(self):
+        out = (C.c_int * 4)()
+        self._check(self.lib.pgicp_debug_counters(self.h, out))
+        return list(out)
 
     def profile_reset(self):
         self._check(self.lib.pgicp_profile_reset(self.h))
