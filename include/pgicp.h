@@ -229,7 +229,8 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
  * With profiling on, every launch of the named kernels is bracketed by HIP
  * events on the context stream; pgicp_profile_get returns launch count and
  * summed device milliseconds.  Kernel ids: 0 knn_grid, 1 knn_brute, 2 trim_select,
- * 3 p2plane_reduce, 4 solve_update, 5 pretransform, 6 covariance, 7 grid_build. */
+ * 3 p2plane_reduce, 4 solve_update, 5 pretransform (+ reading sort), 6 covariance, 7 grid_build,
+ * 8 knn_slow (wave-cooperative resolution of queued queries). */
 #define PGICP_PROF_KNN_GRID 0
 #define PGICP_PROF_KNN_BRUTE 1
 #define PGICP_PROF_TRIM 2
@@ -238,7 +239,8 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
 #define PGICP_PROF_PRETRANSFORM 5
 #define PGICP_PROF_COV 6
 #define PGICP_PROF_GRID_BUILD 7
-#define PGICP_PROF_COUNT 8
+#define PGICP_PROF_KNN_SLOW 8
+#define PGICP_PROF_COUNT 9
 /* diagnostics of the last kNN launch: [0] queries queued by the fast path, [1] queued queries
  * resolved because their existence was unknown, [2] resolved because their lower bound was
  * within the trim threshold, [3] reserved. */

@@ -9,9 +9,6 @@
 //
 // wave = 64 lanes everywhere; no warp-size-32 idiom is used.
 #include "kernels.hpp"
-#ifndef PGICP_TILE_ENABLE
-#define PGICP_TILE_ENABLE 0
-#endif
 
 namespace pgicp {
 
@@ -528,47 +525,43 @@ __device__ __forceinline__ int wave_max_i(int v)
 
 constexpr int kFastRings = 3;       // rings walked per lane before a query is handed to the wave-cooperative path
 constexpr int kFastRingsUnseeded = 8;
-constexpr int kTileRows = 64;       // most (y,z) rows of a tile's neighbourhood box (one lane loads one row's offsets)
-constexpr int kTileWx = 20;         // widest x extent (cells) of that box
-template <typename T> struct TileChunk { static constexpr int value = 512 * 4 / (int)sizeof(T); };   // 8 KiB of points
 
-// Fast path: one WAVE owns a tile of 64 consecutive queries of the sorted
-// reading (one workgroup = one wave, so __syncthreads() is a wave-local fence).
+// Fast path: one query per lane, 64 consecutive queries of the 3-D-compact sorted
+// reading per wave (workgroup = one wave; LDS is wave private).
 //
-// Phase A -- LDS-staged neighbourhood.  The tile's queries occupy a small box of
-// cells; the box grown by R cells holds every cell within Chebyshev radius R of
-// every query.  The wave loads the cell-offset table of that box (rows x
-// x-extent) and then its points -- contiguous per row in the cell-sorted map --
-// into LDS with coalesced loads; each lane then scans only its own cells out of
-// LDS, nearest row first, pruning rows and x-ranges with its current bound.
-// Every map point is fetched once per tile instead of once per lane cache line,
-// which is what bounded the per-lane version.
-// Phase B -- lanes not resolved within radius R (and tiles whose box is too big:
-// sparse far-field points) continue ring by ring on their own up to kFastRings.
+// Phase A -- block of (2R+1)^3 cells around the query's own cell, R = 1 when the
+// previous iteration's match seeds the bound, R = 2 on the first iteration.  The
+// lane first COLLECTS the point ranges of every row of the block it cannot prune
+// (all cell-offset loads are independent, so they are in flight together), then
+// walks the concatenation of its non-empty ranges in ONE flat loop with the next
+// candidate's load issued before the current one is evaluated.  A wave therefore
+// iterates max-over-lanes(total candidates) times, not sum-over-rows(max-over-
+// lanes), which is what lock-step row loops cost on divergent data.
+// Phase B -- lanes not resolved within radius R continue ring by ring.
 // Phase C -- what is still unresolved is queued with a lower bound LB on its true
 // squared distance while d2 keeps an UPPER bound (partial best, or a certificate
 // that a non-empty super-cell lies wholly within maxDist).  The trimmed-distance
 // filter only needs exact values up to its threshold, so k_knn_slow resolves
 // just the queued queries with LB <= threshold (normally none): kept pairs,
 // threshold and n_finite stay exact.
-template <typename T>
+template <typename T, int R>
 __global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                   const T *__restrict__ rd, int *__restrict__ slot_io,
-                                                  T *__restrict__ d2_out, ChainDev<T> ch, int use_seed, int R,
+                                                  T *__restrict__ d2_out, ChainDev<T> ch, int use_seed,
                                                   int *__restrict__ slow_count, int2 *__restrict__ slow_list,
                                                   T *__restrict__ slow_lb)
 {
     using V4 = typename Vec4<T>::type;
-    constexpr int CH = TileChunk<T>::value;
-    __shared__ V4 pts_l[CH];
-    __shared__ int cs_l[kTileRows][kTileWx + 1];
-    __shared__ int row_off[kTileRows + 1];
+    constexpr int NR = (2 * R + 1) * (2 * R + 1);
+    __shared__ int rng_a[NR - 1][64];
+    __shared__ int rng_b[NR - 1][64];
+    __shared__ T rng_l[NR - 1][64];
     const ProblemDev &P = probs[blockIdx.y];
     if (P.done) return;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    if (tile * 64 >= P.n) return;
     const int lane = threadIdx.x;
     const int i = tile * 64 + lane;
+    if (tile * 64 >= P.n) return;
     const bool live = i < P.n;
     const MapDev<T> M = maps[P.map];
     const GridDesc<T> g = M.g;
@@ -588,108 +581,78 @@ __global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ 
     const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
     const int cx = clamp_cell<T>(ux, g.inv_h, g.nx), cy = clamp_cell<T>(uy, g.inv_h, g.ny), cz = clamp_cell<T>(uz, g.inv_h, g.nz);
 
-    // ---- phase A: LDS-staged neighbourhood box ----
-    const int xa = max(wave_min_i(live ? cx : 0x7FFFFFFF) - R, 0), xb = min(wave_max_i(live ? cx : -1) + R, g.nx - 1);
-    const int ya = max(wave_min_i(live ? cy : 0x7FFFFFFF) - R, 0), yb = min(wave_max_i(live ? cy : -1) + R, g.ny - 1);
-    const int za = max(wave_min_i(live ? cz : 0x7FFFFFFF) - R, 0), zb = min(wave_max_i(live ? cz : -1) + R, g.nz - 1);
-    const int wx = xb - xa + 1, wy = yb - ya + 1, nrows = wy * (zb - za + 1);
-    int r_start = 0;
-    if (nrows <= kTileRows && wx <= kTileWx && PGICP_TILE_ENABLE) {
-        // cell offsets of the box: cs_l[r][k] = cell_start[row(r) + xa + k], k = 0..wx
-        for (int t = lane; t < nrows * (wx + 1); t += 64) {
-            const int r = t / (wx + 1), k = t - r * (wx + 1);
-            cs_l[r][k] = M.cell_start[g.nx * ((ya + r % wy) + g.ny * (za + r / wy)) + xa + k];
-        }
-        __syncthreads();
-        // exclusive prefix of the row lengths (lane r <-> row r)
-        int len = 0;
-        if (lane < nrows) len = cs_l[lane][wx] - cs_l[lane][0];
-        int inc = len;
+    // ---- phase A.1: own row first -- it usually holds the neighbour and shrinks the bound ----
+    if (live) scan_row<T>(M, g.nx * (cy + g.ny * cz), max(cx - R, 0), min(cx + R, g.nx - 1), ux, (T)0, qx, qy, qz, best);
+    // ---- phase A.2: collect the ranges of the other rows of the (2R+1)^3 block with that bound ----
+    int ra[NR - 1], rb[NR - 1];
+    T rl[NR - 1];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        row_off[lane + 1 <= kTileRows ? lane + 1 : kTileRows] = inc;   // lane 63 -> slot 64
-        if (lane == 0) row_off[0] = 0;
-        __syncthreads();
-        int r0 = 0;
-        while (r0 < nrows) {
-            // rows [r0, r1) whose points fit the LDS chunk together (at least one row)
-            const int base = row_off[r0];
-            const bool fits = lane >= r0 && lane < nrows && (row_off[lane + 1] - base) <= CH;
-            const unsigned long long fm = __ballot(fits) >> r0;
-            const unsigned long long nfm = ~fm;
-            int r1 = r0 + (nfm ? (int)__builtin_ctzll(nfm) : 64);
-            int c_lo = 0, c_hi = 0;                                   // sub-range of a single over-long row
-            const bool long_row = (r1 == r0);
-            const int long_len = row_off[r0 + 1] - base;
-            if (long_row) r1 = r0 + 1;
-            for (;;) {
-                if (long_row) { c_hi = min(c_lo + CH, long_len); }
-                // stage: 4 rows at a time, 16 lanes each
-                if (long_row) {
-                    const int seg = cs_l[r0][0];
-                    for (int k = lane; k < c_hi - c_lo; k += 64) pts_l[k] = M.pts[seg + c_lo + k];
-                } else {
-                    for (int rr = r0 + (lane >> 4); rr < r1; rr += 4) {
-                        const int seg = cs_l[rr][0], n = cs_l[rr][wx] - seg, dst = row_off[rr] - base;
-                        for (int k = lane & 15; k < n; k += 16) pts_l[dst + k] = M.pts[seg + k];
-                    }
+    for (int t = 0; t < NR - 1; ++t) {
+        const int tt = (t < R * (2 * R + 1) + R) ? t : t + 1;      // skip the centre (own) row
+        const int dy = tt % (2 * R + 1) - R, dz = tt / (2 * R + 1) - R;
+        const int y = cy + dy, z = cz + dz;
+        ra[t] = 0; rb[t] = 0; rl[t] = (T)0;
+        if (live && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
+            const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
+            const T lb2 = ly * ly + lz * lz;
+            if (!(lb2 > best.d2)) {
+                int xlo = max(cx - R, 0), xhi = min(cx + R, g.nx - 1);
+                if (best.d2 < Bits<T>::inf()) {
+                    const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + g.margin;
+                    xlo = max(xlo, clamp_cell<T>(ux - rad, g.inv_h, g.nx));
+                    xhi = min(xhi, clamp_cell<T>(ux + rad, g.inv_h, g.nx));
                 }
-                __syncthreads();
-                if (live) {
-                    // own row first, then the rest of the (2R+1)^2 neighbourhood
-                    for (int t = 0; t < (2 * R + 1) * (2 * R + 1); ++t) {
-                        int dy, dz;
-                        if (t == 0) { dy = 0; dz = 0; }
-                        else {
-                            const int tt = (t - 1 < 2 * R * (R + 1)) ? t - 1 : t;   // skip the centre entry
-                            dy = tt % (2 * R + 1) - R; dz = tt / (2 * R + 1) - R;
-                        }
-                        const int y = cy + dy, z = cz + dz;
-                        if (y < ya || y > yb || z < za || z > zb) continue;
-                        const int r = (y - ya) + wy * (z - za);
-                        if (r < r0 || r >= r1) continue;
-                        const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
-                        const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
-                        const T lb2 = ly * ly + lz * lz;
-                        if (lb2 > best.d2) continue;
-                        int xlo = max(cx - R, xa), xhi = min(cx + R, xb);
-                        if (best.d2 < Bits<T>::inf()) {
-                            const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + g.margin;
-                            xlo = max(xlo, clamp_cell<T>(ux - rad, g.inv_h, g.nx));
-                            xhi = min(xhi, clamp_cell<T>(ux + rad, g.inv_h, g.nx));
-                        }
-                        if (xlo > xhi) continue;
-                        const int seg = cs_l[r][0];
-                        int a = cs_l[r][xlo - xa], b = cs_l[r][xhi + 1 - xa];       // global point indices
-                        int off = row_off[r] - base - seg;                        // LDS position = global index + off
-                        if (long_row) { a = max(a, seg + c_lo); b = min(b, seg + c_hi); off = -(seg + c_lo); }
-                        int j = a;
-                        for (; j + 2 <= b; j += 2) {
-                            const V4 v0 = pts_l[j + off], v1 = pts_l[j + 1 + off];
-                            eval_point<T>(v0, j, qx, qy, qz, best);
-                            eval_point<T>(v1, j + 1, qx, qy, qz, best);
-                        }
-                        if (j < b) eval_point<T>(pts_l[j + off], j, qx, qy, qz, best);
-                    }
+                if (xlo <= xhi) {
+                    const int row = g.nx * (y + g.ny * z);
+                    ra[t] = M.cell_start[row + xlo];
+                    rb[t] = M.cell_start[row + xhi + 1];
+                    rl[t] = lb2;
                 }
-                __syncthreads();
-                if (!long_row) break;
-                c_lo = c_hi;
-                if (c_lo >= long_len) break;
             }
-            r0 = r1;
         }
-        r_start = R + 1;
+    }
+    int nr = 0;
+#pragma unroll
+    for (int t = 0; t < NR - 1; ++t)
+        if (ra[t] < rb[t]) { rng_a[nr][lane] = ra[t]; rng_b[nr][lane] = rb[t]; rng_l[nr][lane] = rl[t]; ++nr; }
+    // ---- flat walk over the concatenated ranges (LDS is only read by the lane that wrote it) ----
+    {
+        int k = -1, j = 0, e = 0;
+        bool valid = false;
+        // advance to the first range that still passes the row test
+        for (;;) {
+            ++k;
+            if (k >= nr) break;
+            if (rng_l[k][lane] > best.d2) continue;
+            j = rng_a[k][lane]; e = rng_b[k][lane]; valid = true;
+            break;
+        }
+        V4 cur = M.pts[valid ? j : 0];
+        while (__any(valid)) {
+            int jn = j + 1, kn = k, en = e;
+            bool vn = valid;
+            if (valid && jn >= e) {
+                vn = false;
+                for (;;) {                                           // next range whose row is still within the bound
+                    ++kn;
+                    if (kn >= nr) break;
+                    if (rng_l[kn][lane] > best.d2) continue;
+                    jn = rng_a[kn][lane]; en = rng_b[kn][lane]; vn = true;
+                    break;
+                }
+            }
+            const V4 nxt = M.pts[vn ? jn : 0];                    // next candidate's load is in flight during the eval
+            if (valid) eval_point<T>(cur, j, qx, qy, qz, best);
+            cur = nxt; j = jn; k = kn; e = en; valid = vn;
+        }
     }
     if (!live) return;
 
-    // ---- phase B: per-lane continuation ----
+    // ---- phase B: per-lane continuation from ring R+1 ----
     T gr;
     // without a seed (first iteration) distances are larger: walk more rings per lane before queueing
-    const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, r_start, use_seed ? kFastRings : kFastRingsUnseeded, best, gr);
+    const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, R + 1, use_seed ? kFastRings : kFastRingsUnseeded, best, gr);
 
     // ---- phase C: bookkeeping for the lazy slow path ----
     if (resolved) {
@@ -1339,8 +1302,10 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
         return;
     }
     (void)hipMemsetAsync(slow_count, 0, sizeof(int), st);
-    hipLaunchKernelGGL(k_knn_grid<T>, dim3(round8(cdiv(max_n, 64)), P), dim3(64), 0, st, probs, maps, rd, slot, d2, ch, use_seed,
-                       use_seed ? 1 : 2, slow_count, slow_list, slow_lb);
+    // R = 1 in both cases: measured, a 5x5x5 collected block on the unseeded first iteration costs
+    // 2.5x the ring-by-ring continuation (nothing prunes it until the own row has a hit)
+    hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, 64)), P), dim3(64), 0, st, probs, maps, rd, slot, d2, ch,
+                       use_seed, slow_count, slow_list, slow_lb);
 }
 
 // resolves the queries the fast path queued: all of them (exact_all, public matcher

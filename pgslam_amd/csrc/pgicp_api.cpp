@@ -447,7 +447,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         // selected (an upper bound of the final one) are searched exactly; then the threshold
         // is re-selected if anything changed.  Kept pairs / threshold / n_finite stay exact.
         {
-            ProfScope ps(c, PGICP_PROF_KNN_GRID, 0, 0);
+            ProfScope ps(c, PGICP_PROF_KNN_SLOW, act_units, act_probs);
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), 0);
         }

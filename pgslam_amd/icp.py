@@ -28,7 +28,7 @@ OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID = rang
 HOST, DEVICE = 0, 1
 MATCHER_GRID, MATCHER_BRUTE = 0, 1
 PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_update", "pretransform",
-              "covariance", "grid_build"]
+              "covariance", "grid_build", "knn_slow"]
 
 # every symbol include/pgicp.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
