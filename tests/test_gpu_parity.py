@@ -260,3 +260,73 @@ def test_icp_double_precision(ctx, oracle64, small):
     o = oracle64.icp(rd, mx, mn, w.T_init[0], **CHAIN)
     dt, dr = pose_error(o["T"], T)
     assert dt < TOL_TRANS and dr < TOL_ROT and st["iterations"] == o["iterations"]
+
+
+# ---------------------------------------------------------------- golden fixtures + full size
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("b", [0, 1])
+def test_gpu_matches_golden_fixture(ctx, b):
+    """HIP path against the committed vectors of the independent numpy/scipy float64 ICP."""
+    z = np.load(os.path.join(GOLD, "scan_to_map_small.npz"))
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    mid = ctx.set_map(z["map_xyz"], z["map_nrm"], center=True)
+    T, st = ctx.align(mid, z[f"reading{b}"], z[f"T_init{b}"])
+    ids, d2 = ctx.match(mid, z[f"reading{b}"], T=z[f"T_init{b}"])
+    ctx.destroy_map(mid)
+    dt, dr = pose_error(z[f"T_final{b}"], T)
+    assert dt < 1e-4 and dr < 1e-5          # float32 chain vs un-centred float64 chain (see tests/test_oracle.py)
+    assert st["iterations"] == int(z[f"iterations{b}"]) and st["n_finite"] == int(z[f"n_finite{b}"])
+    np.testing.assert_allclose(st["cov"], z[f"cov{b}"], rtol=1e-3, atol=1e-12)
+    clear = (z[f"nn_gap{b}"] > 1e-3) & (z[f"nn_d{b}"] < 1.99)
+    assert np.array_equal(ids[clear], z[f"nn_ids{b}"][clear])
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    """BASELINE.json configs[1] sizes: 100k-pt scans vs the 1M-pt map."""
+    from bench import build_workload
+    return build_workload(100_000, 1_000_000, 16)
+
+
+def test_full_size_match_bit_exact(ctx, oracle32, full_size):
+    w = full_size
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=False)
+    for b, T in ((0, w.T_init[0]), (3, w.T_truth[3])):
+        ids, d2 = ctx.match(mid, w.scans_xyz[b], T=T)
+        oid, od2 = oracle32.knn_kdtree(oracle32.transform(T, w.scans_xyz[b]), w.map_xyz, 2.0)
+        assert np.array_equal(ids, oid)
+        assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+    ctx.destroy_map(mid)
+
+
+def test_full_size_icp_parity_and_properties(ctx, oracle32, full_size):
+    w = full_size
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=True)
+    om = oracle32.map_create(w.map_xyz, w.map_nrm)
+    Ts, sts = ctx.align_batch(mid, w.scans_xyz[:4], w.T_init[:4])
+    for b in range(4):
+        o = oracle32.icp_map(om, w.scans_xyz[b], w.T_init[b], **CHAIN)
+        dt, dr = pose_error(o["T"], Ts[b])
+        assert dt < TOL_TRANS and dr < TOL_ROT, (b, dt, dr)
+        assert sts[b]["iterations"] == o["iterations"] and sts[b]["converged"] == o["converged"]
+        assert sts[b]["overlap"] == pytest.approx(o["overlap"], rel=1e-12)
+    oracle32.map_free(om)
+    # size-independent properties: (1) a converged result is a fixed point up to the stop criterion:
+    # restarting from it stops after smoothLength iterations and moves less than minDiffTransErr /
+    # minDiffRotErr; (2) equivariance: moving the reading by S and the guess by
+    # S^-1 describes the same problem up to float32 rounding of the moved reading
+    T2, st2 = ctx.align(mid, w.scans_xyz[0], Ts[0])
+    dt, dr = pose_error(Ts[0], T2)
+    assert st2["iterations"] == 3 and dt < CHAIN["min_diff_trans"] and dr < CHAIN["min_diff_rot"]
+    S = synth.se3(0.4, -0.3, 0.1, 0.05, 0.01, -0.02)
+    moved = oracle32.transform(S, w.scans_xyz[1])
+    T3, st3 = ctx.align(mid, moved, w.T_init[1] @ np.linalg.inv(S))
+    dt, dr = pose_error(Ts[1], T3 @ S)
+    assert dt < CHAIN["min_diff_trans"] and dr < CHAIN["min_diff_rot"]
+    ctx.destroy_map(mid)

@@ -1,0 +1,258 @@
+"""CPU tests that PIN THE ORACLE (oracle/icp_oracle.c): against the golden fixtures
+produced by an independent numpy/scipy float64 implementation
+(tests/golden/make_golden.py), against scipy.cKDTree / numpy directly, and
+against the analytic known answers of SURVEY.md Appendix B.  The reference ships
+no vectors of its own, so this is what stands behind "parity"."""
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from pgslam_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01,
+             smooth_length=3, sensor_std_dev=0.01)
+
+
+def pose_error(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    c = min(1.0, max(-1.0, (np.trace(d[:3, :3]) - 1.0) / 2.0))
+    return np.linalg.norm(d[:3, 3]), math.acos(c)
+
+
+def rng_cloud(seed, n, scale=1.0):
+    return ((synth.uniform01(seed, 3 * n).reshape(n, 3) - 0.5) * scale).astype(np.float32)
+
+
+# ------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("b", [0, 1])
+def test_oracle_matches_golden_scan_to_map(oracle32, oracle64, b):
+    z = np.load(os.path.join(GOLD, "scan_to_map_small.npz"))
+    for o in (oracle32, oracle64):
+        r = o.icp(z[f"reading{b}"], z["map_xyz"], z["map_nrm"], z[f"T_init{b}"], **CHAIN)
+        assert r["status"] == 0
+        dt, dr = pose_error(z[f"T_final{b}"], r["T"])
+        # independent float64 implementation without mean-centring: agreement is limited by
+        # discrete correspondence / trim-set flips, not by rounding
+        assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+        assert r["iterations"] == int(z[f"iterations{b}"])
+        assert r["converged"] == bool(z[f"converged{b}"])
+        assert r["n_finite"] == int(z[f"n_finite{b}"])
+        assert abs(r["n_kept"] - int(z[f"n_kept{b}"])) <= 1
+        assert r["overlap"] == pytest.approx(float(z[f"overlap{b}"]), abs=1e-3)
+        assert r["trim_limit"] == pytest.approx(float(z[f"trim_limit{b}"]), rel=1e-3)
+        assert r["residual"] == pytest.approx(float(z[f"residual{b}"]), rel=1e-2)
+        np.testing.assert_allclose(r["cov"], z[f"cov{b}"], rtol=1e-3, atol=1e-12)
+        # and it is the right answer
+        gt, gr = pose_error(z[f"T_truth{b}"], r["T"])
+        assert gt < 0.03 and gr < 0.003
+
+
+def test_oracle_matches_golden_two_scans(oracle32):
+    z = np.load(os.path.join(GOLD, "two_scans_small.npz"))
+    r = oracle32.icp(z["reading"], z["ref_xyz"], z["ref_nrm"], z["T_init"], **CHAIN)
+    dt, dr = pose_error(z["T_final"], r["T"])
+    assert dt < 1e-4 and dr < 1e-5
+    assert r["iterations"] == int(z["iterations"])
+    np.testing.assert_allclose(r["cov"], z["cov"], rtol=1e-3, atol=1e-12)
+
+
+@pytest.mark.parametrize("b", [0, 1])
+def test_first_iteration_correspondences_match_golden(oracle32, b):
+    """ids equal scipy's wherever the float64 nearest/second-nearest gap leaves no room for float32 rounding."""
+    z = np.load(os.path.join(GOLD, "scan_to_map_small.npz"))
+    q = oracle32.transform(z[f"T_init{b}"], z[f"reading{b}"])
+    for ids, d2 in (oracle32.knn_brute(q, z["map_xyz"], 2.0), oracle32.knn_kdtree(q, z["map_xyz"], 2.0)):
+        clear = (z[f"nn_gap{b}"] > 1e-4) & (z[f"nn_d{b}"] < 1.99)
+        assert clear.mean() > 0.95
+        assert np.array_equal(ids[clear], z[f"nn_ids{b}"][clear])
+        np.testing.assert_allclose(np.sqrt(d2[clear].astype(np.float64)), z[f"nn_d{b}"][clear], rtol=2e-4, atol=2e-6)
+
+
+# ------------------------------------------------------------------ matcher
+@pytest.mark.parametrize("max_dist", [np.inf, 0.2])
+def test_kdtree_equals_brute_bit_exact(oracle32, oracle64, max_dist):
+    for o, dt in ((oracle32, np.float32), (oracle64, np.float64)):
+        m = rng_cloud(1, 3000).astype(dt)
+        m = np.concatenate([m, m[:200]])                 # duplicates -> ties
+        q = rng_cloud(2, 1500, 1.3).astype(dt)
+        ib, db = o.knn_brute(q, m, max_dist)
+        ik, dk = o.knn_kdtree(q, m, max_dist)
+        assert np.array_equal(ib, ik) and np.array_equal(db, dk)
+
+
+def test_matcher_against_scipy_random(oracle64):
+    m = rng_cloud(3, 5000).astype(np.float64)
+    q = rng_cloud(4, 2000, 1.2).astype(np.float64)
+    ids, d2 = oracle64.knn_kdtree(q, m, np.inf)
+    d, i = cKDTree(m).query(q)
+    assert np.array_equal(ids, i)
+    np.testing.assert_allclose(np.sqrt(d2), d, rtol=1e-12)
+
+
+def test_tie_break_lowest_index_and_max_dist_sentinels(oracle32):
+    """Appendix B.4 / B.5."""
+    m = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 0], [1, 0, 0], [5, 5, 5]], dtype=np.float32)
+    q = np.array([[0, 0, 0], [0.5, 0, 0], [1, 0, 0], [100, 0, 0]], dtype=np.float32)
+    for fn in (oracle32.knn_brute, oracle32.knn_kdtree):
+        ids, d2 = fn(q, m, 3.0)
+        assert ids.tolist() == [0, 0, 1, -1]
+        assert d2[:3].tolist() == [0.0, 0.25, 0.0] and np.isinf(d2[3])
+    # squared distance exactly maxDist^2 is accepted
+    ids, d2 = oracle32.knn_brute(np.array([[3, 0, 0]], np.float32), np.zeros((1, 3), np.float32), 3.0)
+    assert ids[0] == 0 and d2[0] == 9.0
+
+
+# ------------------------------------------------------------------ outlier filter
+def test_trim_known_answer(oracle32):
+    """Appendix B.3."""
+    st, w, limit, nf = oracle32.trim_weights(np.arange(10, dtype=np.float32), 0.85)
+    assert st == 0 and limit == 8.0 and nf == 10 and w.sum() == 9
+    d = np.concatenate([np.arange(10, dtype=np.float32), np.full(3, np.inf, np.float32)])
+    st, w, limit, nf = oracle32.trim_weights(d, 0.85)
+    assert limit == 8.0 and nf == 10 and w.sum() == 9 and np.all(w[10:] == 0)
+    st, w, limit, nf = oracle32.trim_weights(d, 1.0)
+    assert limit == 9.0 and w.sum() == 10
+    st, *_ = oracle32.trim_weights(np.full(4, np.inf, np.float32), 0.85)
+    assert st == 1                                                 # ConvergenceError: no outlier to filter
+
+
+def test_trim_against_numpy_partition(oracle32):
+    d2 = (synth.uniform01(5, 9973) ** 2).astype(np.float32)
+    d2[::53] = np.inf
+    for ratio in (0.85, 0.5, 0.1, 0.999):
+        st, w, limit, nf = oracle32.trim_weights(d2, ratio)
+        vals = d2[np.isfinite(d2)]
+        k = int(np.float32(vals.size) * np.float32(ratio))
+        assert nf == vals.size and np.float32(limit) == np.partition(vals, k)[k]
+        assert np.array_equal(w, (d2 <= np.float32(limit)).astype(np.float32))
+
+
+# ------------------------------------------------------------------ error minimiser
+def three_planes(n=400):
+    """points on x=0, y=0, z=0 with exact normals (Appendix B.1)."""
+    u = synth.uniform01(6, 6 * n).reshape(3, n, 2) * 2.0 + 0.5
+    px = np.column_stack([np.zeros(n), u[0]])
+    py = np.column_stack([u[1][:, 0], np.zeros(n), u[1][:, 1]])
+    pz = np.column_stack([u[2], np.zeros(n)])
+    pts = np.concatenate([px, py, pz]).astype(np.float64)
+    nrm = np.concatenate([np.tile([1.0, 0, 0], (n, 1)), np.tile([0, 1.0, 0], (n, 1)), np.tile([0, 0, 1.0], (n, 1))])
+    return pts, nrm
+
+
+def test_point_to_plane_recovers_pure_translation(oracle64):
+    ref, nrm = three_planes()
+    t = np.array([0.03, -0.02, 0.05])
+    reading = ref + t
+    ids = np.arange(ref.shape[0], dtype=np.int32)
+    st, sys_ = oracle64.p2plane_system(reading, ref, nrm, ids, np.ones(ref.shape[0]))
+    x, rank = oracle64.solve6(sys_)
+    assert st == 0 and rank == 6
+    np.testing.assert_allclose(x[:3], 0.0, atol=1e-12)
+    np.testing.assert_allclose(x[3:], -t, atol=1e-12)
+    assert sys_[29] == pytest.approx(ref.shape[0] / 3 * float(np.sum(t ** 2)), rel=1e-12)     # residual
+    T = oracle64.delta_T(x)
+    np.testing.assert_allclose(T[:3, :3], np.eye(3), atol=1e-12)
+
+
+def test_normal_equations_against_numpy(oracle32):
+    z = np.load(os.path.join(GOLD, "scan_to_map_small.npz"))
+    q = oracle32.transform(z["T_init0"], z["reading0"])
+    ids, d2 = oracle32.knn_kdtree(q, z["map_xyz"], 2.0)
+    st, w, limit, nf = oracle32.trim_weights(d2, 0.85)
+    st, sys_ = oracle32.p2plane_system(q, z["map_xyz"], z["map_nrm"], ids, w)
+    k = w > 0
+    p, r, n = q[k].astype(np.float64), z["map_xyz"][ids[k]].astype(np.float64), z["map_nrm"][ids[k]].astype(np.float64)
+    J = np.column_stack([np.cross(p, n), n])
+    e = np.sum(n * (p - r), axis=1)
+    A = J.T @ J
+    np.testing.assert_allclose(sys_[:21], A[np.triu_indices(6)], rtol=1e-11)
+    np.testing.assert_allclose(sys_[21:27], -J.T @ e, rtol=1e-9, atol=1e-10)
+    assert sys_[27] == k.sum() == sys_[28]
+    assert sys_[29] == pytest.approx(np.sum(e * e), rel=1e-11)
+    x, rank = oracle32.solve6(sys_)
+    np.testing.assert_allclose(x, np.linalg.solve(A, -J.T @ e), rtol=1e-8, atol=1e-12)
+
+
+def test_identical_clouds_give_identity(oracle32):
+    """Appendix B.2: x = 0, rotation guard -> identity, residual 0, overlap = ratio."""
+    z = np.load(os.path.join(GOLD, "two_scans_small.npz"))
+    r = oracle32.icp(z["ref_xyz"], z["ref_xyz"], z["ref_nrm"], np.eye(4), **CHAIN)
+    assert r["status"] == 0 and r["iterations"] == 3 and r["converged"]
+    np.testing.assert_allclose(r["T"], np.eye(4), atol=1e-6)
+    assert r["residual"] < 1e-8
+    assert r["overlap"] == pytest.approx(1.0, abs=1e-9) or r["overlap"] >= 0.85   # ties at d2 = 0 are all kept
+
+
+def test_planar_scene_is_rank_deficient_minimal_norm(oracle64):
+    """Appendix B.6: a single plane observes only z, rx, ry; the rest stays 0."""
+    g = np.stack(np.meshgrid(np.linspace(-2, 2, 21), np.linspace(-2, 2, 21), indexing="ij"), -1).reshape(-1, 2)
+    ref = np.column_stack([g, np.zeros(len(g))])
+    nrm = np.tile([0.0, 0, 1.0], (len(g), 1))
+    reading = ref + np.array([0.0, 0.0, 0.04])
+    st, sys_ = oracle64.p2plane_system(reading, ref, nrm, np.arange(len(g), dtype=np.int32), np.ones(len(g)))
+    x, rank = oracle64.solve6(sys_)
+    assert rank == 3
+    np.testing.assert_allclose(x, [0, 0, 0, 0, 0, -0.04], atol=1e-12)
+
+
+# ------------------------------------------------------------------ checkers
+def test_differential_checker_scripted(oracle32):
+    """Appendix B.7: steps of 0.02 m then 0.004 m, smoothLength 3, minDiffTrans 0.01."""
+    c = oracle32.checker(40, 0.001, 0.01, 3)
+    x = 0.0
+    flags = []
+    for step in [0.02, 0.02, 0.02, 0.004, 0.004, 0.004, 0.004]:
+        x += step
+        flags.append(oracle32.checker_check(c, synth.se3(x=x)))
+    # history needs > smoothLength entries; mean of last three steps drops below 0.01 at the 5th check:
+    # (0.02 + 0.004 + 0.004)/3 = 0.0093
+    assert [f & 1 for f in flags[:5]] == [1, 1, 1, 1, 0] and flags[4] & 2
+    c = oracle32.checker(3, 0.0, 0.0, 3)
+    assert [oracle32.checker_check(c, np.eye(4)) for _ in range(3)] == [1, 1, 4]      # counter stop at the third
+
+
+def test_differential_checker_rotation(oracle32):
+    c = oracle32.checker(40, 0.001, 1.0, 3)
+    yaw = 0.0
+    out = []
+    for step in [0.01, 0.01, 0.01, 0.0005, 0.0005, 0.0005]:
+        yaw += step
+        out.append(oracle32.checker_check(c, synth.se3(yaw=yaw)) & 1)
+    assert out == [1, 1, 1, 1, 1, 0]
+
+
+# ------------------------------------------------------------------ transform / map assembly / centroid
+def test_map_assembly_order_and_values(oracle32):
+    """Appendix B.9."""
+    a, b, c = rng_cloud(7, 50), rng_cloud(8, 60), rng_cloud(9, 70)
+    n = np.tile(np.array([[0, 0, 1]], np.float32), (70, 1))
+    Ts = [np.eye(4), synth.se3(1.0, 2.0, 0.5, 0.3), synth.se3(-1.0, 0.0, 0.0, -0.2, 0.1)]
+    x, nn = oracle32.build_local_map([a, b, c], [n[:50], n[:60], n], Ts)
+    assert np.array_equal(x[:50], a)
+    for k, (cl, off) in enumerate([(b, 50), (c, 110)], start=1):
+        exp = cl.astype(np.float64) @ Ts[k][:3, :3].T + Ts[k][:3, 3]
+        np.testing.assert_allclose(x[off: off + cl.shape[0]], exp, atol=2e-6)
+    np.testing.assert_allclose(nn[110:], np.tile(Ts[2][:3, 2], (70, 1)), atol=1e-6)
+
+
+def test_centroid_is_order_independent(oracle32):
+    p = (rng_cloud(10, 5000, 200.0) + np.float32(37.5)).astype(np.float32)
+    m1 = oracle32.centroid(p)
+    m2 = oracle32.centroid(p[::-1].copy())
+    assert np.array_equal(m1, m2)
+    np.testing.assert_allclose(m1, p.astype(np.float64).mean(0), rtol=0, atol=2e-5)
+
+
+def test_partial_chain_matches_manual_steps(oracle32):
+    z = np.load(os.path.join(GOLD, "scan_to_map_small.npz"))
+    r = oracle32.partial_chain(z["reading1"], z["map_xyz"], z["map_nrm"], z["T_init1"], **CHAIN)
+    q = oracle32.transform(z["T_init1"], z["reading1"])
+    ids, d2 = oracle32.knn_brute(q, z["map_xyz"], 2.0)
+    st, w, limit, nf = oracle32.trim_weights(d2, 0.85)
+    st, sys_ = oracle32.p2plane_system(q, z["map_xyz"], z["map_nrm"], ids, w)
+    assert r["status"] == 0 and np.array_equal(r["ids"], ids)
+    assert r["overlap"] == sys_[27] / q.shape[0] and r["residual"] == sys_[29]
