@@ -139,6 +139,107 @@ def cpu_baseline(w, sample_scans, max_threads):
                 mean_iterations=iters, index_build_s=t_build)
 
 
+def build_pairs(n_pts, n_keyframes=24, cache_dir="/tmp"):
+    """Keyframe clouds for BASELINE configs[4] (cached; generated on host cores)."""
+    from pgslam_amd import synth
+    path = os.path.join(cache_dir, f"pgslam_amd_kf_{n_pts}_{n_keyframes}.npz")
+    jitter = np.deg2rad(synth.uniform(synth.WORLD_SEED + 51, n_keyframes, -3.0, 3.0))
+    poses = [synth.se3(x=-12.0 + 1.0 * i, yaw=float(jitter[i])) for i in range(n_keyframes)]
+    if os.path.exists(path):
+        z = np.load(path)
+        return list(z["xyz"]), list(z["nrm"]), poses
+    import multiprocessing as mp
+    rings = 64 if n_pts >= 50_000 else 16
+    jobs = [("kf", 2000 + i, n_pts, rings, poses[i]) for i in range(n_keyframes)]
+    with mp.get_context("fork").Pool(max(1, min(len(jobs), os.cpu_count() or 1, 32))) as pool:
+        res = pool.map(_gen_scan, jobs)
+    xyz, nrm = [r[0] for r in res], [r[1] for r in res]
+    try:
+        np.savez(path + ".tmp.npz", xyz=np.stack(xyz), nrm=np.stack(nrm))
+        os.replace(path + ".tmp.npz", path)
+    except OSError:
+        pass
+    return xyz, nrm, poses
+
+
+def main_loopclosure(args):
+    """BASELINE configs[4]: `--pairs` candidate pairs sharded over the ranks (strong scaling),
+    every rank aligns its shard in device batches, one all-gather of the 512-byte edge records."""
+    import torch
+    import torch.distributed as dist
+    from pgslam_amd import icp, synth, loop_closure as lc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    if rank == 0:
+        xyz, nrm, poses = build_pairs(args.n_scan)
+    if distributed:
+        dist.barrier()
+    if rank != 0:
+        xyz, nrm, poses = build_pairs(args.n_scan)
+    d_xyz = [torch.from_numpy(a).to(dev) for a in xyz]
+    d_nrm = [torch.from_numpy(a).to(dev) for a in nrm]
+    nk = len(xyz)
+    cands = []
+    for p in range(args.pairs):
+        i = p % nk
+        j = min(nk - 1, i + 1 + (p // nk) % 3) if i + 1 < nk else i - 1
+        T_true = synth.se3_inv(poses[i]) @ poses[j]
+        cands.append(lc.Candidate(from_id=i, to_id=j, reading=d_xyz[j], ref_xyz=d_xyz[i], ref_nrm=d_nrm[i],
+                                  T_init=T_true @ synth.perturbation(5000 + p)))
+    cfg = lc.LoopClosureConfig(chain=dict(CHAIN))
+    ctx = icp.Context(local_rank, **CHAIN, check_every=args.check_every)
+    costs = [c.reading.shape[0] + c.ref_xyz.shape[0] for c in cands]
+    mine = lc.shard(costs, world, rank)
+
+    def step():
+        parts = [lc.align_local(ctx, [cands[i] for i in mine[k:k + args.pair_chunk]], cfg)
+                 for k in range(0, len(mine), args.pair_chunk)]
+        local = np.concatenate(parts) if parts else np.zeros(0, dtype=lc.EDGE_DTYPE)
+        return lc.allgather_edges(local, mine, len(cands), device=dev if distributed else None)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        edges = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ok = int(np.sum(edges["status"] == 0))
+        print(json.dumps({
+            "metric": "loop-closure candidate ICPs/sec (100k-pt keyframe vs 100k-pt candidate map)",
+            "value": args.steps * len(cands) / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batched loop-closure ICP, {len(cands)} pairs of {args.n_scan}-pt clouds "
+                                   f"(BASELINE.json configs[4]), index build + ICP + residual check per pair, "
+                                   f"all-gather of 512-byte edge records", "pair_chunk": args.pair_chunk,
+                       "parallelism": f"pairs sharded over {world} rank(s), one all-gather"},
+            "pairs_ok": ok, "pairs_accepted": int(np.sum(edges["accepted"] == 1)),
+            "mean_iterations": float(np.mean(edges["iterations"]))}))
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +256,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--workload", choices=["scan2map", "loopclosure"], default="scan2map",
+                    help="scan2map = BASELINE configs[1] (the headline metric); loopclosure = configs[4]: --pairs candidate "
+                         "scan pairs (100k vs 100k) sharded over the ranks, all-gather of the SE(3) edges")
+    ap.add_argument("--pairs", type=int, default=512)
+    ap.add_argument("--pair-chunk", type=int, default=32, help="pairs aligned per device batch")
     ap.add_argument("--prepare-only", action="store_true",
                     help="generate + cache the synthetic workload and exit (run this before a rocprofv3 --pmc pass: the "
                          "generator forks worker processes, which must not happen under the counter profiler)")
@@ -163,6 +269,8 @@ def main():
     if args.prepare_only:
         build_workload(args.n_scan, args.n_map, args.queries)
         return
+    if args.workload == "loopclosure":
+        return main_loopclosure(args)
 
     import torch
     import torch.distributed as dist

@@ -330,3 +330,26 @@ def test_full_size_icp_parity_and_properties(ctx, oracle32, full_size):
     dt, dr = pose_error(Ts[1], T3 @ S)
     assert dt < CHAIN["min_diff_trans"] and dr < CHAIN["min_diff_rot"]
     ctx.destroy_map(mid)
+
+
+# ---------------------------------------------------------------- loop-closure batch (BASELINE configs[4], small)
+def test_loop_closure_batch_against_oracle(ctx, oracle32):
+    """Per pair: ICP::operator() (LoopCloser.hpp:98) + ComputeResidualError + CheckIcpResult, as one batch."""
+    from pgslam_amd import loop_closure as lc
+    ps = synth.make_pairs(5, n_pts=5000, n_keyframes=6, rings=16)
+    cands = [lc.Candidate(from_id=10 + k, to_id=20 + k, reading=ps.reading_xyz[k], ref_xyz=ps.ref_xyz[k],
+                          ref_nrm=ps.ref_nrm[k], T_init=ps.T_init[k]) for k in range(5)]
+    cfg = lc.LoopClosureConfig(chain=dict(CHAIN, matcher=icp.MATCHER_GRID), residual_error_threshold=50.0)
+    edges = lc.close_loops(ctx, cands, cfg)
+    assert edges.shape == (5,) and np.all(edges["from_id"] == 10 + np.arange(5))
+    for k in range(5):
+        o = oracle32.icp(ps.reading_xyz[k], ps.ref_xyz[k], ps.ref_nrm[k], ps.T_init[k], **CHAIN)
+        dt, dr = pose_error(o["T"], edges[k]["T_from_to"].reshape(4, 4))
+        assert dt < TOL_TRANS and dr < TOL_ROT
+        assert edges[k]["iterations"] == o["iterations"] and edges[k]["overlap"] == pytest.approx(o["overlap"], rel=1e-12)
+        res = oracle32.partial_chain(ps.reading_xyz[k], ps.ref_xyz[k], ps.ref_nrm[k], o["T"], **CHAIN)
+        assert edges[k]["residual"] == pytest.approx(res["residual"], rel=1e-3)
+        expect = (not o["max_iter_reached"]) and o["overlap"] >= 0.8 and res["residual"] <= 50.0
+        assert bool(edges[k]["accepted"]) == expect
+        np.testing.assert_allclose(edges[k]["cov"].reshape(6, 6), o["cov"], rtol=1e-5, atol=1e-14)
+    assert len(lc.accepted_constraints(edges)) == int(edges["accepted"].sum())
