@@ -210,10 +210,12 @@ int pgicp_transform_f64(pgicp_ctx *ctx, const double T[16], const double *in, in
                         int out_stride, int n, int rotate_only, int mem);
 int pgicp_build_local_map_f32(pgicp_ctx *ctx, int n_kf, const float *const *xyz, const float *const *nrm,
                               const int *strides_xyz, const int *strides_nrm, const int *counts,
-                              const double *T_ref_kf, float *out_xyz, float *out_nrm, int out_stride, int mem);
+                              const double *T_ref_kf, float *out_xyz, int out_xyz_stride, float *out_nrm,
+                              int out_nrm_stride, int mem);
 int pgicp_build_local_map_f64(pgicp_ctx *ctx, int n_kf, const double *const *xyz, const double *const *nrm,
                               const int *strides_xyz, const int *strides_nrm, const int *counts,
-                              const double *T_ref_kf, double *out_xyz, double *out_nrm, int out_stride, int mem);
+                              const double *T_ref_kf, double *out_xyz, int out_xyz_stride, double *out_nrm,
+                              int out_nrm_stride, int mem);
 
 /* ---- loop-closure dispatcher helpers (host logic, no GPU needed) -------
  * pgicp_shard_pairs: deterministic longest-processing-time split of n_pairs

@@ -1,0 +1,323 @@
+// pgslam.hpp -- pgslam's templated class API for the ICP hot path, on top of the
+// drop-in PointMatcher (pointmatcher.hpp).  Only the hot-path methods of
+// SURVEY.md §8(a) are provided; map management, candidate search and the
+// pose-graph solve stay CPU-side concerns of the caller (north_star).
+//
+//   pgslam::Types<T>            reference src/pgslam/types.h:13-61
+//   pgslam::BuildLocalMapCloud  LocalMap<T>::BuildCloudFromData   LocalMap.hpp:209-224
+//   pgslam::CloudInFrame        LocalMap<T>::CloudInWorldFrame    LocalMap.hpp:95-98
+//   pgslam::Localizer<T>        ProcessData / ComputeCurrentOverlap / ComputeOverlapWith
+//                               Localizer.hpp:91-135, 276-348
+//   pgslam::LoopCloser<T>       ProcessVertex core / CheckIcpResult / ComputeResidualError
+//                               LoopCloser.hpp:83-110, 308-365
+//   pgslam::LoopClosureBatch<T> LoopCloserMT queue (LoopCloserMT.hpp:26-67) processed as a batch
+#pragma once
+#include <chrono>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pointmatcher.hpp"
+
+namespace pgslam {
+
+template <typename T>
+struct Types {
+    using Time = std::chrono::time_point<std::chrono::high_resolution_clock>;
+    using PM = PointMatcher<T>;
+    using DP = typename PM::DataPoints;
+    using DPPtr = std::shared_ptr<DP>;
+    using Matrix = typename PM::Matrix;
+    using CovMatrix = typename PM::Matrix;          // 6x6 (the reference uses Eigen::Matrix<T,6,6>)
+    using ICP = typename PM::ICP;
+    using ICPSequence = typename PM::ICPSequence;
+    using TransformationPtr = std::shared_ptr<typename PM::Transformation>;
+    using DataPointsFilters = typename PM::DataPointsFilters;
+    using Label = typename DP::Label;
+    using Labels = typename DP::Labels;
+    using Vertex = size_t;                          // the reference uses a Boost.Graph descriptor
+
+    struct Keyframe {
+        size_t id;
+        DPPtr cloud_ptr;
+        Matrix T_world_kf;
+        Matrix optimized_T_world_kf;
+        Time update_time;
+    };
+    struct Constraint {
+        enum Type { kOdomConstraint, kLoopConstraint };
+        Type type;
+        Matrix T_from_to;
+        CovMatrix cov_from_to;
+        T weight;
+    };
+};
+
+#define IMPORT_PGSLAM_TYPES(TYPE)                                            \
+    using Time = typename pgslam::Types<TYPE>::Time;                         \
+    using PM = typename pgslam::Types<TYPE>::PM;                             \
+    using DP = typename pgslam::Types<TYPE>::DP;                             \
+    using DPPtr = typename pgslam::Types<TYPE>::DPPtr;                       \
+    using Matrix = typename pgslam::Types<TYPE>::Matrix;                     \
+    using CovMatrix = typename pgslam::Types<TYPE>::CovMatrix;               \
+    using ICP = typename pgslam::Types<TYPE>::ICP;                           \
+    using ICPSequence = typename pgslam::Types<TYPE>::ICPSequence;           \
+    using TransformationPtr = typename pgslam::Types<TYPE>::TransformationPtr; \
+    using DataPointsFilters = typename pgslam::Types<TYPE>::DataPointsFilters; \
+    using Keyframe = typename pgslam::Types<TYPE>::Keyframe;                 \
+    using Label = typename pgslam::Types<TYPE>::Label;                       \
+    using Labels = typename pgslam::Types<TYPE>::Labels;                     \
+    using Constraint = typename pgslam::Types<TYPE>::Constraint;             \
+    using Vertex = typename pgslam::Types<TYPE>::Vertex;
+
+//! LocalMap<T>::BuildCloudFromData: keyframes[0] is the reference keyframe (copied as is), every
+//! other keyframe cloud is moved by T_refkf_world * optimized_T_world_kf and appended, in the given order
+//! (the reference walks its buffer newest -> oldest, LocalMap.hpp:213-223).  One device pass.
+template <typename T>
+typename Types<T>::DP BuildLocalMapCloud(const std::vector<typename Types<T>::Keyframe> &keyframes)
+{
+    using PMT = PointMatcher<T>;
+    using DP = typename Types<T>::DP;
+    if (keyframes.empty()) return DP();
+    const auto T_refkf_world = keyframes[0].optimized_T_world_kf.inverse();
+    const int k = (int)keyframes.size();
+    bool all_normals = true;
+    long long total = 0;
+    for (auto &kf : keyframes) { all_normals = all_normals && kf.cloud_ptr->descriptorExists("normals"); total += kf.cloud_ptr->getNbPoints(); }
+    DP out;
+    out.features = typename PMT::Matrix(4, (int)total);
+    out.featureLabels = keyframes[0].cloud_ptr->featureLabels;
+    for (long long j = 0; j < total; j++) out.features(3, (int)j) = T(1);
+    if (all_normals) { out.descriptors = typename PMT::Matrix(3, (int)total); out.descriptorLabels.push_back(typename DP::Label("normals", 3)); }
+    std::vector<const T *> xs(k), ns(k);
+    std::vector<int> sx(k), sn(k), cnt(k);
+    std::vector<double> Ts((size_t)16 * k, 0.0);
+    for (int i = 0; i < k; i++) {
+        const DP &c = *keyframes[i].cloud_ptr;
+        xs[i] = c.xyzPtr(); sx[i] = c.xyzStride(); ns[i] = all_normals ? c.normalsPtr() : nullptr; sn[i] = all_normals ? c.normalsStride() : 3;
+        cnt[i] = (int)c.getNbPoints();
+        const auto Tk = (i == 0) ? PMT::Matrix::Identity(4, 4) : T_refkf_world * keyframes[i].optimized_T_world_kf;
+        pgslam_amd::to_row_major16(Tk, Ts.data() + 16 * i);
+    }
+    pgicp_ctx *ctx = pgslam_amd::default_context();
+    PMT::check(ctx, pgslam_amd::Abi<T>::local_map(ctx, k, xs.data(), all_normals ? ns.data() : nullptr, sx.data(), sn.data(), cnt.data(), Ts.data(),
+                                                   out.features.data(), 4, all_normals ? out.descriptors.data() : nullptr, 3));
+    return out;
+}
+
+template <typename T>
+class Localizer {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    Localizer() : rigid_transformation_(PM::get().REG(Transformation).create("RigidTransformation")),
+                  T_refkf_robot_(Matrix::Identity(4, 4)), T_world_robot_(Matrix::Identity(4, 4)),
+                  last_input_T_world_robot_(Matrix::Identity(4, 4)), T_world_refkf_(Matrix::Identity(4, 4)),
+                  overlap_threshold_(T(0.8)), minimal_overlap_(T(0.5)), has_map_(false) {}
+    void SetOverlapThreshold(T v) { overlap_threshold_ = v; }
+    void SetMinimalOverlapThreshold(T v) { minimal_overlap_ = v; }
+    //! Localizer.hpp:54-71 (the YAML text is kept to re-create temporary ICP objects)
+    void SetIcpConfigFromString(const std::string &yaml)
+    {
+        icp_config_buffer_ = yaml;
+        std::istringstream iss(icp_config_buffer_);
+        icp_sequence_.loadFromYaml(iss);
+    }
+    //! Localizer.hpp:148,168,254: the local map (already in the reference keyframe's frame) goes to the device
+    void SetLocalMap(const DP &local_map_cloud, const Matrix &optimized_T_world_refkf)
+    {
+        icp_sequence_.setMap(local_map_cloud);
+        T_world_refkf_ = optimized_T_world_refkf;
+        has_map_ = true;
+    }
+    //! Localizer.hpp:91-135 without the graph bookkeeping: filters, sensor->robot, odometry guess, ICP, world pose
+    Matrix ProcessData(const Matrix &input_T_world_robot, const Matrix &input_T_robot_sensor, DPPtr input_cloud_ptr)
+    {
+        input_cloud_ptr_ = input_cloud_ptr;
+        input_filters_.apply(*input_cloud_ptr_);
+        (*input_cloud_ptr_) = rigid_transformation_->compute(*input_cloud_ptr_, input_T_robot_sensor);
+        if (!has_map_) throw std::logic_error("[Localizer] no local map set");
+        const Matrix input_dT_robot = last_input_T_world_robot_.inverse() * input_T_world_robot;
+        const Matrix input_T_refkf_robot = T_refkf_robot_ * input_dT_robot;
+        T_refkf_robot_ = icp_sequence_(*input_cloud_ptr_, input_T_refkf_robot);
+        T_world_robot_ = T_world_refkf_ * T_refkf_robot_;
+        last_input_T_world_robot_ = input_T_world_robot;
+        return T_refkf_robot_;
+    }
+    //! Localizer.hpp:276-279
+    T ComputeCurrentOverlap() { return icp_sequence_.errorMinimizer->getOverlap(); }
+    Matrix CurrentCovariance() { return icp_sequence_.errorMinimizer->getCovariance(); }
+    bool IsOverlapEnough(T overlap) const { return overlap >= overlap_threshold_; }
+    //! Localizer.hpp:282-348 with the candidate local map given in WORLD frame: index build + one
+    //! findClosests + outlier weights + error elements -> weightedPointUsedRatio, as ONE device pass
+    T ComputeOverlapWith(const DP &candidate_map_in_world_frame)
+    {
+        typename PM::ICP temp_icp;
+        std::istringstream iss(icp_config_buffer_);
+        temp_icp.loadFromYaml(iss);
+        DP reference(candidate_map_in_world_frame);
+        temp_icp.referenceDataPointsFilters.init();
+        temp_icp.referenceDataPointsFilters.apply(reference);
+        temp_icp.matcher->init(reference);
+        DP reading(*input_cloud_ptr_);
+        temp_icp.readingDataPointsFilters.init();
+        temp_icp.readingDataPointsFilters.apply(reading);
+        double Tm[16], ratio = 0, residual = 0;
+        pgslam_amd::to_row_major16(T_world_robot_, Tm);
+        temp_icp.pushParams();
+        PM::check(temp_icp.ctx, pgslam_amd::Abi<T>::partial(temp_icp.ctx, temp_icp.matcher->mapId, reading.xyzPtr(), reading.xyzStride(),
+                                                           (int)reading.getNbPoints(), Tm, &ratio, &residual));
+        return (T)ratio;
+    }
+    const Matrix &T_refkf_robot() const { return T_refkf_robot_; }
+    const Matrix &T_world_robot() const { return T_world_robot_; }
+    ICPSequence &icp() { return icp_sequence_; }
+    DataPointsFilters &input_filters() { return input_filters_; }
+
+private:
+    DPPtr input_cloud_ptr_;
+    TransformationPtr rigid_transformation_;
+    DataPointsFilters input_filters_;
+    ICPSequence icp_sequence_;
+    std::string icp_config_buffer_;
+    Matrix T_refkf_robot_, T_world_robot_, last_input_T_world_robot_, T_world_refkf_;
+    T overlap_threshold_, minimal_overlap_;
+    bool has_map_;
+};
+
+template <typename T>
+class LoopCloser {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    struct Result {
+        bool accepted;
+        Matrix T_refkf_kf;
+        CovMatrix cov;
+        T overlap, residual;
+        bool max_iterations_reached;
+    };
+    LoopCloser() : overlap_threshold_(T(0.8)), residual_error_threshold_(T(5000)) {}
+    void SetOverlapThreshold(T v) { overlap_threshold_ = v; }
+    void SetResidualErrorThreshold(T v) { residual_error_threshold_ = v; }
+    void SetIcpConfigFromString(const std::string &yaml)
+    {
+        icp_config_buffer_ = yaml;
+        std::istringstream iss(icp_config_buffer_);
+        icp_.loadFromYaml(iss);
+    }
+    //! LoopCloser.hpp:95-109 for one candidate: ICP, CheckIcpResult, covariance for the optimizer
+    Result ProcessCandidate(const DP &input_cloud, const DP &candidate_local_map_cloud, const Matrix &input_T_refkf_kf)
+    {
+        Result r;
+        r.T_refkf_kf = icp_(input_cloud, candidate_local_map_cloud, input_T_refkf_kf);
+        r.max_iterations_reached = icp_.getMaxNumIterationsReached();
+        r.overlap = icp_.errorMinimizer->getOverlap();
+        r.cov = icp_.errorMinimizer->getCovariance();
+        r.residual = ComputeResidualError(input_cloud, candidate_local_map_cloud, r.T_refkf_kf);
+        r.accepted = CheckIcpResult(r);
+        return r;
+    }
+    //! LoopCloser.hpp:308-340
+    bool CheckIcpResult(const Result &r) const
+    {
+        if (r.max_iterations_reached) return false;
+        if (r.overlap < overlap_threshold_) return false;
+        if (r.residual > residual_error_threshold_) return false;
+        return true;
+    }
+    //! LoopCloser.hpp:343-365: temp ICP, reading moved by the result, new index on the RAW candidate cloud,
+    //! findClosests, outlier weights, getResidualError -- one device pass
+    T ComputeResidualError(const DP &input_cloud, const DP &candidate_cloud, const Matrix &T_refkf_kf) const
+    {
+        typename PM::ICP temp_icp;
+        std::istringstream iss(icp_config_buffer_);
+        temp_icp.loadFromYaml(iss);
+        temp_icp.matcher->init(candidate_cloud);
+        double Tm[16], ratio = 0, residual = 0;
+        pgslam_amd::to_row_major16(T_refkf_kf, Tm);
+        temp_icp.pushParams();
+        PM::check(temp_icp.ctx, pgslam_amd::Abi<T>::partial(temp_icp.ctx, temp_icp.matcher->mapId, input_cloud.xyzPtr(), input_cloud.xyzStride(),
+                                                           (int)input_cloud.getNbPoints(), Tm, &ratio, &residual));
+        return (T)residual;
+    }
+    ICP &icp() { return icp_; }
+
+private:
+    ICP icp_;
+    std::string icp_config_buffer_;
+    T overlap_threshold_, residual_error_threshold_;
+};
+
+//! The LoopCloserMT queue (LoopCloserMT.hpp:26-67) handled as a batch: all queued candidates of this
+//! rank run concurrently on the GPU, results come back as the 512-byte edge records that ranks all-gather.
+template <typename T>
+class LoopClosureBatch {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    struct Candidate { long long from_id, to_id; DPPtr reading, reference; Matrix T_init; };
+    void SetIcpConfigFromString(const std::string &yaml) { std::istringstream iss(yaml); chain_.loadFromYaml(iss); yaml_ = yaml; }
+    void Add(const Candidate &c) { queue_.push_back(c); }
+    size_t Size() const { return queue_.size(); }
+    //! indices of the queue this rank owns (deterministic LPT split, identical on every rank)
+    std::vector<int> Shard(int world_size, int rank) const
+    {
+        std::vector<int64_t> cost(queue_.size());
+        for (size_t i = 0; i < queue_.size(); i++) cost[i] = (int64_t)queue_[i].reading->getNbPoints() + (int64_t)queue_[i].reference->getNbPoints();
+        std::vector<int> idx(queue_.size());
+        int n = 0;
+        if (pgicp_shard_pairs((int)queue_.size(), cost.data(), world_size, rank, idx.data(), (int)idx.size(), &n) != PGICP_OK)
+            throw std::runtime_error("pgicp_shard_pairs failed");
+        idx.resize(n);
+        return idx;
+    }
+    //! align the given queue entries as one device batch and evaluate CheckIcpResult
+    std::vector<pgicp_edge> Run(const std::vector<int> &mine, T overlap_threshold = T(0.8), T residual_threshold = T(5000))
+    {
+        pgicp_ctx *ctx = chain_.ctx;
+        chain_.pushParams();
+        const int P = (int)mine.size();
+        std::vector<pgicp_problem> pr(P);
+        std::vector<int> maps(P, -1);
+        for (int k = 0; k < P; k++) {
+            const Candidate &c = queue_[mine[k]];
+            PM::check(ctx, pgslam_amd::Abi<T>::map_create(ctx, c.reference->xyzPtr(), c.reference->xyzStride(), c.reference->normalsPtr(),
+                                                         c.reference->normalsStride(), (int)c.reference->getNbPoints(), 1, &maps[k]));
+            pr[k].map_id = maps[k]; pr[k].reading = c.reading->xyzPtr(); pr[k].stride = c.reading->xyzStride();
+            pr[k].n = (int)c.reading->getNbPoints(); pr[k].mem = PGICP_HOST;
+            pgslam_amd::to_row_major16(c.T_init, pr[k].T_init);
+        }
+        std::vector<double> Tout((size_t)16 * P);
+        std::vector<pgicp_stats> st(P);
+        const int rc = sizeof(T) == 4 ? pgicp_align_batch_f32(ctx, P, pr.data(), Tout.data(), st.data())
+                                      : pgicp_align_batch_f64(ctx, P, pr.data(), Tout.data(), st.data());
+        if (rc != PGICP_OK && rc != PGICP_ERR_NO_MATCH && rc != PGICP_ERR_NAN) PM::check(ctx, rc);
+        std::vector<pgicp_edge> edges(P);
+        for (int k = 0; k < P; k++) {
+            const Candidate &c = queue_[mine[k]];
+            pgicp_edge &e = edges[k];
+            std::memset(&e, 0, sizeof e);
+            e.from_id = c.from_id; e.to_id = c.to_id; e.status = st[k].status; e.iterations = st[k].iterations;
+            e.max_iter_reached = st[k].max_iter_reached; e.overlap = st[k].overlap;
+            std::memcpy(e.T_from_to, Tout.data() + 16 * k, sizeof e.T_from_to);
+            std::memcpy(e.cov, st[k].cov, sizeof e.cov);
+            double ratio = 0, residual = 1.0 / 0.0;
+            if (st[k].status == PGICP_OK) {
+                const int prc = pgslam_amd::Abi<T>::partial(ctx, maps[k], c.reading->xyzPtr(), c.reading->xyzStride(), (int)c.reading->getNbPoints(),
+                                                            Tout.data() + 16 * k, &ratio, &residual);
+                if (prc != PGICP_OK) residual = 1.0 / 0.0;
+            }
+            e.residual = residual;
+            e.accepted = pgicp_check_icp_result(&st[k], residual, (double)overlap_threshold, (double)residual_threshold);
+            pgicp_map_destroy(ctx, maps[k]);
+        }
+        return edges;
+    }
+
+private:
+    typename PM::ICP chain_;
+    std::string yaml_;
+    std::vector<Candidate> queue_;
+};
+
+}  // namespace pgslam

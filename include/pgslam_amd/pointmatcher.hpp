@@ -1,0 +1,662 @@
+// pointmatcher.hpp -- drop-in for the part of libpointmatcher's object model that
+// pgslam drives on its ICP hot path, forwarding every numeric stage to the
+// MI355X library through the C ABI of include/pgicp.h.
+//
+// Same spelling as PointMatcher<T> (reference src/pgslam/types.h:19-29 aliases
+// it as PM): DataPoints, Matches, OutlierWeights, Transformation(s),
+// DataPointsFilters, Matcher, OutlierFilters, ErrorMinimizer (+ErrorElements),
+// TransformationCheckers, ICPChainBase, ICP, ICPSequence, ConvergenceError,
+// PM::get().REG(Transformation).create("RigidTransformation").
+// Call sites mirrored: Localizer.hpp:20,70,77,103,106,126,148,168,238,254,278,
+// 309-347; LoopCloser.hpp:73,98,108,317,331,346-362; LocalMap.hpp:37,97,222.
+//
+// Header only; link with -lpgicp.  There is no CPU fallback: constructing an ICP
+// object without a usable GPU throws.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <istream>
+#include <limits>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../pgicp.h"
+#include "matrix.hpp"
+#include "yaml_lite.hpp"
+
+namespace pgslam_amd {
+
+// one lazily created context for objects that are not ICP chains (standalone
+// RigidTransformation, LocalMap assembly); every ICP chain owns its own context
+// and stream, as every pgslam worker owns its own ICP object.
+inline pgicp_ctx *default_context(int device = 0)
+{
+    struct Holder {
+        pgicp_ctx *c = nullptr;
+        ~Holder() { if (c) pgicp_ctx_destroy(c); }
+    };
+    static thread_local Holder h;
+    if (!h.c) {
+        const int st = pgicp_ctx_create(device, &h.c);
+        if (st != PGICP_OK) throw std::runtime_error("pgslam_amd: no usable MI355X device (pgicp_ctx_create failed, code " + std::to_string(st) + ")");
+    }
+    return h.c;
+}
+
+template <typename T> struct Abi;
+template <> struct Abi<float> {
+    static int map_create(pgicp_ctx *c, const float *x, int xs, const float *n, int ns, int m, int center, int *id) { return pgicp_map_create_f32(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
+    static int align(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f32(c, id, r, s, n, PGICP_HOST, Ti, To, st); }
+    static int match(pgicp_ctx *c, int id, const float *r, int s, int n, int32_t *ids, float *d2) { return pgicp_match_f32(c, id, r, s, n, PGICP_HOST, nullptr, ids, d2); }
+    static int weights(pgicp_ctx *c, const float *d2, int n, float *w, float *lim, int *nf) { return pgicp_outlier_weights_f32(c, d2, n, PGICP_HOST, w, lim, nf); }
+    static int stats(pgicp_ctx *c, int id, const float *r, int s, int n, const int32_t *ids, const float *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f32(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
+    static int partial(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
+    static int transform(pgicp_ctx *c, const double *Tm, const float *in, int is, float *out, int os, int n, int ro) { return pgicp_transform_f32(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
+    static int local_map(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
+};
+template <> struct Abi<double> {
+    static int map_create(pgicp_ctx *c, const double *x, int xs, const double *n, int ns, int m, int center, int *id) { return pgicp_map_create_f64(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
+    static int align(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f64(c, id, r, s, n, PGICP_HOST, Ti, To, st); }
+    static int match(pgicp_ctx *c, int id, const double *r, int s, int n, int32_t *ids, double *d2) { return pgicp_match_f64(c, id, r, s, n, PGICP_HOST, nullptr, ids, d2); }
+    static int weights(pgicp_ctx *c, const double *d2, int n, double *w, double *lim, int *nf) { return pgicp_outlier_weights_f64(c, d2, n, PGICP_HOST, w, lim, nf); }
+    static int stats(pgicp_ctx *c, int id, const double *r, int s, int n, const int32_t *ids, const double *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f64(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
+    static int partial(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
+    static int transform(pgicp_ctx *c, const double *Tm, const double *in, int is, double *out, int os, int n, int ro) { return pgicp_transform_f64(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
+    static int local_map(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
+};
+
+}  // namespace pgslam_amd
+
+template <typename T>
+struct PointMatcher {
+    typedef T ScalarType;
+    typedef pgslam_amd::Mat<T> Matrix;
+    typedef pgslam_amd::Mat<int> IntMatrix;
+    typedef Matrix TransformationParameters;
+    typedef Matrix OutlierWeights;
+    using A = pgslam_amd::Abi<T>;
+
+    //! what libpointmatcher throws when a stage cannot proceed; pgslam never catches it
+    struct ConvergenceError : std::runtime_error {
+        explicit ConvergenceError(const std::string &r) : std::runtime_error(r) {}
+    };
+    static void check(pgicp_ctx *c, int st)
+    {
+        if (st == PGICP_OK) return;
+        const std::string msg = c ? pgicp_last_error(c) : "pgicp error";
+        if (st == PGICP_ERR_NO_MATCH || st == PGICP_ERR_NAN) throw ConvergenceError(msg);
+        if (st == PGICP_ERR_NOT_RIGID) throw std::runtime_error("RigidTransformation: " + msg);
+        throw std::runtime_error("pgicp (" + std::to_string(st) + "): " + msg);
+    }
+
+    // ------------------------------------------------------------------ DataPoints
+    struct DataPoints {
+        struct Label {
+            std::string text;
+            size_t span;
+            Label(const std::string &t = "", size_t s = 0) : text(t), span(s) {}
+            bool operator==(const Label &o) const { return text == o.text && span == o.span; }
+        };
+        struct Labels : std::vector<Label> {
+            bool contains(const std::string &t) const { for (auto &l : *this) if (l.text == t) return true; return false; }
+            size_t totalDim() const { size_t d = 0; for (auto &l : *this) d += l.span; return d; }
+        };
+        Matrix features;          //!< (dim+1) x N homogeneous coordinates, column major: one point = 4 contiguous values
+        Labels featureLabels;
+        Matrix descriptors;       //!< D x N
+        Labels descriptorLabels;
+
+        DataPoints() {}
+        DataPoints(const Matrix &f, const Labels &fl) : features(f), featureLabels(fl) {}
+        DataPoints(const Matrix &f, const Labels &fl, const Matrix &d, const Labels &dl) : features(f), featureLabels(fl), descriptors(d), descriptorLabels(dl) {}
+        //! convenience: N x 3 points (+ optional N x 3 normals), row i = point i
+        static DataPoints fromXYZ(const T *xyz, int n, const T *normals = nullptr)
+        {
+            DataPoints dp;
+            dp.features = Matrix(4, n);
+            for (int i = 0; i < n; i++) { for (int a = 0; a < 3; a++) dp.features(a, i) = xyz[3 * i + a]; dp.features(3, i) = T(1); }
+            dp.featureLabels.push_back(Label("x", 1)); dp.featureLabels.push_back(Label("y", 1));
+            dp.featureLabels.push_back(Label("z", 1)); dp.featureLabels.push_back(Label("pad", 1));
+            if (normals) {
+                dp.descriptors = Matrix(3, n);
+                for (int i = 0; i < n; i++) for (int a = 0; a < 3; a++) dp.descriptors(a, i) = normals[3 * i + a];
+                dp.descriptorLabels.push_back(Label("normals", 3));
+            }
+            return dp;
+        }
+        unsigned getNbPoints() const { return (unsigned)features.cols(); }
+        unsigned getEuclideanDim() const { return features.rows() > 0 ? (unsigned)features.rows() - 1 : 0; }
+        bool descriptorExists(const std::string &name) const { return descriptorLabels.contains(name); }
+        int getDescriptorStartingRow(const std::string &name) const
+        {
+            int row = 0;
+            for (auto &l : descriptorLabels) { if (l.text == name) return row; row += (int)l.span; }
+            throw std::runtime_error("DataPoints: descriptor " + name + " not found");
+        }
+        int getDescriptorDimension(const std::string &name) const
+        {
+            for (auto &l : descriptorLabels) if (l.text == name) return (int)l.span;
+            return 0;
+        }
+        //! copy of the rows of one descriptor (Eigen returns a block view; reads are equivalent)
+        Matrix getDescriptorViewByName(const std::string &name) const
+        {
+            return descriptors.block(getDescriptorStartingRow(name), 0, getDescriptorDimension(name), descriptors.cols());
+        }
+        void addDescriptor(const std::string &name, const Matrix &d)
+        {
+            if (d.cols() != features.cols()) throw std::runtime_error("DataPoints::addDescriptor: wrong number of points");
+            if (descriptorExists(name)) throw std::runtime_error("DataPoints::addDescriptor: " + name + " exists");
+            const int old = descriptors.rows();
+            Matrix nd(old + d.rows(), features.cols());
+            for (int j = 0; j < features.cols(); j++) {
+                for (int i = 0; i < old; i++) nd(i, j) = descriptors(i, j);
+                for (int i = 0; i < d.rows(); i++) nd(old + i, j) = d(i, j);
+            }
+            descriptors = nd;
+            descriptorLabels.push_back(Label(name, d.rows()));
+        }
+        //! append dp; only descriptors present in BOTH clouds (same name and span) are kept
+        void concatenate(const DataPoints &dp)
+        {
+            if (features.cols() == 0) { *this = dp; return; }
+            if (dp.features.rows() != features.rows()) throw std::runtime_error("DataPoints::concatenate: feature dimensions differ");
+            const int n0 = features.cols(), n1 = dp.features.cols();
+            Matrix f(features.rows(), n0 + n1);
+            std::memcpy(f.data(), features.data(), sizeof(T) * features.size());
+            std::memcpy(f.data() + features.size(), dp.features.data(), sizeof(T) * dp.features.size());
+            Labels keep;
+            int rows = 0;
+            for (auto &l : descriptorLabels)
+                if (dp.descriptorLabels.contains(l.text) && dp.getDescriptorDimension(l.text) == (int)l.span) { keep.push_back(l); rows += (int)l.span; }
+            Matrix d(rows, n0 + n1);
+            int r = 0;
+            for (auto &l : keep) {
+                const int a = getDescriptorStartingRow(l.text), b = dp.getDescriptorStartingRow(l.text);
+                for (int k = 0; k < (int)l.span; k++) {
+                    for (int j = 0; j < n0; j++) d(r + k, j) = descriptors(a + k, j);
+                    for (int j = 0; j < n1; j++) d(r + k, n0 + j) = dp.descriptors(b + k, j);
+                }
+                r += (int)l.span;
+            }
+            features = f; descriptors = d; descriptorLabels = keep;
+        }
+        // (pointer, stride) views handed to the C ABI
+        const T *xyzPtr() const { return features.data(); }
+        int xyzStride() const { return features.rows(); }
+        const T *normalsPtr() const { return descriptorExists("normals") ? descriptors.data() + getDescriptorStartingRow("normals") : nullptr; }
+        int normalsStride() const { return descriptors.rows(); }
+    };
+
+    // ------------------------------------------------------------------ Matches
+    struct Matches {
+        typedef Matrix Dists;
+        typedef IntMatrix Ids;
+        static constexpr int InvalidId = -1;
+        static T InvalidDist() { return std::numeric_limits<T>::infinity(); }
+        Dists dists;      //!< knn x N SQUARED distances
+        Ids ids;          //!< knn x N indices into the reference
+        Matches() {}
+        Matches(int knn, int n) : dists(knn, n), ids(knn, n) {}
+    };
+
+    // ------------------------------------------------------------------ Transformation
+    struct Transformation {
+        virtual ~Transformation() {}
+        virtual DataPoints compute(const DataPoints &input, const TransformationParameters &parameters) const = 0;
+        virtual bool checkParameters(const TransformationParameters &parameters) const = 0;
+    };
+    struct RigidTransformation : Transformation {
+        pgicp_ctx *ctx;
+        explicit RigidTransformation(pgicp_ctx *c = nullptr) : ctx(c) {}
+        bool checkParameters(const TransformationParameters &p) const override
+        {
+            double e = 0;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    double s = 0;
+                    for (int k = 0; k < 3; k++) s += (double)p(k, i) * (double)p(k, j);
+                    e = std::max(e, std::fabs(s - (i == j ? 1.0 : 0.0)));
+                }
+            return e < 1e-3;
+        }
+        //! features' = T * features; the normals / observationDirections descriptors are rotated
+        DataPoints compute(const DataPoints &input, const TransformationParameters &parameters) const override
+        {
+            pgicp_ctx *c = ctx ? ctx : pgslam_amd::default_context();
+            DataPoints out(input);
+            double Tm[16];
+            pgslam_amd::to_row_major16(parameters, Tm);
+            const int n = (int)input.getNbPoints();
+            if (n == 0) return out;
+            check(c, A::transform(c, Tm, input.features.data(), input.features.rows(), out.features.data(), out.features.rows(), n, 0));
+            for (const char *name : {"normals", "observationDirections"}) {
+                if (!input.descriptorExists(name) || input.getDescriptorDimension(name) != 3) continue;
+                const int row = input.getDescriptorStartingRow(name);
+                check(c, A::transform(c, Tm, input.descriptors.data() + row, input.descriptors.rows(), out.descriptors.data() + row,
+                                      out.descriptors.rows(), n, 1));
+            }
+            return out;
+        }
+    };
+    struct Transformations : std::vector<std::shared_ptr<Transformation>> {
+        //! LoopCloser.hpp:352 -- temp_icp.transformations.apply(reading, T)
+        void apply(DataPoints &cloud, const TransformationParameters &parameters) const
+        {
+            DataPoints t(cloud);
+            for (auto &tr : *this) t = tr->compute(t, parameters);
+            cloud = t;
+        }
+    };
+
+    // ------------------------------------------------------------------ DataPointsFilters
+    struct DataPointsFilter {
+        virtual ~DataPointsFilter() {}
+        virtual void init() {}
+        virtual void inPlaceFilter(DataPoints &cloud) = 0;
+    };
+    struct IdentityDataPointsFilter : DataPointsFilter { void inPlaceFilter(DataPoints &) override {} };
+    //! keeps points whose distance to the origin is below (MaxDist) / above (MinDist) a limit -- host side, O(N)
+    struct DistLimitDataPointsFilter : DataPointsFilter {
+        T limit; bool keepInside;
+        DistLimitDataPointsFilter(T l, bool inside) : limit(l), keepInside(inside) {}
+        void inPlaceFilter(DataPoints &c) override
+        {
+            const int n = c.features.cols();
+            int k = 0;
+            for (int j = 0; j < n; j++) {
+                const double r2 = (double)c.features(0, j) * c.features(0, j) + (double)c.features(1, j) * c.features(1, j) + (double)c.features(2, j) * c.features(2, j);
+                const bool in = r2 < (double)limit * limit;
+                if (in != keepInside) continue;
+                if (k != j) {
+                    for (int i = 0; i < c.features.rows(); i++) c.features(i, k) = c.features(i, j);
+                    for (int i = 0; i < c.descriptors.rows(); i++) c.descriptors(i, k) = c.descriptors(i, j);
+                }
+                k++;
+            }
+            c.features.conservativeResize(c.features.rows(), k);
+            if (c.descriptors.rows()) c.descriptors.conservativeResize(c.descriptors.rows(), k);
+        }
+    };
+    struct DataPointsFilters : std::vector<std::shared_ptr<DataPointsFilter>> {
+        DataPointsFilters() {}
+        //! Localizer.hpp:77 -- a YAML list of filters
+        explicit DataPointsFilters(std::istream &in)
+        {
+            std::stringstream ss;
+            ss << "filters:\n" << in.rdbuf();          // a bare sequence: give it a section name
+            const auto chain = pgslam_amd::yaml_lite::parse(ss);
+            if (chain.has("filters")) load(chain.sections.at("filters"));
+        }
+        void load(const std::vector<pgslam_amd::yaml_lite::Module> &mods)
+        {
+            using pgslam_amd::yaml_lite::to_double;
+            for (auto &m : mods) {
+                if (m.name == "IdentityDataPointsFilter") this->push_back(std::make_shared<IdentityDataPointsFilter>());
+                else if (m.name == "MaxDistDataPointsFilter" || m.name == "MinDistDataPointsFilter") {
+                    if (m.params.count("dim") && m.params.at("dim") != "-1") throw std::runtime_error(m.name + ": only dim = -1 (radius) is supported");
+                    const T lim = (T)to_double(m.params.count("maxDist") ? m.params.at("maxDist") : m.params.count("minDist") ? m.params.at("minDist") : "1", m.name);
+                    this->push_back(std::make_shared<DistLimitDataPointsFilter>(lim, m.name == "MaxDistDataPointsFilter"));
+                } else
+                    throw std::runtime_error("DataPointsFilters: unsupported filter '" + m.name +
+                                             "' (surface-normal / sampling filters are scheduled work, SURVEY.md §8(f))");
+            }
+        }
+        void init() { for (auto &f : *this) f->init(); }
+        void apply(DataPoints &cloud) { for (auto &f : *this) f->inPlaceFilter(cloud); }
+    };
+
+    struct ICPChainBase;
+
+    // ------------------------------------------------------------------ Matcher
+    struct Matcher {
+        ICPChainBase *chain;
+        int knn = 1; T epsilon = 0; T maxDist = std::numeric_limits<T>::infinity();
+        int mapId = -1; int mapSize = 0;
+        explicit Matcher(ICPChainBase *c) : chain(c) {}
+        virtual ~Matcher() { release(); }
+        void release() { if (mapId >= 0 && chain && chain->ctx) { pgicp_map_destroy(chain->ctx, mapId); mapId = -1; } }
+        //! Localizer.hpp:317, LoopCloser.hpp:356 -- index over the cloud AS GIVEN (not centred)
+        virtual void init(const DataPoints &filteredReference) { initImpl(filteredReference, 0); }
+        void initImpl(const DataPoints &ref, int center)
+        {
+            release();
+            chain->pushParams();
+            check(chain->ctx, A::map_create(chain->ctx, ref.xyzPtr(), ref.xyzStride(), ref.normalsPtr(), ref.normalsStride(), (int)ref.getNbPoints(), center, &mapId));
+            mapSize = (int)ref.getNbPoints();
+        }
+        //! Localizer.hpp:328, LoopCloser.hpp:358
+        virtual Matches findClosests(const DataPoints &filteredReading)
+        {
+            if (mapId < 0) throw std::runtime_error("Matcher::findClosests: init() was not called");
+            const int n = (int)filteredReading.getNbPoints();
+            Matches m(1, n);
+            chain->pushParams();
+            check(chain->ctx, A::match(chain->ctx, mapId, filteredReading.xyzPtr(), filteredReading.xyzStride(), n, m.ids.data(), m.dists.data()));
+            return m;
+        }
+    };
+
+    // ------------------------------------------------------------------ OutlierFilters
+    struct OutlierFilter {
+        virtual ~OutlierFilter() {}
+        virtual OutlierWeights compute(const DataPoints &reading, const DataPoints &reference, const Matches &input) = 0;
+    };
+    struct TrimmedDistOutlierFilter : OutlierFilter {
+        ICPChainBase *chain; T ratio;
+        TrimmedDistOutlierFilter(ICPChainBase *c, T r) : chain(c), ratio(r) {}
+        OutlierWeights compute(const DataPoints &, const DataPoints &, const Matches &input) override
+        {
+            OutlierWeights w(input.dists.rows(), input.dists.cols());
+            chain->pushParams();
+            T lim; int nf;
+            check(chain->ctx, A::weights(chain->ctx, input.dists.data(), (int)input.dists.size(), w.data(), &lim, &nf));
+            return w;
+        }
+    };
+    struct OutlierFilters : std::vector<std::shared_ptr<OutlierFilter>> {
+        //! Localizer.hpp:330, LoopCloser.hpp:360 -- element-wise product of the filters' weights
+        OutlierWeights compute(const DataPoints &reading, const DataPoints &reference, const Matches &input)
+        {
+            if (this->empty()) return OutlierWeights::Constant(input.ids.rows(), input.ids.cols(), T(1));
+            OutlierWeights w = (*this)[0]->compute(reading, reference, input);
+            for (size_t k = 1; k < this->size(); k++) {
+                const OutlierWeights o = (*this)[k]->compute(reading, reference, input);
+                for (int j = 0; j < w.cols(); j++) for (int i = 0; i < w.rows(); i++) w(i, j) *= o(i, j);
+            }
+            return w;
+        }
+    };
+
+    // ------------------------------------------------------------------ ErrorMinimizer
+    struct ErrorMinimizer {
+        //! the matched, weighted pairs (Localizer.hpp:332): compaction of the non-zero-weight matches
+        struct ErrorElements {
+            DataPoints reading, reference;
+            OutlierWeights weights;
+            Matches matches;
+            int nbRejectedMatches = 0, nbRejectedPoints = 0;
+            T pointUsedRatio = 0, weightedPointUsedRatio = 0;
+            ErrorElements() {}
+            ErrorElements(const DataPoints &requestedPts, const DataPoints &sourcePts, const OutlierWeights &outlierWeights, const Matches &m)
+            {
+                const int knn = outlierWeights.rows(), n = outlierWeights.cols();
+                int kept = 0; double wsum = 0;
+                for (int k = 0; k < knn; k++) for (int i = 0; i < n; i++) if (outlierWeights(k, i) != T(0)) { kept++; wsum += (double)outlierWeights(k, i); }
+                if (kept == 0) throw ConvergenceError("ErrorMnimizer: no point to minimize");
+                reading.features = Matrix(requestedPts.features.rows(), kept); reading.featureLabels = requestedPts.featureLabels;
+                reading.descriptors = Matrix(requestedPts.descriptors.rows(), kept); reading.descriptorLabels = requestedPts.descriptorLabels;
+                reference.features = Matrix(sourcePts.features.rows(), kept); reference.featureLabels = sourcePts.featureLabels;
+                reference.descriptors = Matrix(sourcePts.descriptors.rows(), kept); reference.descriptorLabels = sourcePts.descriptorLabels;
+                weights = OutlierWeights(1, kept); matches = Matches(1, kept);
+                int j = 0;
+                for (int k = 0; k < knn; k++)
+                    for (int i = 0; i < n; i++) {
+                        if (outlierWeights(k, i) == T(0)) continue;
+                        const int id = m.ids(k, i);
+                        for (int r = 0; r < reading.features.rows(); r++) reading.features(r, j) = requestedPts.features(r, i);
+                        for (int r = 0; r < reading.descriptors.rows(); r++) reading.descriptors(r, j) = requestedPts.descriptors(r, i);
+                        for (int r = 0; r < reference.features.rows(); r++) reference.features(r, j) = sourcePts.features(r, id);
+                        for (int r = 0; r < reference.descriptors.rows(); r++) reference.descriptors(r, j) = sourcePts.descriptors(r, id);
+                        weights(0, j) = outlierWeights(k, i); matches.ids(0, j) = id; matches.dists(0, j) = m.dists(k, i);
+                        j++;
+                    }
+                nbRejectedMatches = knn * n - kept;
+                pointUsedRatio = (T)((double)kept / (double)(knn * n));
+                weightedPointUsedRatio = (T)(wsum / (double)(knn * n));
+            }
+        };
+        ICPChainBase *chain;
+        T sensorStdDev = T(0.01);
+        bool withCov = false;
+        // state of the last ICP run / compute()
+        T lastOverlap = 0; T lastResidual = 0; Matrix lastCov = Matrix::Zero(6, 6);
+        explicit ErrorMinimizer(ICPChainBase *c) : chain(c) {}
+        virtual ~ErrorMinimizer() {}
+        //! Localizer.hpp:278, LoopCloser.hpp:331: weightedPointUsedRatio of the last error elements (the reading
+        //! carries no simpleSensorNoise descriptor in pgslam's use -- SURVEY.md A.7)
+        T getOverlap() const { return lastOverlap; }
+        T getWeightedPointUsedRatio() const { return lastOverlap; }
+        //! Localizer.hpp:238, LoopCloser.hpp:108: 6x6 Censi covariance, order [x y z rx ry rz]; zeros without "WithCov"
+        Matrix getCovariance() const { return withCov ? lastCov : Matrix::Zero(6, 6); }
+        //! LoopCloser.hpp:362: sum w (n.(p-q))^2 -- `reference` must be the cloud given to matcher->init
+        T getResidualError(const DataPoints &filteredReading, const DataPoints &, const OutlierWeights &w, const Matches &m) const
+        {
+            double ratio, res;
+            if (!chain->matcher || chain->matcher->mapId < 0) throw std::runtime_error("getResidualError: matcher->init() was not called");
+            check(chain->ctx, A::stats(chain->ctx, chain->matcher->mapId, filteredReading.xyzPtr(), filteredReading.xyzStride(),
+                                       (int)filteredReading.getNbPoints(), m.ids.data(), w.data(), &ratio, &res, nullptr));
+            return (T)res;
+        }
+    };
+
+    // ------------------------------------------------------------------ TransformationCheckers
+    struct TransformationChecker { virtual ~TransformationChecker() {} std::string name; };
+    struct CounterTransformationChecker : TransformationChecker { int maxIterationCount = 40; };
+    struct DifferentialTransformationChecker : TransformationChecker { T minDiffRotErr = T(0.001), minDiffTransErr = T(0.001); int smoothLength = 3; };
+    struct TransformationCheckers : std::vector<std::shared_ptr<TransformationChecker>> {};
+
+    // ------------------------------------------------------------------ ICP chain
+    struct ICPChainBase {
+        DataPointsFilters readingDataPointsFilters, readingStepDataPointsFilters, referenceDataPointsFilters;
+        Transformations transformations;
+        std::shared_ptr<Matcher> matcher;
+        OutlierFilters outlierFilters;
+        std::shared_ptr<ErrorMinimizer> errorMinimizer;
+        TransformationCheckers transformationCheckers;
+        pgicp_ctx *ctx = nullptr;
+        pgicp_stats lastStats;
+
+        explicit ICPChainBase(int device = 0)
+        {
+            const int st = pgicp_ctx_create(device, &ctx);
+            if (st != PGICP_OK) throw std::runtime_error("PointMatcher::ICP: no usable MI355X device (code " + std::to_string(st) + "); there is no CPU fallback");
+            std::memset(&lastStats, 0, sizeof lastStats);
+            setDefault();
+        }
+        ICPChainBase(const ICPChainBase &) = delete;
+        ICPChainBase &operator=(const ICPChainBase &) = delete;
+        virtual ~ICPChainBase()
+        {
+            matcher.reset();
+            if (ctx) pgicp_ctx_destroy(ctx);
+        }
+        void cleanup()
+        {
+            readingDataPointsFilters.clear(); readingStepDataPointsFilters.clear(); referenceDataPointsFilters.clear();
+            transformations.clear(); outlierFilters.clear(); transformationCheckers.clear();
+            matcher.reset(); errorMinimizer.reset();
+        }
+        //! libpointmatcher defaults: KDTreeMatcher, TrimmedDist 0.85, PointToPlane, Counter(40)+Differential
+        virtual void setDefault()
+        {
+            cleanup();
+            transformations.push_back(std::make_shared<RigidTransformation>(ctx));
+            matcher = std::make_shared<Matcher>(this);
+            outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
+            errorMinimizer = std::make_shared<ErrorMinimizer>(this);
+            transformationCheckers.push_back(std::make_shared<CounterTransformationChecker>());
+            transformationCheckers.push_back(std::make_shared<DifferentialTransformationChecker>());
+        }
+        //! Localizer.hpp:70,311; LoopCloser.hpp:73,348
+        virtual void loadFromYaml(std::istream &in)
+        {
+            using pgslam_amd::yaml_lite::to_double;
+            const auto y = pgslam_amd::yaml_lite::parse(in);
+            cleanup();
+            transformations.push_back(std::make_shared<RigidTransformation>(ctx));
+            if (y.has("readingDataPointsFilters")) readingDataPointsFilters.load(y.sections.at("readingDataPointsFilters"));
+            if (y.has("readingStepDataPointsFilters")) readingStepDataPointsFilters.load(y.sections.at("readingStepDataPointsFilters"));
+            if (y.has("referenceDataPointsFilters")) referenceDataPointsFilters.load(y.sections.at("referenceDataPointsFilters"));
+            matcher = std::make_shared<Matcher>(this);
+            if (y.has("matcher") && !y.sections.at("matcher").empty()) {
+                const auto &m = y.sections.at("matcher")[0];
+                if (m.name != "KDTreeMatcher") throw std::runtime_error("loadFromYaml: unsupported matcher " + m.name);
+                for (auto &kv : m.params) {
+                    if (kv.first == "knn") matcher->knn = (int)to_double(kv.second, "knn");
+                    else if (kv.first == "epsilon") matcher->epsilon = (T)to_double(kv.second, "epsilon");
+                    else if (kv.first == "maxDist") matcher->maxDist = (T)to_double(kv.second, "maxDist");
+                    else if (kv.first == "searchType") {}      // both search types return the same neighbours here
+                    else throw std::runtime_error("KDTreeMatcher: unknown parameter " + kv.first);
+                }
+            }
+            if (y.has("outlierFilters"))
+                for (auto &m : y.sections.at("outlierFilters")) {
+                    if (m.name != "TrimmedDistOutlierFilter") throw std::runtime_error("loadFromYaml: unsupported outlier filter " + m.name);
+                    outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, m.params.count("ratio") ? (T)to_double(m.params.at("ratio"), "ratio") : T(0.85)));
+                }
+            else outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
+            if (outlierFilters.size() > 1) throw std::runtime_error("loadFromYaml: one TrimmedDistOutlierFilter is supported");
+            errorMinimizer = std::make_shared<ErrorMinimizer>(this);
+            if (y.has("errorMinimizer") && !y.sections.at("errorMinimizer").empty()) {
+                const auto &m = y.sections.at("errorMinimizer")[0];
+                if (m.name == "PointToPlaneWithCovErrorMinimizer") errorMinimizer->withCov = true;
+                else if (m.name != "PointToPlaneErrorMinimizer") throw std::runtime_error("loadFromYaml: unsupported error minimizer " + m.name);
+                for (auto &kv : m.params) {
+                    if (kv.first == "sensorStdDev") errorMinimizer->sensorStdDev = (T)to_double(kv.second, "sensorStdDev");
+                    else if ((kv.first == "force2D" || kv.first == "force4DOF") && (kv.second == "0" || kv.second == "false")) {}
+                    else throw std::runtime_error(m.name + ": unsupported parameter " + kv.first);
+                }
+            }
+            if (y.has("transformationCheckers"))
+                for (auto &m : y.sections.at("transformationCheckers")) {
+                    if (m.name == "CounterTransformationChecker") {
+                        auto c = std::make_shared<CounterTransformationChecker>();
+                        if (m.params.count("maxIterationCount")) c->maxIterationCount = (int)to_double(m.params.at("maxIterationCount"), "maxIterationCount");
+                        transformationCheckers.push_back(c);
+                    } else if (m.name == "DifferentialTransformationChecker") {
+                        auto c = std::make_shared<DifferentialTransformationChecker>();
+                        if (m.params.count("minDiffRotErr")) c->minDiffRotErr = (T)to_double(m.params.at("minDiffRotErr"), "minDiffRotErr");
+                        if (m.params.count("minDiffTransErr")) c->minDiffTransErr = (T)to_double(m.params.at("minDiffTransErr"), "minDiffTransErr");
+                        if (m.params.count("smoothLength")) c->smoothLength = (int)to_double(m.params.at("smoothLength"), "smoothLength");
+                        transformationCheckers.push_back(c);
+                    } else
+                        throw std::runtime_error("loadFromYaml: unsupported transformation checker " + m.name);
+                }
+            else {
+                transformationCheckers.push_back(std::make_shared<CounterTransformationChecker>());
+                transformationCheckers.push_back(std::make_shared<DifferentialTransformationChecker>());
+            }
+        }
+        //! chain objects -> pgicp_params
+        void pushParams()
+        {
+            pgicp_params p;
+            pgicp_default_params(&p);
+            pgicp_params cur;
+            pgicp_get_params(ctx, &cur);
+            p.matcher = cur.matcher; p.grid_cell = cur.grid_cell; p.check_every = cur.check_every;
+            if (matcher) { p.knn = matcher->knn; p.epsilon = (double)matcher->epsilon; p.max_dist = (double)matcher->maxDist; }
+            if (!outlierFilters.empty())
+                if (auto t = std::dynamic_pointer_cast<TrimmedDistOutlierFilter>(outlierFilters[0])) p.trim_ratio = (double)t->ratio;
+            if (errorMinimizer) p.sensor_std_dev = (double)errorMinimizer->sensorStdDev;
+            bool hasCounter = false, hasDiff = false;
+            for (auto &c : transformationCheckers) {
+                if (auto cc = std::dynamic_pointer_cast<CounterTransformationChecker>(c)) { p.max_iters = cc->maxIterationCount; hasCounter = true; }
+                if (auto dc = std::dynamic_pointer_cast<DifferentialTransformationChecker>(c)) {
+                    p.min_diff_rot = (double)dc->minDiffRotErr; p.min_diff_trans = (double)dc->minDiffTransErr; p.smooth_length = dc->smoothLength; hasDiff = true;
+                }
+            }
+            if (!hasCounter) p.max_iters = 1 << 20;
+            if (!hasDiff) { p.min_diff_rot = 0; p.min_diff_trans = 0; }
+            check(ctx, pgicp_set_params(ctx, &p));
+        }
+        //! LoopCloser.hpp:317
+        bool getMaxNumIterationsReached() const { return lastStats.max_iter_reached != 0; }
+        unsigned getPrefilteredReadingPtsCount() const { return prefilteredReadingPtsCount; }
+        unsigned getPrefilteredReferencePtsCount() const { return prefilteredReferencePtsCount; }
+
+    protected:
+        unsigned prefilteredReadingPtsCount = 0, prefilteredReferencePtsCount = 0;
+        void storeStats(const pgicp_stats &s)
+        {
+            lastStats = s;
+            errorMinimizer->lastOverlap = (T)s.overlap;
+            errorMinimizer->lastResidual = (T)s.residual;
+            Matrix cov(6, 6);
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) cov(i, j) = (T)s.cov[i * 6 + j];
+            errorMinimizer->lastCov = cov;
+        }
+        TransformationParameters alignOnMap(const DataPoints &readingIn, const TransformationParameters &T_init)
+        {
+            DataPoints reading(readingIn);
+            readingDataPointsFilters.init();
+            readingDataPointsFilters.apply(reading);
+            prefilteredReadingPtsCount = reading.getNbPoints();
+            if (!readingStepDataPointsFilters.empty()) throw std::runtime_error("ICP: readingStepDataPointsFilters are not supported on the device loop");
+            double Ti[16], To[16];
+            pgslam_amd::to_row_major16(T_init, Ti);
+            pgicp_stats st;
+            pushParams();
+            const int rc = A::align(ctx, matcher->mapId, reading.xyzPtr(), reading.xyzStride(), (int)reading.getNbPoints(), Ti, To, &st);
+            storeStats(st);
+            check(ctx, rc);
+            return pgslam_amd::from_row_major16<T>(To);
+        }
+    };
+
+    struct ICP : ICPChainBase {
+        explicit ICP(int device = 0) : ICPChainBase(device) {}
+        TransformationParameters operator()(const DataPoints &readingIn, const DataPoints &referenceIn) { return (*this)(readingIn, referenceIn, Matrix::Identity(4, 4)); }
+        //! LoopCloser.hpp:98 -- reference filters, mean-centring, index build, loop
+        TransformationParameters operator()(const DataPoints &readingIn, const DataPoints &referenceIn, const TransformationParameters &initialTransformationParameters)
+        {
+            return compute(readingIn, referenceIn, initialTransformationParameters);
+        }
+        TransformationParameters compute(const DataPoints &readingIn, const DataPoints &referenceIn, const TransformationParameters &T_init)
+        {
+            DataPoints reference(referenceIn);
+            this->referenceDataPointsFilters.init();
+            this->referenceDataPointsFilters.apply(reference);
+            this->prefilteredReferencePtsCount = reference.getNbPoints();
+            if (!reference.descriptorExists("normals")) throw std::runtime_error("PointToPlaneErrorMinimizer: the reference has no 'normals' descriptor");
+            this->matcher->initImpl(reference, 1);
+            return this->alignOnMap(readingIn, T_init);
+        }
+    };
+
+    struct ICPSequence : ICP {
+        explicit ICPSequence(int device = 0) : ICP(device) {}
+        bool hasMap() const { return mapPointCloud.getNbPoints() != 0; }
+        //! Localizer.hpp:148,168,254 -- copy, reference filters, mean-centre, build the index; stays resident in HBM
+        bool setMap(const DataPoints &inputCloud)
+        {
+            mapPointCloud = inputCloud;
+            this->referenceDataPointsFilters.init();
+            this->referenceDataPointsFilters.apply(mapPointCloud);
+            this->prefilteredReferencePtsCount = mapPointCloud.getNbPoints();
+            if (!mapPointCloud.descriptorExists("normals")) throw std::runtime_error("PointToPlaneErrorMinimizer: the map has no 'normals' descriptor");
+            this->matcher->initImpl(mapPointCloud, 1);
+            return true;
+        }
+        void clearMap() { mapPointCloud = DataPoints(); this->matcher->release(); }
+        const DataPoints &getPrefilteredMap() const { return mapPointCloud; }
+        TransformationParameters operator()(const DataPoints &cloudIn) { return (*this)(cloudIn, Matrix::Identity(4, 4)); }
+        //! Localizer.hpp:126.  Without a map the first cloud becomes the map and identity is returned
+        TransformationParameters operator()(const DataPoints &cloudIn, const TransformationParameters &initialTransformationParameters)
+        {
+            if (!hasMap()) { setMap(cloudIn); return Matrix::Identity(4, 4); }
+            return this->alignOnMap(cloudIn, initialTransformationParameters);
+        }
+    private:
+        DataPoints mapPointCloud;
+    };
+
+    // ------------------------------------------------------------------ registrar (PM::get().REG(Transformation).create(...))
+    struct TransformationRegistrarT {
+        std::shared_ptr<Transformation> create(const std::string &name) const
+        {
+            if (name == "RigidTransformation") return std::make_shared<RigidTransformation>();
+            throw std::runtime_error("Registrar: unknown transformation " + name);
+        }
+    };
+    TransformationRegistrarT TransformationRegistrar;
+    static PointMatcher &get() { static PointMatcher pm; return pm; }
+};
+
+#ifndef REG
+#define REG(name) name##Registrar
+#endif

@@ -786,9 +786,9 @@ int transform(pgicp_ctx *c, const double *T16, const T *in, int in_stride, T *ou
 
 template <typename T>
 int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const *nrm, const int *sx, const int *sn,
-                    const int *counts, const double *T_ref_kf, T *out_xyz, T *out_nrm, int out_stride, int mem)
+                    const int *counts, const double *T_ref_kf, T *out_xyz, int out_stride, T *out_nrm, int out_nstride, int mem)
 {
-    if (!c || n_kf <= 0 || !xyz || !counts || !T_ref_kf || !out_xyz || out_stride < 3)
+    if (!c || n_kf <= 0 || !xyz || !counts || !T_ref_kf || !out_xyz || out_stride < 3 || (out_nrm && out_nstride < 3))
         return fail(c, PGICP_ERR_ARG, "pgicp_build_local_map: bad argument");
     HIPC(c, hipSetDevice(c->device));
     State<T> &S = state<T>(c);
@@ -801,13 +801,14 @@ int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const 
     }
     T *d_ox = out_xyz, *d_on = out_nrm;
     const size_t ob = sizeof(T) * ((size_t)(total - 1) * out_stride + 3);
+    const size_t onb = out_nrm ? sizeof(T) * ((size_t)(total - 1) * out_nstride + 3) : 0;
     if (mem == PGICP_HOST) {
         HIPC(c, S.staging.ensure(stage));
-        HIPC(c, S.stage_aux.ensure(2 * ((ob + 255) & ~(size_t)255)));
+        HIPC(c, S.stage_aux.ensure(((ob + 255) & ~(size_t)255) + onb + 256));
         d_ox = S.stage_aux.template as<T>();
         d_on = out_nrm ? (T *)((char *)S.stage_aux.p + ((ob + 255) & ~(size_t)255)) : nullptr;
         HIPC(c, hipMemcpyAsync(d_ox, out_xyz, ob, hipMemcpyHostToDevice, c->stream));
-        if (out_nrm) HIPC(c, hipMemcpyAsync(d_on, out_nrm, ob, hipMemcpyHostToDevice, c->stream));
+        if (out_nrm) HIPC(c, hipMemcpyAsync(d_on, out_nrm, onb, hipMemcpyHostToDevice, c->stream));
     }
     size_t soff = 0;
     long long off = 0;
@@ -825,13 +826,13 @@ int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const 
             st = to_device<T>(c, nrm[k], sn[k], counts[k], mem, S.staging, soff, &d_n);
             if (st) return st;
             if (mem == PGICP_HOST) soff += staged_bytes(sizeof(T), sn[k], counts[k]);
-            launch_transform<T>(c->stream, d_n, sn[k], d_on + off * out_stride, out_stride, counts[k], Tk, 1);
+            launch_transform<T>(c->stream, d_n, sn[k], d_on + off * out_nstride, out_nstride, counts[k], Tk, 1);
         }
         off += counts[k];
     }
     if (mem == PGICP_HOST) {
         HIPC(c, hipMemcpyAsync(out_xyz, d_ox, ob, hipMemcpyDeviceToHost, c->stream));
-        if (out_nrm) HIPC(c, hipMemcpyAsync(out_nrm, d_on, ob, hipMemcpyDeviceToHost, c->stream));
+        if (out_nrm) HIPC(c, hipMemcpyAsync(out_nrm, d_on, onb, hipMemcpyDeviceToHost, c->stream));
     }
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
@@ -1032,11 +1033,11 @@ int pgicp_transform_f64(pgicp_ctx *c, const double T[16], const double *in, int 
 { return transform<double>(c, T, in, is, out, os, n, ro, mem); }
 
 int pgicp_build_local_map_f32(pgicp_ctx *c, int n_kf, const float *const *xyz, const float *const *nrm, const int *sx,
-                              const int *sn, const int *counts, const double *T_ref_kf, float *ox, float *on, int os, int mem)
-{ return build_local_map<float>(c, n_kf, xyz, nrm, sx, sn, counts, T_ref_kf, ox, on, os, mem); }
+                              const int *sn, const int *counts, const double *T_ref_kf, float *ox, int os, float *on, int ons, int mem)
+{ return build_local_map<float>(c, n_kf, xyz, nrm, sx, sn, counts, T_ref_kf, ox, os, on, ons, mem); }
 int pgicp_build_local_map_f64(pgicp_ctx *c, int n_kf, const double *const *xyz, const double *const *nrm, const int *sx,
-                              const int *sn, const int *counts, const double *T_ref_kf, double *ox, double *on, int os, int mem)
-{ return build_local_map<double>(c, n_kf, xyz, nrm, sx, sn, counts, T_ref_kf, ox, on, os, mem); }
+                              const int *sn, const int *counts, const double *T_ref_kf, double *ox, int os, double *on, int ons, int mem)
+{ return build_local_map<double>(c, n_kf, xyz, nrm, sx, sn, counts, T_ref_kf, ox, os, on, ons, mem); }
 
 int pgicp_shard_pairs(int n_pairs, const int64_t *cost, int world, int rank, int *out_idx, int cap, int *n_out)
 {

@@ -331,7 +331,7 @@ class Context:
         PP = C.c_void_p * k
         fn = getattr(self.lib, "pgicp_build_local_map" + self._sfx(dtype))
         self._check(fn(self.h, C.c_int(k), PP(*[b.ptr for b in xs]), PP(*[b.ptr for b in ns]), sx, sn, counts,
-                       C.c_void_p(Ts.ctypes.data), C.c_void_p(out_x.ctypes.data), C.c_void_p(out_n.ctypes.data),
+                       C.c_void_p(Ts.ctypes.data), C.c_void_p(out_x.ctypes.data), C.c_int(3), C.c_void_p(out_n.ctypes.data),
                        C.c_int(3), C.c_int(HOST)))
         return out_x, out_n
 

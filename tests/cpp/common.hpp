@@ -1,0 +1,86 @@
+// shared helpers of the C++ drop-in tests
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "pgslam_amd/pgslam.hpp"
+
+#define CHECK(cond)                                                                           \
+    do {                                                                                      \
+        if (!(cond)) { std::fprintf(stderr, "CHECK failed: %s  (%s:%d)\n", #cond, __FILE__, __LINE__); std::exit(1); } \
+    } while (0)
+
+static const char *kIcpYaml =
+    "readingDataPointsFilters:\n"
+    "  - IdentityDataPointsFilter\n"
+    "matcher:\n"
+    "  KDTreeMatcher:\n"
+    "    knn: 1\n"
+    "    epsilon: 0\n"
+    "    maxDist: 2.0     # metres\n"
+    "outlierFilters:\n"
+    "  - TrimmedDistOutlierFilter:\n"
+    "      ratio: 0.85\n"
+    "errorMinimizer:\n"
+    "  PointToPlaneWithCovErrorMinimizer:\n"
+    "    sensorStdDev: 0.01\n"
+    "transformationCheckers:\n"
+    "  - CounterTransformationChecker:\n"
+    "      maxIterationCount: 30\n"
+    "  - DifferentialTransformationChecker:\n"
+    "      minDiffRotErr: 0.001\n"
+    "      minDiffTransErr: 0.01\n"
+    "      smoothLength: 3\n"
+    "inspector:\n"
+    "  NullInspector\n"
+    "logger:\n"
+    "  NullLogger\n";
+
+// deterministic LCG in [0,1)
+struct Lcg {
+    unsigned long long s;
+    explicit Lcg(unsigned long long seed) : s(seed) {}
+    double next() { s = s * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(s >> 11) / 9007199254740992.0; }
+};
+
+// room corner: floor z=0, walls x=0 and y=0, a box; points with analytic normals
+template <typename T>
+typename PointMatcher<T>::DataPoints make_corner(int per_plane, unsigned long long seed, double jitter = 0.0)
+{
+    std::vector<T> xyz, nrm;
+    Lcg g(seed);
+    auto push = [&](double x, double y, double z, double nx, double ny, double nz) {
+        xyz.push_back((T)x); xyz.push_back((T)y); xyz.push_back((T)z);
+        nrm.push_back((T)nx); nrm.push_back((T)ny); nrm.push_back((T)nz);
+    };
+    for (int i = 0; i < per_plane; i++) {
+        const double a = 0.2 + 5.0 * g.next(), b = 0.2 + 5.0 * g.next(), j = jitter * (g.next() - 0.5);
+        push(a, b, j, 0, 0, 1);
+        push(j, a, 0.1 + 0.5 * b, 1, 0, 0);
+        push(a, j, 0.1 + 0.5 * b, 0, 1, 0);
+        if (i % 4 == 0) push(2.0 + 0.2 * a, 2.0 + 0.2 * b, 1.0 + j, 0, 0, 1);   // a table top
+    }
+    return PointMatcher<T>::DataPoints::fromXYZ(xyz.data(), (int)xyz.size() / 3, nrm.data());
+}
+
+template <typename T>
+pgslam_amd::Mat<T> pose(double x, double y, double z, double yaw, double pitch = 0, double roll = 0)
+{
+    pgslam_amd::Mat<T> m = pgslam_amd::Mat<T>::Identity(4, 4);
+    const double cy = std::cos(yaw), sy = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch), cr = std::cos(roll), sr = std::sin(roll);
+    m(0, 0) = (T)(cy * cp); m(0, 1) = (T)(cy * sp * sr - sy * cr); m(0, 2) = (T)(cy * sp * cr + sy * sr);
+    m(1, 0) = (T)(sy * cp); m(1, 1) = (T)(sy * sp * sr + cy * cr); m(1, 2) = (T)(sy * sp * cr - cy * sr);
+    m(2, 0) = (T)(-sp);     m(2, 1) = (T)(cp * sr);                m(2, 2) = (T)(cp * cr);
+    m(0, 3) = (T)x; m(1, 3) = (T)y; m(2, 3) = (T)z;
+    return m;
+}
+
+template <typename T>
+double pose_diff(const pgslam_amd::Mat<T> &a, const pgslam_amd::Mat<T> &b)
+{
+    double e = 0;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) e = std::max(e, std::fabs((double)a(i, j) - (double)b(i, j)));
+    return e;
+}

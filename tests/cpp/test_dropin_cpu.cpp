@@ -1,0 +1,99 @@
+// CPU-only checks of the C++ drop-in layer (no GPU in the build container):
+// type spelling instantiates for float and double (mirrors the reference's only
+// test, tests/instantiation.cpp), DataPoints / YAML / matrix semantics, and the
+// "no CPU fallback" rule: constructing an ICP object without a GPU must throw.
+#include "common.hpp"
+
+template <typename T>
+void type_spelling()
+{
+    IMPORT_PGSLAM_TYPES(T)
+    Keyframe kf;
+    kf.id = 3; kf.T_world_kf = Matrix::Identity(4, 4); kf.optimized_T_world_kf = Matrix::Identity(4, 4);
+    kf.cloud_ptr = std::make_shared<DP>();
+    Constraint c;
+    c.type = Constraint::kLoopConstraint; c.T_from_to = Matrix::Identity(4, 4); c.cov_from_to = CovMatrix::Identity(6, 6); c.weight = T(1);
+    CHECK(c.cov_from_to.rows() == 6 && kf.cloud_ptr->getNbPoints() == 0);
+    TransformationPtr t = PM::get().REG(Transformation).create("RigidTransformation");
+    CHECK(t->checkParameters(Matrix::Identity(4, 4)));
+    Matrix bad = Matrix::Identity(4, 4); bad(0, 0) = T(2);
+    CHECK(!t->checkParameters(bad));
+    DataPointsFilters none;
+    DP empty;
+    none.init(); none.apply(empty);
+}
+
+template <typename T>
+void datapoints_semantics()
+{
+    using PM = PointMatcher<T>;
+    using DP = typename PM::DataPoints;
+    const T a_xyz[] = {0, 0, 0, 1, 0, 0}, a_n[] = {0, 0, 1, 0, 0, 1};
+    const T b_xyz[] = {2, 2, 2}, b_n[] = {1, 0, 0};
+    DP a = DP::fromXYZ(a_xyz, 2, a_n), b = DP::fromXYZ(b_xyz, 1, b_n);
+    typename PM::Matrix extra(1, 2); extra(0, 0) = 5; extra(0, 1) = 6;
+    a.addDescriptor("intensity", extra);                    // only in a -> dropped by concatenate
+    CHECK(a.features.rows() == 4 && a.features(3, 1) == T(1) && a.xyzStride() == 4 && a.normalsStride() == 4);
+    a.concatenate(b);
+    CHECK(a.getNbPoints() == 3 && a.descriptors.rows() == 3 && a.descriptorExists("normals") && !a.descriptorExists("intensity"));
+    CHECK(a.features(0, 2) == T(2) && a.getDescriptorViewByName("normals")(0, 2) == T(1));
+    DP e;
+    e.concatenate(b);
+    CHECK(e.getNbPoints() == 1);
+    // ErrorElements compaction
+    typename PM::Matches m(1, 3); typename PM::OutlierWeights w(1, 3);
+    m.ids(0, 0) = 2; m.ids(0, 1) = 0; m.ids(0, 2) = -1; m.dists(0, 0) = 1; m.dists(0, 1) = 2; m.dists(0, 2) = PM::Matches::InvalidDist();
+    w(0, 0) = 1; w(0, 1) = 0; w(0, 2) = 0;
+    typename PM::ErrorMinimizer::ErrorElements ee(a, a, w, m);
+    CHECK(ee.reading.getNbPoints() == 1 && ee.reference.features(0, 0) == T(2));
+    CHECK(std::fabs((double)ee.weightedPointUsedRatio - 1.0 / 3.0) < 1e-6 && ee.nbRejectedMatches == 2);
+    w(0, 0) = 0;
+    bool threw = false;
+    try { typename PM::ErrorMinimizer::ErrorElements bad(a, a, w, m); } catch (const typename PM::ConvergenceError &) { threw = true; }
+    CHECK(threw);
+}
+
+void yaml_and_matrix()
+{
+    auto y = pgslam_amd::yaml_lite::parse_string(kIcpYaml);
+    CHECK(y.sections.at("matcher")[0].name == "KDTreeMatcher" && y.sections.at("matcher")[0].params.at("maxDist") == "2.0");
+    CHECK(y.sections.at("transformationCheckers").size() == 2 && y.sections.at("transformationCheckers")[1].params.at("smoothLength") == "3");
+    CHECK(y.sections.at("outlierFilters")[0].params.at("ratio") == "0.85" && y.sections.at("inspector")[0].name == "NullInspector");
+    CHECK(y.sections.at("readingDataPointsFilters")[0].name == "IdentityDataPointsFilter");
+    bool threw = false;
+    try { pgslam_amd::yaml_lite::parse_string("matcher:\n\tKDTreeMatcher:\n"); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    auto P = pose<double>(1, 2, 3, 0.3, -0.1, 0.05);
+    CHECK(pose_diff(P * P.inverse(), pgslam_amd::Mat<double>::Identity(4, 4)) < 1e-12);
+    double rm[16];
+    pgslam_amd::to_row_major16(P, rm);
+    CHECK(rm[3] == 1.0 && rm[7] == 2.0 && rm[11] == 3.0 && pose_diff(pgslam_amd::from_row_major16<double>(rm), P) == 0.0);
+    // filters from YAML (Localizer::SetInputFiltersConfig)
+    std::istringstream fs("- MaxDistDataPointsFilter:\n    maxDist: 1.5\n- IdentityDataPointsFilter\n");
+    PointMatcher<float>::DataPointsFilters f(fs);
+    const float xyz[] = {1, 0, 0, 2, 0, 0, 0, 1, 0};
+    auto dp = PointMatcher<float>::DataPoints::fromXYZ(xyz, 3);
+    f.init(); f.apply(dp);
+    CHECK(f.size() == 2 && dp.getNbPoints() == 2 && dp.features(1, 1) == 1.0f);
+    std::istringstream bad("- SurfaceNormalDataPointsFilter:\n    knn: 10\n");
+    threw = false;
+    try { PointMatcher<float>::DataPointsFilters g(bad); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+}
+
+int main()
+{
+    type_spelling<float>();
+    type_spelling<double>();
+    datapoints_semantics<float>();
+    datapoints_semantics<double>();
+    yaml_and_matrix();
+    if (pgicp_device_count() == 0) {
+        bool threw = false;
+        try { PointMatcher<float>::ICP icp; } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);            // no CPU fallback
+        std::puts("no GPU: ICP construction refuses, as required");
+    }
+    std::puts("dropin cpu tests ok");
+    return 0;
+}

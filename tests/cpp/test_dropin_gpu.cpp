@@ -1,0 +1,120 @@
+// GPU checks of the C++ drop-in layer: the same call sequences pgslam makes
+// (reference src/pgslam/Localizer.hpp:126,148,282-348; LoopCloser.hpp:83-110,
+// 308-365; LocalMap.hpp:209-224), on a synthetic room-corner scene with a known
+// answer.  Mirrors tests/instantiation.cpp by running for float and double.
+#include "common.hpp"
+
+template <typename T>
+void run(const char *name)
+{
+    IMPORT_PGSLAM_TYPES(T)
+    const DP map = make_corner<T>(6000, 11, 0.004);
+    const DP scan_world = make_corner<T>(2500, 12, 0.004);
+    // the scan is observed from a robot pose P: reading = P^-1 * scan_world
+    const Matrix P = pose<T>(0.40, -0.25, 0.10, 0.06, 0.01, -0.015);
+    TransformationPtr rigid = PM::get().REG(Transformation).create("RigidTransformation");
+    const DP reading = rigid->compute(scan_world, P.inverse());
+    CHECK(reading.descriptorExists("normals") && reading.getNbPoints() == scan_world.getNbPoints());
+    const Matrix guess = P * pose<T>(0.08, -0.05, 0.03, 0.02, 0.0, 0.0);
+
+    // --- ICP::operator()(reading, reference, T_init)  (LoopCloser.hpp:98)
+    ICP icp;
+    { std::istringstream iss(kIcpYaml); icp.loadFromYaml(iss); }
+    const Matrix T1 = icp(reading, map, guess);
+    CHECK(pose_diff(T1, P) < 5e-3);
+    CHECK(!icp.getMaxNumIterationsReached());
+    const T overlap = icp.errorMinimizer->getOverlap();
+    CHECK(overlap > T(0.84) && overlap <= T(1));
+    const Matrix cov = icp.errorMinimizer->getCovariance();
+    CHECK(cov.rows() == 6 && cov(0, 0) > 0 && cov(5, 5) > 0 && std::fabs((double)cov(0, 1) - (double)cov(1, 0)) < 1e-9);
+
+    // --- ICPSequence: setMap once, then operator()(cloud, T_init)  (Localizer.hpp:126,148)
+    ICPSequence seq;
+    { std::istringstream iss(kIcpYaml); seq.loadFromYaml(iss); }
+    CHECK(!seq.hasMap());
+    CHECK(seq.setMap(map) && seq.hasMap());
+    const Matrix T2 = seq(reading, guess);
+    CHECK(pose_diff(T1, T2) == 0.0);                                   // same chain, same arithmetic
+    ICPSequence first;                                                  // no map yet: first cloud becomes the map
+    CHECK(pose_diff(first(map, guess), Matrix::Identity(4, 4)) == 0.0 && first.hasMap());
+
+    // --- hand-driven partial chain, exactly as Localizer::ComputeOverlapWith does (Localizer.hpp:309-347)
+    ICP temp;
+    { std::istringstream iss(kIcpYaml); temp.loadFromYaml(iss); }
+    DP reference(map);
+    temp.referenceDataPointsFilters.init(); temp.referenceDataPointsFilters.apply(reference);
+    temp.matcher->init(reference);
+    DP moved = rigid->compute(reading, T1);
+    const typename PM::Matches matches(temp.matcher->findClosests(moved));
+    const typename PM::OutlierWeights w(temp.outlierFilters.compute(moved, reference, matches));
+    typename PM::ErrorMinimizer::ErrorElements matched(moved, reference, w, matches);
+    CHECK(matches.ids.cols() == (int)moved.getNbPoints());
+    CHECK(std::fabs((double)matched.weightedPointUsedRatio - 0.85) < 0.01);
+    const T residual = temp.errorMinimizer->getResidualError(moved, reference, w, matches);
+    CHECK(residual >= 0 && residual < T(1.0));
+
+    // --- pgslam::Localizer hot path
+    pgslam::Localizer<T> loc;
+    loc.SetIcpConfigFromString(kIcpYaml);
+    loc.SetLocalMap(map, Matrix::Identity(4, 4));
+    auto cloud_ptr = std::make_shared<DP>(reading);
+    // first call: T_refkf_robot_ = I, odometry says the robot is at `guess`
+    // (last_input = I), so the ICP starts from `guess`
+    const Matrix T3 = loc.ProcessData(guess, Matrix::Identity(4, 4), cloud_ptr);
+    CHECK(pose_diff(T3, T1) == 0.0);
+    CHECK(loc.ComputeCurrentOverlap() == overlap && loc.IsOverlapEnough(overlap));
+    const T ov2 = loc.ComputeOverlapWith(map);                         // candidate map in world frame (here refkf == world)
+    CHECK(std::fabs((double)ov2 - (double)matched.weightedPointUsedRatio) < 1e-6);
+
+    // --- pgslam::LoopCloser hot path
+    pgslam::LoopCloser<T> lc;
+    lc.SetIcpConfigFromString(kIcpYaml);
+    auto r = lc.ProcessCandidate(reading, map, guess);
+    CHECK(pose_diff(r.T_refkf_kf, T1) == 0.0 && r.accepted && !r.max_iterations_reached);
+    CHECK(std::fabs((double)r.residual - (double)residual) <= 1e-3 * (double)residual + 1e-6);
+    lc.SetResidualErrorThreshold(T(0));
+    CHECK(!lc.CheckIcpResult(r) || r.residual == T(0));
+
+    // --- batch dispatcher: 3 candidates, 2 ranks, union == all, results == single
+    pgslam::LoopClosureBatch<T> batch;
+    batch.SetIcpConfigFromString(kIcpYaml);
+    auto rp = std::make_shared<DP>(reading), mp = std::make_shared<DP>(map);
+    for (int k = 0; k < 3; k++) batch.Add({100 + k, 200 + k, rp, mp, guess});
+    auto s0 = batch.Shard(2, 0), s1 = batch.Shard(2, 1);
+    CHECK(s0.size() + s1.size() == 3);
+    auto e0 = batch.Run(s0), e1 = batch.Run(s1);
+    for (auto &e : e0) {
+        CHECK(e.accepted == 1 && e.status == 0 && e.from_id >= 100);
+        CHECK(pose_diff(pgslam_amd::from_row_major16<T>(e.T_from_to), T1) == 0.0);
+    }
+    CHECK(sizeof(pgicp_edge) == 512 && e1.size() == s1.size());
+
+    // --- LocalMap::BuildCloudFromData  (LocalMap.hpp:209-224)
+    std::vector<Keyframe> kfs(2);
+    kfs[0].id = 0; kfs[0].cloud_ptr = mp; kfs[0].optimized_T_world_kf = pose<T>(1, 0, 0, 0.1);
+    kfs[1].id = 1; kfs[1].cloud_ptr = rp; kfs[1].optimized_T_world_kf = pose<T>(1.5, 0.2, 0, 0.15);
+    const DP local = pgslam::BuildLocalMapCloud<T>(kfs);
+    CHECK(local.getNbPoints() == map.getNbPoints() + reading.getNbPoints() && local.descriptorExists("normals"));
+    CHECK(local.features(0, 5) == map.features(0, 5) && local.features(3, (int)local.getNbPoints() - 1) == T(1));
+    const DP expect = rigid->compute(reading, kfs[0].optimized_T_world_kf.inverse() * kfs[1].optimized_T_world_kf);
+    const int off = (int)map.getNbPoints();
+    for (int j : {0, 17, (int)reading.getNbPoints() - 1})
+        for (int a = 0; a < 3; a++) {
+            CHECK(local.features(a, off + j) == expect.features(a, j));
+            CHECK(local.descriptors(a, off + j) == expect.descriptors(a, j));
+        }
+
+    // --- ConvergenceError propagates like libpointmatcher's
+    bool threw = false;
+    try { seq(reading, pose<T>(500, 0, 0, 0)); } catch (const typename PM::ConvergenceError &) { threw = true; }
+    CHECK(threw);
+    std::printf("%s: ok  (overlap %.3f, residual %.4g, |T - P| %.2e)\n", name, (double)overlap, (double)residual, pose_diff(T1, P));
+}
+
+int main()
+{
+    run<float>("PoseGraphSlam<float> hot path");
+    run<double>("PoseGraphSlam<double> hot path");
+    std::puts("dropin gpu tests ok");
+    return 0;
+}

@@ -1,0 +1,33 @@
+"""Builds and runs the C++ drop-in tests (g++ against include/ and libpgicp.so)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def build(name):
+    exe = os.path.join(CPP, name)
+    src = exe + ".cpp"
+    deps = [src, os.path.join(CPP, "common.hpp")] + [os.path.join(ROOT, "include", "pgslam_amd", f) for f in
+                                                     ("pointmatcher.hpp", "pgslam.hpp", "matrix.hpp", "yaml_lite.hpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-local-typedefs", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
+                               "-L" + os.path.join(ROOT, "pgslam_amd", "lib"), "-lpgicp",
+                               "-Wl,-rpath," + os.path.join(ROOT, "pgslam_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_dropin_cpu():
+    out = subprocess.run([build("test_dropin_cpu")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "dropin cpu tests ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_dropin_gpu():
+    out = subprocess.run([build("test_dropin_gpu")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "dropin gpu tests ok" in out.stdout
