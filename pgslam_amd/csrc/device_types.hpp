@@ -30,6 +30,7 @@ struct MapDev {
     const typename Vec4<T>::type *nrm;   // (nx, ny, nz, 0) same order; may be null
     const int *cell_start;               // ncells + 1 exclusive prefix sums
     const int *sc_count;                 // points per 8x8x8 super-cell (coarse occupancy)
+    const int *slot_of;                  // original index -> position in pts / nrm
     GridDesc<T> g;
     int m;
     int nsx, nsy, nsz;                   // super-cell grid dims

@@ -460,8 +460,9 @@ __device__ __forceinline__ T ring_guarantee(const GridDesc<T> &g, T ux, T uy, T 
 // per-lane path); returns false if unresolved, with the last guaranteed radius.
 template <typename T>
 __device__ __forceinline__ bool grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T max_dist, int r_start, int max_rings,
-                                        Best<T> &best, T &gr_out)
+                                        T stop_d2, Best<T> &best, T &gr_out, int &r_next)
 {
+    r_next = r_start;
     const GridDesc<T> g = M.g;
     const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
     const int c0x = clamp_cell<T>(ux, g.inv_h, g.nx), c0y = clamp_cell<T>(uy, g.inv_h, g.ny),
@@ -473,6 +474,7 @@ __device__ __forceinline__ bool grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T 
         gr = gr - g.margin;
         gr_out = gr;
         if (gr > (T)0 && (best.d2 < gr * gr || gr > max_dist)) return true;
+        if (gr > (T)0 && gr * gr > stop_d2) return false;               // far enough for the caller: leave it unresolved
     }
     for (int r = r_start; r <= max_rings; ++r) {
         const int z0 = max(c0z - r, 0), z1 = min(c0z + r, g.nz - 1);
@@ -499,6 +501,8 @@ __device__ __forceinline__ bool grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T 
         gr = gr - g.margin;
         gr_out = gr;
         if (gr > (T)0 && (best.d2 < gr * gr || gr > max_dist)) return true;
+        r_next = r + 1;
+        if (gr > (T)0 && gr * gr > stop_d2) return false;
     }
     return false;
 }
@@ -523,8 +527,60 @@ __device__ __forceinline__ int wave_max_i(int v)
     return v;
 }
 
-constexpr int kFastRings = 3;       // rings walked per lane before a query is handed to the wave-cooperative path
-constexpr int kFastRingsUnseeded = 8;
+// Phase C of the fast path (shared by both fast kernels): store a resolved result, or queue the
+// query with a lower bound while d2 keeps an upper bound (see k_knn_grid's header).
+template <typename T>
+__device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<T> &g, const ChainDev<T> &ch, bool resolved, T gr,
+                                             Best<T> best, T qx, T qy, T qz, T ux, T uy, T uz, int cx, int cy, int cz, int prob,
+                                             int i, long long pos, int r_next, int *__restrict__ slot_io, T *__restrict__ d2_out,
+                                             int *__restrict__ slow_count, int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
+                                             int *__restrict__ slow_ring)
+{
+    // ---- phase C: bookkeeping for the lazy slow path ----
+    if (resolved) {
+        if (best.slot < 0) best.d2 = Bits<T>::inf();
+    } else {
+        T lb = gr > (T)0 ? gr * gr : (T)0;
+        if (best.slot < 0) {
+            // no candidate yet: look for a certificate that a neighbour within maxDist exists
+            const T H = g.h * (T)8;
+            const int Cx = cx >> 3, Cy = cy >> 3, Cz = cz >> 3;
+            T ub = Bits<T>::inf();
+            for (int t = 0; t < 27 && !(ub < Bits<T>::inf()); ++t) {
+                const int order = (t + 13) % 27;               // own super-cell first
+                const int X = Cx + order % 3 - 1, Y = Cy + (order / 3) % 3 - 1, Z = Cz + order / 9 - 1;
+                if (X < 0 || X >= M.nsx || Y < 0 || Y >= M.nsy || Z < 0 || Z >= M.nsz) continue;
+                if (M.sc_count[X + M.nsx * (Y + M.nsy * Z)] <= 0) continue;
+                const T fx = slab_far(ux, (T)X * H, (T)(X + 1) * H) + g.margin, fy = slab_far(uy, (T)Y * H, (T)(Y + 1) * H) + g.margin,
+                        fz = slab_far(uz, (T)Z * H, (T)(Z + 1) * H) + g.margin;
+                const T far2 = (fx * fx + fy * fy) + fz * fz;
+                if (far2 <= ch.max_dist2) ub = far2;
+            }
+            if (!(ub < Bits<T>::inf()) && M.m > 0 && !(ch.max_dist2 < Bits<T>::inf())) {
+                // maxDist = inf: the whole (non-empty) grid is a certificate
+                const T fx = slab_far(ux, (T)0, (T)g.nx * g.h) + g.margin, fy = slab_far(uy, (T)0, (T)g.ny * g.h) + g.margin,
+                        fz = slab_far(uz, (T)0, (T)g.nz * g.h) + g.margin;
+                ub = (fx * fx + fy * fy) + fz * fz;
+            }
+            if (ub < Bits<T>::inf()) { best.d2 = ub; best.slot = -2; }   // exists, not located
+            else { best.d2 = ch.max_dist2; best.slot = -2; lb = (T)-1; } // existence unknown: always resolved later
+        }
+        // one atomic per wave: the unresolved lanes of the wave reserve consecutive queue slots
+        const unsigned long long m = __ballot(1);
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(slow_count, __popcll(m));
+        base = __shfl(base, leader, 64);
+        const int k = base + __popcll(m & ((1ULL << lane) - 1ULL));
+        slow_list[k] = make_int2(prob, i);
+        slow_lb[k] = lb;
+        slow_ring[k] = r_next;
+    }
+    slot_io[pos] = best.slot;
+    d2_out[pos] = best.d2;
+}
+
 
 // Fast path: one query per lane, 64 consecutive queries of the 3-D-compact sorted
 // reading per wave (workgroup = one wave; LDS is wave private).
@@ -547,9 +603,9 @@ constexpr int kFastRingsUnseeded = 8;
 template <typename T, int R>
 __global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                   const T *__restrict__ rd, int *__restrict__ slot_io,
-                                                  T *__restrict__ d2_out, ChainDev<T> ch, int use_seed,
+                                                  T *__restrict__ d2_out, ChainDev<T> ch, int use_seed, int fast_rings,
                                                   int *__restrict__ slow_count, int2 *__restrict__ slow_list,
-                                                  T *__restrict__ slow_lb)
+                                                  T *__restrict__ slow_lb, int *__restrict__ slow_ring)
 {
     using V4 = typename Vec4<T>::type;
     constexpr int NR = (2 * R + 1) * (2 * R + 1);
@@ -583,6 +639,10 @@ __global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ 
 
     // ---- phase A.1: own row first -- it usually holds the neighbour and shrinks the bound ----
     if (live) scan_row<T>(M, g.nx * (cy + g.ny * cz), max(cx - R, 0), min(cx + R, g.nx - 1), ux, (T)0, qx, qy, qz, best);
+#if defined(PGICP_ABLATE_A2)
+    if (false)
+#endif
+    {
     // ---- phase A.2: collect the ranges of the other rows of the (2R+1)^3 block with that bound ----
     int ra[NR - 1], rb[NR - 1];
     T rl[NR - 1];
@@ -647,48 +707,68 @@ __global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ 
             cur = nxt; j = jn; k = kn; e = en; valid = vn;
         }
     }
+    }
     if (!live) return;
 
     // ---- phase B: per-lane continuation from ring R+1 ----
     T gr;
-    // without a seed (first iteration) distances are larger: walk more rings per lane before queueing
-    const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, R + 1, use_seed ? kFastRings : kFastRingsUnseeded, best, gr);
+    // Everything beyond the trim threshold is discarded by the outlier filter, so a lane stops as soon as
+    // its guaranteed radius passes (1.1x) the PREVIOUS iteration's threshold and leaves the query queued
+    // with that lower bound (lazy resolution keeps the result exact).  Lanes that need more than
+    // `fast_rings` rings are queued too: k_knn_med continues them in waves made only of such queries.
+    const T stop_d2 = use_seed ? (T)(1.21 * P.limit) : Bits<T>::inf();
+    int r_next;
+    const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, R + 1, fast_rings, stop_d2, best, gr, r_next);
+    finish_query<T>(M, g, ch, resolved, gr, best, qx, qy, qz, ux, uy, uz, cx, cy, cz, (int)blockIdx.y, i, P.off + i, r_next, slot_io,
+                    d2_out, slow_count, slow_list, slow_lb, slow_ring);
+}
 
-    // ---- phase C: bookkeeping for the lazy slow path ----
-    if (resolved) {
-        if (best.slot < 0) best.d2 = Bits<T>::inf();
-    } else {
-        T lb = gr > (T)0 ? gr * gr : (T)0;
-        if (best.slot < 0) {
-            // no candidate yet: look for a certificate that a neighbour within maxDist exists
-            const T H = g.h * (T)8;
-            const int Cx = cx >> 3, Cy = cy >> 3, Cz = cz >> 3;
-            T ub = Bits<T>::inf();
-            for (int t = 0; t < 27 && !(ub < Bits<T>::inf()); ++t) {
-                const int order = (t + 13) % 27;               // own super-cell first
-                const int X = Cx + order % 3 - 1, Y = Cy + (order / 3) % 3 - 1, Z = Cz + order / 9 - 1;
-                if (X < 0 || X >= M.nsx || Y < 0 || Y >= M.nsy || Z < 0 || Z >= M.nsz) continue;
-                if (M.sc_count[X + M.nsx * (Y + M.nsy * Z)] <= 0) continue;
-                const T fx = slab_far(ux, (T)X * H, (T)(X + 1) * H) + g.margin, fy = slab_far(uy, (T)Y * H, (T)(Y + 1) * H) + g.margin,
-                        fz = slab_far(uz, (T)Z * H, (T)(Z + 1) * H) + g.margin;
-                const T far2 = (fx * fx + fy * fy) + fz * fz;
-                if (far2 <= ch.max_dist2) ub = far2;
-            }
-            if (!(ub < Bits<T>::inf()) && M.m > 0 && !(ch.max_dist2 < Bits<T>::inf())) {
-                // maxDist = inf: the whole (non-empty) grid is a certificate
-                const T fx = slab_far(ux, (T)0, (T)g.nx * g.h) + g.margin, fy = slab_far(uy, (T)0, (T)g.ny * g.h) + g.margin,
-                        fz = slab_far(uz, (T)0, (T)g.nz * g.h) + g.margin;
-                ub = (fx * fx + fy * fy) + fz * fz;
-            }
-            if (ub < Bits<T>::inf()) { best.d2 = ub; best.slot = -2; }   // exists, not located
-            else { best.d2 = ch.max_dist2; best.slot = -2; lb = (T)-1; } // existence unknown: always resolved later
+// Medium path: the queued queries that can still matter (lower bound within the threshold just
+// selected, or existence unknown) continue their ring search one query per LANE -- but in waves made
+// only of such queries, so easy queries no longer wait for hard ones.  A lane stops when it is
+// resolved, when its guaranteed radius passes 1.1x the threshold, or after kMedRings rings (the
+// wave-cooperative slow path takes what is left).  Entries it finishes are marked with LB = +inf.
+constexpr int kMedRings = 12;
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
+                                                 const T *__restrict__ rd, int *__restrict__ slot_io, T *__restrict__ d2_out,
+                                                 ChainDev<T> ch, const int *__restrict__ slow_count,
+                                                 const int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
+                                                 int *__restrict__ slow_ring)
+{
+    const int count = *slow_count;
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
+        const T lb = slow_lb[k];
+        const int2 e = slow_list[k];
+        ProblemDev &P = probs[e.x];
+        const T limit = (T)P.limit;
+        if (lb >= (T)0 && lb > limit) continue;               // cannot influence the result: stays lazy
+        const int i = e.y;
+        const T *q = rd + 3 * (P.off + i);
+        T qx, qy, qz;
+        apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
+        const MapDev<T> M = maps[P.map];
+        Best<T> best;
+        best.d2 = ch.max_dist2; best.idx = 0x7FFFFFFF; best.slot = -1;
+        const int prev = slot_io[P.off + i];
+        if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
+        T gr;
+        int r_next;
+        const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, slow_ring[k], kMedRings, (T)1.21 * limit, best, gr, r_next);
+        if (resolved) {
+            if (best.slot < 0) best.d2 = Bits<T>::inf();
+            slot_io[P.off + i] = best.slot;
+            d2_out[P.off + i] = best.d2;
+            slow_lb[k] = Bits<T>::inf();                      // finished: later passes skip it
+            P.n_refined = 1;                                  // a flag: every writer stores the same value
+        } else {
+            // still open: keep the better upper bound (if a real candidate exists) and the larger lower bound
+            if (best.slot >= 0) { slot_io[P.off + i] = best.slot; d2_out[P.off + i] = best.d2; P.n_refined = 1; }
+            if (lb >= (T)0 || best.slot >= 0) slow_lb[k] = gr > (T)0 ? gr * gr : (T)0;
+            slow_ring[k] = r_next;
         }
-        const int k = atomicAdd(slow_count, 1);
-        slow_list[k] = make_int2((int)blockIdx.y, i);
-        slow_lb[k] = lb;
     }
-    slot_io[P.off + i] = best.slot;
-    d2_out[P.off + i] = best.d2;
 }
 
 // Slow path: one WAVE per queued query (no neighbour proven within kFastRings
@@ -715,7 +795,7 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
         const int i = e.y;
         if (!exact_all) {
             // lazy: only queries whose lower bound does not already exceed the (upper bound of the)
-            // trim threshold can influence the result
+            // trim threshold can influence the result (entries k_knn_med finished carry LB = +inf)
             const T lb = slow_lb[k];
             if (lb >= (T)0 && lb > (T)P.limit) continue;
             if (lane == 0) {
@@ -1293,7 +1373,8 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
-                T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb)
+                T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
+                int *slow_ring, int fast_rings)
 {
     if (matcher == 1) {
         hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot, d2,
@@ -1305,7 +1386,15 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
     // R = 1 in both cases: measured, a 5x5x5 collected block on the unseeded first iteration costs
     // 2.5x the ring-by-ring continuation (nothing prunes it until the own row has a hit)
     hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, 64)), P), dim3(64), 0, st, probs, maps, rd, slot, d2, ch,
-                       use_seed, slow_count, slow_list, slow_lb);
+                       use_seed, fast_rings, slow_count, slow_list, slow_lb, slow_ring);
+}
+
+template <typename T>
+void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
+                    const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring)
+{
+    hipLaunchKernelGGL(k_knn_med<T>, dim3(8192), dim3(64), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list, slow_lb,
+                       slow_ring);
 }
 
 // resolves the queries the fast path queued: all of them (exact_all, public matcher
@@ -1392,7 +1481,9 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
-                                const ChainDev<T> &, int, int, int, int *, int2 *, T *);                                  \
+                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int);                      \
+    template void launch_knn_med<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                  \
+                                    const ChainDev<T> &, const int *, const int2 *, T *, int *);                          \
     template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \
                                      const ChainDev<T> &, const int *, const int2 *, const T *, int);                     \
     template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int, int);             \

@@ -22,7 +22,11 @@ template <typename T>
 void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, T *rd_pre, int P, int max_n);
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
-                T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb);
+                T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
+                int *slow_ring, int fast_rings);
+template <typename T>
+void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
+                    const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring);
 template <typename T>
 void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                      const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb, int exact_all);

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -75,8 +76,9 @@ struct pgicp_ctx {
     State<float> f32;
     State<double> f64;
     DevBuf probs, src, partials, sums, small, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
-    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb;
+    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
+    int fast_rings_seeded = 2, fast_rings_unseeded = 4;   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
     std::vector<ProfEvent> prof_events;
     long long prof_launches[PGICP_PROF_COUNT] = {0};
@@ -223,6 +225,7 @@ int sync_maps_table(pgicp_ctx *c)
         const MapHost<T> &m = S.maps[i];
         h[i].pts = m.pts; h[i].nrm = m.nrm; h[i].cell_start = m.cell_start; h[i].g = m.g; h[i].m = m.used ? m.m : 0;
         h[i].sc_count = m.sc_count;
+        h[i].slot_of = m.slot_of;
         h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
     }
     HIPC(c, hipMemcpyAsync(S.d_maps.p, h.data(), sizeof(MapDev<T>) * n, hipMemcpyHostToDevice, c->stream));
@@ -375,6 +378,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         HIPC(c, c->order.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
         HIPC(c, c->slow_lb.ensure(sizeof(T) * (size_t)L.total));
+        HIPC(c, c->slow_ring.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->qcounts.ensure(sizeof(int) * nbins));
         HIPC(c, c->qcursor.ensure(sizeof(int) * nbins));
         HIPC(c, c->qstart.ensure(sizeof(int) * (nbins + 1)));
@@ -436,7 +440,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, L.P, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
-                      c->slow_lb.as<T>());
+                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded);
     }
     {
         ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
@@ -448,6 +452,8 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         // is re-selected if anything changed.  Kept pairs / threshold / n_finite stay exact.
         {
             ProfScope ps(c, PGICP_PROF_KNN_SLOW, act_units, act_probs);
+            launch_knn_med<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
+                              ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), c->slow_ring.as<int>());
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), 0);
         }
@@ -601,7 +607,8 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
-                      S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>());
+                      S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
+                      c->slow_ring.as<int>(), c->fast_rings_unseeded);
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
@@ -883,6 +890,8 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     pgicp_ctx *c = new pgicp_ctx();
     c->device = device;
     pgicp_default_params(&c->prm);
+    if (const char *e = std::getenv("PGICP_FAST_RINGS_SEEDED")) c->fast_rings_seeded = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         delete c;
@@ -904,7 +913,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
-                      &c->qcursor, &c->slow_list, &c->slow_lb})
+                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
