@@ -77,7 +77,7 @@ struct SrcDesc { const void *ptr; int stride; int pad_; };   // where a problem'
 
 constexpr int kKnnBlock = 256;
 constexpr int kReduceBlock = 256;
-constexpr int kReduceItems = 2;      // queries per thread in the reduce kernels
+constexpr int kReduceItems = 4;      // queries per thread in the reduce kernels
 constexpr int kSelectBlock = 1024;
 constexpr int kCovTerms = 42;        // 21 (H upper) + 21 (G upper)
 

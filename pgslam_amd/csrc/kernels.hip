@@ -9,6 +9,9 @@
 //
 // wave = 64 lanes everywhere; no warp-size-32 idiom is used.
 #include "kernels.hpp"
+#ifndef PGICP_FAST_BLOCK
+#define PGICP_FAST_BLOCK 64
+#endif
 
 namespace pgicp {
 
@@ -386,7 +389,26 @@ struct Best {
     T d2;
     int idx;
     int slot;
+#ifdef PGICP_KNN_STATS
+    int cnt = 0;      // diagnostics build only: candidates evaluated
+#endif
 };
+
+#ifdef PGICP_KNN_STATS
+__device__ unsigned long long g_knn_stats[16];
+#define KNN_STAT_WAVE_ADD(slot_, v_)                                                              \
+    do {                                                                                          \
+        long long s_ = (v_);                                                                      \
+        for (int o_ = 32; o_ > 0; o_ >>= 1) s_ += __shfl_xor(s_, o_, 64);                          \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_stats[slot_], (unsigned long long)s_);      \
+    } while (0)
+#define KNN_STAT_WAVE_MAX(slot_, v_)                                                              \
+    do {                                                                                          \
+        int s_ = (v_);                                                                            \
+        for (int o_ = 32; o_ > 0; o_ >>= 1) s_ = max(s_, __shfl_xor(s_, o_, 64));                  \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_stats[slot_], (unsigned long long)s_);      \
+    } while (0)
+#endif
 
 template <typename T>
 __device__ __forceinline__ void eval_point(const typename Vec4<T>::type v, int s, T qx, T qy, T qz, Best<T> &best)
@@ -395,6 +417,9 @@ __device__ __forceinline__ void eval_point(const typename Vec4<T>::type v, int s
     const T d = (dx * dx + dy * dy) + dz * dz;
     const int idx = Bits<T>::unpack_idx(v.w);
     if (d < best.d2 || (d == best.d2 && idx < best.idx)) { best.d2 = d; best.idx = idx; best.slot = s; }
+#ifdef PGICP_KNN_STATS
+    best.cnt++;
+#endif
 }
 
 template <typename T>
@@ -532,7 +557,8 @@ __device__ __forceinline__ int wave_max_i(int v)
 template <typename T>
 __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<T> &g, const ChainDev<T> &ch, bool resolved, T gr,
                                              Best<T> best, T qx, T qy, T qz, T ux, T uy, T uz, int cx, int cy, int cz, int prob,
-                                             int i, long long pos, int r_next, int *__restrict__ slot_io, T *__restrict__ d2_out,
+                                             int i, long long pos, int r_next, T lb_override, int *__restrict__ slot_io,
+                                             T *__restrict__ d2_out,
                                              int *__restrict__ slow_count, int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
                                              int *__restrict__ slow_ring)
 {
@@ -540,7 +566,7 @@ __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<
     if (resolved) {
         if (best.slot < 0) best.d2 = Bits<T>::inf();
     } else {
-        T lb = gr > (T)0 ? gr * gr : (T)0;
+        T lb = lb_override >= (T)0 ? lb_override : (gr > (T)0 ? gr * gr : (T)0);
         if (best.slot < 0) {
             // no candidate yet: look for a certificate that a neighbour within maxDist exists
             const T H = g.h * (T)8;
@@ -600,38 +626,53 @@ __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<
 // filter only needs exact values up to its threshold, so k_knn_slow resolves
 // just the queued queries with LB <= threshold (normally none): kept pairs,
 // threshold and n_finite stay exact.
+constexpr int kFastBlock = PGICP_FAST_BLOCK;
+
 template <typename T, int R>
-__global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
+__global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                   const T *__restrict__ rd, int *__restrict__ slot_io,
                                                   T *__restrict__ d2_out, ChainDev<T> ch, int use_seed, int fast_rings,
                                                   int *__restrict__ slow_count, int2 *__restrict__ slow_list,
-                                                  T *__restrict__ slow_lb, int *__restrict__ slow_ring)
+                                                  T *__restrict__ slow_lb, int *__restrict__ slow_ring,
+                                                  const int *__restrict__ active)
 {
     using V4 = typename Vec4<T>::type;
     constexpr int NR = (2 * R + 1) * (2 * R + 1);
-    __shared__ int rng_a[NR - 1][64];
-    __shared__ int rng_b[NR - 1][64];
-    __shared__ T rng_l[NR - 1][64];
-    const ProblemDev &P = probs[blockIdx.y];
+    __shared__ int rng_a[NR - 1][kFastBlock];      // column `lane` is private to that lane: no barrier needed
+    __shared__ int rng_b[NR - 1][kFastBlock];
+    __shared__ T rng_l[NR - 1][kFastBlock];
+    const int prob = active[blockIdx.y];           // only problems still iterating are launched
+    const ProblemDev &P = probs[prob];
     if (P.done) return;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x;
-    const int i = tile * 64 + lane;
-    if (tile * 64 >= P.n) return;
+    const int i = tile * kFastBlock + lane;
+    if (tile * kFastBlock >= P.n) return;
     const bool live = i < P.n;
     const MapDev<T> M = maps[P.map];
     const GridDesc<T> g = M.g;
     T qx = 0, qy = 0, qz = 0;
-    Best<T> best;
-    best.d2 = ch.max_dist2;            // anything farther than maxDist is useless
+    // The outlier filter discards everything beyond its threshold, so the search itself is bounded by
+    // 1.21x the PREVIOUS iteration's threshold (cap2): rows and cells farther than that are never
+    // visited, which spares the ~15 % of queries that will be trimmed the full 27-cell scan.  A query
+    // with nothing inside the cap is queued with LB = cap2 and its seed as upper bound; should this
+    // iteration's threshold exceed the cap, the lazy medium/slow path resolves it exactly.
+    const T cap2 = use_seed ? (T)(1.21 * P.limit) : Bits<T>::inf();
+    const bool capped = cap2 < ch.max_dist2;
+    Best<T> best, seed;
+    best.d2 = capped ? cap2 : ch.max_dist2;            // anything farther is useless
     best.idx = 0x7FFFFFFF;
     best.slot = -1;
+    seed.d2 = Bits<T>::inf(); seed.idx = 0x7FFFFFFF; seed.slot = -1;
     if (live) {
         const T *q = rd + 3 * (P.off + i);
         apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
         if (use_seed) {
             const int prev = slot_io[P.off + i];
-            if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
+            if (prev >= 0) {
+                eval_point<T>(M.pts[prev], prev, qx, qy, qz, seed);
+                if (seed.d2 <= best.d2) best = seed;
+            }
         }
     }
     const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
@@ -639,6 +680,13 @@ __global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ 
 
     // ---- phase A.1: own row first -- it usually holds the neighbour and shrinks the bound ----
     if (live) scan_row<T>(M, g.nx * (cy + g.ny * cz), max(cx - R, 0), min(cx + R, g.nx - 1), ux, (T)0, qx, qy, qz, best);
+#ifdef PGICP_KNN_STATS
+    KNN_STAT_WAVE_ADD(0, (threadIdx.x & 63) == 0 ? 1 : 0);
+    KNN_STAT_WAVE_MAX(1, best.cnt);
+    KNN_STAT_WAVE_ADD(2, best.cnt);
+    const int cnt_a1 = best.cnt;
+    int flat_iters = 0;
+#endif
 #if defined(PGICP_ABLATE_A2)
     if (false)
 #endif
@@ -705,9 +753,17 @@ __global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ 
             const V4 nxt = M.pts[vn ? jn : 0];                    // next candidate's load is in flight during the eval
             if (valid) eval_point<T>(cur, j, qx, qy, qz, best);
             cur = nxt; j = jn; k = kn; e = en; valid = vn;
+#ifdef PGICP_KNN_STATS
+            flat_iters++;
+#endif
         }
     }
     }
+#ifdef PGICP_KNN_STATS
+    KNN_STAT_WAVE_MAX(3, flat_iters);
+    KNN_STAT_WAVE_ADD(4, best.cnt - cnt_a1);
+    const int cnt_a = best.cnt;
+#endif
     if (!live) return;
 
     // ---- phase B: per-lane continuation from ring R+1 ----
@@ -716,11 +772,24 @@ __global__ __launch_bounds__(64) void k_knn_grid(const ProblemDev *__restrict__ 
     // its guaranteed radius passes (1.1x) the PREVIOUS iteration's threshold and leaves the query queued
     // with that lower bound (lazy resolution keeps the result exact).  Lanes that need more than
     // `fast_rings` rings are queued too: k_knn_med continues them in waves made only of such queries.
-    const T stop_d2 = use_seed ? (T)(1.21 * P.limit) : Bits<T>::inf();
     int r_next;
-    const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, R + 1, fast_rings, stop_d2, best, gr, r_next);
-    finish_query<T>(M, g, ch, resolved, gr, best, qx, qy, qz, ux, uy, uz, cx, cy, cz, (int)blockIdx.y, i, P.off + i, r_next, slot_io,
-                    d2_out, slow_count, slow_list, slow_lb, slow_ring);
+    bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, R + 1, fast_rings, cap2, best, gr, r_next);
+#ifdef PGICP_KNN_STATS
+    atomicAdd(&g_knn_stats[5], (unsigned long long)(best.cnt - cnt_a));
+    atomicAdd(&g_knn_stats[6], (unsigned long long)(resolved ? 0 : 1));
+    atomicAdd(&g_knn_stats[7], (unsigned long long)(best.cnt > cnt_a ? 1 : 0));
+#endif
+    T lb_override = (T)-1;
+    if (capped && best.slot < 0) {
+        // nothing within the cap: that is not "no neighbour", only "farther than the cap"
+        if (resolved) lb_override = cap2;              // every cell within sqrt(cap2) was examined
+        resolved = false;
+        // the seed is an upper bound (and the next seed) only while it is itself within maxDist
+        if (seed.slot >= 0 && seed.d2 <= ch.max_dist2) best = seed;
+        else best.d2 = ch.max_dist2;
+    }
+    finish_query<T>(M, g, ch, resolved, gr, best, qx, qy, qz, ux, uy, uz, cx, cy, cz, prob, i, P.off + i, r_next, lb_override,
+                    slot_io, d2_out, slow_count, slow_list, slow_lb, slow_ring);
 }
 
 // Medium path: the queued queries that can still matter (lower bound within the threshold just
@@ -749,13 +818,26 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
         T qx, qy, qz;
         apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
         const MapDev<T> M = maps[P.map];
-        Best<T> best;
-        best.d2 = ch.max_dist2; best.idx = 0x7FFFFFFF; best.slot = -1;
+        const T cap2 = (T)1.21 * limit;
+        const bool capped = cap2 < ch.max_dist2;
+        Best<T> best, seed;
+        best.d2 = capped ? cap2 : ch.max_dist2; best.idx = 0x7FFFFFFF; best.slot = -1;
+        seed.d2 = Bits<T>::inf(); seed.idx = 0x7FFFFFFF; seed.slot = -1;
         const int prev = slot_io[P.off + i];
-        if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
+        if (prev >= 0) {
+            eval_point<T>(M.pts[prev], prev, qx, qy, qz, seed);
+            if (seed.d2 <= best.d2) best = seed;
+        }
         T gr;
         int r_next;
-        const bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, slow_ring[k], kMedRings, (T)1.21 * limit, best, gr, r_next);
+        bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, slow_ring[k], kMedRings, cap2, best, gr, r_next);
+        if (capped && best.slot < 0) {
+            // nothing within 1.1x the threshold: irrelevant for the filter, keep it queued beyond reach
+            const bool seed_ok = seed.slot >= 0 && seed.d2 <= ch.max_dist2;
+            if (resolved && (lb >= (T)0 || seed_ok)) { slow_lb[k] = cap2; slow_ring[k] = r_next; continue; }
+            resolved = false;
+            if (seed_ok) best = seed;
+        }
         if (resolved) {
             if (best.slot < 0) best.d2 = Bits<T>::inf();
             slot_io[P.off + i] = best.slot;
@@ -889,11 +971,11 @@ template <typename T>
 __global__ __launch_bounds__(kKnnBlock) void k_knn_brute(const ProblemDev *__restrict__ probs,
                                                           const MapDev<T> *__restrict__ maps, const T *__restrict__ rd_pre,
                                                           int *__restrict__ slot_out, T *__restrict__ d2_out,
-                                                          ChainDev<T> ch)
+                                                          ChainDev<T> ch, const int *__restrict__ active)
 {
     using V4 = typename Vec4<T>::type;
     __shared__ V4 tile[kBruteTile];
-    const ProblemDev &P = probs[blockIdx.y];
+    const ProblemDev &P = probs[active[blockIdx.y]];
     if (P.done) return;
     if (blockIdx.x * kKnnBlock >= P.n) return;
     const MapDev<T> M = maps[P.map];
@@ -949,11 +1031,22 @@ __device__ void trim_select_block(const T *__restrict__ d2, int n, T ratio, T &l
         const int shift = KB - done_bits - width;
         for (int b = threadIdx.x; b < 2048; b += blockDim.x) hist[b] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const U key = Bits<T>::key(d2[i]);
-            if (key >= inf_key) continue;                         // +inf (no neighbour) is not a value
-            if (done_bits == 0 || (key >> (KB - done_bits)) == prefix)
-                atomicAdd(&hist[(int)((key >> shift) & (U)((1u << width) - 1u))], 1);
+        // 8 independent loads in flight per thread: with one load per iteration this loop is
+        // latency bound (one block owns a whole problem, measured 68 us per selection)
+        for (int base = threadIdx.x; base < n; base += 8 * blockDim.x) {
+            U keys[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * blockDim.x;
+                keys[u] = i < n ? Bits<T>::key(d2[i]) : inf_key;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const U key = keys[u];
+                if (key >= inf_key) continue;                     // +inf (no neighbour) is not a value
+                if (done_bits == 0 || (key >> (KB - done_bits)) == prefix)
+                    atomicAdd(&hist[(int)((key >> shift) & (U)((1u << width) - 1u))], 1);
+            }
         }
         __syncthreads();
         // block scan over 2048 bins: 2 bins per thread (blockDim = 1024)
@@ -992,9 +1085,9 @@ __device__ void trim_select_block(const T *__restrict__ d2, int n, T ratio, T &l
 
 template <typename T>
 __global__ __launch_bounds__(kSelectBlock) void k_trim_select(ProblemDev *__restrict__ probs, const T *__restrict__ d2,
-                                                               ChainDev<T> ch, int second)
+                                                               ChainDev<T> ch, int second, const int *__restrict__ active)
 {
-    ProblemDev &P = probs[blockIdx.x];
+    ProblemDev &P = probs[active[blockIdx.x]];
     if (P.done) return;
     if (second) {                      // re-select only if the slow path refined something
         if (P.n_refined == 0) return;
@@ -1079,9 +1172,10 @@ __global__ __launch_bounds__(kReduceBlock) void k_p2plane_reduce(const ProblemDe
                                                                   const MapDev<T> *__restrict__ maps,
                                                                   const T *__restrict__ rd_pre, const int *__restrict__ slot,
                                                                   const T *__restrict__ d2, double *__restrict__ partials,
-                                                                  int max_blocks)
+                                                                  int max_blocks, const int *__restrict__ active)
 {
-    const ProblemDev &P = probs[blockIdx.y];
+    const int prob = active[blockIdx.y];
+    const ProblemDev &P = probs[prob];
     if (P.done) return;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     if (tile * (kReduceBlock * kReduceItems) >= P.n) return;      // whole block past the end: partial stays unused
@@ -1090,24 +1184,40 @@ __global__ __launch_bounds__(kReduceBlock) void k_p2plane_reduce(const ProblemDe
     double acc[kSys];
 #pragma unroll
     for (int k = 0; k < kSys; k++) acc[k] = 0.0;
+    // three load stages, each with kReduceItems independent loads in flight per lane:
+    // (slot, d2) -> gathered (point, normal, reading) -> arithmetic
+    using V4 = typename Vec4<T>::type;
+    int ss[kReduceItems];
+    bool keep[kReduceItems];
 #pragma unroll
     for (int it = 0; it < kReduceItems; it++) {
         const int i = tile * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
-        if (i < P.n) {
-            const T dd = d2[P.off + i];
-            const int s = slot[P.off + i];
-            if (s >= 0 && dd <= limit) {
-                const T *q = rd_pre + 3 * (P.off + i);
-                T px, py, pz;
-                apply_T<T>(P.Tcur, q[0], q[1], q[2], px, py, pz);
-                const auto mp = M.pts[s];
-                const auto mn = M.nrm[s];
-                accumulate_pair(acc, 1.0, (double)px, (double)py, (double)pz, (double)mp.x, (double)mp.y, (double)mp.z,
-                                (double)mn.x, (double)mn.y, (double)mn.z);
-            }
+        ss[it] = -1;
+        T dd = Bits<T>::inf();
+        if (i < P.n) { dd = d2[P.off + i]; ss[it] = slot[P.off + i]; }
+        keep[it] = ss[it] >= 0 && dd <= limit;
+    }
+    V4 mp[kReduceItems], mn[kReduceItems];
+    T qv[kReduceItems][3];
+#pragma unroll
+    for (int it = 0; it < kReduceItems; it++) {
+        const int i = tile * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
+        const int s = keep[it] ? ss[it] : 0;
+        mp[it] = M.pts[s];
+        mn[it] = M.nrm[s];
+        const T *q = rd_pre + 3 * (P.off + (keep[it] ? i : 0));
+        qv[it][0] = q[0]; qv[it][1] = q[1]; qv[it][2] = q[2];
+    }
+#pragma unroll
+    for (int it = 0; it < kReduceItems; it++) {
+        if (keep[it]) {
+            T px, py, pz;
+            apply_T<T>(P.Tcur, qv[it][0], qv[it][1], qv[it][2], px, py, pz);
+            accumulate_pair(acc, 1.0, (double)px, (double)py, (double)pz, (double)mp[it].x, (double)mp[it].y, (double)mp[it].z,
+                            (double)mn[it].x, (double)mn[it].y, (double)mn[it].z);
         }
     }
-    block_reduce_store<kSys>(acc, partials + ((long long)blockIdx.y * max_blocks + tile) * kSys);
+    block_reduce_store<kSys>(acc, partials + ((long long)prob * max_blocks + tile) * kSys);
 }
 
 // stage-level ErrorElements/residual with caller-provided ids (original
@@ -1186,14 +1296,16 @@ __device__ __forceinline__ double sum_partials_256(const double *__restrict__ pa
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_solve_update(ProblemDev *__restrict__ probs, const double *__restrict__ partials,
-                                                       int max_blocks, ChainDev<T> ch, int *__restrict__ n_done)
+                                                       int max_blocks, ChainDev<T> ch, int *__restrict__ n_done,
+                                                       const int *__restrict__ active)
 {
-    ProblemDev &P = probs[blockIdx.x];
+    const int prob = active[blockIdx.x];
+    ProblemDev &P = probs[prob];
     if (P.done) return;
     __shared__ double sys[kSys];
     __shared__ double red[8][32];
     const int nb = (P.n + kReduceBlock * kReduceItems - 1) / (kReduceBlock * kReduceItems);
-    const double tot = sum_partials_256(partials + (long long)blockIdx.x * max_blocks * kSys, nb, kSys, red);
+    const double tot = sum_partials_256(partials + (long long)prob * max_blocks * kSys, nb, kSys, red);
     if (threadIdx.x < kSys) {
         sys[threadIdx.x] = tot;
         P.sys[threadIdx.x] = tot;
@@ -1225,6 +1337,56 @@ __global__ __launch_bounds__(256) void k_solve_update(ProblemDev *__restrict__ p
         P.done = 1;
         atomicAdd(n_done, 1);
     }
+}
+
+// active[] = ids of the problems still iterating, followed by the finished ones (so a stale, larger
+// launch count only adds blocks that exit at once).  One block; P is at most a few thousand.
+__global__ __launch_bounds__(1024) void k_compact_active(const ProblemDev *__restrict__ probs, int P, int *__restrict__ active)
+{
+    __shared__ int lds[32];
+    __shared__ int base_live, base_done;
+    if (threadIdx.x == 0) { base_live = 0; base_done = 0; }
+    __syncthreads();
+    int n_live_total = 0;
+    for (int b = 0; b < P; b += 1024) n_live_total += 0;     // (kept simple: two passes below)
+    // pass 1: count live
+    int live_cnt = 0;
+    for (int p = threadIdx.x; p < P; p += 1024) live_cnt += probs[p].done ? 0 : 1;
+    int tot;
+    block_exclusive_scan_1024(live_cnt, lds, tot);
+    const int n_live = tot;
+    // pass 2: stable placement chunk by chunk
+    for (int b = 0; b < P; b += 1024) {
+        const int p = b + threadIdx.x;
+        const int is_live = (p < P && !probs[p].done) ? 1 : 0;
+        const int is_done = (p < P && probs[p].done) ? 1 : 0;
+        int tl, td;
+        const int el = block_exclusive_scan_1024(is_live, lds, tl);
+        const int ed = block_exclusive_scan_1024(is_done, lds, td);
+        if (is_live) active[base_live + el] = p;
+        if (is_done) active[n_live + base_done + ed] = p;
+        __syncthreads();
+        if (threadIdx.x == 0) { base_live += tl; base_done += td; }
+        __syncthreads();
+    }
+    (void)n_live_total;
+}
+
+int knn_stats_read(unsigned long long out[16], int reset)
+{
+#ifdef PGICP_KNN_STATS
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof z); }
+    return 0;
+#else
+    (void)out; (void)reset;
+    return -1;
+#endif
+}
+
+void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active)
+{
+    hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, st, probs, P, active);
 }
 
 // ---------------------------------------------------------------------------
@@ -1374,19 +1536,19 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings)
+                int *slow_ring, int fast_rings, const int *active)
 {
     if (matcher == 1) {
         hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot, d2,
-                           ch);
+                           ch, active);
         (void)hipMemsetAsync(slow_count, 0, sizeof(int), st);
         return;
     }
     (void)hipMemsetAsync(slow_count, 0, sizeof(int), st);
     // R = 1 in both cases: measured, a 5x5x5 collected block on the unseeded first iteration costs
     // 2.5x the ring-by-ring continuation (nothing prunes it until the own row has a hit)
-    hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, 64)), P), dim3(64), 0, st, probs, maps, rd, slot, d2, ch,
-                       use_seed, fast_rings, slow_count, slow_list, slow_lb, slow_ring);
+    hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, kFastBlock)), P), dim3(kFastBlock), 0, st, probs, maps, rd, slot, d2, ch,
+                       use_seed, fast_rings, slow_count, slow_list, slow_lb, slow_ring, active);
 }
 
 template <typename T>
@@ -1408,27 +1570,28 @@ void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, c
 }
 
 template <typename T>
-void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second)
+void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second,
+                        const int *active)
 {
-    hipLaunchKernelGGL(k_trim_select<T>, dim3(P), dim3(kSelectBlock), 0, st, probs, d2, ch, second);
+    hipLaunchKernelGGL(k_trim_select<T>, dim3(P), dim3(kSelectBlock), 0, st, probs, d2, ch, second, active);
 }
 
 int reduce_blocks(int max_n) { return round8(cdiv(max_n, kReduceBlock * kReduceItems)); }
 
 template <typename T>
 void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
-                   const T *d2, double *partials, int P, int max_n)
+                   const T *d2, double *partials, int P, int max_n, const int *active)
 {
     const int nb = reduce_blocks(max_n);
     hipLaunchKernelGGL(k_p2plane_reduce<T>, dim3(nb, P), dim3(kReduceBlock), 0, st, probs, maps, rd_pre, slot, d2, partials,
-                       nb);
+                       nb, active);
 }
 
 template <typename T>
 void launch_solve(hipStream_t st, ProblemDev *probs, const double *partials, const ChainDev<T> &ch, int *n_done, int P,
-                  int max_n)
+                  int max_n, const int *active)
 {
-    hipLaunchKernelGGL(k_solve_update<T>, dim3(P), dim3(256), 0, st, probs, partials, reduce_blocks(max_n), ch, n_done);
+    hipLaunchKernelGGL(k_solve_update<T>, dim3(P), dim3(256), 0, st, probs, partials, reduce_blocks(max_n), ch, n_done, active);
 }
 
 template <typename T>
@@ -1481,15 +1644,16 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
-                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int);                      \
+                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *);         \
     template void launch_knn_med<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                  \
                                     const ChainDev<T> &, const int *, const int2 *, T *, int *);                          \
     template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \
                                      const ChainDev<T> &, const int *, const int2 *, const T *, int);                     \
-    template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int, int);             \
+    template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int, int, const int *); \
     template void launch_reduce<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, const int *, const T *, \
-                                   double *, int, int);                                                                   \
-    template void launch_solve<T>(hipStream_t, ProblemDev *, const double *, const ChainDev<T> &, int *, int, int);       \
+                                   double *, int, int, const int *);                                                      \
+    template void launch_solve<T>(hipStream_t, ProblemDev *, const double *, const ChainDev<T> &, int *, int, int,        \
+                                  const int *);                                                                           \
     template void launch_cov<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, const int *, const T *,    \
                                 double *, double *, int, int);                                                            \
     template void launch_trim_raw<T>(hipStream_t, const T *, int, T, T *, T *);                                           \

@@ -23,7 +23,7 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings);
+                int *slow_ring, int fast_rings, const int *active);
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                     const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring);
@@ -31,14 +31,17 @@ template <typename T>
 void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                      const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb, int exact_all);
 template <typename T>
-void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second);
+void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second,
+                        const int *active);
+int knn_stats_read(unsigned long long out[16], int reset);   // diagnostics build (-DPGICP_KNN_STATS) only
+void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active);
 int reduce_blocks(int max_n);
 template <typename T>
 void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
-                   const T *d2, double *partials, int P, int max_n);
+                   const T *d2, double *partials, int P, int max_n, const int *active);
 template <typename T>
 void launch_solve(hipStream_t st, ProblemDev *probs, const double *partials, const ChainDev<T> &ch, int *n_done, int P,
-                  int max_n);
+                  int max_n, const int *active);
 template <typename T>
 void launch_cov(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
                 const T *d2, double *partials, double *out, int P, int max_n);

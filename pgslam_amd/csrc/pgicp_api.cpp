@@ -76,7 +76,7 @@ struct pgicp_ctx {
     State<float> f32;
     State<double> f64;
     DevBuf probs, src, partials, sums, small, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
-    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring;
+    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, active;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     int fast_rings_seeded = 2, fast_rings_unseeded = 4;   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
@@ -379,6 +379,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
         HIPC(c, c->slow_lb.ensure(sizeof(T) * (size_t)L.total));
         HIPC(c, c->slow_ring.ensure(sizeof(int) * (size_t)L.total));
+        HIPC(c, c->active.ensure(sizeof(int) * (size_t)P));
         HIPC(c, c->qcounts.ensure(sizeof(int) * nbins));
         HIPC(c, c->qcursor.ensure(sizeof(int) * nbins));
         HIPC(c, c->qstart.ensure(sizeof(int) * (nbins + 1)));
@@ -414,6 +415,9 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     }
     HIPC(c, hipMemcpyAsync(c->probs.p, hp.data(), sizeof(ProblemDev) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->src.p, hs.data(), sizeof(SrcDesc) * P, hipMemcpyHostToDevice, c->stream));
+    std::vector<int> ident(P);
+    std::iota(ident.begin(), ident.end(), 0);
+    HIPC(c, hipMemcpyAsync(c->active.p, ident.data(), sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
     {
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
@@ -433,18 +437,21 @@ template <typename T>
 void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bool with_solve, long long act_units,
                    long long act_probs, int use_seed)
 {
+    // only the problems still iterating are launched: `active` lists them first (k_compact_active)
+    const int nA = (int)act_probs;
+    const int *active = c->active.as<int>();
     State<T> &S = state<T>(c);
     const MapDev<T> *maps = S.d_maps.template as<MapDev<T>>();
     ProblemDev *probs = c->probs.as<ProblemDev>();
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
-                      S.d2.template as<T>(), ch, L.P, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
-                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded);
+                      S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
+                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active);
     }
     {
         ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, L.P, 0);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, 0, active);
     }
     if (c->prm.matcher == PGICP_MATCHER_GRID) {
         // lazy resolution: only queued queries whose lower bound is within the threshold just
@@ -458,16 +465,17 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), 0);
         }
         ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, L.P, 1);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, 1, active);
     }
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
         launch_reduce<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
-                         c->partials.as<double>(), L.P, L.max_n);
+                         c->partials.as<double>(), nA, L.max_n, active);
     }
     if (with_solve) {
         ProfScope ps(c, PGICP_PROF_SOLVE, act_units, act_probs);
-        launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), L.P, L.max_n);
+        launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), nA, L.max_n, active);
+        launch_compact_active(c->stream, probs, L.P, c->active.as<int>());
     }
 }
 
@@ -608,7 +616,7 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                      c->slow_ring.as<int>(), c->fast_rings_unseeded);
+                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>());
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
@@ -618,12 +626,12 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
         {
             ProfScope ps(c, PGICP_PROF_TRIM, n);
-            launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, 1, 0);
+            launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, 1, 0, c->active.as<int>());
         }
         {
             ProfScope ps(c, PGICP_PROF_REDUCE, n);
             launch_reduce<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
-                             S.d2.template as<T>(), c->partials.as<double>(), 1, n);
+                             S.d2.template as<T>(), c->partials.as<double>(), 1, n, c->active.as<int>());
         }
         launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(n), kSys, probs, 0, c->sums.as<double>(), 1);
     }
@@ -913,7 +921,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
-                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring})
+                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->active})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1094,6 +1102,14 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
 {
     if (!c || !out) return PGICP_ERR_ARG;
     HIPC(c, hipMemcpy(out, c->small.as<int>() + 16, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (std::getenv("PGICP_KNN_STATS_DUMP")) {          // diagnostics build only
+        unsigned long long s[16];
+        (void)hipDeviceSynchronize();
+        if (knn_stats_read(s, 1) == 0) {
+            std::fprintf(stderr, "knn_stats waves=%llu a1_max=%llu a1_sum=%llu flat_iters_max=%llu a2_sum=%llu b_cand=%llu unresolved=%llu b_lanes=%llu\n",
+                         s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+        }
+    }
     return PGICP_OK;
 }
 
