@@ -416,25 +416,65 @@ __device__ __forceinline__ void eval_point(const typename Vec4<T>::type v, int s
     const T dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
     const T d = (dx * dx + dy * dy) + dz * dz;
     const int idx = Bits<T>::unpack_idx(v.w);
-    if (d < best.d2 || (d == best.d2 && idx < best.idx)) { best.d2 = d; best.idx = idx; best.slot = s; }
+    // selects, not branches: the update is rare and the loop bodies must stay straight-line
+    const bool better = (d < best.d2) | ((d == best.d2) & (idx < best.idx));
+    best.d2 = better ? d : best.d2;
+    best.idx = better ? idx : best.idx;
+    best.slot = better ? s : best.slot;
 #ifdef PGICP_KNN_STATS
     best.cnt++;
 #endif
 }
 
+// predicated form for straight-line loops (field-wise selects: a struct-typed ?: goes through scratch)
 template <typename T>
-__device__ __forceinline__ void scan_range(const typename Vec4<T>::type *__restrict__ pts, int a, int b, T qx, T qy,
+__device__ __forceinline__ void eval_point_if(bool on, const typename Vec4<T>::type v, int s, T qx, T qy, T qz, Best<T> &best)
+{
+    const T dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+    const T d = (dx * dx + dy * dy) + dz * dz;
+    const int idx = Bits<T>::unpack_idx(v.w);
+    const bool better = on & ((d < best.d2) | ((d == best.d2) & (idx < best.idx)));
+    best.d2 = better ? d : best.d2;
+    best.idx = better ? idx : best.idx;
+    best.slot = better ? s : best.slot;
+#ifdef PGICP_KNN_STATS
+    best.cnt += on ? 1 : 0;
+#endif
+}
+
+// map arrays are reached through pointers stored in a struct, which the compiler can only treat as
+// generic (flat) addresses; they are always device-global memory, and global loads do not occupy
+// the LDS counter
+template <typename V>
+__device__ __forceinline__ const __attribute__((address_space(1))) V *as_global(const V *p)
+{
+    return (const __attribute__((address_space(1))) V *)p;
+}
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Raw4<double> { typedef double type __attribute__((ext_vector_type(4))); };
+// one aligned 16/32-byte global load of a map record
+template <typename T>
+__device__ __forceinline__ typename Vec4<T>::type load_rec(const typename Vec4<T>::type *p, int j)
+{
+    const typename Raw4<T>::type r = as_global(reinterpret_cast<const typename Raw4<T>::type *>(p))[j];
+    return make_v4(r.x, r.y, r.z, r.w);
+}
+
+template <typename T>
+__device__ __forceinline__ void scan_range(const typename Vec4<T>::type *__restrict__ pts_generic, int a, int b, T qx, T qy,
                                            T qz, Best<T> &best)
 {
+    const auto *pts = pts_generic;
     int s = a;
     for (; s + 4 <= b; s += 4) {                 // four independent loads in flight
-        const auto v0 = pts[s], v1 = pts[s + 1], v2 = pts[s + 2], v3 = pts[s + 3];
+        const auto v0 = load_rec<T>(pts, s), v1 = load_rec<T>(pts, s + 1), v2 = load_rec<T>(pts, s + 2), v3 = load_rec<T>(pts, s + 3);
         eval_point<T>(v0, s, qx, qy, qz, best);
         eval_point<T>(v1, s + 1, qx, qy, qz, best);
         eval_point<T>(v2, s + 2, qx, qy, qz, best);
         eval_point<T>(v3, s + 3, qx, qy, qz, best);
     }
-    for (; s < b; ++s) eval_point<T>(pts[s], s, qx, qy, qz, best);
+    for (; s < b; ++s) eval_point<T>(load_rec<T>(pts, s), s, qx, qy, qz, best);
 }
 
 // distance from coordinate offset u (= x - origin) to the slab of cell c
@@ -459,7 +499,8 @@ __device__ __forceinline__ void scan_row(const MapDev<T> &M, int row_base, int x
         xb = min(xb, clamp_cell<T>(ux + rad, M.g.inv_h, M.g.nx));
         if (xa > xb) return;
     }
-    scan_range<T>(M.pts, M.cell_start[row_base + xa], M.cell_start[row_base + xb + 1], qx, qy, qz, best);
+    const auto *cs = as_global(M.cell_start);
+    scan_range<T>(M.pts, cs[row_base + xa], cs[row_base + xb + 1], qx, qy, qz, best);
 }
 
 // guaranteed radius after ring r: every cell outside Chebyshev ring r around c0 is at
@@ -713,8 +754,8 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
                 }
                 if (xlo <= xhi) {
                     const int row = g.nx * (y + g.ny * z);
-                    ra[t] = M.cell_start[row + xlo];
-                    rb[t] = M.cell_start[row + xhi + 1];
+                    ra[t] = as_global(M.cell_start)[row + xlo];
+                    rb[t] = as_global(M.cell_start)[row + xhi + 1];
                     rl[t] = lb2;
                 }
             }
@@ -726,33 +767,22 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
         if (ra[t] < rb[t]) { rng_a[nr][lane] = ra[t]; rng_b[nr][lane] = rb[t]; rng_l[nr][lane] = rl[t]; ++nr; }
     // ---- flat walk over the concatenated ranges (LDS is only read by the lane that wrote it) ----
     {
-        int k = -1, j = 0, e = 0;
-        bool valid = false;
-        // advance to the first range that still passes the row test
-        for (;;) {
-            ++k;
-            if (k >= nr) break;
-            if (rng_l[k][lane] > best.d2) continue;
-            j = rng_a[k][lane]; e = rng_b[k][lane]; valid = true;
-            break;
-        }
-        V4 cur = M.pts[valid ? j : 0];
+        int k = 0, j = 0, e = 0;
+        bool valid = nr > 0;
+        if (valid) { j = rng_a[0][lane]; e = rng_b[0][lane]; }
         while (__any(valid)) {
-            int jn = j + 1, kn = k, en = e;
-            bool vn = valid;
-            if (valid && jn >= e) {
-                vn = false;
-                for (;;) {                                           // next range whose row is still within the bound
-                    ++kn;
-                    if (kn >= nr) break;
-                    if (rng_l[kn][lane] > best.d2) continue;
-                    jn = rng_a[kn][lane]; en = rng_b[kn][lane]; vn = true;
-                    break;
-                }
+            // two candidates per trip (the second only if it is still inside the current range)
+            const bool two = valid & (j + 1 < e);
+            const V4 v0 = load_rec<T>(M.pts, valid ? j : 0);
+            const V4 v1 = load_rec<T>(M.pts, two ? j + 1 : 0);
+            eval_point_if<T>(valid, v0, j, qx, qy, qz, best);
+            eval_point_if<T>(two, v1, j + 1, qx, qy, qz, best);
+            j += 2;
+            if (valid & (j >= e)) {                                   // next non-empty range of this lane
+                ++k;
+                valid = k < nr;
+                if (valid) { j = rng_a[k][lane]; e = rng_b[k][lane]; }
             }
-            const V4 nxt = M.pts[vn ? jn : 0];                    // next candidate's load is in flight during the eval
-            if (valid) eval_point<T>(cur, j, qx, qy, qz, best);
-            cur = nxt; j = jn; k = kn; e = en; valid = vn;
 #ifdef PGICP_KNN_STATS
             flat_iters++;
 #endif
