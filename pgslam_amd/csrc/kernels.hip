@@ -832,17 +832,21 @@ constexpr int kMedRings = 12;
 template <typename T>
 __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                  const T *__restrict__ rd, int *__restrict__ slot_io, T *__restrict__ d2_out,
-                                                 ChainDev<T> ch, const int *__restrict__ slow_count,
+                                                 ChainDev<T> ch, int *__restrict__ slow_count,
                                                  const int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
-                                                 int *__restrict__ slow_ring)
+                                                 int *__restrict__ slow_ring, int *__restrict__ slow2_idx)
 {
     const int count = *slow_count;
-    for (int k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
+    const int lane = threadIdx.x;
+    for (int base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {
+      bool survivor = false;                                  // still matters after this pass -> wave-cooperative path
+      const int k = base + lane;
+      if (k < count) do {
         const T lb = slow_lb[k];
         const int2 e = slow_list[k];
         ProblemDev &P = probs[e.x];
         const T limit = (T)P.limit;
-        if (lb >= (T)0 && lb > limit) continue;               // cannot influence the result: stays lazy
+        if (lb >= (T)0 && lb > limit) break;                  // cannot influence the result: stays lazy
         const int i = e.y;
         const T *q = rd + 3 * (P.off + i);
         T qx, qy, qz;
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
         if (capped && best.slot < 0) {
             // nothing within 1.1x the threshold: irrelevant for the filter, keep it queued beyond reach
             const bool seed_ok = seed.slot >= 0 && seed.d2 <= ch.max_dist2;
-            if (resolved && (lb >= (T)0 || seed_ok)) { slow_lb[k] = cap2; slow_ring[k] = r_next; continue; }
+            if (resolved && (lb >= (T)0 || seed_ok)) { slow_lb[k] = cap2; slow_ring[k] = r_next; break; }
             resolved = false;
             if (seed_ok) best = seed;
         }
@@ -877,9 +881,20 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
         } else {
             // still open: keep the better upper bound (if a real candidate exists) and the larger lower bound
             if (best.slot >= 0) { slot_io[P.off + i] = best.slot; d2_out[P.off + i] = best.d2; P.n_refined = 1; }
-            if (lb >= (T)0 || best.slot >= 0) slow_lb[k] = gr > (T)0 ? gr * gr : (T)0;
+            T nlb = lb;
+            if (lb >= (T)0 || best.slot >= 0) { nlb = gr > (T)0 ? gr * gr : (T)0; slow_lb[k] = nlb; }
             slow_ring[k] = r_next;
+            survivor = nlb < (T)0 || !(nlb > limit);
         }
+      } while (false);
+      // survivors of this wave reserve consecutive slots of the second-stage list
+      const unsigned long long m = __ballot(survivor);
+      if (m) {
+          int b0 = 0;
+          if (lane == 0) b0 = atomicAdd(slow_count + 3, __popcll(m));
+          b0 = __shfl(b0, 0, 64);
+          if (survivor) slow2_idx[b0 + __popcll(m & ((1ULL << lane) - 1ULL))] = k;
+      }
     }
 }
 
@@ -895,25 +910,23 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
                                                    const T *__restrict__ rd, int *__restrict__ slot_io,
                                                    T *__restrict__ d2_out, ChainDev<T> ch,
                                                    const int *__restrict__ slow_count, const int2 *__restrict__ slow_list,
-                                                   const T *__restrict__ slow_lb, int exact_all)
+                                                   const T *__restrict__ slow_lb, const int *__restrict__ slow2_idx,
+                                                   int exact_all)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int count = *slow_count;
-    for (int k = wave; k < count; k += nwaves) {
+    // lazy mode walks the list k_knn_med left behind (entries that still matter); exact_all (public
+    // matcher output) walks every queued query
+    const int count = exact_all ? slow_count[0] : slow_count[3];
+    for (int t = wave; t < count; t += nwaves) {
+        const int k = exact_all ? t : slow2_idx[t];
         const int2 e = slow_list[k];
         ProblemDev &P = probs[e.x];
         const int i = e.y;
-        if (!exact_all) {
-            // lazy: only queries whose lower bound does not already exceed the (upper bound of the)
-            // trim threshold can influence the result (entries k_knn_med finished carry LB = +inf)
-            const T lb = slow_lb[k];
-            if (lb >= (T)0 && lb > (T)P.limit) continue;
-            if (lane == 0) {
-                atomicAdd(&P.n_refined, 1);
-                atomicAdd(const_cast<int *>(slow_count) + (lb < (T)0 ? 1 : 2), 1);     // diagnostics: forced / bound-hit
-            }
+        if (!exact_all && lane == 0) {
+            atomicAdd(&P.n_refined, 1);
+            atomicAdd(const_cast<int *>(slow_count) + (slow_lb[k] < (T)0 ? 1 : 2), 1);     // diagnostics: forced / bound-hit
         }
         const T *q = rd + 3 * (P.off + i);
         T qx, qy, qz;
@@ -1571,10 +1584,10 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
     if (matcher == 1) {
         hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot, d2,
                            ch, active);
-        (void)hipMemsetAsync(slow_count, 0, sizeof(int), st);
+        (void)hipMemsetAsync(slow_count, 0, 4 * sizeof(int), st);
         return;
     }
-    (void)hipMemsetAsync(slow_count, 0, sizeof(int), st);
+    (void)hipMemsetAsync(slow_count, 0, 4 * sizeof(int), st);
     // R = 1 in both cases: measured, a 5x5x5 collected block on the unseeded first iteration costs
     // 2.5x the ring-by-ring continuation (nothing prunes it until the own row has a hit)
     hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, kFastBlock)), P), dim3(kFastBlock), 0, st, probs, maps, rd, slot, d2, ch,
@@ -1583,20 +1596,21 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
 
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
-                    const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring)
+                    const ChainDev<T> &ch, int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring, int *slow2_idx)
 {
     hipLaunchKernelGGL(k_knn_med<T>, dim3(8192), dim3(64), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list, slow_lb,
-                       slow_ring);
+                       slow_ring, slow2_idx);
 }
 
 // resolves the queries the fast path queued: all of them (exact_all, public matcher
 // output) or only those that can still matter for the trimmed filter (lazy)
 template <typename T>
 void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
-                     const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb, int exact_all)
+                     const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb,
+                     const int *slow2_idx, int exact_all)
 {
     hipLaunchKernelGGL(k_knn_slow<T>, dim3(1024), dim3(256), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list,
-                       slow_lb, exact_all);
+                       slow_lb, slow2_idx, exact_all);
 }
 
 template <typename T>
@@ -1676,9 +1690,9 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
                                 const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *);         \
     template void launch_knn_med<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                  \
-                                    const ChainDev<T> &, const int *, const int2 *, T *, int *);                          \
+                                    const ChainDev<T> &, int *, const int2 *, T *, int *, int *);                         \
     template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \
-                                     const ChainDev<T> &, const int *, const int2 *, const T *, int);                     \
+                                     const ChainDev<T> &, const int *, const int2 *, const T *, const int *, int);        \
     template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int, int, const int *); \
     template void launch_reduce<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, const int *, const T *, \
                                    double *, int, int, const int *);                                                      \

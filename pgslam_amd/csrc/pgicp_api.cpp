@@ -76,7 +76,7 @@ struct pgicp_ctx {
     State<float> f32;
     State<double> f64;
     DevBuf probs, src, partials, sums, small, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
-    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, active;
+    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     int fast_rings_seeded = 2, fast_rings_unseeded = 4;   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
@@ -379,6 +379,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
         HIPC(c, c->slow_lb.ensure(sizeof(T) * (size_t)L.total));
         HIPC(c, c->slow_ring.ensure(sizeof(int) * (size_t)L.total));
+        HIPC(c, c->slow2.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->active.ensure(sizeof(int) * (size_t)P));
         HIPC(c, c->qcounts.ensure(sizeof(int) * nbins));
         HIPC(c, c->qcursor.ensure(sizeof(int) * nbins));
@@ -460,9 +461,11 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         {
             ProfScope ps(c, PGICP_PROF_KNN_SLOW, act_units, act_probs);
             launch_knn_med<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
-                              ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), c->slow_ring.as<int>());
+                              ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), c->slow_ring.as<int>(),
+                              c->slow2.as<int>());
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
-                               S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), 0);
+                               S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
+                               c->slow2.as<int>(), 0);
         }
         ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
         launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, 1, active);
@@ -620,7 +623,8 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
-                               S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), 1);
+                               S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
+                               c->slow2.as<int>(), 1);
     }
     if (do_trim) {
         if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
@@ -921,7 +925,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
-                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->active})
+                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
