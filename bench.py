@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="independent scans aligned per step")
+    ap.add_argument("--batch", type=int, default=128, help="independent scans aligned per step")
     ap.add_argument("--queries", type=int, default=16, help="distinct query scans generated (cycled to fill the batch)")
     ap.add_argument("--n-scan", type=int, default=100_000)
     ap.add_argument("--n-map", type=int, default=1_000_000)
@@ -256,6 +256,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="contexts (HIP streams, one host thread each) the batch is split over; each keeps its own "
+                         "resident copy of the map.  >1 overlaps one sub-batch's convergence tail with another's head")
     ap.add_argument("--workload", choices=["scan2map", "loopclosure"], default="scan2map",
                     help="scan2map = BASELINE configs[1] (the headline metric); loopclosure = configs[4]: --pairs candidate "
                          "scan pairs (100k vs 100k) sharded over the ranks, all-gather of the SE(3) edges")
@@ -297,8 +300,10 @@ def main():
     chain = dict(CHAIN)
     if args.fixed_iters:
         chain.update(min_diff_rot=0.0, min_diff_trans=0.0)
-    ctx = icp.Context(local_rank, **chain, matcher=icp.MATCHER_GRID if args.matcher == "grid" else icp.MATCHER_BRUTE,
-                      grid_cell=args.grid_cell, check_every=args.check_every)
+    S = max(1, args.streams)
+    ctxs = [icp.Context(local_rank, **chain, matcher=icp.MATCHER_GRID if args.matcher == "grid" else icp.MATCHER_BRUTE,
+                        grid_cell=args.grid_cell, check_every=args.check_every) for _ in range(S)]
+    ctx = ctxs[0]
     d_map_xyz = torch.from_numpy(w.map_xyz).to(dev)
     d_map_nrm = torch.from_numpy(w.map_nrm).to(dev)
     d_scans = [torch.from_numpy(s).to(dev) for s in w.scans_xyz]
@@ -306,6 +311,7 @@ def main():
     t0 = time.perf_counter()
     map_id = ctx.set_map(d_map_xyz, d_map_nrm, center=True)
     t_setmap = time.perf_counter() - t0
+    map_ids = [map_id] + [c.set_map(d_map_xyz, d_map_nrm, center=True) for c in ctxs[1:]]
 
     B = args.batch
     readings = [d_scans[b % len(d_scans)] for b in range(B)]
@@ -314,7 +320,22 @@ def main():
     T_inits = [w.T_truth[b % len(d_scans)] @ synth.perturbation(1000 * rank + b) for b in range(B)]
 
     def step():
-        T, st = ctx.align_batch(map_id, readings, T_inits, raise_on_error=False)
+        if S == 1:
+            return ctx.align_batch(map_id, readings, T_inits, raise_on_error=False)
+        # sub-batch k -> context k (own stream, own host thread; ctypes releases the GIL)
+        out = [None] * S
+        def work(k):
+            out[k] = ctxs[k].align_batch(map_ids[k], readings[k::S], T_inits[k::S], raise_on_error=False)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        T = np.zeros((B, 4, 4))
+        st = [None] * B
+        for k in range(S):
+            T[k::S] = out[k][0]
+            st[k::S] = out[k][1]
         return T, st
 
     for _ in range(args.warmup):
@@ -410,7 +431,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"scan-to-map ICP, {args.n_scan}-pt Velodyne-shaped scan vs {args.n_map}-pt local map, "
                                    f"<=30 iterations (BASELINE.json configs[1])",
-                       "batch_scans_per_step": B, "distinct_scans": len(d_scans), "matcher": args.matcher,
+                       "batch_scans_per_step": B, "distinct_scans": len(d_scans), "matcher": args.matcher, "streams": S,
                        "chain": chain, "fixed_iterations": bool(args.fixed_iters),
                        "parallelism": f"{world} independent replica(s), one process per GPU"},
             "scans_total": scans_all,
@@ -425,8 +446,9 @@ def main():
         if cpu and cpu["value"] > 0:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out))
-    ctx.destroy_map(map_id)
-    ctx.close()
+    for c_, m_ in zip(ctxs, map_ids):
+        c_.destroy_map(m_)
+        c_.close()
     if distributed:
         dist.destroy_process_group()
 

@@ -248,7 +248,13 @@ __global__ __launch_bounds__(256) void k_rank_place(const T *__restrict__ xyz, i
     const int c = cell_of[i];
     const int a = cell_start[c], b = cell_start[c + 1];
     int rank = 0;
-    for (int k = a; k < b; ++k) rank += (order_tmp[k] < i) ? 1 : 0;
+    for (int k = a; k < b; k += 8) {
+        int w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = order_tmp[min(k + u, b - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (k + u < b && w[u] < i) ? 1 : 0;
+    }
     const int pos = a + rank;
     const T x = xyz[(long long)i * stride] - mx, y = xyz[(long long)i * stride + 1] - my,
             z = xyz[(long long)i * stride + 2] - mz;
@@ -333,32 +339,38 @@ __global__ __launch_bounds__(256) void k_qbin(const ProblemDev *__restrict__ pro
 
 __global__ __launch_bounds__(256) void k_qscatter(const ProblemDev *__restrict__ probs, int max_bins,
                                                    const int *__restrict__ qbin, int *__restrict__ cursor,
-                                                   int *__restrict__ qtmp)
+                                                   unsigned long long *__restrict__ qtmp)
 {
     const ProblemDev &P = probs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
-    qtmp[atomicAdd(&cursor[(long long)blockIdx.y * max_bins + (qbin[P.off + i] >> 6)], 1)] = i;
+    const int key = qbin[P.off + i];
+    // (cell-in-block key, index) packed: the rank kernel compares these words straight from the bin segment
+    qtmp[atomicAdd(&cursor[(long long)blockIdx.y * max_bins + (key >> 6)], 1)] =
+        ((unsigned long long)(unsigned int)(key & 63) << 32) | (unsigned int)i;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_qrank(const ProblemDev *__restrict__ probs, int max_bins,
                                                 const int *__restrict__ qbin, const int *__restrict__ qstart,
-                                                const int *__restrict__ qtmp, const T *__restrict__ rd_pre,
+                                                const unsigned long long *__restrict__ qtmp, const T *__restrict__ rd_pre,
                                                 T *__restrict__ rd_sorted, int *__restrict__ order)
 {
     const ProblemDev &P = probs[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n) return;
-    const int i = qtmp[P.off + j];
-    const int key = qbin[P.off + i];
-    const long long bin = (long long)blockIdx.y * max_bins + (key >> 6);
+    const unsigned long long me = qtmp[P.off + j];
+    const int i = (int)(unsigned int)(me & 0xFFFFFFFFu);
+    const long long bin = (long long)blockIdx.y * max_bins + (qbin[P.off + i] >> 6);
     const int a = qstart[bin], b = qstart[bin + 1];
     int rank = 0;
-    for (int k = a; k < b; ++k) {
-        const int ik = qtmp[k];
-        const int kk = qbin[P.off + ik];                    // same bin: compares the cell-in-block bits
-        rank += (kk < key || (kk == key && ik < i)) ? 1 : 0;
+    // (cell-in-block, index) order; 8 independent contiguous reads in flight per trip
+    for (int k = a; k < b; k += 8) {
+        unsigned long long w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = qtmp[min(k + u, b - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (k + u < b && w[u] < me) ? 1 : 0;
     }
     const int f = a + rank;                                 // global position (the scan runs over all problems)
     order[f] = i;
@@ -1542,7 +1554,7 @@ void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, i
 // once per scan: order every problem's pre-transformed reading by (map row, x)
 template <typename T>
 void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
-                       int *qrow, int *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
+                       int *qrow, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
                        int max_n, int max_rows)
 {
     const long long nbins = (long long)P * max_rows;
@@ -1556,7 +1568,7 @@ void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> 
                        qstart, cursor);
     hipLaunchKernelGGL(k_qscatter, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, cursor, qtmp);
     hipLaunchKernelGGL(k_qrank<T>, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, (const int *)qstart,
-                       (const int *)qtmp, rd_pre, rd_sorted, order);
+                       (const unsigned long long *)qtmp, rd_pre, rd_sorted, order);
 }
 
 template <typename T>
@@ -1683,8 +1695,8 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_grid_build<T>(hipStream_t, const T *, int, const T *, int, int, const T[3], const GridDesc<T> &, \
                                        int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,                \
                                        typename Vec4<T>::type *, int *, int *);                                           \
-    template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *, int *,  \
-                                       int *, int *, int *, int *, int *, int, int, int);                                 \
+    template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *,         \
+                                       unsigned long long *, int *, int *, int *, int *, int *, int, int, int);           \
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \

@@ -13,7 +13,7 @@ void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, i
                        int *sc_count);
 template <typename T>
 void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
-                       int *qrow, int *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
+                       int *qrow, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
                        int max_n, int max_rows);
 template <typename T>
 void launch_transform(hipStream_t st, const T *in, int in_stride, T *out, int out_stride, int n, const double *T16,

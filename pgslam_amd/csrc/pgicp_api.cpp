@@ -374,7 +374,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     {
         const size_t nbins = (size_t)P * L.max_rows;
         HIPC(c, c->qrow.ensure(sizeof(int) * (size_t)L.total));
-        HIPC(c, c->qtmp.ensure(sizeof(int) * (size_t)L.total));
+        HIPC(c, c->qtmp.ensure(sizeof(unsigned long long) * (size_t)L.total));
         HIPC(c, c->order.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
         HIPC(c, c->slow_lb.ensure(sizeof(T) * (size_t)L.total));
@@ -425,7 +425,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         launch_pretransform<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.rd_pre.template as<T>(), P, L.max_n);
         // order each reading by (map row, x) once: waves stay spatially coherent for every iteration
         launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(),
-                             S.rd_pre.template as<T>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<int>(),
+                             S.rd_pre.template as<T>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<unsigned long long>(),
                              c->order.as<int>(), c->qcounts.as<int>(), c->qblock.as<int>(), c->qstart.as<int>(),
                              c->qcursor.as<int>(), P, L.max_n, L.max_rows);
     }
