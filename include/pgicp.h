@@ -142,6 +142,15 @@ int pgicp_map_create_f32(pgicp_ctx *ctx, const float *xyz, int xyz_stride, const
                          int m, int mem, int center, int *map_id);
 int pgicp_map_create_f64(pgicp_ctx *ctx, const double *xyz, int xyz_stride, const double *nrm, int nrm_stride,
                          int m, int mem, int center, int *map_id);
+/* n reference clouds in one call (one per loop-closure pair, LoopCloser.hpp:98 builds the matcher of
+ * `reference` inside icp_): one host round trip for all of them.  Arrays are indexed by cloud;
+ * nrm[k] (and nrm itself) may be NULL. */
+int pgicp_map_create_batch_f32(pgicp_ctx *ctx, int n_maps, const float *const *xyz, const int *xyz_stride,
+                               const float *const *nrm, const int *nrm_stride, const int *m, int mem, int center,
+                               int *map_ids);
+int pgicp_map_create_batch_f64(pgicp_ctx *ctx, int n_maps, const double *const *xyz, const int *xyz_stride,
+                               const double *const *nrm, const int *nrm_stride, const int *m, int mem, int center,
+                               int *map_ids);
 int pgicp_map_destroy(pgicp_ctx *ctx, int map_id);
 int pgicp_map_size(pgicp_ctx *ctx, int map_id, int *m);
 
@@ -197,6 +206,13 @@ int pgicp_partial_chain_f32(pgicp_ctx *ctx, int map_id, const float *reading, in
                             const double *T, double *weighted_point_used_ratio, double *residual);
 int pgicp_partial_chain_f64(pgicp_ctx *ctx, int map_id, const double *reading, int stride, int n, int mem,
                             const double *T, double *weighted_point_used_ratio, double *residual);
+/* the same chain for a batch of (map, reading, T = problems[p].T_init): the residual check of every
+ * loop-closure candidate of a batch (LoopCloser.hpp:340-363) in one device pass.  status[p] is
+ * PGICP_OK or PGICP_ERR_NO_MATCH; the call returns the worst status.  Output arrays may be NULL. */
+int pgicp_partial_chain_batch_f32(pgicp_ctx *ctx, int n_problems, const pgicp_problem *problems,
+                                  double *weighted_point_used_ratio, double *residual, int *status);
+int pgicp_partial_chain_batch_f64(pgicp_ctx *ctx, int n_problems, const pgicp_problem *problems,
+                                  double *weighted_point_used_ratio, double *residual, int *status);
 
 /* ---- rigid transform and local-map assembly ---------------------------
  * pgicp_transform = rigid_transformation_->compute (Localizer.hpp:106,323,

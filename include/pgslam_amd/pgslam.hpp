@@ -277,12 +277,21 @@ public:
         pgicp_ctx *ctx = chain_.ctx;
         chain_.pushParams();
         const int P = (int)mine.size();
+        std::vector<pgicp_edge> edges(P);
+        if (P == 0) return edges;
         std::vector<pgicp_problem> pr(P);
-        std::vector<int> maps(P, -1);
+        std::vector<int> maps(P, -1), xs(P), ns(P), ms(P);
+        std::vector<const T *> xyz(P), nrm(P);
         for (int k = 0; k < P; k++) {
             const Candidate &c = queue_[mine[k]];
-            PM::check(ctx, pgslam_amd::Abi<T>::map_create(ctx, c.reference->xyzPtr(), c.reference->xyzStride(), c.reference->normalsPtr(),
-                                                         c.reference->normalsStride(), (int)c.reference->getNbPoints(), 1, &maps[k]));
+            xyz[k] = c.reference->xyzPtr(); xs[k] = c.reference->xyzStride();
+            nrm[k] = c.reference->normalsPtr(); ns[k] = c.reference->normalsStride();
+            ms[k] = (int)c.reference->getNbPoints();
+        }
+        // every candidate's reference is indexed in one call (ICP::operator() builds it inside, LoopCloser.hpp:98)
+        PM::check(ctx, pgslam_amd::Abi<T>::map_create_batch(ctx, P, xyz.data(), xs.data(), nrm.data(), ns.data(), ms.data(), 1, maps.data()));
+        for (int k = 0; k < P; k++) {
+            const Candidate &c = queue_[mine[k]];
             pr[k].map_id = maps[k]; pr[k].reading = c.reading->xyzPtr(); pr[k].stride = c.reading->xyzStride();
             pr[k].n = (int)c.reading->getNbPoints(); pr[k].mem = PGICP_HOST;
             pgslam_amd::to_row_major16(c.T_init, pr[k].T_init);
@@ -292,7 +301,23 @@ public:
         const int rc = sizeof(T) == 4 ? pgicp_align_batch_f32(ctx, P, pr.data(), Tout.data(), st.data())
                                       : pgicp_align_batch_f64(ctx, P, pr.data(), Tout.data(), st.data());
         if (rc != PGICP_OK && rc != PGICP_ERR_NO_MATCH && rc != PGICP_ERR_NAN) PM::check(ctx, rc);
-        std::vector<pgicp_edge> edges(P);
+        // ComputeResidualError (LoopCloser.hpp:343-365) of every aligned pair, one device pass
+        std::vector<pgicp_problem> chk;
+        std::vector<int> chk_of;
+        for (int k = 0; k < P; k++)
+            if (st[k].status == PGICP_OK) {
+                pgicp_problem q = pr[k];
+                std::memcpy(q.T_init, Tout.data() + 16 * k, sizeof q.T_init);
+                chk.push_back(q); chk_of.push_back(k);
+            }
+        std::vector<double> residual(P, 1.0 / 0.0), res(chk.size());
+        std::vector<int> cst(chk.size());
+        if (!chk.empty()) {
+            const int prc = sizeof(T) == 4 ? pgicp_partial_chain_batch_f32(ctx, (int)chk.size(), chk.data(), nullptr, res.data(), cst.data())
+                                           : pgicp_partial_chain_batch_f64(ctx, (int)chk.size(), chk.data(), nullptr, res.data(), cst.data());
+            if (prc != PGICP_OK && prc != PGICP_ERR_NO_MATCH) PM::check(ctx, prc);
+            for (size_t i = 0; i < chk.size(); i++) if (cst[i] == PGICP_OK) residual[chk_of[i]] = res[i];
+        }
         for (int k = 0; k < P; k++) {
             const Candidate &c = queue_[mine[k]];
             pgicp_edge &e = edges[k];
@@ -301,14 +326,8 @@ public:
             e.max_iter_reached = st[k].max_iter_reached; e.overlap = st[k].overlap;
             std::memcpy(e.T_from_to, Tout.data() + 16 * k, sizeof e.T_from_to);
             std::memcpy(e.cov, st[k].cov, sizeof e.cov);
-            double ratio = 0, residual = 1.0 / 0.0;
-            if (st[k].status == PGICP_OK) {
-                const int prc = pgslam_amd::Abi<T>::partial(ctx, maps[k], c.reading->xyzPtr(), c.reading->xyzStride(), (int)c.reading->getNbPoints(),
-                                                            Tout.data() + 16 * k, &ratio, &residual);
-                if (prc != PGICP_OK) residual = 1.0 / 0.0;
-            }
-            e.residual = residual;
-            e.accepted = pgicp_check_icp_result(&st[k], residual, (double)overlap_threshold, (double)residual_threshold);
+            e.residual = residual[k];
+            e.accepted = pgicp_check_icp_result(&st[k], residual[k], (double)overlap_threshold, (double)residual_threshold);
             pgicp_map_destroy(ctx, maps[k]);
         }
         return edges;

@@ -53,6 +53,7 @@ template <> struct Abi<float> {
     static int match(pgicp_ctx *c, int id, const float *r, int s, int n, int32_t *ids, float *d2) { return pgicp_match_f32(c, id, r, s, n, PGICP_HOST, nullptr, ids, d2); }
     static int weights(pgicp_ctx *c, const float *d2, int n, float *w, float *lim, int *nf) { return pgicp_outlier_weights_f32(c, d2, n, PGICP_HOST, w, lim, nf); }
     static int stats(pgicp_ctx *c, int id, const float *r, int s, int n, const int32_t *ids, const float *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f32(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
+    static int map_create_batch(pgicp_ctx *c, int k, const float *const *x, const int *xs, const float *const *n, const int *ns, const int *m, int center, int *ids) { return pgicp_map_create_batch_f32(c, k, x, xs, n, ns, m, PGICP_HOST, center, ids); }
     static int partial(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const float *in, int is, float *out, int os, int n, int ro) { return pgicp_transform_f32(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
@@ -63,6 +64,7 @@ template <> struct Abi<double> {
     static int match(pgicp_ctx *c, int id, const double *r, int s, int n, int32_t *ids, double *d2) { return pgicp_match_f64(c, id, r, s, n, PGICP_HOST, nullptr, ids, d2); }
     static int weights(pgicp_ctx *c, const double *d2, int n, double *w, double *lim, int *nf) { return pgicp_outlier_weights_f64(c, d2, n, PGICP_HOST, w, lim, nf); }
     static int stats(pgicp_ctx *c, int id, const double *r, int s, int n, const int32_t *ids, const double *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f64(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
+    static int map_create_batch(pgicp_ctx *c, int k, const double *const *x, const int *xs, const double *const *n, const int *ns, const int *m, int center, int *ids) { return pgicp_map_create_batch_f64(c, k, x, xs, n, ns, m, PGICP_HOST, center, ids); }
     static int partial(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const double *in, int is, double *out, int os, int n, int ro) { return pgicp_transform_f64(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }

@@ -135,11 +135,13 @@ __global__ __launch_bounds__(256) void k_cell_count(const T *__restrict__ xyz, i
             z = xyz[(long long)i * stride + 2] - mz;
     const int c = build_cell(g, x, y, z);
     cell_of[i] = c;
-    atomicAdd(&counts[c], 1);
-    // occupancy of the 8x8x8 super-cell (used by the wave-cooperative slow path)
-    const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
-    const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3;
-    atomicAdd(&sc_count[(cx >> 3) + nsx * ((cy >> 3) + nsy * (cz >> 3))], 1);
+    // occupancy flag of the 8x8x8 super-cell (used by the wave-cooperative slow path): set by the first
+    // point of every fine cell with a plain store -- a contended atomic per point serialises on dense maps
+    if (atomicAdd(&counts[c], 1) == 0) {
+        const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+        const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3;
+        sc_count[(cx >> 3) + nsx * ((cy >> 3) + nsy * (cz >> 3))] = 1;
+    }
 }
 
 // three-phase exclusive scan over `n` ints (n up to 2^27)

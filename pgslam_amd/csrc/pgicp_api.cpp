@@ -48,6 +48,7 @@ struct MapHost {
     int *cell_start = nullptr;
     int *slot_of = nullptr;
     int *sc_count = nullptr;
+    char *block = nullptr;          // the one device allocation holding all of the above
     GridDesc<T> g{};
 };
 
@@ -75,7 +76,7 @@ struct pgicp_ctx {
     pgicp_params prm{};
     State<float> f32;
     State<double> f64;
-    DevBuf probs, src, partials, sums, small, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
+    DevBuf probs, src, partials, sums, small, stats, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
     DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     int fast_rings_seeded = 2, fast_rings_unseeded = 4;   // rings walked in the fast kernel before a query is queued
@@ -236,105 +237,151 @@ int sync_maps_table(pgicp_ctx *c)
 template <typename T>
 void free_map(MapHost<T> &m)
 {
-    if (m.pts) (void)hipFree(m.pts);
-    if (m.nrm) (void)hipFree(m.nrm);
-    if (m.cell_start) (void)hipFree(m.cell_start);
-    if (m.slot_of) (void)hipFree(m.slot_of);
-    if (m.sc_count) (void)hipFree(m.sc_count);
+    if (m.block) (void)hipFree(m.block);
     m = MapHost<T>();
+}
+
+// one reference cloud of a batched map creation
+template <typename T>
+struct MapSrc {
+    const T *xyz; int xyz_stride; const T *nrm; int nrm_stride; int m;
+};
+
+// Builds n maps with ONE host round trip: all centroid/bbox kernels first, one copy back of the
+// statistics, then every grid build back to back on the context stream.  Each map's arrays live in a
+// single device allocation.
+template <typename T>
+int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int center, int *map_ids)
+{
+    if (!c || n <= 0 || !src || !map_ids) return fail(c, PGICP_ERR_ARG, "pgicp_map_create: bad argument");
+    for (int k = 0; k < n; k++)
+        if (!src[k].xyz || src[k].m <= 0 || src[k].xyz_stride < 3 || (src[k].nrm && src[k].nrm_stride < 3))
+            return fail(c, PGICP_ERR_ARG, "pgicp_map_create: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    State<T> &S = state<T>(c);
+    using V4 = typename Vec4<T>::type;
+    // ---- phase 1: inputs on the device, centroid + bbox of every cloud ----
+    std::vector<const T *> d_xyz(n), d_nrm(n, nullptr);
+    if (mem == PGICP_HOST) {
+        size_t tot = 0;
+        for (int k = 0; k < n; k++)
+            tot += staged_bytes(sizeof(T), src[k].xyz_stride, src[k].m) + (src[k].nrm ? staged_bytes(sizeof(T), src[k].nrm_stride, src[k].m) : 0);
+        HIPC(c, S.staging.ensure(tot));
+    }
+    size_t soff = 0;
+    for (int k = 0; k < n; k++) {
+        int st = to_device<T>(c, src[k].xyz, src[k].xyz_stride, src[k].m, mem, S.staging, soff, &d_xyz[k]);
+        if (st) return st;
+        if (mem == PGICP_HOST) soff += staged_bytes(sizeof(T), src[k].xyz_stride, src[k].m);
+        if (src[k].nrm) {
+            st = to_device<T>(c, src[k].nrm, src[k].nrm_stride, src[k].m, mem, S.staging, soff, &d_nrm[k]);
+            if (st) return st;
+            if (mem == PGICP_HOST) soff += staged_bytes(sizeof(T), src[k].nrm_stride, src[k].m);
+        }
+    }
+    std::vector<unsigned long long> h_stats((size_t)9 * n);
+    for (int k = 0; k < n; k++) {
+        unsigned long long *s = h_stats.data() + 9 * k;
+        s[0] = s[1] = s[2] = 0; s[3] = s[4] = s[5] = ~0ULL; s[6] = s[7] = s[8] = 0;
+    }
+    HIPC(c, c->stats.ensure(sizeof(unsigned long long) * 9 * (size_t)n));
+    HIPC(c, hipMemcpyAsync(c->stats.p, h_stats.data(), sizeof(unsigned long long) * 9 * n, hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < n; k++) {
+        ProfScope ps(c, PGICP_PROF_GRID_BUILD, src[k].m);
+        launch_centroid_bbox<T>(c->stream, d_xyz[k], src[k].xyz_stride, src[k].m, c->stats.as<unsigned long long>() + 9 * k);
+    }
+    HIPC(c, hipMemcpyAsync(h_stats.data(), c->stats.p, sizeof(unsigned long long) * 9 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+
+    // ---- phase 2: grids ----
+    std::vector<MapHost<T>> Ms(n);
+    size_t max_m = 0, max_cells = 0;
+    for (int k = 0; k < n; k++) {
+        MapHost<T> &M = Ms[k];
+        const int m = src[k].m;
+        const unsigned long long *st = h_stats.data() + 9 * k;
+        M.used = true; M.m = m; M.has_nrm = src[k].nrm != nullptr;
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+            const double mean_d = ((double)(long long)st[a] / 16777216.0) / (double)m;
+            M.mean[a] = center ? (T)mean_d : (T)0;
+            // rounding is monotone: min/max of fl(x - mean) are fl(min - mean), fl(max - mean)
+            lo[a] = (double)((T)key_to_double(st[3 + a]) - M.mean[a]);
+            hi[a] = (double)((T)key_to_double(st[6 + a]) - M.mean[a]);
+            if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a]))
+                return fail(c, PGICP_ERR_ARG, "pgicp_map_create: non-finite coordinates");
+        }
+        const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        double h = c->prm.grid_cell;
+        if (!(h > 0)) {
+            // Range-scan clouds sit on surfaces (and, ring by ring, on curves): cells sized for ~2
+            // points per cell of the projected bounding-box area end up holding ~15-20 points where
+            // the data actually is (measured on the Velodyne-shaped benchmark map).
+            const double area = ex * ey + ey * ez + ex * ez;
+            h = std::sqrt(2.0 * std::max(area, 1e-12) / (double)m);
+            const double diag = std::sqrt(ex * ex + ey * ey + ez * ez);
+            if (!(h > diag * 1e-4)) h = std::max(diag * 1e-4, 1e-6);
+        }
+        for (;;) {   // bound the dense cell table
+            const double nx = std::floor(ex / h) + 1, ny = std::floor(ey / h) + 1, nz = std::floor(ez / h) + 1;
+            if (nx <= 65535 && ny <= 65535 && nz <= 65535 && nx * ny * nz <= 67108864.0) break;
+            h *= 1.26;
+        }
+        GridDesc<T> &g = M.g;
+        g.h = (T)h; g.inv_h = (T)1 / g.h; g.margin = (T)0.02 * g.h;
+        g.ox = (T)lo[0]; g.oy = (T)lo[1]; g.oz = (T)lo[2];
+        g.nx = (int)std::floor(ex / (double)g.h) + 1; g.ny = (int)std::floor(ey / (double)g.h) + 1;
+        g.nz = (int)std::floor(ez / (double)g.h) + 1;
+        max_m = std::max(max_m, (size_t)m);
+        max_cells = std::max(max_cells, (size_t)g.nx * g.ny * g.nz);
+    }
+    // scratch sized for the largest map BEFORE any build is queued (a later grow would free buffers in use)
+    HIPC(c, c->tmp_a.ensure(sizeof(int) * max_m));                                  // cell_of
+    HIPC(c, c->tmp_b.ensure(sizeof(int) * max_cells));                              // counts
+    HIPC(c, c->tmp_c.ensure(sizeof(int) * (max_cells / kScanChunkHost + 2)));       // block sums
+    HIPC(c, c->tmp_d.ensure(sizeof(int) * max_cells));                              // cursor
+    HIPC(c, c->tmp_e.ensure(sizeof(int) * max_m));                                  // order_tmp
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    for (int k = 0; k < n; k++) {
+        MapHost<T> &M = Ms[k];
+        const GridDesc<T> &g = M.g;
+        const int m = M.m;
+        const size_t ncells = (size_t)g.nx * g.ny * g.nz;
+        const size_t nsc = (size_t)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
+        const size_t b_pts = up(sizeof(V4) * (size_t)m), b_nrm = M.has_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (ncells + 1)),
+                     b_slot = up(sizeof(int) * (size_t)m), b_sc = up(sizeof(int) * nsc);
+        char *base = nullptr;
+        HIPC(c, hipMalloc((void **)&base, b_pts + b_nrm + b_cs + b_slot + b_sc));
+        M.block = base;
+        M.pts = (V4 *)base;
+        M.nrm = M.has_nrm ? (V4 *)(base + b_pts) : nullptr;
+        M.cell_start = (int *)(base + b_pts + b_nrm);
+        M.slot_of = (int *)(base + b_pts + b_nrm + b_cs);
+        M.sc_count = (int *)(base + b_pts + b_nrm + b_cs + b_slot);
+        ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
+        launch_grid_build<T>(c->stream, d_xyz[k], src[k].xyz_stride, d_nrm[k], src[k].nrm_stride, m, M.mean, g, c->tmp_a.as<int>(),
+                             c->tmp_b.as<int>(), c->tmp_c.as<int>(), M.cell_start, c->tmp_d.as<int>(), c->tmp_e.as<int>(), M.pts, M.nrm,
+                             M.slot_of, M.sc_count);
+    }
+    HIPC(c, hipGetLastError());
+    // ---- phase 3: register ----
+    for (int k = 0; k < n; k++) {
+        int id = -1;
+        for (size_t i = 0; i < S.maps.size(); i++) if (!S.maps[i].used) { id = (int)i; break; }
+        if (id < 0) { S.maps.push_back(MapHost<T>()); id = (int)S.maps.size() - 1; }
+        S.maps[id] = Ms[k];
+        map_ids[k] = id | id_tag<T>();
+    }
+    return sync_maps_table<T>(c);
 }
 
 template <typename T>
 int map_create(pgicp_ctx *c, const T *xyz, int xyz_stride, const T *nrm, int nrm_stride, int m, int mem, int center,
                int *map_id)
 {
-    if (!c || !xyz || m <= 0 || xyz_stride < 3 || (nrm && nrm_stride < 3) || !map_id)
-        return fail(c, PGICP_ERR_ARG, "pgicp_map_create: bad argument");
-    HIPC(c, hipSetDevice(c->device));
-    State<T> &S = state<T>(c);
-    const T *d_xyz = nullptr, *d_nrm = nullptr;
-    const size_t b_xyz = staged_bytes(sizeof(T), xyz_stride, m), b_nrm = nrm ? staged_bytes(sizeof(T), nrm_stride, m) : 0;
-    if (mem == PGICP_HOST) HIPC(c, S.staging.ensure(b_xyz + b_nrm));
-    int st = to_device<T>(c, xyz, xyz_stride, m, mem, S.staging, 0, &d_xyz);
-    if (st) return st;
-    if (nrm) { st = to_device<T>(c, nrm, nrm_stride, m, mem, S.staging, b_xyz, &d_nrm); if (st) return st; }
-
-    // centroid + bbox
-    HIPC(c, c->small.ensure(256));
-    unsigned long long h_stats[9] = {0, 0, 0, ~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
-    HIPC(c, hipMemcpyAsync(c->small.p, h_stats, sizeof h_stats, hipMemcpyHostToDevice, c->stream));
-    {
-        ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
-        launch_centroid_bbox<T>(c->stream, d_xyz, xyz_stride, m, c->small.as<unsigned long long>());
-    }
-    HIPC(c, hipMemcpyAsync(h_stats, c->small.p, sizeof h_stats, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-
-    MapHost<T> M;
-    M.used = true; M.m = m; M.has_nrm = nrm != nullptr;
-    double lo[3], hi[3];
-    for (int a = 0; a < 3; a++) {
-        const double mean_d = ((double)(long long)h_stats[a] / 16777216.0) / (double)m;
-        M.mean[a] = center ? (T)mean_d : (T)0;
-        // rounding is monotone: min/max of fl(x - mean) are fl(min - mean), fl(max - mean)
-        lo[a] = (double)((T)key_to_double(h_stats[3 + a]) - M.mean[a]);
-        hi[a] = (double)((T)key_to_double(h_stats[6 + a]) - M.mean[a]);
-        if (!(lo[a] <= hi[a]) || !std::isfinite(lo[a]) || !std::isfinite(hi[a]))
-            return fail(c, PGICP_ERR_ARG, "pgicp_map_create: non-finite coordinates");
-    }
-    const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-    double h = c->prm.grid_cell;
-    if (!(h > 0)) {
-        // Range-scan clouds sit on surfaces (and, ring by ring, on curves): cells sized for ~2
-        // points per cell of the projected bounding-box area end up holding ~15-20 points where
-        // the data actually is (measured on the Velodyne-shaped benchmark map).
-        const double area = ex * ey + ey * ez + ex * ez;
-        h = std::sqrt(2.0 * std::max(area, 1e-12) / (double)m);
-        const double diag = std::sqrt(ex * ex + ey * ey + ez * ez);
-        if (!(h > diag * 1e-4)) h = std::max(diag * 1e-4, 1e-6);
-    }
-    for (;;) {   // bound the dense cell table
-        const double nx = std::floor(ex / h) + 1, ny = std::floor(ey / h) + 1, nz = std::floor(ez / h) + 1;
-        if (nx <= 65535 && ny <= 65535 && nz <= 65535 && nx * ny * nz <= 67108864.0) break;
-        h *= 1.26;
-    }
-    GridDesc<T> &g = M.g;
-    g.h = (T)h; g.inv_h = (T)1 / g.h; g.margin = (T)0.02 * g.h;
-    g.ox = (T)lo[0]; g.oy = (T)lo[1]; g.oz = (T)lo[2];
-    g.nx = (int)std::floor(ex / (double)g.h) + 1; g.ny = (int)std::floor(ey / (double)g.h) + 1;
-    g.nz = (int)std::floor(ez / (double)g.h) + 1;
-    const long long ncells = (long long)g.nx * g.ny * g.nz;
-
-    using V4 = typename Vec4<T>::type;
-    HIPC(c, hipMalloc((void **)&M.pts, sizeof(V4) * (size_t)m));
-    if (nrm) HIPC(c, hipMalloc((void **)&M.nrm, sizeof(V4) * (size_t)m));
-    HIPC(c, hipMalloc((void **)&M.cell_start, sizeof(int) * (size_t)(ncells + 1)));
-    HIPC(c, hipMalloc((void **)&M.slot_of, sizeof(int) * (size_t)m));
-    {
-        const size_t nsc = (size_t)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
-        HIPC(c, hipMalloc((void **)&M.sc_count, sizeof(int) * nsc));
-    }
-    const int nb = (int)((ncells + kScanChunkHost - 1) / kScanChunkHost);
-    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)m));             // cell_of
-    HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)ncells));        // counts
-    HIPC(c, c->tmp_c.ensure(sizeof(int) * (size_t)(nb + 1)));      // block sums
-    HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)ncells));        // cursor
-    HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)m));             // order_tmp
-    {
-        ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
-        launch_grid_build<T>(c->stream, d_xyz, xyz_stride, d_nrm, nrm_stride, m, M.mean, g, c->tmp_a.as<int>(),
-                             c->tmp_b.as<int>(), c->tmp_c.as<int>(), M.cell_start, c->tmp_d.as<int>(), c->tmp_e.as<int>(), M.pts, M.nrm,
-                             M.slot_of, M.sc_count);
-    }
-    HIPC(c, hipGetLastError());
-    int id = -1;
-    for (size_t i = 0; i < S.maps.size(); i++) if (!S.maps[i].used) { id = (int)i; break; }
-    if (id < 0) { S.maps.push_back(MapHost<T>()); id = (int)S.maps.size() - 1; }
-    S.maps[id] = M;
-    st = sync_maps_table<T>(c);
-    if (st) return st;
-    *map_id = id | id_tag<T>();
-    return PGICP_OK;
+    if (!map_id) return fail(c, PGICP_ERR_ARG, "pgicp_map_create: bad argument");
+    MapSrc<T> s{xyz, xyz_stride, nrm, nrm_stride, m};
+    return map_create_batch<T>(c, 1, &s, mem, center, map_id);
 }
 
 void translation(const double *t3, double sign, double *T)
@@ -595,7 +642,7 @@ int icp_pair(pgicp_ctx *c, const T *reading, int rd_stride, int n, const T *ref_
 
 // matcher-only / partial chain on one problem
 template <typename T>
-int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem, const double *Tmove, bool do_trim,
+int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem, const double *Tmove,
                 BatchLayout &L, std::vector<ProblemDev> &hp)
 {
     MapHost<T> *M = get_map<T>(c, map_id);
@@ -626,19 +673,6 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
                                c->slow2.as<int>(), 1);
     }
-    if (do_trim) {
-        if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
-        {
-            ProfScope ps(c, PGICP_PROF_TRIM, n);
-            launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, 1, 0, c->active.as<int>());
-        }
-        {
-            ProfScope ps(c, PGICP_PROF_REDUCE, n);
-            launch_reduce<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
-                             S.d2.template as<T>(), c->partials.as<double>(), 1, n, c->active.as<int>());
-        }
-        launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(n), kSys, probs, 0, c->sums.as<double>(), 1);
-    }
     return PGICP_OK;
 }
 
@@ -649,7 +683,7 @@ int match(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem
     HIPC(c, hipSetDevice(c->device));
     BatchLayout L;
     std::vector<ProblemDev> hp;
-    int st = run_partial<T>(c, map_id, reading, stride, n, mem, Tm, false, L, hp);
+    int st = run_partial<T>(c, map_id, reading, stride, n, mem, Tm, L, hp);
     if (st) return st;
     State<T> &S = state<T>(c);
     HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)n));
@@ -664,26 +698,60 @@ int match(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem
     return PGICP_OK;
 }
 
+// transform -> match -> trimmed outlier filter -> error elements for P (map, reading, T) problems in
+// one device pass; the same lazily-exact matcher pipeline one ICP iteration uses, without the solve.
+template <typename T>
+int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ratio, double *residual, int *status)
+{
+    if (!c || P <= 0 || !pr) return fail(c, PGICP_ERR_ARG, "pgicp_partial_chain: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    for (int p = 0; p < P; p++) {
+        MapHost<T> *M = get_map<T>(c, pr[p].map_id);
+        if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_partial_chain: unknown map id");
+        if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
+    }
+    BatchLayout L;
+    std::vector<ProblemDev> hp;
+    int st = batch_begin<T>(c, P, pr, [&](int p, double *Tpre) {
+        MapHost<T> *M = get_map<T>(c, pr[p].map_id);
+        double mean[3] = {(double)M->mean[0], (double)M->mean[1], (double)M->mean[2]};
+        double Tm_inv[16];
+        translation(mean, -1.0, Tm_inv);
+        mat4_mul(Tm_inv, pr[p].T_init, Tpre);
+    }, L, hp);
+    if (st) return st;
+    const ChainDev<T> ch = make_chain<T>(c->prm);
+    one_iteration<T>(c, L, ch, false, L.total, P, 0);
+    launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(L.max_n), kSys, c->probs.as<ProblemDev>(), 0,
+                        c->sums.as<double>(), P);
+    std::vector<double> sys((size_t)P * kSys);
+    HIPC(c, hipMemcpyAsync(sys.data(), c->sums.p, sizeof(double) * sys.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(hp.data(), c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    int worst = PGICP_OK;
+    for (int p = 0; p < P; p++) {
+        const double *s = sys.data() + (size_t)p * kSys;
+        const bool ok = hp[p].n_finite != 0 && s[28] > 0.0;
+        if (status) status[p] = ok ? PGICP_OK : PGICP_ERR_NO_MATCH;
+        if (!ok) worst = PGICP_ERR_NO_MATCH;
+        if (ratio) ratio[p] = ok ? s[27] / (double)pr[p].n : 0.0;
+        if (residual) residual[p] = ok ? s[29] : 0.0;
+    }
+    if (worst != PGICP_OK) return fail(c, worst, "no point to minimize (ConvergenceError)");
+    return PGICP_OK;
+}
+
 template <typename T>
 int partial_chain(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem, const double *Tm, double *ratio,
                   double *residual)
 {
     if (!c || !reading || n <= 0) return fail(c, PGICP_ERR_ARG, "pgicp_partial_chain: bad argument");
-    HIPC(c, hipSetDevice(c->device));
-    BatchLayout L;
-    std::vector<ProblemDev> hp;
-    int st = run_partial<T>(c, map_id, reading, stride, n, mem, Tm, true, L, hp);
-    if (st) return st;
-    double sys[kSys];
-    ProblemDev D;
-    HIPC(c, hipMemcpyAsync(sys, c->sums.p, sizeof sys, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(&D, c->probs.p, sizeof D, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    HIPC(c, hipGetLastError());
-    if (D.n_finite == 0 || !(sys[28] > 0.0)) return fail(c, PGICP_ERR_NO_MATCH, "no point to minimize (ConvergenceError)");
-    if (ratio) *ratio = sys[27] / (double)n;
-    if (residual) *residual = sys[29];
-    return PGICP_OK;
+    pgicp_problem pr;
+    pr.map_id = map_id; pr.reading = reading; pr.stride = stride; pr.n = n; pr.mem = mem;
+    mat4_identity(pr.T_init);
+    if (Tm) std::memcpy(pr.T_init, Tm, sizeof pr.T_init);
+    return partial_chain_batch<T>(c, 1, &pr, ratio, residual, nullptr);
 }
 
 template <typename T>
@@ -863,6 +931,15 @@ int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const 
 // ---------------------------------------------------------------------------
 // extern "C" surface
 // ---------------------------------------------------------------------------
+template <typename T>
+int map_create_batch_abi(pgicp_ctx *c, int n, const T *const *xyz, const int *xs, const T *const *nrm, const int *ns,
+                                const int *m, int mem, int center, int *ids)
+{
+    if (!c || n <= 0 || !xyz || !xs || !m || !ids || (nrm && !ns)) return fail(c, PGICP_ERR_ARG, "pgicp_map_create_batch: bad argument");
+    std::vector<MapSrc<T>> src(n);
+    for (int k = 0; k < n; k++) src[k] = MapSrc<T>{xyz[k], xs[k], nrm ? nrm[k] : nullptr, nrm ? ns[k] : 0, m[k]};
+    return map_create_batch<T>(c, n, src.data(), mem, center, ids);
+}
 extern "C" {
 
 int pgicp_abi_version(void) { return PGICP_ABI_VERSION; }
@@ -923,7 +1000,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     for (auto &m : c->f64.maps) free_map(m);
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
-                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
+                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
                       &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active})
         b->release();
@@ -970,6 +1047,13 @@ int pgicp_map_create_f32(pgicp_ctx *c, const float *xyz, int xs, const float *nr
 { return map_create<float>(c, xyz, xs, nrm, ns, m, mem, center, id); }
 int pgicp_map_create_f64(pgicp_ctx *c, const double *xyz, int xs, const double *nrm, int ns, int m, int mem, int center, int *id)
 { return map_create<double>(c, xyz, xs, nrm, ns, m, mem, center, id); }
+
+int pgicp_map_create_batch_f32(pgicp_ctx *c, int n, const float *const *xyz, const int *xs, const float *const *nrm,
+                               const int *ns, const int *m, int mem, int center, int *ids)
+{ return map_create_batch_abi<float>(c, n, xyz, xs, nrm, ns, m, mem, center, ids); }
+int pgicp_map_create_batch_f64(pgicp_ctx *c, int n, const double *const *xyz, const int *xs, const double *const *nrm,
+                               const int *ns, const int *m, int mem, int center, int *ids)
+{ return map_create_batch_abi<double>(c, n, xyz, xs, nrm, ns, m, mem, center, ids); }
 
 int pgicp_map_destroy(pgicp_ctx *c, int id)
 {
@@ -1047,6 +1131,11 @@ int pgicp_partial_chain_f32(pgicp_ctx *c, int map_id, const float *rd, int strid
 int pgicp_partial_chain_f64(pgicp_ctx *c, int map_id, const double *rd, int stride, int n, int mem, const double *T,
                             double *ratio, double *residual)
 { return partial_chain<double>(c, map_id, rd, stride, n, mem, T, ratio, residual); }
+
+int pgicp_partial_chain_batch_f32(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ratio, double *residual, int *status)
+{ return partial_chain_batch<float>(c, P, pr, ratio, residual, status); }
+int pgicp_partial_chain_batch_f64(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ratio, double *residual, int *status)
+{ return partial_chain_batch<double>(c, P, pr, ratio, residual, status); }
 
 int pgicp_transform_f32(pgicp_ctx *c, const double T[16], const float *in, int is, float *out, int os, int n, int ro, int mem)
 { return transform<float>(c, T, in, is, out, os, n, ro, mem); }

@@ -34,11 +34,13 @@ PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_u
 ABI_SYMBOLS = [
     "pgicp_abi_version", "pgicp_device_count", "pgicp_ctx_create", "pgicp_ctx_destroy", "pgicp_last_error",
     "pgicp_ctx_stream", "pgicp_ctx_synchronize", "pgicp_default_params", "pgicp_set_params", "pgicp_get_params",
-    "pgicp_map_create_f32", "pgicp_map_create_f64", "pgicp_map_destroy", "pgicp_map_size",
+    "pgicp_map_create_f32", "pgicp_map_create_f64", "pgicp_map_create_batch_f32", "pgicp_map_create_batch_f64",
+    "pgicp_map_destroy", "pgicp_map_size",
     "pgicp_align_f32", "pgicp_align_f64", "pgicp_align_batch_f32", "pgicp_align_batch_f64",
     "pgicp_icp_pair_f32", "pgicp_icp_pair_f64", "pgicp_match_f32", "pgicp_match_f64",
     "pgicp_outlier_weights_f32", "pgicp_outlier_weights_f64", "pgicp_error_stats_f32", "pgicp_error_stats_f64",
-    "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_transform_f32", "pgicp_transform_f64",
+    "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_partial_chain_batch_f32",
+    "pgicp_partial_chain_batch_f64", "pgicp_transform_f32", "pgicp_transform_f64",
     "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
     "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters",
 ]
@@ -205,6 +207,23 @@ class Context:
                        C.c_int(nb.stride if nb else 0), C.c_int(x.n), C.c_int(x.mem), C.c_int(int(center)), C.byref(mid)))
         return mid.value
 
+    def set_maps(self, xyzs, normals=None, center=True, dtype=None):
+        """Index several reference clouds with one host round trip (pgicp_map_create_batch)."""
+        n = len(xyzs)
+        xb = [_Buf(x, dtype) for x in xyzs]
+        nb = [_Buf(v, xb[0].dtype) for v in normals] if normals is not None else None
+        assert all(b.mem == xb[0].mem and b.dtype == xb[0].dtype for b in xb)
+        assert nb is None or all(b.n == x.n and b.mem == x.mem for b, x in zip(nb, xb))
+        ptrs = (C.c_void_p * n)(*[b.ptr for b in xb])
+        strides = (C.c_int * n)(*[b.stride for b in xb])
+        sizes = (C.c_int * n)(*[b.n for b in xb])
+        nptrs = (C.c_void_p * n)(*[b.ptr for b in nb]) if nb else None
+        nstrides = (C.c_int * n)(*[b.stride for b in nb]) if nb else None
+        ids = (C.c_int * n)()
+        fn = getattr(self.lib, "pgicp_map_create_batch" + self._sfx(xb[0].dtype))
+        self._check(fn(self.h, C.c_int(n), ptrs, strides, nptrs, nstrides, sizes, C.c_int(xb[0].mem), C.c_int(int(center)), ids))
+        return list(ids)
+
     def destroy_map(self, map_id):
         self._check(self.lib.pgicp_map_destroy(self.h, C.c_int(map_id)))
 
@@ -307,6 +326,25 @@ class Context:
         self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem),
                        _T16(T) if T is not None else None, C.byref(ratio), C.byref(resid)))
         return ratio.value, resid.value
+
+    def partial_chain_batch(self, map_ids, readings, Ts, dtype=None, raise_on_error=True):
+        """(weightedPointUsedRatio, residual, status) arrays of a batch of (map, reading, T) in one device pass."""
+        P = len(readings)
+        bufs = [_Buf(r, dtype) for r in readings]
+        probs = (Problem * P)()
+        for p in range(P):
+            probs[p].map_id = map_ids[p]
+            probs[p].reading = bufs[p].ptr
+            probs[p].stride = bufs[p].stride
+            probs[p].n = bufs[p].n
+            probs[p].mem = bufs[p].mem
+            probs[p].T_init = _T16(Ts[p])
+        ratio, resid, status = (C.c_double * P)(), (C.c_double * P)(), (C.c_int * P)()
+        fn = getattr(self.lib, "pgicp_partial_chain_batch" + self._sfx(bufs[0].dtype))
+        rc = fn(self.h, C.c_int(P), probs, ratio, resid, status)
+        if raise_on_error or rc not in (OK, ERR_NO_MATCH):
+            self._check(rc)
+        return np.array(ratio[:]), np.array(resid[:]), np.array(status[:])
 
     def transform(self, T, pts, rotate_only=False, dtype=None):
         r = _Buf(pts, dtype)

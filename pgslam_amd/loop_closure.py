@@ -73,17 +73,18 @@ def align_local(ctx: icp.Context, cands, cfg: LoopClosureConfig):
         ctx.set_params(**cfg.chain)
     if not cands:
         return np.zeros(0, dtype=EDGE_DTYPE)
-    map_ids = [ctx.set_map(c.ref_xyz, c.ref_nrm, center=True) for c in cands]
-    Ts, stats = ctx.align_batch(map_ids, [c.reading for c in cands], [c.T_init for c in cands], raise_on_error=False)
+    map_ids = ctx.set_maps([c.ref_xyz for c in cands], [c.ref_nrm for c in cands], center=True)
+    readings = [c.reading for c in cands]
+    Ts, stats = ctx.align_batch(map_ids, readings, [c.T_init for c in cands], raise_on_error=False)
+    ok = [k for k in range(len(cands)) if stats[k]["status"] == 0]
+    residual = np.full(len(cands), np.inf)
+    if ok:
+        _, res, st = ctx.partial_chain_batch([map_ids[k] for k in ok], [readings[k] for k in ok], [Ts[k] for k in ok],
+                                             raise_on_error=False)
+        residual[ok] = np.where(st == 0, res, np.inf)
     edges = np.zeros(len(cands), dtype=EDGE_DTYPE)
     for k, c in enumerate(cands):
-        residual = float("inf")
-        if stats[k]["status"] == 0:
-            try:
-                _, residual = ctx.partial_chain(map_ids[k], c.reading, T=Ts[k])
-            except icp.ConvergenceError:
-                residual = float("inf")
-        edges[k] = make_edge(c.from_id, c.to_id, Ts[k], stats[k], residual, cfg)
+        edges[k] = make_edge(c.from_id, c.to_id, Ts[k], stats[k], float(residual[k]), cfg)
     for m in map_ids:
         ctx.destroy_map(m)
     return edges

@@ -353,3 +353,24 @@ def test_loop_closure_batch_against_oracle(ctx, oracle32):
         assert bool(edges[k]["accepted"]) == expect
         np.testing.assert_allclose(edges[k]["cov"].reshape(6, 6), o["cov"], rtol=1e-5, atol=1e-14)
     assert len(lc.accepted_constraints(edges)) == int(edges["accepted"].sum())
+
+
+def test_batch_entry_points_equal_single_calls(ctx):
+    """pgicp_map_create_batch / pgicp_partial_chain_batch give bit-identical results to the per-object calls."""
+    ps = synth.make_pairs(4, n_pts=4000, n_keyframes=5, rings=16)
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    ids_b = ctx.set_maps([ps.ref_xyz[k] for k in range(4)], [ps.ref_nrm[k] for k in range(4)], center=True)
+    ids_s = [ctx.set_map(ps.ref_xyz[k], ps.ref_nrm[k], center=True) for k in range(4)]
+    assert len(set(ids_b + ids_s)) == 8
+    Ts = [ps.T_true[k] if hasattr(ps, "T_true") else ps.T_init[k] for k in range(4)]
+    rb, eb, sb = ctx.partial_chain_batch(ids_b, [ps.reading_xyz[k] for k in range(4)], Ts)
+    assert np.all(sb == 0)
+    for k in range(4):
+        r1, e1 = ctx.partial_chain(ids_s[k], ps.reading_xyz[k], T=Ts[k])
+        assert r1 == rb[k] and e1 == eb[k]
+        ia, da = ctx.match(ids_b[k], ps.reading_xyz[k], T=Ts[k])
+        i1, d1 = ctx.match(ids_s[k], ps.reading_xyz[k], T=Ts[k])
+        np.testing.assert_array_equal(ia, i1)
+        np.testing.assert_array_equal(da, d1)
+    for m in ids_b + ids_s:
+        ctx.destroy_map(m)
