@@ -319,36 +319,60 @@ __device__ __forceinline__ int clamp_cell(T u, T inv_h, int n)
     return min(max((int)fmin(fmax(floor(u * inv_h), -lim), lim), 0), n - 1);
 }
 
+// Readings arrive in scan order, so the lanes of a wave fall into a handful of bins: the lanes of
+// each distinct bin are counted with ONE atomic (up to 8 leader rounds, then plain per-lane atomics
+// for incoherent input).  The value the atomic returns is the point's arrival position inside its
+// bin, so the scatter pass needs no second round of atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void k_qbin(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                const T *__restrict__ rd_pre, int max_bins, int *__restrict__ qbin,
-                                               int *__restrict__ counts)
+                                               int *__restrict__ counts, int *__restrict__ qpos)
 {
     const ProblemDev &P = probs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    const GridDesc<T> g = maps[P.map].g;
-    const T *q = rd_pre + 3 * (P.off + i);
-    const int cx = clamp_cell<T>(q[0] - g.ox, g.inv_h, g.nx), cy = clamp_cell<T>(q[1] - g.oy, g.inv_h, g.ny),
-              cz = clamp_cell<T>(q[2] - g.oz, g.inv_h, g.nz);
-    const int nbx = (g.nx + 3) >> 2, nby = (g.ny + 3) >> 2;
-    int bin = (cx >> 2) + nbx * ((cy >> 2) + nby * (cz >> 2));
-    if (bin >= max_bins) bin = max_bins - 1;
-    const int local = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
-    qbin[P.off + i] = (bin << 6) | local;                  // bin < 2^25 (<= 2^26 cells / 64 + slack)
-    atomicAdd(&counts[(long long)blockIdx.y * max_bins + bin], 1);
+    const bool live = i < P.n;
+    int bin = -1;
+    if (live) {
+        const GridDesc<T> g = maps[P.map].g;
+        const T *q = rd_pre + 3 * (P.off + i);
+        const int cx = clamp_cell<T>(q[0] - g.ox, g.inv_h, g.nx), cy = clamp_cell<T>(q[1] - g.oy, g.inv_h, g.ny),
+                  cz = clamp_cell<T>(q[2] - g.oz, g.inv_h, g.nz);
+        const int nbx = (g.nx + 3) >> 2, nby = (g.ny + 3) >> 2;
+        bin = (cx >> 2) + nbx * ((cy >> 2) + nby * (cz >> 2));
+        if (bin >= max_bins) bin = max_bins - 1;
+        const int local = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
+        qbin[P.off + i] = (bin << 6) | local;              // bin < 2^25 (<= 2^26 cells / 64 + slack)
+    }
+    int *cnt = counts + (long long)blockIdx.y * max_bins;
+    const int lane = threadIdx.x & 63;
+    int pos = 0;
+    bool todo = live;
+    for (int round = 0; round < 8; ++round) {
+        const unsigned long long pending = __ballot(todo);
+        if (pending == 0ULL) break;
+        const int leader = __ffsll((long long)pending) - 1;
+        const int lbin = __shfl(bin, leader, 64);
+        const bool mine = todo && bin == lbin;
+        const unsigned long long grp = __ballot(mine);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&cnt[lbin], __popcll(grp));
+        base = __shfl(base, leader, 64);
+        if (mine) { pos = base + __popcll(grp & ((1ULL << lane) - 1ULL)); todo = false; }
+    }
+    if (todo) pos = atomicAdd(&cnt[bin], 1);
+    if (live) qpos[P.off + i] = pos;
 }
 
 __global__ __launch_bounds__(256) void k_qscatter(const ProblemDev *__restrict__ probs, int max_bins,
-                                                   const int *__restrict__ qbin, int *__restrict__ cursor,
-                                                   unsigned long long *__restrict__ qtmp)
+                                                   const int *__restrict__ qbin, const int *__restrict__ qstart,
+                                                   const int *__restrict__ qpos, unsigned long long *__restrict__ qtmp)
 {
     const ProblemDev &P = probs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     const int key = qbin[P.off + i];
     // (cell-in-block key, index) packed: the rank kernel compares these words straight from the bin segment
-    qtmp[atomicAdd(&cursor[(long long)blockIdx.y * max_bins + (key >> 6)], 1)] =
+    qtmp[qstart[(long long)blockIdx.y * max_bins + (key >> 6)] + qpos[P.off + i]] =
         ((unsigned long long)(unsigned int)(key & 63) << 32) | (unsigned int)i;
 }
 
@@ -409,7 +433,7 @@ struct Best {
 };
 
 #ifdef PGICP_KNN_STATS
-__device__ unsigned long long g_knn_stats[16];
+__device__ unsigned long long g_knn_stats[48];   // [16..31] histogram of own-row, [32..47] of flat-walk candidates per lane (log2 bins)
 #define KNN_STAT_WAVE_ADD(slot_, v_)                                                              \
     do {                                                                                          \
         long long s_ = (v_);                                                                      \
@@ -806,6 +830,11 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
 #ifdef PGICP_KNN_STATS
     KNN_STAT_WAVE_MAX(3, flat_iters);
     KNN_STAT_WAVE_ADD(4, best.cnt - cnt_a1);
+    if (live) {
+        atomicAdd(&g_knn_stats[16 + (cnt_a1 <= 0 ? 0 : min(15, 32 - __clz(cnt_a1)))], 1ULL);
+        const int c2 = best.cnt - cnt_a1;
+        atomicAdd(&g_knn_stats[32 + (c2 <= 0 ? 0 : min(15, 32 - __clz(c2)))], 1ULL);
+    }
     const int cnt_a = best.cnt;
 #endif
     if (!live) return;
@@ -822,6 +851,8 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
     atomicAdd(&g_knn_stats[5], (unsigned long long)(best.cnt - cnt_a));
     atomicAdd(&g_knn_stats[6], (unsigned long long)(resolved ? 0 : 1));
     atomicAdd(&g_knn_stats[7], (unsigned long long)(best.cnt > cnt_a ? 1 : 0));
+    KNN_STAT_WAVE_MAX(8, best.cnt - cnt_a);
+    KNN_STAT_WAVE_MAX(9, best.cnt);
 #endif
     T lb_override = (T)-1;
     if (capped && best.slot < 0) {
@@ -1429,11 +1460,11 @@ __global__ __launch_bounds__(1024) void k_compact_active(const ProblemDev *__res
     (void)n_live_total;
 }
 
-int knn_stats_read(unsigned long long out[16], int reset)
+int knn_stats_read(unsigned long long out[48], int reset)
 {
 #ifdef PGICP_KNN_STATS
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof z); }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), 48 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[48] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof z); }
     return 0;
 #else
     (void)out; (void)reset;
@@ -1562,13 +1593,14 @@ void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> 
     const long long nbins = (long long)P * max_rows;
     (void)hipMemsetAsync(counts, 0, sizeof(int) * nbins, st);
     const dim3 grid(cdiv(max_n, 256), P);
-    hipLaunchKernelGGL(k_qbin<T>, grid, dim3(256), 0, st, probs, maps, rd_pre, max_rows, qrow, counts);
+    hipLaunchKernelGGL(k_qbin<T>, grid, dim3(256), 0, st, probs, maps, rd_pre, max_rows, qrow, counts, order);
     const int nb = cdiv(nbins, kScanChunk);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, (const int *)block_sums,
                        qstart, cursor);
-    hipLaunchKernelGGL(k_qscatter, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, cursor, qtmp);
+    // `order` carries the arrival positions until k_qrank overwrites it with the final permutation
+    hipLaunchKernelGGL(k_qscatter, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, (const int *)qstart, (const int *)order, qtmp);
     hipLaunchKernelGGL(k_qrank<T>, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, (const int *)qstart,
                        (const unsigned long long *)qtmp, rd_pre, rd_sorted, order);
 }

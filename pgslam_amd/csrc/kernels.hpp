@@ -34,7 +34,7 @@ void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, c
 template <typename T>
 void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second,
                         const int *active);
-int knn_stats_read(unsigned long long out[16], int reset);   // diagnostics build (-DPGICP_KNN_STATS) only
+int knn_stats_read(unsigned long long out[48], int reset);   // diagnostics build (-DPGICP_KNN_STATS) only
 void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active);
 int reduce_blocks(int max_n);
 template <typename T>

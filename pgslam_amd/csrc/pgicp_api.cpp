@@ -1196,11 +1196,16 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
     if (!c || !out) return PGICP_ERR_ARG;
     HIPC(c, hipMemcpy(out, c->small.as<int>() + 16, 4 * sizeof(int), hipMemcpyDeviceToHost));
     if (std::getenv("PGICP_KNN_STATS_DUMP")) {          // diagnostics build only
-        unsigned long long s[16];
+        unsigned long long s[48];
         (void)hipDeviceSynchronize();
         if (knn_stats_read(s, 1) == 0) {
-            std::fprintf(stderr, "knn_stats waves=%llu a1_max=%llu a1_sum=%llu flat_iters_max=%llu a2_sum=%llu b_cand=%llu unresolved=%llu b_lanes=%llu\n",
-                         s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+            std::fprintf(stderr, "knn_stats waves=%llu a1_max=%llu a1_sum=%llu flat_iters_max=%llu a2_sum=%llu b_cand=%llu unresolved=%llu b_lanes=%llu b_max=%llu tot_max=%llu\n",
+                         s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9]);
+            std::fprintf(stderr, "  own-row hist (0,1,2-3,4-7,...):");
+            for (int i = 0; i < 12; i++) std::fprintf(stderr, " %llu", s[16 + i]);
+            std::fprintf(stderr, "\n  flat hist:");
+            for (int i = 0; i < 12; i++) std::fprintf(stderr, " %llu", s[32 + i]);
+            std::fprintf(stderr, "\n");
         }
     }
     return PGICP_OK;
