@@ -31,6 +31,7 @@ struct MapDev {
     const int *cell_start;               // ncells + 1 exclusive prefix sums
     const int *sc_count;                 // points per 8x8x8 super-cell (coarse occupancy)
     const int *slot_of;                  // original index -> position in pts / nrm
+    const int *near;                     // per cell: a nearby occupied cell (itself when occupied), -1 if none within kNearReach
     GridDesc<T> g;
     int m;
     int nsx, nsy, nsz;                   // super-cell grid dims
@@ -79,6 +80,7 @@ constexpr int kKnnBlock = 256;
 constexpr int kReduceBlock = 256;
 constexpr int kReduceItems = 4;      // queries per thread in the reduce kernels
 constexpr int kSelectBlock = 1024;
-constexpr int kCovTerms = 42;        // 21 (H upper) + 21 (G upper)
+constexpr int kCovTerms = 42;
+constexpr int kNearReach = 8;     // cells searched per axis for MapDev::near        // 21 (H upper) + 21 (G upper)
 
 }  // namespace pgicp

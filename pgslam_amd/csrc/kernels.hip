@@ -124,24 +124,111 @@ __device__ __forceinline__ int build_cell(const GridDesc<T> &g, T x, T y, T z)
     return cx + g.nx * (cy + g.ny * cz);
 }
 
+// One atomic per distinct key among the lanes of a wave (clouds arrive in scan order, so neighbouring
+// lanes mostly share a cell); falls back to per-lane atomics after 8 leader rounds.  Returns the
+// lane's arrival position inside its key's bucket.
+__device__ __forceinline__ int wave_bucket_add(int *__restrict__ counts, int key, bool live)
+{
+    const int lane = threadIdx.x & 63;
+    int pos = 0;
+    bool todo = live;
+    for (int round = 0; round < 8; ++round) {
+        const unsigned long long pending = __ballot(todo);
+        if (pending == 0ULL) break;
+        const int leader = __ffsll((long long)pending) - 1;
+        const int lkey = __shfl(key, leader, 64);
+        const bool mine = todo && key == lkey;
+        const unsigned long long grp = __ballot(mine);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counts[lkey], __popcll(grp));
+        base = __shfl(base, leader, 64);
+        if (mine) { pos = base + __popcll(grp & ((1ULL << lane) - 1ULL)); todo = false; }
+    }
+    if (todo) pos = atomicAdd(&counts[key], 1);
+    return pos;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_cell_count(const T *__restrict__ xyz, int stride, int m, T mx, T my, T mz,
                                                      GridDesc<T> g, int *__restrict__ cell_of, int *__restrict__ counts,
-                                                     int *__restrict__ sc_count)
+                                                     int *__restrict__ sc_count, int *__restrict__ arrival)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const T x = xyz[(long long)i * stride] - mx, y = xyz[(long long)i * stride + 1] - my,
-            z = xyz[(long long)i * stride + 2] - mz;
-    const int c = build_cell(g, x, y, z);
-    cell_of[i] = c;
+    const bool live = i < m;
+    int c = 0;
+    if (live) {
+        const T x = xyz[(long long)i * stride] - mx, y = xyz[(long long)i * stride + 1] - my,
+                z = xyz[(long long)i * stride + 2] - mz;
+        c = build_cell(g, x, y, z);
+        cell_of[i] = c;
+    }
+    const int pos = wave_bucket_add(counts, c, live);
+    if (!live) return;
+    arrival[i] = pos;
     // occupancy flag of the 8x8x8 super-cell (used by the wave-cooperative slow path): set by the first
     // point of every fine cell with a plain store -- a contended atomic per point serialises on dense maps
-    if (atomicAdd(&counts[c], 1) == 0) {
+    if (pos == 0) {
         const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
         const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3;
         sc_count[(cx >> 3) + nsx * ((cy >> 3) + nsy * (cz >> 3))] = 1;
     }
+}
+
+// ---------------------------------------------------------------------------
+// MapDev::near -- for every cell a nearby OCCUPIED cell (three separable sweeps: nearest occupied
+// cell of the row, then the best of the neighbouring rows' answers in y, then in z).  The answer is
+// a heuristic, not a nearest-cell guarantee: the matcher only uses it to give a query that starts
+// in empty space a first candidate, so that its exact ring search prunes from the first row on.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_near_x(const int *__restrict__ cell_start, int nx, long long ncells, int reach, int *__restrict__ out)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const int x = (int)(c % nx);
+    int found = -1;
+    for (int d = 0; d <= reach && found < 0; ++d) {
+        if (x - d >= 0 && cell_start[c - d + 1] > cell_start[c - d]) found = x - d;
+        else if (x + d < nx && cell_start[c + d + 1] > cell_start[c + d]) found = x + d;
+    }
+    out[c] = found;
+}
+
+// in: nearest occupied x of each row cell; out: (x', y') packed x' | y' << 16, or -1
+__global__ __launch_bounds__(256) void k_near_y(const int *__restrict__ in, int nx, int ny, long long ncells, int reach, int *__restrict__ out)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const int x = (int)(c % nx), y = (int)((c / nx) % ny);
+    int best = -1, bd = 0x7FFFFFFF;
+    for (int d = -reach; d <= reach; ++d) {
+        const int yy = y + d;
+        if (yy < 0 || yy >= ny) continue;
+        const int xx = in[c + (long long)d * nx];
+        if (xx < 0) continue;
+        const int dist = (xx - x) * (xx - x) + d * d;
+        if (dist < bd) { bd = dist; best = xx | (yy << 16); }
+    }
+    out[c] = best;
+}
+
+// in: (x', y') of each cell's xy-plane answer; out: linear index of the chosen occupied cell, or -1
+__global__ __launch_bounds__(256) void k_near_z(const int *__restrict__ in, int nx, int ny, int nz, long long ncells, int reach, int *__restrict__ out)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const long long plane = (long long)nx * ny;
+    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / plane);
+    int best = -1, bd = 0x7FFFFFFF;
+    for (int d = -reach; d <= reach; ++d) {
+        const int zz = z + d;
+        if (zz < 0 || zz >= nz) continue;
+        const int v = in[c + d * plane];
+        if (v < 0) continue;
+        const int xx = v & 0xFFFF, yy = v >> 16;
+        const int dist = (xx - x) * (xx - x) + (yy - y) * (yy - y) + d * d;
+        if (dist < bd) { bd = dist; best = (int)(xx + (long long)nx * (yy + (long long)ny * zz)); }
+    }
+    out[c] = best;
 }
 
 // three-phase exclusive scan over `n` ints (n up to 2^27)
@@ -229,12 +316,12 @@ __global__ __launch_bounds__(1024) void k_scan_final(const int *__restrict__ in,
 // rank kernel then places every point at cell_start + (number of points of the
 // same cell with a smaller original index), so the resident layout -- and with
 // it every later sum order -- is reproducible run to run.
-__global__ __launch_bounds__(256) void k_scatter_idx(int m, const int *__restrict__ cell_of, int *__restrict__ cursor,
-                                                      int *__restrict__ order_tmp)
+__global__ __launch_bounds__(256) void k_scatter_idx(int m, const int *__restrict__ cell_of, const int *__restrict__ cell_start,
+                                                      const int *__restrict__ arrival, int *__restrict__ order_tmp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    order_tmp[atomicAdd(&cursor[cell_of[i]], 1)] = i;
+    order_tmp[cell_start[cell_of[i]] + arrival[i]] = i;      // arrival position from k_cell_count: no second atomic
 }
 
 template <typename T>
@@ -325,8 +412,8 @@ __device__ __forceinline__ int clamp_cell(T u, T inv_h, int n)
 // bin, so the scatter pass needs no second round of atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void k_qbin(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
-                                               const T *__restrict__ rd_pre, int max_bins, int *__restrict__ qbin,
-                                               int *__restrict__ counts, int *__restrict__ qpos)
+                                               const T *__restrict__ rd_pre, int max_bins, int bin_shift,
+                                               int *__restrict__ qbin, int *__restrict__ counts, int *__restrict__ qpos)
 {
     const ProblemDev &P = probs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,29 +424,14 @@ __global__ __launch_bounds__(256) void k_qbin(const ProblemDev *__restrict__ pro
         const T *q = rd_pre + 3 * (P.off + i);
         const int cx = clamp_cell<T>(q[0] - g.ox, g.inv_h, g.nx), cy = clamp_cell<T>(q[1] - g.oy, g.inv_h, g.ny),
                   cz = clamp_cell<T>(q[2] - g.oz, g.inv_h, g.nz);
-        const int nbx = (g.nx + 3) >> 2, nby = (g.ny + 3) >> 2;
-        bin = (cx >> 2) + nbx * ((cy >> 2) + nby * (cz >> 2));
+        const int s = bin_shift, r = (1 << s) - 1;
+        const int nbx = (g.nx + r) >> s, nby = (g.ny + r) >> s;
+        bin = (cx >> s) + nbx * ((cy >> s) + nby * (cz >> s));
         if (bin >= max_bins) bin = max_bins - 1;
-        const int local = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
+        const int local = (cx & r) | ((cy & r) << s) | ((cz & r) << (2 * s));
         qbin[P.off + i] = (bin << 6) | local;              // bin < 2^25 (<= 2^26 cells / 64 + slack)
     }
-    int *cnt = counts + (long long)blockIdx.y * max_bins;
-    const int lane = threadIdx.x & 63;
-    int pos = 0;
-    bool todo = live;
-    for (int round = 0; round < 8; ++round) {
-        const unsigned long long pending = __ballot(todo);
-        if (pending == 0ULL) break;
-        const int leader = __ffsll((long long)pending) - 1;
-        const int lbin = __shfl(bin, leader, 64);
-        const bool mine = todo && bin == lbin;
-        const unsigned long long grp = __ballot(mine);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&cnt[lbin], __popcll(grp));
-        base = __shfl(base, leader, 64);
-        if (mine) { pos = base + __popcll(grp & ((1ULL << lane) - 1ULL)); todo = false; }
-    }
-    if (todo) pos = atomicAdd(&cnt[bin], 1);
+    const int pos = wave_bucket_add(counts + (long long)blockIdx.y * max_bins, bin, live);
     if (live) qpos[P.off + i] = pos;
 }
 
@@ -757,6 +829,20 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
     const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
     const int cx = clamp_cell<T>(ux, g.inv_h, g.nx), cy = clamp_cell<T>(uy, g.inv_h, g.ny), cz = clamp_cell<T>(uz, g.inv_h, g.nz);
 
+    // no previous match (first iteration, or nothing located last time): a query that starts in an empty
+    // cell takes the points of a nearby occupied cell as first candidates, so every later row test prunes
+    // against a finite bound and "a neighbour exists within maxDist" is settled by a real candidate
+    if (live && seed.slot < 0) {
+        const int c = cx + g.nx * (cy + g.ny * cz);
+        const int nc = as_global(M.near)[c];
+        // (the own cell is scanned by phase A.1 anyway -- but under the cap, which hides what lies beyond it)
+        if (nc >= 0 && (nc != c || capped)) {
+            Best<T> ns;
+            ns.d2 = ch.max_dist2; ns.idx = 0x7FFFFFFF; ns.slot = -1;
+            scan_range<T>(M.pts, as_global(M.cell_start)[nc], as_global(M.cell_start)[nc + 1], qx, qy, qz, ns);
+            if (ns.slot >= 0) { seed = ns; if (seed.d2 <= best.d2) best = seed; }
+        }
+    }
     // ---- phase A.1: own row first -- it usually holds the neighbour and shrinks the bound ----
     if (live) scan_row<T>(M, g.nx * (cy + g.ny * cz), max(cx - R, 0), min(cx + R, g.nx - 1), ux, (T)0, qx, qy, qz, best);
 #ifdef PGICP_KNN_STATS
@@ -927,7 +1013,9 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
             // still open: keep the better upper bound (if a real candidate exists) and the larger lower bound
             if (best.slot >= 0) { slot_io[P.off + i] = best.slot; d2_out[P.off + i] = best.d2; P.n_refined = 1; }
             T nlb = lb;
-            if (lb >= (T)0 || best.slot >= 0) { nlb = gr > (T)0 ? gr * gr : (T)0; slow_lb[k] = nlb; }
+            const T reached = gr > (T)0 ? gr * gr : (T)0;
+            if (lb >= (T)0 || best.slot >= 0) { nlb = reached; slow_lb[k] = nlb; }
+            else slow_lb[k] = -((T)1 + reached);              // existence still unknown; -(1 + proven lower bound)
             slow_ring[k] = r_next;
             survivor = nlb < (T)0 || !(nlb > limit);
         }
@@ -969,9 +1057,13 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
         const int2 e = slow_list[k];
         ProblemDev &P = probs[e.x];
         const int i = e.y;
+        // (a plain flag store: contended atomics on one address serialise the waves, and on gfx9 every
+        // later load of the wave waits behind them)
         if (!exact_all && lane == 0) {
-            atomicAdd(&P.n_refined, 1);
+            P.n_refined = 1;
+#ifdef PGICP_KNN_STATS
             atomicAdd(const_cast<int *>(slow_count) + (slow_lb[k] < (T)0 ? 1 : 2), 1);     // diagnostics: forced / bound-hit
+#endif
         }
         const T *q = rd + 3 * (P.off + i);
         T qx, qy, qz;
@@ -983,12 +1075,22 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
         best.d2 = ch.max_dist2; best.idx = 0x7FFFFFFF; best.slot = -1;
         const int prev = slot_io[P.off + i];
         if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
+        // An entry whose neighbour -- if it has one -- is already proven farther than the threshold only
+        // needs the answer to "is there any point within maxDist" (n_finite): the first candidate ends it,
+        // and its distance stays in d2 as an upper bound like any other unresolved entry's.
+        const T lbk = slow_lb[k];
+        const bool exist_only = !exact_all && lbk < (T)0 && (-lbk - (T)1) > (T)P.limit;
+#ifdef PGICP_KNN_STATS
+        const long long t_begin = clock64();
+        int st_sc = 0, st_rows = 0, st_trips = 0, st_R = 0;
+#endif
+        bool found = exist_only && prev >= 0 && best.slot >= 0;
         const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
         const int Cx = clamp_cell<T>(ux, g.inv_h, g.nx) >> 3, Cy = clamp_cell<T>(uy, g.inv_h, g.ny) >> 3,
                   Cz = clamp_cell<T>(uz, g.inv_h, g.nz) >> 3;
-        for (int R = 0;; ++R) {
+        for (int R = 0; !found; ++R) {
             const int side = 2 * R + 1, total = side * side * side;
-            for (int base = 0; base < total; base += 64) {
+            for (int base = 0; base < total && !found; base += 64) {
                 const int t = base + lane;
                 const int dx = t % side - R, dy = (t / side) % side - R, dz = t / (side * side) - R;
                 const int X = Cx + dx, Y = Cy + dy, Z = Cz + dz;
@@ -1005,19 +1107,53 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
                     const int src = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     const int SX = __shfl(X, src, 64), SY = __shfl(Y, src, 64), SZ = __shfl(Z, src, 64);
+                    // lane r looks up row r of the super-cell (bound, x-range, point range) ...
                     const int y = 8 * SY + (lane & 7), z = 8 * SZ + (lane >> 3);
+                    int ra = 0, rb = 0;
+                    T rlb = (T)0;
                     if (y < g.ny && z < g.nz) {
                         const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
                         const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
                         const T lb2 = ly * ly + lz * lz;
-                        if (!(lb2 > best.d2))
-                            scan_row<T>(M, g.nx * (y + g.ny * z), 8 * SX, min(8 * SX + 7, g.nx - 1), ux, lb2, qx, qy, qz, best);
+                        if (!(lb2 > best.d2)) {
+                            int xa = 8 * SX, xb = min(8 * SX + 7, g.nx - 1);
+                            if (best.d2 < Bits<T>::inf()) {
+                                const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + g.margin;
+                                xa = max(xa, clamp_cell<T>(ux - rad, g.inv_h, g.nx));
+                                xb = min(xb, clamp_cell<T>(ux + rad, g.inv_h, g.nx));
+                            }
+                            if (xa <= xb) {
+                                const int row = g.nx * (y + g.ny * z);
+                                ra = as_global(M.cell_start)[row + xa];
+                                rb = as_global(M.cell_start)[row + xb + 1];
+                                rlb = lb2;
+                            }
+                        }
                     }
-                    // share the tightest bound (pruning only; the winner is reduced at the end)
-                    T wmin = best.d2;
+                    // ... then the WHOLE wave scans each non-empty row, 64 consecutive points per trip: the
+                    // rows of a dense super-cell hold thousands of points in a few rows (ground near the
+                    // sensor), which one lane per row would walk serially
+                    unsigned long long rows = __ballot(ra < rb);
+#ifdef PGICP_KNN_STATS
+                    st_sc++; st_rows += __popcll(rows);
+#endif
+                    while (rows) {
+                        const int r = __ffsll((long long)rows) - 1;
+                        rows &= rows - 1;
+                        const int pa = __shfl(ra, r, 64), pb = __shfl(rb, r, 64);
+                        const T l2 = __shfl(rlb, r, 64);
+                        if (l2 > best.d2) continue;                     // best.d2 is wave-uniform here
+                        for (int s = pa + lane; s < pb; s += 64) eval_point<T>(load_rec<T>(M.pts, s), s, qx, qy, qz, best);
+#ifdef PGICP_KNN_STATS
+                        st_trips += (pb - pa + 63) / 64;
+#endif
+                        // share the tightest bound (pruning only; the winner is reduced at the end)
+                        T wmin = best.d2;
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) wmin = fmin(wmin, __shfl_xor(wmin, o, 64));
-                    if (wmin < best.d2) { best.d2 = wmin; best.idx = 0x7FFFFFFF; best.slot = -1; }
+                        for (int o = 32; o > 0; o >>= 1) wmin = fmin(wmin, __shfl_xor(wmin, o, 64));
+                        if (wmin < best.d2) { best.d2 = wmin; best.idx = 0x7FFFFFFF; best.slot = -1; }
+                    }
+                    if (exist_only && best.d2 < ch.max_dist2) { found = true; break; }    // wave-uniform
                 }
             }
             // every super-cell outside ring R is at least this far away (wave-uniform)
@@ -1047,6 +1183,15 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
             if (best.slot < 0) best.d2 = Bits<T>::inf();
             slot_io[P.off + i] = best.slot;
             d2_out[P.off + i] = best.d2;
+#ifdef PGICP_KNN_STATS
+            const unsigned long long dt = (unsigned long long)(clock64() - t_begin);
+            atomicAdd(&g_knn_stats[10], 1ULL);
+            atomicAdd(&g_knn_stats[11], dt);
+            const unsigned long long old = atomicMax(&g_knn_stats[12], dt);
+            if (dt > old) { g_knn_stats[13] = ((unsigned long long)st_sc << 40) | ((unsigned long long)st_rows << 20) | (unsigned long long)st_trips;
+                            g_knn_stats[14] = ((unsigned long long)(exist_only ? 1 : 0) << 32) | (unsigned long long)(best.slot >= 0 ? 1 : 0); }
+            atomicAdd(&g_knn_stats[15], (unsigned long long)st_trips);
+#endif
         }
     }
 }
@@ -1566,34 +1711,41 @@ template <typename T>
 void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, int nstride, int m, const T mean[3],
                        const GridDesc<T> &g, int *cell_of, int *counts, int *block_sums, int *cell_start, int *cursor,
                        int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of,
-                       int *sc_count)
+                       int *sc_count, int *near, int near_reach)
 {
     const long long ncells = (long long)g.nx * g.ny * g.nz;
     const long long nsc = (long long)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
     (void)hipMemsetAsync(counts, 0, sizeof(int) * ncells, st);
     (void)hipMemsetAsync(sc_count, 0, sizeof(int) * nsc, st);
     hipLaunchKernelGGL(k_cell_count<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, m, mean[0], mean[1], mean[2], g,
-                       cell_of, counts, sc_count);
+                       cell_of, counts, sc_count, slot_of /* arrival positions until k_rank_place overwrites it */);
     const int nb = cdiv(ncells, kScanChunk);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)ncells, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)ncells, (const int *)block_sums,
                        cell_start, cursor);
-    hipLaunchKernelGGL(k_scatter_idx, dim3(cdiv(m, 256)), dim3(256), 0, st, m, (const int *)cell_of, cursor, order_tmp);
+    hipLaunchKernelGGL(k_scatter_idx, dim3(cdiv(m, 256)), dim3(256), 0, st, m, (const int *)cell_of, (const int *)cell_start,
+                       (const int *)slot_of, order_tmp);
     hipLaunchKernelGGL(k_rank_place<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, nrm, nstride, m, mean[0], mean[1],
                        mean[2], (const int *)cell_of, (const int *)cell_start, (const int *)order_tmp, pts, nrm_out, slot_of);
+    // counts / cursor are free again: scratch of the three sweeps
+    const int nbc = cdiv(ncells, 256);
+    const int reach = near_reach < 1 ? 1 : (near_reach > kNearReach ? kNearReach : near_reach);
+    hipLaunchKernelGGL(k_near_x, dim3(nbc), dim3(256), 0, st, (const int *)cell_start, g.nx, ncells, reach, counts);
+    hipLaunchKernelGGL(k_near_y, dim3(nbc), dim3(256), 0, st, (const int *)counts, g.nx, g.ny, ncells, reach, cursor);
+    hipLaunchKernelGGL(k_near_z, dim3(nbc), dim3(256), 0, st, (const int *)cursor, g.nx, g.ny, g.nz, ncells, reach, near);
 }
 
 // once per scan: order every problem's pre-transformed reading by (map row, x)
 template <typename T>
 void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
                        int *qrow, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
-                       int max_n, int max_rows)
+                       int max_n, int max_rows, int bin_shift)
 {
     const long long nbins = (long long)P * max_rows;
     (void)hipMemsetAsync(counts, 0, sizeof(int) * nbins, st);
     const dim3 grid(cdiv(max_n, 256), P);
-    hipLaunchKernelGGL(k_qbin<T>, grid, dim3(256), 0, st, probs, maps, rd_pre, max_rows, qrow, counts, order);
+    hipLaunchKernelGGL(k_qbin<T>, grid, dim3(256), 0, st, probs, maps, rd_pre, max_rows, bin_shift, qrow, counts, order);
     const int nb = cdiv(nbins, kScanChunk);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
@@ -1650,12 +1802,14 @@ void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, co
 
 // resolves the queries the fast path queued: all of them (exact_all, public matcher
 // output) or only those that can still matter for the trimmed filter (lazy)
+constexpr int kSlowBlocks = 2048;
+
 template <typename T>
 void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                      const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb,
                      const int *slow2_idx, int exact_all)
 {
-    hipLaunchKernelGGL(k_knn_slow<T>, dim3(1024), dim3(256), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list,
+    hipLaunchKernelGGL(k_knn_slow<T>, dim3(kSlowBlocks), dim3(256), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list,
                        slow_lb, slow2_idx, exact_all);
 }
 
@@ -1728,9 +1882,9 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_centroid_bbox<T>(hipStream_t, const T *, int, int, unsigned long long *);                        \
     template void launch_grid_build<T>(hipStream_t, const T *, int, const T *, int, int, const T[3], const GridDesc<T> &, \
                                        int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,                \
-                                       typename Vec4<T>::type *, int *, int *);                                           \
+                                       typename Vec4<T>::type *, int *, int *, int *, int);                               \
     template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *,         \
-                                       unsigned long long *, int *, int *, int *, int *, int *, int, int, int);           \
+                                       unsigned long long *, int *, int *, int *, int *, int *, int, int, int, int);      \
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \

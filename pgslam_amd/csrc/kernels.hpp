@@ -10,11 +10,11 @@ template <typename T>
 void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, int nstride, int m, const T mean[3],
                        const GridDesc<T> &g, int *cell_of, int *counts, int *block_sums, int *cell_start, int *cursor,
                        int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of,
-                       int *sc_count);
+                       int *sc_count, int *near, int near_reach);
 template <typename T>
 void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
                        int *qrow, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
-                       int max_n, int max_rows);
+                       int max_n, int max_rows, int bin_shift);
 template <typename T>
 void launch_transform(hipStream_t st, const T *in, int in_stride, T *out, int out_stride, int n, const double *T16,
                       int rotate_only);

@@ -15,6 +15,7 @@
 #include <limits>
 #include <numeric>
 #include <string>
+#include <map>
 #include <vector>
 
 using namespace pgicp;
@@ -48,7 +49,9 @@ struct MapHost {
     int *cell_start = nullptr;
     int *slot_of = nullptr;
     int *sc_count = nullptr;
+    int *near = nullptr;
     char *block = nullptr;          // the one device allocation holding all of the above
+    size_t block_bytes = 0;
     GridDesc<T> g{};
 };
 
@@ -79,7 +82,11 @@ struct pgicp_ctx {
     DevBuf probs, src, partials, sums, small, stats, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
     DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
-    int fast_rings_seeded = 2, fast_rings_unseeded = 4;   // rings walked in the fast kernel before a query is queued
+    // Freed map blocks are kept for reuse: hipFree synchronises the device, and loop closing creates
+    // and destroys one index per candidate pair.
+    std::multimap<size_t, char *> block_pool;
+    size_t pooled_bytes = 0;
+    int fast_rings_seeded = 1, fast_rings_unseeded = 3;   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
     std::vector<ProfEvent> prof_events;
     long long prof_launches[PGICP_PROF_COUNT] = {0};
@@ -227,6 +234,7 @@ int sync_maps_table(pgicp_ctx *c)
         h[i].pts = m.pts; h[i].nrm = m.nrm; h[i].cell_start = m.cell_start; h[i].g = m.g; h[i].m = m.used ? m.m : 0;
         h[i].sc_count = m.sc_count;
         h[i].slot_of = m.slot_of;
+        h[i].near = m.near;
         h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
     }
     HIPC(c, hipMemcpyAsync(S.d_maps.p, h.data(), sizeof(MapDev<T>) * n, hipMemcpyHostToDevice, c->stream));
@@ -234,10 +242,34 @@ int sync_maps_table(pgicp_ctx *c)
     return PGICP_OK;
 }
 
-template <typename T>
-void free_map(MapHost<T> &m)
+constexpr size_t kPoolLimitBytes = (size_t)8 << 30;
+
+int block_alloc(pgicp_ctx *c, size_t bytes, char **out, size_t *got)
 {
-    if (m.block) (void)hipFree(m.block);
+    auto it = c->block_pool.lower_bound(bytes);
+    if (it != c->block_pool.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+        *out = it->second; *got = it->first;
+        c->pooled_bytes -= it->first;
+        c->block_pool.erase(it);
+        return PGICP_OK;
+    }
+    HIPC(c, hipMalloc((void **)out, bytes));
+    *got = bytes;
+    return PGICP_OK;
+}
+
+// The caller guarantees that no work using the map is still queued on another stream; work on the
+// context stream is ordered before whatever reuses the block.
+template <typename T>
+void free_map(pgicp_ctx *c, MapHost<T> &m)
+{
+    if (m.block) {
+        if (c && c->pooled_bytes + m.block_bytes <= kPoolLimitBytes) {
+            c->block_pool.emplace(m.block_bytes, m.block);
+            c->pooled_bytes += m.block_bytes;
+        } else
+            (void)hipFree(m.block);
+    }
     m = MapHost<T>();
 }
 
@@ -349,19 +381,23 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         const size_t ncells = (size_t)g.nx * g.ny * g.nz;
         const size_t nsc = (size_t)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
         const size_t b_pts = up(sizeof(V4) * (size_t)m), b_nrm = M.has_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (ncells + 1)),
-                     b_slot = up(sizeof(int) * (size_t)m), b_sc = up(sizeof(int) * nsc);
+                     b_slot = up(sizeof(int) * (size_t)m), b_sc = up(sizeof(int) * nsc), b_near = up(sizeof(int) * ncells);
         char *base = nullptr;
-        HIPC(c, hipMalloc((void **)&base, b_pts + b_nrm + b_cs + b_slot + b_sc));
+        { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + b_sc + b_near, &base, &M.block_bytes); if (ast) return ast; }
         M.block = base;
         M.pts = (V4 *)base;
         M.nrm = M.has_nrm ? (V4 *)(base + b_pts) : nullptr;
         M.cell_start = (int *)(base + b_pts + b_nrm);
         M.slot_of = (int *)(base + b_pts + b_nrm + b_cs);
         M.sc_count = (int *)(base + b_pts + b_nrm + b_cs + b_slot);
+        M.near = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc);
+        // a first candidate farther than ~a third of maxDist prunes little: do not look for one beyond that
+        const double reach_len = std::isfinite(c->prm.max_dist) ? 0.35 * c->prm.max_dist : 1e30;
+        const int near_reach = (int)std::min((double)kNearReach, std::max(2.0, std::ceil(reach_len / (double)g.h)));
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
         launch_grid_build<T>(c->stream, d_xyz[k], src[k].xyz_stride, d_nrm[k], src[k].nrm_stride, m, M.mean, g, c->tmp_a.as<int>(),
                              c->tmp_b.as<int>(), c->tmp_c.as<int>(), M.cell_start, c->tmp_d.as<int>(), c->tmp_e.as<int>(), M.pts, M.nrm,
-                             M.slot_of, M.sc_count);
+                             M.slot_of, M.sc_count, M.near, near_reach);
     }
     HIPC(c, hipGetLastError());
     // ---- phase 3: register ----
@@ -394,6 +430,7 @@ struct BatchLayout {
     int P = 0;
     int max_n = 0;
     int max_rows = 1;
+    int bin_shift = 2;          // reading-sort bins are (1 << bin_shift)^3 map cells
     long long total = 0;
 };
 
@@ -405,16 +442,30 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     State<T> &S = state<T>(c);
     L.P = P; L.max_n = 0; L.max_rows = 1; L.total = 0;
     size_t stage_total = 0;
+    double dens = 0.0;                         // largest reading-to-map size ratio of the batch
     for (int p = 0; p < P; p++) {
         if (pr[p].n <= 0 || !pr[p].reading || pr[p].stride < 3)
             return fail(c, PGICP_ERR_ARG, "pgicp: bad reading in problem " + std::to_string(p));
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp: unknown map id " + std::to_string(pr[p].map_id));
         L.max_n = std::max(L.max_n, pr[p].n);
-        // bins of the reading sort: 4x4x4-cell blocks of the map grid
-        L.max_rows = std::max(L.max_rows, ((M->g.nx + 3) >> 2) * ((M->g.ny + 3) >> 2) * ((M->g.nz + 3) >> 2));
+        dens = std::max(dens, (double)pr[p].n / (double)M->m);
         L.total += pr[p].n;
         if (pr[p].mem == PGICP_HOST) stage_total += staged_bytes(sizeof(T), pr[p].stride, pr[p].n);
+    }
+    // Bins of the reading sort are blocks of map cells.  The rank pass costs O(bin population) per
+    // point and map cells hold ~17 points where the data is, so a reading as dense as its map gets
+    // single-cell bins and a sparse one 4x4x4-cell bins; the bin table is kept under 2^26 entries.
+    L.bin_shift = dens <= 0.25 ? 2 : (dens <= 2.0 ? 1 : 0);
+    for (;; ++L.bin_shift) {
+        const int s = L.bin_shift, r = (1 << s) - 1;
+        L.max_rows = 1;
+        for (int p = 0; p < P; p++) {
+            const GridDesc<T> &g = get_map<T>(c, pr[p].map_id)->g;
+            const long long rows = (long long)((g.nx + r) >> s) * ((g.ny + r) >> s) * ((g.nz + r) >> s);
+            L.max_rows = (int)std::max<long long>(L.max_rows, std::min<long long>(rows, 1LL << 30));
+        }
+        if (s >= 2 || ((long long)L.max_rows < (1LL << 25) && (long long)L.max_rows * P <= (1LL << 26))) break;
     }
     HIPC(c, S.rd_pre.ensure(sizeof(T) * 3 * (size_t)L.total));
     HIPC(c, S.rd_sorted.ensure(sizeof(T) * 3 * (size_t)L.total));
@@ -474,7 +525,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(),
                              S.rd_pre.template as<T>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<unsigned long long>(),
                              c->order.as<int>(), c->qcounts.as<int>(), c->qblock.as<int>(), c->qstart.as<int>(),
-                             c->qcursor.as<int>(), P, L.max_n, L.max_rows);
+                             c->qcursor.as<int>(), P, L.max_n, L.max_rows, L.bin_shift);
     }
     // hs/hp must outlive the async copies
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -636,7 +687,7 @@ int icp_pair(pgicp_ctx *c, const T *reading, int rd_stride, int n, const T *ref_
     std::memcpy(pr.T_init, T_init, sizeof pr.T_init);
     st = align_batch<T>(c, 1, &pr, T_out, stats);
     (void)hipStreamSynchronize(c->stream);
-    if (MapHost<T> *mh = get_map<T>(c, id)) free_map(*mh);
+    if (MapHost<T> *mh = get_map<T>(c, id)) free_map(c, *mh);
     return st;
 }
 
@@ -996,8 +1047,10 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    for (auto &m : c->f32.maps) free_map(m);
-    for (auto &m : c->f64.maps) free_map(m);
+    for (auto &m : c->f32.maps) free_map<float>(nullptr, m);
+    for (auto &m : c->f64.maps) free_map<double>(nullptr, m);
+    for (auto &kv : c->block_pool) (void)hipFree(kv.second);
+    c->block_pool.clear();
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
@@ -1060,9 +1113,8 @@ int pgicp_map_destroy(pgicp_ctx *c, int id)
     if (!c) return PGICP_ERR_ARG;
     (void)hipSetDevice(c->device);
     // a map id is unique across precisions only per State; try both, f32 first
-    (void)hipStreamSynchronize(c->stream);
-    if (MapHost<float> *m = get_map<float>(c, id)) { free_map(*m); return PGICP_OK; }
-    if (MapHost<double> *m = get_map<double>(c, id)) { free_map(*m); return PGICP_OK; }
+    if (MapHost<float> *m = get_map<float>(c, id)) { free_map(c, *m); return PGICP_OK; }
+    if (MapHost<double> *m = get_map<double>(c, id)) { free_map(c, *m); return PGICP_OK; }
     return fail(c, PGICP_ERR_ARG, "pgicp_map_destroy: unknown map id");
 }
 
@@ -1201,6 +1253,8 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
         if (knn_stats_read(s, 1) == 0) {
             std::fprintf(stderr, "knn_stats waves=%llu a1_max=%llu a1_sum=%llu flat_iters_max=%llu a2_sum=%llu b_cand=%llu unresolved=%llu b_lanes=%llu b_max=%llu tot_max=%llu\n",
                          s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9]);
+            std::fprintf(stderr, "  slow: entries=%llu cycles_sum=%llu cycles_max=%llu (worst: supercells=%llu rows=%llu trips=%llu exist_only=%llu found=%llu) trips_sum=%llu\n",
+                         s[10], s[11], s[12], s[13] >> 40, (s[13] >> 20) & 0xFFFFF, s[13] & 0xFFFFF, s[14] >> 32, s[14] & 1, s[15]);
             std::fprintf(stderr, "  own-row hist (0,1,2-3,4-7,...):");
             for (int i = 0; i < 12; i++) std::fprintf(stderr, " %llu", s[16 + i]);
             std::fprintf(stderr, "\n  flat hist:");
