@@ -240,6 +240,170 @@ def main_loopclosure(args):
         dist.destroy_process_group()
 
 
+def build_drive(n_scans, n_pts, step, cache_dir="/tmp"):
+    """Scans of synth.make_drive (BASELINE configs[2]) with the ray casting spread over host cores, cached."""
+    from pgslam_amd import synth
+    path = os.path.join(cache_dir, f"pgslam_amd_drive_{n_scans}_{n_pts}_{step}.npz")
+    import math
+    u = synth.uniform01(synth.DRIVE_SEED, 3 * n_scans)
+    poses, odom = [], []
+    T_o = None
+    for s in range(n_scans):                       # same poses / odometry as synth.make_drive
+        T = synth.se3(x=-40.0 + step * s, y=0.8 * math.sin(0.05 * s), yaw=math.radians(3.0) * math.sin(0.15 * s))
+        if s == 0:
+            T_o = T.copy()
+        else:
+            err = synth.se3(x=0.02 * (2 * u[3 * s] - 1), y=0.02 * (2 * u[3 * s + 1] - 1),
+                            yaw=math.radians(0.15) * (2 * u[3 * s + 2] - 1))
+            T_o = T_o @ (synth.se3_inv(poses[-1]) @ T) @ err
+        poses.append(T)
+        odom.append(T_o.copy())
+    if os.path.exists(path):
+        z = np.load(path)
+        return poses, odom, list(z["xyz"]), list(z["nrm"])
+    import multiprocessing as mp
+    rings = 64 if n_pts >= 50_000 else 16
+    jobs = [("drive", 7000 + s, n_pts, rings, poses[s]) for s in range(n_scans)]
+    with mp.get_context("fork").Pool(max(1, min(len(jobs), os.cpu_count() or 1, 32))) as pool:
+        res = pool.map(_gen_scan, jobs)
+    xyz, nrm = [r[0] for r in res], [r[1] for r in res]
+    try:
+        np.savez(path + ".tmp.npz", xyz=np.stack(xyz), nrm=np.stack(nrm))
+        os.replace(path + ".tmp.npz", path)
+    except OSError:
+        pass
+    return poses, odom, xyz, nrm
+
+
+def main_stream(args):
+    """BASELINE configs[2]: a scan feed through the streaming local mapper -- ICP against a sliding,
+    device-resident map of `--capacity` keyframes (20 x 100k = 2M points), new keyframe when the overlap
+    drops below 0.8, the next map assembled and indexed on a background context while scans keep
+    aligning.  A "step" is one pass of every stream over the timed scans; `--streams` independent
+    vehicles (one mapper, one host thread, one HIP stream each) share the GPU.  Scans are staged in
+    HBM before the timed region (the PCIe-inclusive figure is reported separately)."""
+    import torch
+    import torch.distributed as dist
+    from pgslam_amd import icp
+    from pgslam_amd.local_mapper import Keyframe, LocalMapperConfig, StreamingLocalMapper
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    n_prime = args.capacity - 1
+    n_total = n_prime * args.prime_stride + args.stream_scans
+    if rank == 0:
+        drive = build_drive(n_total, args.n_scan, args.stream_step)
+    if distributed:
+        dist.barrier()
+    if rank != 0:
+        drive = build_drive(n_total, args.n_scan, args.stream_step)
+    poses, odom, xyz, nrm = drive
+    if args.prepare_only:
+        return
+    first = n_prime * args.prime_stride
+    # the map so far is taken as accurate: keyframes sit at their true poses and the odometry frame is
+    # re-based on the truth at the first timed scan, so the final error below is the mapper's own
+    rebase = poses[first] @ np.linalg.inv(odom[first])
+    odom = [poses[s] if s < first else rebase @ odom[s] for s in range(n_total)]
+    d_xyz = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in xyz]
+    d_nrm = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in nrm]
+
+    class Vehicle:
+        def __init__(self):
+            self.ctx = icp.Context(local_rank, **CHAIN)
+            self.builder = icp.Context(local_rank, **CHAIN) if not args.sync_rebuild else None
+            self.new()
+
+        def new(self):
+            cfg = LocalMapperConfig(capacity=args.capacity, overlap_threshold=0.8, chain=dict(CHAIN),
+                                    async_rebuild=not args.sync_rebuild)
+            self.m = StreamingLocalMapper(self.ctx, cfg, builder=self.builder)
+            # the window the vehicle would have after the drive so far: every prime_stride-th earlier scan
+            for k in range(n_prime):
+                s = k * args.prime_stride
+                self.m.window.append(Keyframe(self.m.next_kf_id, d_xyz[s], d_nrm[s], odom[s].copy()))
+                self.m.next_kf_id += 1
+            self.m.process(odom[first], d_xyz[first], d_nrm[first])        # becomes the reference keyframe; builds the map
+
+        def run(self, out):
+            its, conv = 0, 0
+            for s in range(first + 1, n_total):
+                self.m.process(odom[s], d_xyz[s], d_nrm[s])
+                st = self.m.last_stats
+                its += st["iterations"]
+                conv += int(st["status"] == 0 and st["converged"])
+            out.append((its, conv, len(self.m.keyframe_scans) - 1, self.m.rebuilds,
+                        float(np.linalg.norm((np.linalg.inv(poses[n_total - 1]) @ self.m.T_world_robot)[:3, 3]))))
+
+        def reset(self):
+            self.m.close()
+            self.new()
+
+    vehicles = [Vehicle() for _ in range(args.streams)]
+    per_step = (n_total - first - 1) * args.streams
+
+    def step():
+        outs = [[] for _ in vehicles]
+        ths = [threading.Thread(target=v.run, args=(o,)) for v, o in zip(vehicles, outs)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return [o[0] for o in outs]
+
+    for _ in range(args.warmup):
+        step()
+        for v in vehicles:
+            v.reset()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = 0.0
+    for k in range(args.steps):
+        t0 = time.perf_counter()
+        res = step()
+        torch.cuda.synchronize()
+        elapsed += time.perf_counter() - t0
+        if k + 1 < args.steps:
+            for v in vehicles:                      # rewinding the vehicles is not part of the feed
+                v.reset()
+    if distributed:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        its = sum(r[0] for r in res)
+        conv = sum(r[1] for r in res)
+        print(json.dumps({
+            "metric": "streamed scans/sec through the local mapper (100k-pt scans, sliding 2M-pt device-resident map)",
+            "value": args.steps * per_step * world / elapsed, "unit": "scans/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"streaming local mapper, {args.stream_scans - 1} timed scans of {args.n_scan} pts per vehicle, "
+                                   f"{args.capacity}-keyframe sliding map ({args.capacity * args.n_scan} pts, BASELINE.json configs[2]), "
+                                   f"{args.streams} vehicle(s) per GPU, {'synchronous' if args.sync_rebuild else 'background'} map rebuild",
+                       "parallelism": f"{world} GPU(s) x {args.streams} independent vehicles (replicas)"},
+            "ms_per_scan_per_vehicle": elapsed * 1e3 / (args.steps * (n_total - first - 1)),
+            "mean_iterations": its / per_step, "converged_fraction": conv / per_step,
+            "new_keyframes_per_vehicle": res[0][2], "map_rebuilds_per_vehicle": res[0][3], "final_position_error_m": res[0][4]}))
+    for v in vehicles:
+        v.m.close()
+        v.ctx.close()
+        if v.builder:
+            v.builder.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,7 +423,12 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams, one host thread each) the batch is split over; each keeps its own "
                          "resident copy of the map.  >1 overlaps one sub-batch's convergence tail with another's head")
-    ap.add_argument("--workload", choices=["scan2map", "loopclosure"], default="scan2map",
+    ap.add_argument("--capacity", type=int, default=20, help="stream: keyframes in the sliding map")
+    ap.add_argument("--stream-scans", type=int, default=41, help="stream: scans per vehicle (the first becomes a keyframe, untimed)")
+    ap.add_argument("--stream-step", type=float, default=0.35, help="stream: metres travelled between scans (10 Hz at 3.5 m/s)")
+    ap.add_argument("--prime-stride", type=int, default=3, help="stream: earlier scans between the keyframes that pre-fill the window")
+    ap.add_argument("--sync-rebuild", action="store_true", help="stream: rebuild the map in line, as the reference does")
+    ap.add_argument("--workload", choices=["scan2map", "loopclosure", "stream"], default="scan2map",
                     help="scan2map = BASELINE configs[1] (the headline metric); loopclosure = configs[4]: --pairs candidate "
                          "scan pairs (100k vs 100k) sharded over the ranks, all-gather of the SE(3) edges")
     ap.add_argument("--pairs", type=int, default=512)
@@ -269,6 +438,8 @@ def main():
                          "generator forks worker processes, which must not happen under the counter profiler)")
     args = ap.parse_args()
 
+    if args.workload == "stream":
+        return main_stream(args)
     if args.prepare_only:
         build_workload(args.n_scan, args.n_map, args.queries)
         return

@@ -153,6 +153,12 @@ int pgicp_map_create_batch_f64(pgicp_ctx *ctx, int n_maps, const double *const *
                                int *map_ids);
 int pgicp_map_destroy(pgicp_ctx *ctx, int map_id);
 int pgicp_map_size(pgicp_ctx *ctx, int map_id, int *m);
+/* Hands a map from one context to another of the same device without copying it.  A background
+ * context (its own stream and scratch) can so assemble and index the next local map --
+ * LocalMap::UpdateToNewComposition + setMap, Localizer.hpp:262-266 -- while `to` keeps aligning
+ * scans against the current one.  `to`'s stream waits, on the device, for the work queued on
+ * `from`'s stream so far; the host does not block.  The id is invalid in `from` afterwards. */
+int pgicp_map_transfer(pgicp_ctx *from, int map_id, pgicp_ctx *to, int *new_id);
 
 /* ---- full ICP --------------------------------------------------------
  * pgicp_align = ICPSequence::operator()(reading, T_init) (Localizer.hpp:126).

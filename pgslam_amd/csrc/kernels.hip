@@ -956,16 +956,15 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
 // Medium path: the queued queries that can still matter (lower bound within the threshold just
 // selected, or existence unknown) continue their ring search one query per LANE -- but in waves made
 // only of such queries, so easy queries no longer wait for hard ones.  A lane stops when it is
-// resolved, when its guaranteed radius passes 1.1x the threshold, or after kMedRings rings (the
+// resolved, when its guaranteed radius passes 1.1x the threshold, or after `med_rings` rings (the
 // wave-cooperative slow path takes what is left).  Entries it finishes are marked with LB = +inf.
-constexpr int kMedRings = 12;
 
 template <typename T>
 __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                  const T *__restrict__ rd, int *__restrict__ slot_io, T *__restrict__ d2_out,
                                                  ChainDev<T> ch, int *__restrict__ slow_count,
                                                  const int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
-                                                 int *__restrict__ slow_ring, int *__restrict__ slow2_idx)
+                                                 int *__restrict__ slow_ring, int *__restrict__ slow2_idx, int med_rings)
 {
     const int count = *slow_count;
     const int lane = threadIdx.x;
@@ -995,7 +994,7 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
         }
         T gr;
         int r_next;
-        bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, slow_ring[k], kMedRings, cap2, best, gr, r_next);
+        bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, slow_ring[k], med_rings, cap2, best, gr, r_next);
         if (capped && best.slot < 0) {
             // nothing within 1.1x the threshold: irrelevant for the filter, keep it queued beyond reach
             const bool seed_ok = seed.slot >= 0 && seed.d2 <= ch.max_dist2;
@@ -1794,10 +1793,11 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
 
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
-                    const ChainDev<T> &ch, int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring, int *slow2_idx)
+                    const ChainDev<T> &ch, int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring, int *slow2_idx,
+                    int med_rings)
 {
     hipLaunchKernelGGL(k_knn_med<T>, dim3(8192), dim3(64), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list, slow_lb,
-                       slow_ring, slow2_idx);
+                       slow_ring, slow2_idx, med_rings);
 }
 
 // resolves the queries the fast path queued: all of them (exact_all, public matcher
@@ -1890,7 +1890,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
                                 const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *);         \
     template void launch_knn_med<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                  \
-                                    const ChainDev<T> &, int *, const int2 *, T *, int *, int *);                         \
+                                    const ChainDev<T> &, int *, const int2 *, T *, int *, int *, int);                    \
     template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \
                                      const ChainDev<T> &, const int *, const int2 *, const T *, const int *, int);        \
     template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int, int, const int *); \

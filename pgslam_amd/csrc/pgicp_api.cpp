@@ -86,7 +86,8 @@ struct pgicp_ctx {
     // and destroys one index per candidate pair.
     std::multimap<size_t, char *> block_pool;
     size_t pooled_bytes = 0;
-    int fast_rings_seeded = 1, fast_rings_unseeded = 3;   // rings walked in the fast kernel before a query is queued
+    int fast_rings_seeded = 1, fast_rings_unseeded = 3;
+    int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
     std::vector<ProfEvent> prof_events;
     long long prof_launches[PGICP_PROF_COUNT] = {0};
@@ -560,7 +561,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
             ProfScope ps(c, PGICP_PROF_KNN_SLOW, act_units, act_probs);
             launch_knn_med<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
                               ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), c->slow_ring.as<int>(),
-                              c->slow2.as<int>());
+                              c->slow2.as<int>(), c->med_rings);
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
                                c->slow2.as<int>(), 0);
@@ -991,6 +992,26 @@ int map_create_batch_abi(pgicp_ctx *c, int n, const T *const *xyz, const int *xs
     for (int k = 0; k < n; k++) src[k] = MapSrc<T>{xyz[k], xs[k], nrm ? nrm[k] : nullptr, nrm ? ns[k] : 0, m[k]};
     return map_create_batch<T>(c, n, src.data(), mem, center, ids);
 }
+template <typename T>
+int map_transfer_impl(pgicp_ctx *from, int id, pgicp_ctx *to, int *new_id)
+{
+    MapHost<T> *src = get_map<T>(from, id);
+    if (!src) return -1;
+    hipEvent_t ev;
+    HIPC(to, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPC(to, hipEventRecord(ev, from->stream));
+    HIPC(to, hipStreamWaitEvent(to->stream, ev, 0));
+    HIPC(to, hipEventDestroy(ev));                 // released once the recorded work has completed
+    State<T> &S = state<T>(to);
+    int slot = -1;
+    for (size_t i = 0; i < S.maps.size(); i++) if (!S.maps[i].used) { slot = (int)i; break; }
+    if (slot < 0) { S.maps.push_back(MapHost<T>()); slot = (int)S.maps.size() - 1; }
+    S.maps[slot] = *src;
+    *src = MapHost<T>();                           // ownership of the device block moves with the record
+    *new_id = slot | id_tag<T>();
+    return sync_maps_table<T>(to);
+}
+
 extern "C" {
 
 int pgicp_abi_version(void) { return PGICP_ABI_VERSION; }
@@ -1031,6 +1052,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     c->device = device;
     pgicp_default_params(&c->prm);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_SEEDED")) c->fast_rings_seeded = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
@@ -1116,6 +1138,18 @@ int pgicp_map_destroy(pgicp_ctx *c, int id)
     if (MapHost<float> *m = get_map<float>(c, id)) { free_map(c, *m); return PGICP_OK; }
     if (MapHost<double> *m = get_map<double>(c, id)) { free_map(c, *m); return PGICP_OK; }
     return fail(c, PGICP_ERR_ARG, "pgicp_map_destroy: unknown map id");
+}
+
+int pgicp_map_transfer(pgicp_ctx *from, int id, pgicp_ctx *to, int *new_id)
+{
+    if (!from || !to || !new_id) return PGICP_ERR_ARG;
+    if (from == to) { *new_id = id; return PGICP_OK; }
+    if (from->device != to->device) return fail(to, PGICP_ERR_ARG, "pgicp_map_transfer: contexts are on different devices");
+    (void)hipSetDevice(to->device);
+    int st = map_transfer_impl<float>(from, id, to, new_id);
+    if (st == -1) st = map_transfer_impl<double>(from, id, to, new_id);
+    if (st == -1) return fail(to, PGICP_ERR_ARG, "pgicp_map_transfer: unknown map id");
+    return st;
 }
 
 int pgicp_map_size(pgicp_ctx *c, int id, int *m)

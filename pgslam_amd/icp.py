@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "pgicp_abi_version", "pgicp_device_count", "pgicp_ctx_create", "pgicp_ctx_destroy", "pgicp_last_error",
     "pgicp_ctx_stream", "pgicp_ctx_synchronize", "pgicp_default_params", "pgicp_set_params", "pgicp_get_params",
     "pgicp_map_create_f32", "pgicp_map_create_f64", "pgicp_map_create_batch_f32", "pgicp_map_create_batch_f64",
-    "pgicp_map_destroy", "pgicp_map_size",
+    "pgicp_map_destroy", "pgicp_map_size", "pgicp_map_transfer",
     "pgicp_align_f32", "pgicp_align_f64", "pgicp_align_batch_f32", "pgicp_align_batch_f64",
     "pgicp_icp_pair_f32", "pgicp_icp_pair_f64", "pgicp_match_f32", "pgicp_match_f64",
     "pgicp_outlier_weights_f32", "pgicp_outlier_weights_f64", "pgicp_error_stats_f32", "pgicp_error_stats_f64",
@@ -356,22 +356,40 @@ class Context:
         return out
 
     def build_local_map(self, clouds_xyz, clouds_nrm, T_ref_kf, dtype=np.float32):
+        """LocalMap::BuildCloudFromData.  numpy clouds -> numpy outputs; torch CUDA clouds (a device-resident
+        keyframe cache) -> torch CUDA outputs, nothing crosses PCIe."""
         k = len(clouds_xyz)
         xs = [_Buf(c, dtype) for c in clouds_xyz]
         ns = [_Buf(c, dtype) for c in clouds_nrm]
+        dtype = xs[0].dtype
+        mem = xs[0].mem
+        assert all(b.mem == mem and b.dtype == dtype for b in xs + ns)
         counts = (C.c_int * k)(*[b.n for b in xs])
         sx = (C.c_int * k)(*[b.stride for b in xs])
         sn = (C.c_int * k)(*[b.stride for b in ns])
         Ts = np.ascontiguousarray(np.stack([np.asarray(t, dtype=np.float64).reshape(4, 4) for t in T_ref_kf]))
         total = sum(b.n for b in xs)
-        out_x = np.zeros((total, 3), dtype=dtype)
-        out_n = np.zeros((total, 3), dtype=dtype)
+        if mem == DEVICE:
+            import torch
+            like = clouds_xyz[0]
+            out_x = torch.empty((total, 3), dtype=like.dtype, device=like.device)
+            out_n = torch.empty((total, 3), dtype=like.dtype, device=like.device)
+            px, pn = out_x.data_ptr(), out_n.data_ptr()
+        else:
+            out_x = np.zeros((total, 3), dtype=dtype)
+            out_n = np.zeros((total, 3), dtype=dtype)
+            px, pn = out_x.ctypes.data, out_n.ctypes.data
         PP = C.c_void_p * k
         fn = getattr(self.lib, "pgicp_build_local_map" + self._sfx(dtype))
         self._check(fn(self.h, C.c_int(k), PP(*[b.ptr for b in xs]), PP(*[b.ptr for b in ns]), sx, sn, counts,
-                       C.c_void_p(Ts.ctypes.data), C.c_void_p(out_x.ctypes.data), C.c_int(3), C.c_void_p(out_n.ctypes.data),
-                       C.c_int(3), C.c_int(HOST)))
+                       C.c_void_p(Ts.ctypes.data), C.c_void_p(px), C.c_int(3), C.c_void_p(pn), C.c_int(3), C.c_int(mem)))
         return out_x, out_n
+
+    def adopt_map(self, other: "Context", map_id: int) -> int:
+        """Take over a map built by another context of the same device (pgicp_map_transfer)."""
+        new_id = C.c_int(-1)
+        self._check(self.lib.pgicp_map_transfer(other.h, C.c_int(map_id), self.h, C.byref(new_id)))
+        return new_id.value
 
     # ---- measurement --------------------------------------------------------
     def profile_enable(self, on=True):

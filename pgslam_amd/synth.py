@@ -332,3 +332,39 @@ def make_two_scans(n_pts: int = 10_000, rings: int = 16):
     T_true = se3_inv(T_a) @ T_b
     return dict(ref_xyz=ref_xyz, ref_nrm=ref_nrm, reading_xyz=rd_xyz, reading_nrm=rd_nrm,
                 T_truth=T_true, T_init=T_true @ perturbation(9000))
+
+
+@dataclass
+class Drive:
+    poses_true: list    # S x 4x4 T_world_robot
+    odom: list          # S x 4x4 odometry poses (true increments + drift)
+    scans_xyz: list     # S x (N,3) robot frame
+    scans_nrm: list
+
+
+DRIVE_SEED = 0x5EED0004
+
+
+def make_drive(n_scans: int, n_pts: int = 100_000, step: float = 0.35, rings: int = 64, x0: float = -40.0,
+               odom_sigma_t: float = 0.02, odom_sigma_yaw_deg: float = 0.15) -> Drive:
+    """BASELINE.json configs[2]: a 10 Hz feed along the street (`step` m per scan, gentle weaving);
+    the odometry reports every true increment with a small error, so its pose drifts and the ICP
+    has something to correct (Localizer.hpp:119-127)."""
+    world = make_world()
+    u = uniform01(DRIVE_SEED, 3 * n_scans)
+    poses, odom = [], []
+    T_o = None
+    for s in range(n_scans):
+        yaw = math.radians(3.0) * math.sin(0.15 * s)
+        T = se3(x=x0 + step * s, y=0.8 * math.sin(0.05 * s), yaw=yaw)
+        if s == 0:
+            T_o = T.copy()
+        else:
+            d_true = se3_inv(poses[-1]) @ T
+            err = se3(x=odom_sigma_t * (2 * u[3 * s] - 1), y=odom_sigma_t * (2 * u[3 * s + 1] - 1),
+                      yaw=math.radians(odom_sigma_yaw_deg) * (2 * u[3 * s + 2] - 1))
+            T_o = T_o @ d_true @ err
+        poses.append(T)
+        odom.append(T_o.copy())
+    scans = [make_scan(world, poses[s], n_pts, 7000 + s, rings=rings) for s in range(n_scans)]
+    return Drive(poses, odom, [c[0] for c in scans], [c[1] for c in scans])
