@@ -525,7 +525,9 @@ def main():
     last = None
     for _ in range(args.steps):
         T, st = step()
-        converged += sum(1 for s in st if s["status"] == 0 and s["converged"])
+        # --fixed-iters disables the Differential checker (workload-stable figure):
+        # every scan that ran its 30 iterations with status OK counts
+        converged += sum(1 for s in st if s["status"] == 0 and (s["converged"] or args.fixed_iters))
         iters += [s["iterations"] for s in st]
         last = (T, st)
     fence()
@@ -588,7 +590,8 @@ def main():
     if rank == 0:
         value = converged_all / elapsed_max
         out = {
-            "metric": "ICP-converged scans/sec at 100k-pt scan vs 1M-pt local map",
+            "metric": ("ICP-converged scans/sec at 100k-pt scan vs 1M-pt local map" if not args.fixed_iters else
+                       "scans/sec at 100k-pt scan vs 1M-pt local map, fixed 30 iterations"),
             "value": value,
             "unit": "scans/s",
             "n_gpus": world,

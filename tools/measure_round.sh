@@ -1,0 +1,24 @@
+#!/bin/bash
+# The round's measurement record (run on the GPU box through gpurun): default bench line, the kernel
+# trace of the same command, the HBM-traffic counters in their own passes, and the two other workloads.
+set -u
+OUT=gpurun_out/measure
+mkdir -p $OUT
+python3 bench.py --prepare-only > /dev/null 2>&1
+python3 bench.py --workload stream --prepare-only > /dev/null 2>&1
+python3 bench.py 2>/dev/null | tail -1 > $OUT/bench_n1.json
+python3 bench.py --fixed-iters --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_n1_fixed30.json
+python3 bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_loopclosure.json
+python3 bench.py --workload stream --streams 1 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_1.json
+python3 bench.py --workload stream --streams 4 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_4.json
+REPO=$PWD
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace -o t -- python3 $REPO/bench.py > $REPO/$OUT/trace.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $REPO/$OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $REPO/$OUT/pmc_write.log 2>&1
+cd $REPO
+python3 tools/trace_summary.py $OUT/trace > $OUT/trace_summary.txt 2>&1
+python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/knn_traffic.json 100000 1000000 128 > $OUT/pmc.log 2>&1
+rm -rf $OUT/pmc_fetch/*/*.db $OUT/trace/*.db 2>/dev/null
+for f in $OUT/bench_*.json; do echo "$f: $(cut -c1-260 $f)"; done
+cat $OUT/pmc.log | tail -2; head -8 $OUT/trace_summary.txt
