@@ -239,6 +239,21 @@ int pgicp_build_local_map_f64(pgicp_ctx *ctx, int n_kf, const double *const *xyz
                               const double *T_ref_kf, double *out_xyz, int out_xyz_stride, double *out_nrm,
                               int out_nrm_stride, int mem);
 
+/* ---- input filters ---------------------------------------------------------
+ * pgicp_surface_normals = [EXT] libpointmatcher SurfaceNormalDataPointsFilter{knn, maxDist,
+ * epsilon = 0, keepNormals = 1, keepEigenValues, keepMatchedIds} as a user's input-filter or
+ * reference-filter YAML applies it (input_filters_.apply, Localizer.hpp:103; referenceDataPointsFilters
+ * .apply, Localizer.hpp:315): for every point the knn nearest points of the SAME cloud (itself
+ * included, within maxDist), their scatter matrix, and the unit eigenvector of its smallest
+ * eigenvalue.  out_nrm: 3 values per point at out_stride; out_eig (optional): 3 eigenvalues per
+ * point, ascending; out_ids / out_d2 (optional): knn neighbour indices / squared distances per
+ * point in (distance, index) order, -1 / +inf where fewer than knn lie within maxDist.  A scatter
+ * of rank < 2 yields libpointmatcher's defaults: normal (0,1,0), eigenvalues (0,0,1).  knn <= 32. */
+int pgicp_surface_normals_f32(pgicp_ctx *ctx, const float *xyz, int stride, int n, int mem, int knn, double max_dist,
+                              float *out_nrm, int out_stride, float *out_eig, int32_t *out_ids, float *out_d2);
+int pgicp_surface_normals_f64(pgicp_ctx *ctx, const double *xyz, int stride, int n, int mem, int knn, double max_dist,
+                              double *out_nrm, int out_stride, double *out_eig, int32_t *out_ids, double *out_d2);
+
 /* ---- loop-closure dispatcher helpers (host logic, no GPU needed) -------
  * pgicp_shard_pairs: deterministic longest-processing-time split of n_pairs
  * candidate ICPs (cost[i] ~ N_i + M_i) over world_size ranks; writes the pair
@@ -264,7 +279,8 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
 #define PGICP_PROF_COV 6
 #define PGICP_PROF_GRID_BUILD 7
 #define PGICP_PROF_KNN_SLOW 8
-#define PGICP_PROF_COUNT 9
+#define PGICP_PROF_NORMALS 9
+#define PGICP_PROF_COUNT 10
 /* diagnostics of the last kNN launch: [0] queries queued by the fast path, [1] queued queries
  * resolved because their existence was unknown, [2] resolved because their lower bound was
  * within the trim threshold, [3] reserved. */

@@ -54,6 +54,7 @@ template <> struct Abi<float> {
     static int weights(pgicp_ctx *c, const float *d2, int n, float *w, float *lim, int *nf) { return pgicp_outlier_weights_f32(c, d2, n, PGICP_HOST, w, lim, nf); }
     static int stats(pgicp_ctx *c, int id, const float *r, int s, int n, const int32_t *ids, const float *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f32(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
     static int map_create_batch(pgicp_ctx *c, int k, const float *const *x, const int *xs, const float *const *n, const int *ns, const int *m, int center, int *ids) { return pgicp_map_create_batch_f32(c, k, x, xs, n, ns, m, PGICP_HOST, center, ids); }
+    static int normals(pgicp_ctx *c, const float *x, int xs, int n, int knn, double md, float *out, int os, float *eig) { return pgicp_surface_normals_f32(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, nullptr, nullptr); }
     static int partial(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const float *in, int is, float *out, int os, int n, int ro) { return pgicp_transform_f32(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
@@ -65,6 +66,7 @@ template <> struct Abi<double> {
     static int weights(pgicp_ctx *c, const double *d2, int n, double *w, double *lim, int *nf) { return pgicp_outlier_weights_f64(c, d2, n, PGICP_HOST, w, lim, nf); }
     static int stats(pgicp_ctx *c, int id, const double *r, int s, int n, const int32_t *ids, const double *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f64(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
     static int map_create_batch(pgicp_ctx *c, int k, const double *const *x, const int *xs, const double *const *n, const int *ns, const int *m, int center, int *ids) { return pgicp_map_create_batch_f64(c, k, x, xs, n, ns, m, PGICP_HOST, center, ids); }
+    static int normals(pgicp_ctx *c, const double *x, int xs, int n, int knn, double md, double *out, int os, double *eig) { return pgicp_surface_normals_f64(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, nullptr, nullptr); }
     static int partial(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const double *in, int is, double *out, int os, int n, int ro) { return pgicp_transform_f64(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
@@ -283,6 +285,32 @@ struct PointMatcher {
             if (c.descriptors.rows()) c.descriptors.conservativeResize(c.descriptors.rows(), k);
         }
     };
+    //! [EXT] SurfaceNormalDataPointsFilter{knn, maxDist, epsilon, keepNormals, keepEigenValues}: normals (and,
+    //! on request, eigenvalues) of every point from its knn neighbours, computed on the device by
+    //! pgicp_surface_normals_*; the descriptors are appended as libpointmatcher appends them.
+    struct SurfaceNormalDataPointsFilter : DataPointsFilter {
+        int knn = 5; T maxDist = std::numeric_limits<T>::infinity(); bool keepNormals = true, keepEigenValues = false;
+        pgicp_ctx *ctx = nullptr;
+        SurfaceNormalDataPointsFilter(int k, T md, bool kn, bool ke) : knn(k), maxDist(md), keepNormals(kn), keepEigenValues(ke)
+        {
+            const int st = pgicp_ctx_create(0, &ctx);
+            if (st != PGICP_OK) throw std::runtime_error(std::string("SurfaceNormalDataPointsFilter: ") + pgicp_last_error(nullptr));
+        }
+        ~SurfaceNormalDataPointsFilter() override { if (ctx) pgicp_ctx_destroy(ctx); }
+        SurfaceNormalDataPointsFilter(const SurfaceNormalDataPointsFilter &) = delete;
+        SurfaceNormalDataPointsFilter &operator=(const SurfaceNormalDataPointsFilter &) = delete;
+        void inPlaceFilter(DataPoints &c) override
+        {
+            const int n = (int)c.features.cols();
+            if (n == 0 || (!keepNormals && !keepEigenValues)) return;
+            Matrix nrm(3, n), eig(3, n);
+            const double md = std::isfinite((double)maxDist) ? (double)maxDist : 1e300;
+            check(ctx, pgslam_amd::Abi<T>::normals(ctx, c.features.data(), (int)c.features.rows(), n, knn, md, nrm.data(), 3,
+                                                   keepEigenValues ? eig.data() : nullptr));
+            if (keepNormals) c.addDescriptor("normals", nrm);
+            if (keepEigenValues) c.addDescriptor("eigValues", eig);
+        }
+    };
     struct DataPointsFilters : std::vector<std::shared_ptr<DataPointsFilter>> {
         DataPointsFilters() {}
         //! Localizer.hpp:77 -- a YAML list of filters
@@ -302,9 +330,19 @@ struct PointMatcher {
                     if (m.params.count("dim") && m.params.at("dim") != "-1") throw std::runtime_error(m.name + ": only dim = -1 (radius) is supported");
                     const T lim = (T)to_double(m.params.count("maxDist") ? m.params.at("maxDist") : m.params.count("minDist") ? m.params.at("minDist") : "1", m.name);
                     this->push_back(std::make_shared<DistLimitDataPointsFilter>(lim, m.name == "MaxDistDataPointsFilter"));
+                } else if (m.name == "SurfaceNormalDataPointsFilter") {
+                    auto get = [&](const char *k, const char *def) { return m.params.count(k) ? m.params.at(k) : std::string(def); };
+                    if (to_double(get("epsilon", "0"), m.name) != 0.0) throw std::runtime_error(m.name + ": only epsilon = 0 (exact search) is supported");
+                    for (const char *k : {"keepDensities", "keepEigenVectors", "keepMatchedIds", "keepMeanDist", "smoothNormals"})
+                        if (to_double(get(k, "0"), m.name) != 0.0) throw std::runtime_error(m.name + ": " + k + " is not supported");
+                    const int knn = (int)to_double(get("knn", "5"), m.name);
+                    if (knn < 3 || knn > 32) throw std::runtime_error(m.name + ": knn must be in [3, 32]");
+                    this->push_back(std::make_shared<SurfaceNormalDataPointsFilter>(knn, (T)to_double(get("maxDist", "inf"), m.name),
+                                                                                     to_double(get("keepNormals", "1"), m.name) != 0.0,
+                                                                                     to_double(get("keepEigenValues", "0"), m.name) != 0.0));
                 } else
                     throw std::runtime_error("DataPointsFilters: unsupported filter '" + m.name +
-                                             "' (surface-normal / sampling filters are scheduled work, SURVEY.md §8(f))");
+                                             "' (supported: Identity, MinDist, MaxDist, SurfaceNormal)");
             }
         }
         void init() { for (auto &f : *this) f->init(); }

@@ -55,9 +55,11 @@
 
 #ifdef ORC_DOUBLE
 typedef double real;
+#define REAL_EPS DBL_EPSILON
 #define FN(name) name##_f64
 #else
 typedef float real;
+#define REAL_EPS FLT_EPSILON
 #define FN(name) name##_f32
 #endif
 
@@ -303,6 +305,137 @@ void FN(orc_kdtree_knn)(const void *h, const real *q, int nq, real max_dist, int
         if (bi >= 0 && best <= md2) { ids[i] = bi; d2[i] = best; }
         else { ids[i] = -1; d2[i] = INFINITY; }
     }
+}
+
+/* --------------------------------------------------------------------------
+ * k nearest neighbours (k > 1) -- libnabo's KDTreeMatcher with knn = k as
+ * SurfaceNormalDataPointsFilter uses it on the cloud itself.  Per query the k
+ * best (d2, index) pairs in lexicographic order; missing ones are -1 / +inf.
+ * ------------------------------------------------------------------------ */
+typedef struct { real *d; int *i; int k; } kbest;
+
+static inline void kbest_push(kbest *b, real d, int j)
+{
+    const int k = b->k;
+    if (!(d < b->d[k - 1] || (d == b->d[k - 1] && j < b->i[k - 1]))) return;
+    int p = k - 1;
+    while (p > 0 && (d < b->d[p - 1] || (d == b->d[p - 1] && j < b->i[p - 1]))) { b->d[p] = b->d[p - 1]; b->i[p] = b->i[p - 1]; --p; }
+    b->d[p] = d; b->i[p] = j;
+}
+
+static void kd_search_k(const kdtree *t, int node, const real *q, kbest *b)
+{
+    const int ax = t->node_axis[node];
+    if (ax < 0) {
+        for (int i = t->node_lo[node]; i < t->node_hi[node]; i++) {
+            const int j = t->perm[i];
+            kbest_push(b, dist2(q, t->pts + 3 * j), j);
+        }
+        return;
+    }
+    const real diff = q[ax] - t->node_split[node];
+    const int near = diff < 0 ? t->node_left[node] : t->node_right[node];
+    const int far = diff < 0 ? t->node_right[node] : t->node_left[node];
+    kd_search_k(t, near, q, b);
+    if (!(diff * diff > b->d[b->k - 1])) kd_search_k(t, far, q, b);     /* same conservative prune as kd_search */
+}
+
+void FN(orc_kdtree_knn_k)(const void *h, const real *q, int nq, int k, real max_dist, int *ids, real *d2)
+{
+    const kdtree *t = (const kdtree *)h;
+    const real md2 = max_dist * max_dist;
+    for (int i = 0; i < nq; i++) {
+        kbest b = { d2 + (size_t)i * k, ids + (size_t)i * k, k };
+        for (int j = 0; j < k; j++) { b.d[j] = md2; b.i[j] = INT32_MAX; }   /* anything beyond maxDist is useless */
+        if (t->n > 0) kd_search_k(t, 0, q + 3 * i, &b);
+        for (int j = 0; j < k; j++)
+            if (b.i[j] == INT32_MAX || !(b.d[j] <= md2)) { b.i[j] = -1; b.d[j] = INFINITY; }
+    }
+}
+
+/* cyclic Jacobi eigen-decomposition of a symmetric 3x3 (double): a -> diag(ev), columns of v */
+static void jacobi3(double a[3][3], double v[3][3], double ev[3])
+{
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) v[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; sweep++) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                for (int r = 0; r < 3; r++) {                 /* A <- A J */
+                    const double arp = a[r][p], arq = a[r][q];
+                    a[r][p] = c * arp - s * arq; a[r][q] = s * arp + c * arq;
+                }
+                for (int r = 0; r < 3; r++) {                 /* A <- J^T A */
+                    const double apr = a[p][r], aqr = a[q][r];
+                    a[p][r] = c * apr - s * aqr; a[q][r] = s * apr + c * aqr;
+                }
+                for (int r = 0; r < 3; r++) {
+                    const double vrp = v[r][p], vrq = v[r][q];
+                    v[r][p] = c * vrp - s * vrq; v[r][q] = s * vrp + c * vrq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; i++) ev[i] = a[i][i];
+}
+
+/* --------------------------------------------------------------------------
+ * [EXT] SurfaceNormalDataPointsFilter{knn, maxDist, epsilon = 0, keepNormals, keepEigenValues}
+ * (libpointmatcher, version unpinned; applied by pgslam at Localizer.hpp:103 / 314-326 when the
+ * user's YAML asks for it).  Per point: its knn nearest neighbours in the cloud itself (the point
+ * included), mean and scatter matrix C = sum (p - mean)(p - mean)^T accumulated in T in
+ * neighbour order, eigen-decomposition, normal = unit eigenvector of the smallest eigenvalue
+ * (the sign is the solver's; point-to-plane ICP is invariant to it).  A neighbourhood whose
+ * scatter has rank < 2 keeps libpointmatcher's defaults (eigenvalues (1,0,0), eigenvectors I),
+ * which makes the normal (0,1,0) -- [EXT, unverified here].  Eigenvalues are returned ascending
+ * (sortEigen = 1).  The eigen solver is cyclic Jacobi in double, not Eigen's EigenSolver.
+ * ------------------------------------------------------------------------ */
+int FN(orc_surface_normals)(const real *xyz, int n, int knn, real max_dist, real *nrm, real *eigval, int *ids_out, real *d2_out)
+{
+    if (n <= 0 || knn < 1) return ORC_ERR_ARG;
+    void *tree = FN(orc_kdtree_build)(xyz, n);
+    int *ids = ids_out ? ids_out : (int *)malloc(sizeof(int) * (size_t)n * knn);
+    real *d2 = d2_out ? d2_out : (real *)malloc(sizeof(real) * (size_t)n * knn);
+    FN(orc_kdtree_knn_k)(tree, xyz, n, knn, max_dist, ids, d2);
+    for (int i = 0; i < n; i++) {
+        const int *nb = ids + (size_t)i * knn;
+        int cnt = 0;
+        real sx = 0, sy = 0, sz = 0;
+        for (int j = 0; j < knn; j++)
+            if (nb[j] >= 0) { sx += xyz[3 * nb[j]]; sy += xyz[3 * nb[j] + 1]; sz += xyz[3 * nb[j] + 2]; cnt++; }
+        real c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+        if (cnt > 0) {
+            const real mx = sx / (real)cnt, my = sy / (real)cnt, mz = sz / (real)cnt;
+            for (int j = 0; j < knn; j++)
+                if (nb[j] >= 0) {
+                    const real dx = xyz[3 * nb[j]] - mx, dy = xyz[3 * nb[j] + 1] - my, dz = xyz[3 * nb[j] + 2] - mz;
+                    c00 += dx * dx; c01 += dx * dy; c02 += dx * dz; c11 += dy * dy; c12 += dy * dz; c22 += dz * dz;
+                }
+        }
+        double A[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}}, V[3][3], ev[3];
+        jacobi3(A, V, ev);
+        int lo = 0, hi = 0;
+        for (int k = 1; k < 3; k++) { if (ev[k] < ev[lo]) lo = k; if (ev[k] > ev[hi]) hi = k; }
+        const int mid = 3 - lo - hi;
+        /* rank >= 2  <=>  the middle eigenvalue is not negligible against the largest */
+        const double tol = 3.0 * (double)REAL_EPS;
+        const int degenerate = lo == hi || !(ev[hi] > 0.0) || !(ev[mid] > tol * ev[hi]);
+        if (degenerate) {
+            nrm[3 * i] = 0; nrm[3 * i + 1] = 1; nrm[3 * i + 2] = 0;
+            if (eigval) { eigval[3 * i] = 0; eigval[3 * i + 1] = 0; eigval[3 * i + 2] = 1; }
+        } else {
+            nrm[3 * i] = (real)V[0][lo]; nrm[3 * i + 1] = (real)V[1][lo]; nrm[3 * i + 2] = (real)V[2][lo];
+            if (eigval) { eigval[3 * i] = (real)ev[lo]; eigval[3 * i + 1] = (real)ev[mid]; eigval[3 * i + 2] = (real)ev[hi]; }
+        }
+    }
+    FN(orc_kdtree_free)(tree);
+    if (!ids_out) free(ids);
+    if (!d2_out) free(d2);
+    return ORC_OK;
 }
 
 /* --------------------------------------------------------------------------

@@ -152,6 +152,30 @@ class Oracle:
                                   self._p(w), self._p(dT), C.c_double(sensor_std_dev), self._p(cov))
         return cov
 
+    def knn_k(self, ref, q, k, max_dist=np.inf):
+        """k nearest neighbours of every q in ref: (ids (n,k), d2 (n,k)), lexicographic (d2, index) order."""
+        ref, q = self._a(ref), self._a(q)
+        f = self._f("orc_kdtree_build"); f.restype = C.c_void_p
+        t = C.c_void_p(f(self._p(ref), C.c_int(ref.shape[0])))
+        ids = np.empty((q.shape[0], k), dtype=np.int32)
+        d2 = np.empty((q.shape[0], k), dtype=self.dtype)
+        self._f("orc_kdtree_knn_k")(t, self._p(q), C.c_int(q.shape[0]), C.c_int(k), self.real(max_dist), self._p(ids), self._p(d2))
+        self._f("orc_kdtree_free")(t)
+        return ids, d2
+
+    def surface_normals(self, xyz, knn, max_dist=np.inf):
+        """SurfaceNormalDataPointsFilter: dict(normals (n,3), eigen_values (n,3) ascending, ids (n,knn), d2 (n,knn))."""
+        xyz = self._a(xyz)
+        n = xyz.shape[0]
+        nrm = np.empty((n, 3), dtype=self.dtype)
+        ev = np.empty((n, 3), dtype=self.dtype)
+        ids = np.empty((n, knn), dtype=np.int32)
+        d2 = np.empty((n, knn), dtype=self.dtype)
+        st = self._f("orc_surface_normals")(self._p(xyz), C.c_int(n), C.c_int(knn), self.real(max_dist), self._p(nrm), self._p(ev),
+                                            self._p(ids), self._p(d2))
+        assert st == 0
+        return dict(normals=nrm, eigen_values=ev, ids=ids, d2=d2)
+
     def build_local_map(self, clouds_xyz, clouds_nrm, T_ref_kf):
         """clouds[0] is the reference keyframe; T_ref_kf[k] moves cloud k into its frame."""
         k = len(clouds_xyz)

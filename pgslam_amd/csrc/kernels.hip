@@ -1195,6 +1195,198 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
     }
 }
 
+// ---------------------------------------------------------------------------
+// SurfaceNormalDataPointsFilter ([EXT] libpointmatcher): per point
+// of a cloud its knn nearest neighbours IN the cloud, the scatter matrix of those neighbours and the
+// eigenvector of its smallest eigenvalue.  The cloud is indexed like any map; lane i owns the point
+// in slot i, so a wave is 64 points of one run of cells and shares its neighbourhood in L1.
+// The K-entry candidate list lives in registers (every loop over it is unrolled, no dynamic index);
+// K - knn dummy entries with distance -1 sit at its front and are never displaced, so the last entry
+// is always the current knn-th best: the pruning bound.  Order = lexicographic (d2, original index),
+// the order the oracle's k-d tree produces.
+// ---------------------------------------------------------------------------
+template <typename T, int K>
+struct TopK {
+    T d[K];
+    int idx[K];
+    int slot[K];
+};
+
+template <typename T, int K>
+__device__ __forceinline__ void topk_offer(TopK<T, K> &L, T d, int idx, int slot)
+{
+    if (!(d < L.d[K - 1] || (d == L.d[K - 1] && idx < L.idx[K - 1]))) return;
+    L.d[K - 1] = d; L.idx[K - 1] = idx; L.slot[K - 1] = slot;
+#pragma unroll
+    for (int p = K - 1; p > 0; --p) {
+        const bool sw = L.d[p] < L.d[p - 1] || (L.d[p] == L.d[p - 1] && L.idx[p] < L.idx[p - 1]);
+        const T td = L.d[p]; const int ti = L.idx[p], ts = L.slot[p];
+        L.d[p] = sw ? L.d[p - 1] : td;       L.idx[p] = sw ? L.idx[p - 1] : ti;       L.slot[p] = sw ? L.slot[p - 1] : ts;
+        L.d[p - 1] = sw ? td : L.d[p - 1];   L.idx[p - 1] = sw ? ti : L.idx[p - 1];   L.slot[p - 1] = sw ? ts : L.slot[p - 1];
+    }
+}
+
+template <typename T, int K>
+__device__ __forceinline__ void topk_row(const MapDev<T> &M, int row_base, int xa, int xb, T ux, T lb2, T qx, T qy, T qz,
+                                         TopK<T, K> &L)
+{
+    const T bound = L.d[K - 1];
+    if (bound < Bits<T>::inf()) {
+        const T rad = sqrt(fmax(bound - lb2, (T)0)) + M.g.margin;
+        xa = max(xa, clamp_cell<T>(ux - rad, M.g.inv_h, M.g.nx));
+        xb = min(xb, clamp_cell<T>(ux + rad, M.g.inv_h, M.g.nx));
+        if (xa > xb) return;
+    }
+    const auto *cs = as_global(M.cell_start);
+    const int a = cs[row_base + xa], b = cs[row_base + xb + 1];
+    for (int s = a; s < b; ++s) {
+        const auto v = load_rec<T>(M.pts, s);
+        const T dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+        topk_offer<T, K>(L, (dx * dx + dy * dy) + dz * dz, Bits<T>::unpack_idx(v.w), s);
+    }
+}
+
+// cyclic Jacobi on a symmetric 3x3 in double -- the same sequence of operations as the oracle's jacobi3
+__device__ __forceinline__ void jacobi3(double a[3][3], double v[3][3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) v[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; sweep++) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const double arp = a[r][p], arq = a[r][q];
+                    a[r][p] = c * arp - s * arq; a[r][q] = s * arp + c * arq;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const double apr = a[p][r], aqr = a[q][r];
+                    a[p][r] = c * apr - s * aqr; a[q][r] = s * apr + c * aqr;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const double vrp = v[r][p], vrq = v[r][q];
+                    v[r][p] = c * vrp - s * vrq; v[r][q] = s * vrp + c * vrq;
+                }
+            }
+    }
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(128) void k_surface_normals(const MapDev<T> *__restrict__ maps, int map, int knn, T max_dist,
+                                                          T eps_rank, T *__restrict__ out_nrm, int out_stride,
+                                                          T *__restrict__ out_eig, int *__restrict__ out_ids,
+                                                          T *__restrict__ out_d2)
+{
+    const MapDev<T> M = maps[map];
+    const GridDesc<T> g = M.g;
+    const int s0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s0 >= M.m) return;
+    const auto me = load_rec<T>(M.pts, s0);
+    const T qx = me.x, qy = me.y, qz = me.z;
+    const int self = Bits<T>::unpack_idx(me.w);
+    const T md2 = max_dist * max_dist;
+    TopK<T, K> L;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const bool real = j >= K - knn;
+        L.d[j] = real ? md2 : (T)-1;              // anything beyond maxDist is useless
+        L.idx[j] = real ? 0x7FFFFFFF : -1;
+        L.slot[j] = -1;
+    }
+    const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
+    const int c0x = clamp_cell<T>(ux, g.inv_h, g.nx), c0y = clamp_cell<T>(uy, g.inv_h, g.ny), c0z = clamp_cell<T>(uz, g.inv_h, g.nz);
+    for (int r = 0;; ++r) {
+        const int z0 = max(c0z - r, 0), z1 = min(c0z + r, g.nz - 1);
+        const int y0 = max(c0y - r, 0), y1 = min(c0y + r, g.ny - 1);
+        const int xa = max(c0x - r, 0), xb = min(c0x + r, g.nx - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
+            const bool zo = (z - c0z == r) || (c0z - z == r);
+            for (int y = y0; y <= y1; ++y) {
+                const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
+                const T lb2 = ly * ly + lz * lz;
+                if (lb2 > L.d[K - 1]) continue;
+                const int row = g.nx * (y + g.ny * z);
+                if (zo || (y - c0y == r) || (c0y - y == r)) {
+                    topk_row<T, K>(M, row, xa, xb, ux, lb2, qx, qy, qz, L);
+                } else {                         // inner row of the shell: only its two end cells are new
+                    if (c0x - r >= 0) topk_row<T, K>(M, row, c0x - r, c0x - r, ux, lb2, qx, qy, qz, L);
+                    if (c0x + r <= g.nx - 1 && r > 0) topk_row<T, K>(M, row, c0x + r, c0x + r, ux, lb2, qx, qy, qz, L);
+                }
+            }
+        }
+        T gr = ring_guarantee<T>(g, ux, uy, uz, c0x, c0y, c0z, r);
+        if (!(gr < Bits<T>::inf())) break;                         // grid exhausted
+        gr = gr - g.margin;
+        if (gr > (T)0 && (L.d[K - 1] < gr * gr || gr > max_dist)) break;
+    }
+    // ---- scatter matrix of the neighbours, in list order (the oracle's order), in T ----
+    int cnt = 0;
+    T sx = 0, sy = 0, sz = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++)
+        if (j >= K - knn && L.slot[j] >= 0) {
+            const auto v = load_rec<T>(M.pts, L.slot[j]);
+            sx += v.x; sy += v.y; sz += v.z; cnt++;
+        }
+    T c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    if (cnt > 0) {
+        const T mx = sx / (T)cnt, my = sy / (T)cnt, mz = sz / (T)cnt;
+#pragma unroll
+        for (int j = 0; j < K; j++)
+            if (j >= K - knn && L.slot[j] >= 0) {
+                const auto v = load_rec<T>(M.pts, L.slot[j]);
+                const T dx = v.x - mx, dy = v.y - my, dz = v.z - mz;
+                c00 += dx * dx; c01 += dx * dy; c02 += dx * dz; c11 += dy * dy; c12 += dy * dz; c22 += dz * dz;
+            }
+    }
+    double A[3][3] = {{(double)c00, (double)c01, (double)c02}, {(double)c01, (double)c11, (double)c12}, {(double)c02, (double)c12, (double)c22}};
+    double V[3][3];
+    jacobi3(A, V);
+    const double e0 = A[0][0], e1 = A[1][1], e2 = A[2][2];
+    int lo = 0, hi = 0;
+    double elo = e0, ehi = e0;
+    if (e1 < elo) { lo = 1; elo = e1; }
+    if (e2 < elo) { lo = 2; elo = e2; }
+    if (e1 > ehi) { hi = 1; ehi = e1; }
+    if (e2 > ehi) { hi = 2; ehi = e2; }
+    const int mid = 3 - lo - hi;
+    const double emid = lo == hi ? e0 : (mid == 0 ? e0 : (mid == 1 ? e1 : e2));
+    const bool degenerate = lo == hi || !(ehi > 0.0) || !(emid > 3.0 * (double)eps_rank * ehi);
+    T nx = 0, ny = 1, nz = 0, w0 = 0, w1 = 0, w2 = 1;              // libpointmatcher's defaults for a rank < 2 scatter
+    if (!degenerate) {
+        nx = (T)(lo == 0 ? V[0][0] : (lo == 1 ? V[0][1] : V[0][2]));
+        ny = (T)(lo == 0 ? V[1][0] : (lo == 1 ? V[1][1] : V[1][2]));
+        nz = (T)(lo == 0 ? V[2][0] : (lo == 1 ? V[2][1] : V[2][2]));
+        w0 = (T)elo; w1 = (T)emid; w2 = (T)ehi;
+    }
+    T *o = out_nrm + (long long)self * out_stride;
+    o[0] = nx; o[1] = ny; o[2] = nz;
+    if (out_eig) { out_eig[3LL * self] = w0; out_eig[3LL * self + 1] = w1; out_eig[3LL * self + 2] = w2; }
+    if (out_ids || out_d2) {
+#pragma unroll
+        for (int j = 0; j < K; j++)
+            if (j >= K - knn) {
+                const int jj = j - (K - knn);
+                const bool ok = L.slot[j] >= 0;
+                if (out_ids) out_ids[(long long)self * knn + jj] = ok ? L.idx[j] : -1;
+                if (out_d2) out_d2[(long long)self * knn + jj] = ok ? L.d[j] : Bits<T>::inf();
+            }
+    }
+}
+
 // Brute force (parity path): a block owns 256 queries; the map streams through
 // LDS in tiles, every lane reads the same LDS address (broadcast, conflict free).
 constexpr int kBruteTile = 1024;
@@ -1820,6 +2012,18 @@ void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const Ch
     hipLaunchKernelGGL(k_trim_select<T>, dim3(P), dim3(kSelectBlock), 0, st, probs, d2, ch, second, active);
 }
 
+template <typename T>
+int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m, int knn, T max_dist, T eps_rank, T *out_nrm,
+                           int out_stride, T *out_eig, int *out_ids, T *out_d2)
+{
+    const dim3 grid(cdiv(m, 128)), block(128);
+    if (knn <= 8) hipLaunchKernelGGL((k_surface_normals<T, 8>), grid, block, 0, st, maps, map, knn, max_dist, eps_rank, out_nrm, out_stride, out_eig, out_ids, out_d2);
+    else if (knn <= 16) hipLaunchKernelGGL((k_surface_normals<T, 16>), grid, block, 0, st, maps, map, knn, max_dist, eps_rank, out_nrm, out_stride, out_eig, out_ids, out_d2);
+    else if (knn <= 32) hipLaunchKernelGGL((k_surface_normals<T, 32>), grid, block, 0, st, maps, map, knn, max_dist, eps_rank, out_nrm, out_stride, out_eig, out_ids, out_d2);
+    else return -1;
+    return 0;
+}
+
 int reduce_blocks(int max_n) { return round8(cdiv(max_n, kReduceBlock * kReduceItems)); }
 
 template <typename T>
@@ -1903,6 +2107,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_trim_raw<T>(hipStream_t, const T *, int, T, T *, T *);                                           \
     template void launch_error_stats<T>(hipStream_t, const MapDev<T> *, int, const int *, const T *, int, const int *,    \
                                         const T *, int, const T[3], double *, double *);                                  \
+    template int launch_surface_normals<T>(hipStream_t, const MapDev<T> *, int, int, int, T, T, T *, int, T *, int *, T *); \
     template void launch_unpermute<T>(hipStream_t, const MapDev<T> *, int, const int *, const int *, const T *, int,      \
                                       int *, T *);
 

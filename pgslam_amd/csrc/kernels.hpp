@@ -37,6 +37,9 @@ void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const Ch
                         const int *active);
 int knn_stats_read(unsigned long long out[48], int reset);   // diagnostics build (-DPGICP_KNN_STATS) only
 void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active);
+template <typename T>
+int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m, int knn, T max_dist, T eps_rank, T *out_nrm,
+                           int out_stride, T *out_eig, int *out_ids, T *out_d2);
 int reduce_blocks(int max_n);
 template <typename T>
 void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,

@@ -978,6 +978,49 @@ int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const 
     return PGICP_OK;
 }
 
+template <typename T>
+int surface_normals(pgicp_ctx *c, const T *xyz, int stride, int n, int mem, int knn, double max_dist, T *out_nrm,
+                    int out_stride, T *out_eig, int32_t *out_ids, T *out_d2)
+{
+    if (!c || !xyz || n <= 0 || stride < 3 || !out_nrm || out_stride < 3 || knn < 1 || knn > 32 || !(max_dist > 0))
+        return fail(c, PGICP_ERR_ARG, "pgicp_surface_normals: bad argument (1 <= knn <= 32)");
+    HIPC(c, hipSetDevice(c->device));
+    int id = -1;
+    int st = map_create<T>(c, xyz, stride, nullptr, 0, n, mem, 0, &id);       // uncentred: coordinates stay exact
+    if (st) return st;
+    State<T> &S = state<T>(c);
+    T *d_nrm = out_nrm, *d_eig = out_eig, *d_d2 = out_d2;
+    int32_t *d_ids = out_ids;
+    const size_t b_nrm = sizeof(T) * ((size_t)(n - 1) * out_stride + 3), b_eig = sizeof(T) * 3 * (size_t)n,
+                 b_ids = sizeof(int32_t) * (size_t)knn * n, b_d2 = sizeof(T) * (size_t)knn * n;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    if (mem == PGICP_HOST) {
+        HIPC(c, S.stage_aux.ensure(up(b_nrm) + up(b_eig) + up(b_ids) + up(b_d2) + 256));
+        char *base = (char *)S.stage_aux.p;
+        d_nrm = (T *)base;
+        d_eig = out_eig ? (T *)(base + up(b_nrm)) : nullptr;
+        d_ids = out_ids ? (int32_t *)(base + up(b_nrm) + up(b_eig)) : nullptr;
+        d_d2 = out_d2 ? (T *)(base + up(b_nrm) + up(b_eig) + up(b_ids)) : nullptr;
+        if (out_stride > 3) HIPC(c, hipMemcpyAsync(d_nrm, out_nrm, b_nrm, hipMemcpyHostToDevice, c->stream));   // keep the caller's padding
+    }
+    {
+        ProfScope ps(c, PGICP_PROF_NORMALS, n);
+        if (launch_surface_normals<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, id), n, knn, (T)max_dist,
+                                      std::numeric_limits<T>::epsilon(), d_nrm, out_stride, d_eig, d_ids, d_d2) != 0)
+            return fail(c, PGICP_ERR_ARG, "pgicp_surface_normals: knn > 32");
+    }
+    if (mem == PGICP_HOST) {
+        HIPC(c, hipMemcpyAsync(out_nrm, d_nrm, b_nrm, hipMemcpyDeviceToHost, c->stream));
+        if (out_eig) HIPC(c, hipMemcpyAsync(out_eig, d_eig, b_eig, hipMemcpyDeviceToHost, c->stream));
+        if (out_ids) HIPC(c, hipMemcpyAsync(out_ids, d_ids, b_ids, hipMemcpyDeviceToHost, c->stream));
+        if (out_d2) HIPC(c, hipMemcpyAsync(out_d2, d_d2, b_d2, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    if (MapHost<T> *mh = get_map<T>(c, id)) free_map(c, *mh);
+    return PGICP_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1222,6 +1265,13 @@ int pgicp_partial_chain_batch_f32(pgicp_ctx *c, int P, const pgicp_problem *pr, 
 { return partial_chain_batch<float>(c, P, pr, ratio, residual, status); }
 int pgicp_partial_chain_batch_f64(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ratio, double *residual, int *status)
 { return partial_chain_batch<double>(c, P, pr, ratio, residual, status); }
+
+int pgicp_surface_normals_f32(pgicp_ctx *c, const float *xyz, int stride, int n, int mem, int knn, double max_dist,
+                              float *out_nrm, int out_stride, float *out_eig, int32_t *out_ids, float *out_d2)
+{ return surface_normals<float>(c, xyz, stride, n, mem, knn, max_dist, out_nrm, out_stride, out_eig, out_ids, out_d2); }
+int pgicp_surface_normals_f64(pgicp_ctx *c, const double *xyz, int stride, int n, int mem, int knn, double max_dist,
+                              double *out_nrm, int out_stride, double *out_eig, int32_t *out_ids, double *out_d2)
+{ return surface_normals<double>(c, xyz, stride, n, mem, knn, max_dist, out_nrm, out_stride, out_eig, out_ids, out_d2); }
 
 int pgicp_transform_f32(pgicp_ctx *c, const double T[16], const float *in, int is, float *out, int os, int n, int ro, int mem)
 { return transform<float>(c, T, in, is, out, os, n, ro, mem); }

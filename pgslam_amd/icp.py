@@ -28,7 +28,7 @@ OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID = rang
 HOST, DEVICE = 0, 1
 MATCHER_GRID, MATCHER_BRUTE = 0, 1
 PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_update", "pretransform",
-              "covariance", "grid_build", "knn_slow"]
+              "covariance", "grid_build", "knn_slow", "surface_normals"]
 
 # every symbol include/pgicp.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "pgicp_outlier_weights_f32", "pgicp_outlier_weights_f64", "pgicp_error_stats_f32", "pgicp_error_stats_f64",
     "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_partial_chain_batch_f32",
     "pgicp_partial_chain_batch_f64", "pgicp_transform_f32", "pgicp_transform_f64",
-    "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
+    "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_surface_normals_f32", "pgicp_surface_normals_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
     "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters",
 ]
 
@@ -384,6 +384,36 @@ class Context:
         self._check(fn(self.h, C.c_int(k), PP(*[b.ptr for b in xs]), PP(*[b.ptr for b in ns]), sx, sn, counts,
                        C.c_void_p(Ts.ctypes.data), C.c_void_p(px), C.c_int(3), C.c_void_p(pn), C.c_int(3), C.c_int(mem)))
         return out_x, out_n
+
+    def surface_normals(self, xyz, knn=10, max_dist=float("inf"), dtype=None, want_eigen=False, want_ids=False):
+        """SurfaceNormalDataPointsFilter on the device.  numpy in -> numpy out, torch CUDA in -> torch CUDA out.
+        Returns normals (n,3) [, eigenvalues (n,3) ascending] [, ids (n,knn), d2 (n,knn)]."""
+        x = _Buf(xyz, dtype)
+        n = x.n
+        md = 1e300 if not np.isfinite(max_dist) else float(max_dist)
+        if x.mem == DEVICE:
+            import torch
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=xyz.device)
+            nrm = mk((n, 3), xyz.dtype)
+            eig = mk((n, 3), xyz.dtype) if want_eigen else None
+            ids = mk((n, knn), torch.int32) if want_ids else None
+            d2 = mk((n, knn), xyz.dtype) if want_ids else None
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        else:
+            nrm = np.empty((n, 3), dtype=x.dtype)
+            eig = np.empty((n, 3), dtype=x.dtype) if want_eigen else None
+            ids = np.empty((n, knn), dtype=np.int32) if want_ids else None
+            d2 = np.empty((n, knn), dtype=x.dtype) if want_ids else None
+            ptr = lambda t: C.c_void_p(t.ctypes.data) if t is not None else None
+        fn = getattr(self.lib, "pgicp_surface_normals" + self._sfx(x.dtype))
+        self._check(fn(self.h, C.c_void_p(x.ptr), C.c_int(x.stride), C.c_int(n), C.c_int(x.mem), C.c_int(knn), C.c_double(md),
+                       ptr(nrm), C.c_int(3), ptr(eig), ptr(ids), ptr(d2)))
+        out = [nrm]
+        if want_eigen:
+            out.append(eig)
+        if want_ids:
+            out += [ids, d2]
+        return out[0] if len(out) == 1 else tuple(out)
 
     def adopt_map(self, other: "Context", map_id: int) -> int:
         """Take over a map built by another context of the same device (pgicp_map_transfer)."""

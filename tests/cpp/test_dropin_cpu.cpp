@@ -75,10 +75,15 @@ void yaml_and_matrix()
     auto dp = PointMatcher<float>::DataPoints::fromXYZ(xyz, 3);
     f.init(); f.apply(dp);
     CHECK(f.size() == 2 && dp.getNbPoints() == 2 && dp.features(1, 1) == 1.0f);
-    std::istringstream bad("- SurfaceNormalDataPointsFilter:\n    knn: 10\n");
-    threw = false;
-    try { PointMatcher<float>::DataPointsFilters g(bad); } catch (const std::runtime_error &) { threw = true; }
-    CHECK(threw);
+    // anything outside the supported set is refused at load time, never ignored
+    for (const char *txt : {"- RandomSamplingDataPointsFilter:\n    prob: 0.5\n",
+                            "- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: 3.16\n",
+                            "- SurfaceNormalDataPointsFilter:\n    knn: 64\n"}) {
+        std::istringstream bad(txt);
+        threw = false;
+        try { PointMatcher<float>::DataPointsFilters g(bad); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
+    }
 }
 
 int main()

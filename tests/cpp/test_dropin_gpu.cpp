@@ -104,6 +104,29 @@ void run(const char *name)
             CHECK(local.descriptors(a, off + j) == expect.descriptors(a, j));
         }
 
+    // --- SurfaceNormalDataPointsFilter from YAML (a reference filter, Localizer.hpp:314-315): a map that
+    //     arrives without normals gets them on the device and point-to-plane ICP lands on the same pose
+    {
+        DP bare(map.features, map.featureLabels);
+        CHECK(!bare.descriptorExists("normals"));
+        std::istringstream fs("- SurfaceNormalDataPointsFilter:\n    knn: 12\n    maxDist: 1.0\n    keepEigenValues: 1\n");
+        typename PM::DataPointsFilters nf(fs);
+        nf.init(); nf.apply(bare);
+        CHECK(bare.descriptorExists("normals") && bare.descriptorExists("eigValues") && bare.descriptors.rows() == 6);
+        int agree = 0;
+        const int n = (int)bare.getNbPoints(), r0 = bare.getDescriptorStartingRow("normals"), t0 = map.getDescriptorStartingRow("normals");
+        for (int j = 0; j < n; j++) {
+            double dot = 0, nn = 0;
+            for (int k = 0; k < 3; k++) { dot += (double)bare.descriptors(r0 + k, j) * (double)map.descriptors(t0 + k, j); nn += (double)bare.descriptors(r0 + k, j) * (double)bare.descriptors(r0 + k, j); }
+            CHECK(std::fabs(nn - 1.0) < 1e-4);
+            if (std::fabs(dot) > 0.95) agree++;
+        }
+        CHECK(agree > 0.9 * n);                                      // edges of the corner scene are the exceptions
+        ICP icp2;
+        { std::istringstream iss(kIcpYaml); icp2.loadFromYaml(iss); }
+        CHECK(pose_diff(icp2(reading, bare, guess), P) < 1e-2);
+    }
+
     // --- ConvergenceError propagates like libpointmatcher's
     bool threw = false;
     try { seq(reading, pose<T>(500, 0, 0, 0)); } catch (const typename PM::ConvergenceError &) { threw = true; }

@@ -173,6 +173,27 @@ def main():
     np.savez_compressed(os.path.join(here, "two_scans_small.npz"), reading=t["reading_xyz"], ref_xyz=t["ref_xyz"],
                         ref_nrm=t["ref_nrm"], T_init=t["T_init"], T_final=r["T"], iterations=r["iterations"],
                         overlap=r["overlap"], cov=r["cov"])
+    # ---- surface normals: independent float64 restatement (scipy k-d tree + numpy eigh) -------
+    # SurfaceNormalDataPointsFilter{knn=10, maxDist=2}: neighbours within maxDist, scatter about their
+    # mean, eigenvector of the smallest eigenvalue.  `margin` is how far the 10th neighbour is from the
+    # 11th (float32 evaluations may order a closer pair differently), `gap` the relative separation of
+    # the two smallest eigenvalues (the normal is only defined where it is not tiny).
+    s = synth.make_two_scans(3000, rings=16)
+    xyz = s["ref_xyz"]
+    knn, md = 10, 2.0
+    x64 = xyz.astype(np.float64)
+    d, idx = cKDTree(x64).query(x64, k=knn + 1)
+    valid = d[:, :knn] <= md
+    ids = np.where(valid, idx[:, :knn], -1).astype(np.int32)
+    P = x64[np.where(valid, idx[:, :knn], 0)]
+    cnt = valid.sum(1)
+    mean = (P * valid[:, :, None]).sum(1) / cnt[:, None]
+    D = (P - mean[:, None, :]) * valid[:, :, None]
+    Cm = np.einsum("nki,nkj->nij", D, D)
+    w, v = np.linalg.eigh(Cm)
+    np.savez_compressed(os.path.join(here, "surface_normals_small.npz"), xyz=xyz, knn=knn, max_dist=md, ids=ids,
+                        normals=v[:, :, 0], eigen_values=w, margin=d[:, knn] - d[:, knn - 1],
+                        gap=(w[:, 1] - w[:, 0]) / np.maximum(w[:, 2], 1e-300), true_normals=s["ref_nrm"])
     print("wrote fixtures:", [f for f in os.listdir(here) if f.endswith(".npz")])
 
 
