@@ -13,6 +13,7 @@
 //   pgslam::LoopClosureBatch<T> LoopCloserMT queue (LoopCloserMT.hpp:26-67) processed as a batch
 #pragma once
 #include <chrono>
+#include <deque>
 #include <memory>
 #include <sstream>
 #include <string>
@@ -184,6 +185,124 @@ private:
     Matrix T_refkf_robot_, T_world_robot_, last_input_T_world_robot_, T_world_refkf_;
     T overlap_threshold_, minimal_overlap_;
     bool has_map_;
+};
+
+//! LocalMap<T> without the graph: a circular window of keyframes whose BACK is the reference keyframe
+//! (LocalMap.hpp:20-31, 116-127); the cloud is rebuilt by BuildCloudFromData (LocalMap.hpp:209-224).
+template <typename T>
+class LocalMap {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    explicit LocalMap(size_t capacity) : capacity_(capacity) {}
+    size_t Capacity() const { return capacity_; }
+    bool HasCloud() const { return cloud_.features.cols() != 0; }
+    const DP &Cloud() const { return cloud_; }
+    const std::deque<Keyframe> &Data() const { return data_; }
+    const Keyframe &ReferenceKeyframe() const { return data_.back(); }
+    //! push_back on the circular buffer: the oldest keyframe drops out once the window is full
+    void PushKeyframe(const Keyframe &kf) { data_.push_back(kf); if (data_.size() > capacity_) data_.pop_front(); }
+    //! LocalMap.hpp:185-203: the FIRST keyframe at minimal distance (Metrics::Distance = translation norm)
+    size_t FindClosest(const Matrix &T_world_x) const
+    {
+        size_t best = 0;
+        double bd = dist(data_[0].optimized_T_world_kf, T_world_x);
+        for (size_t i = 1; i < data_.size(); i++) { const double d = dist(data_[i].optimized_T_world_kf, T_world_x); if (d < bd) { bd = d; best = i; } }
+        return best;
+    }
+    void MakeReference(size_t i) { std::swap(data_[i], data_.back()); }      // std::iter_swap, Localizer.hpp:220
+    //! reference keyframe first, then newest -> oldest (LocalMap.hpp:213-223), one device pass
+    void BuildCloudFromData()
+    {
+        std::vector<Keyframe> order;
+        order.push_back(data_.back());
+        for (size_t i = data_.size() - 1; i-- > 0;) order.push_back(data_[i]);
+        cloud_ = BuildLocalMapCloud<T>(order);
+    }
+
+private:
+    static double dist(const Matrix &A, const Matrix &B)
+    {
+        double s = 0;
+        for (int k = 0; k < 3; k++) { const double d = (double)B(k, 3) - (double)A(k, 3); s += d * d; }
+        return std::sqrt(s);
+    }
+    size_t capacity_;
+    std::deque<Keyframe> data_;
+    DP cloud_;
+};
+
+//! Localizer::ProcessData + the graph-free part of UpdateAfterIcp (Localizer.hpp:91-135, 178-268) on a
+//! sliding LocalMap: first cloud = first keyframe; overlap >= threshold keeps the keyframe set and makes the
+//! keyframe closest to the robot the reference; otherwise the scan becomes a new keyframe.  A changed
+//! composition rebuilds the cloud and calls setMap; a changed reference re-expresses the robot pose
+//! (UpdateRefkfRobotPose).  `pgslam_amd/local_mapper.py` is the same policy with device-resident keyframes
+//! and a background rebuild.
+template <typename T>
+class StreamingLocalizer {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    explicit StreamingLocalizer(size_t capacity = 3)
+        : local_map_(capacity), rigid_transformation_(PM::get().REG(Transformation).create("RigidTransformation")),
+          T_refkf_robot_(Matrix::Identity(4, 4)), T_world_robot_(Matrix::Identity(4, 4)),
+          last_input_T_world_robot_(Matrix::Identity(4, 4)), overlap_threshold_(T(0.8)), next_id_(0), rebuilds_(0) {}
+    void SetOverlapThreshold(T v) { overlap_threshold_ = v; }
+    void SetIcpConfigFromString(const std::string &yaml) { std::istringstream iss(yaml); icp_sequence_.loadFromYaml(iss); }
+    DataPointsFilters &input_filters() { return input_filters_; }
+    const LocalMap<T> &local_map() const { return local_map_; }
+    const Matrix &T_world_robot() const { return T_world_robot_; }
+    int rebuilds() const { return rebuilds_; }
+    T last_overlap() const { return last_overlap_; }
+
+    Matrix ProcessData(const Matrix &input_T_world_robot, const Matrix &input_T_robot_sensor, DPPtr cloud)
+    {
+        input_filters_.apply(*cloud);
+        (*cloud) = rigid_transformation_->compute(*cloud, input_T_robot_sensor);
+        if (!local_map_.HasCloud()) {                                       // ProcessFirstCloud, Localizer.hpp:137-152
+            AddKeyframe(cloud, input_T_world_robot);
+            Rebuild();
+            T_refkf_robot_ = Matrix::Identity(4, 4);
+            T_world_robot_ = input_T_world_robot;
+            last_input_T_world_robot_ = input_T_world_robot;
+            return T_world_robot_;
+        }
+        const Matrix input_dT_robot = last_input_T_world_robot_.inverse() * input_T_world_robot;
+        T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * input_dT_robot);
+        T_world_robot_ = local_map_.ReferenceKeyframe().optimized_T_world_kf * T_refkf_robot_;
+        last_overlap_ = icp_sequence_.errorMinimizer->getOverlap();
+        const size_t old_ref = local_map_.ReferenceKeyframe().id;
+        bool changed = false;
+        if (last_overlap_ >= overlap_threshold_) {
+            const size_t closest = local_map_.FindClosest(T_world_robot_);
+            if (local_map_.Data()[closest].id != old_ref) { local_map_.MakeReference(closest); changed = true; }
+        } else {
+            AddKeyframe(cloud, T_world_robot_);
+            changed = true;
+        }
+        if (changed) {
+            Rebuild();
+            if (local_map_.ReferenceKeyframe().id != old_ref)
+                T_refkf_robot_ = local_map_.ReferenceKeyframe().optimized_T_world_kf.inverse() * T_world_robot_;   // Localizer.hpp:273
+        }
+        last_input_T_world_robot_ = input_T_world_robot;
+        return T_world_robot_;
+    }
+
+private:
+    void AddKeyframe(DPPtr cloud, const Matrix &T_world_kf)
+    {
+        Keyframe kf;
+        kf.id = next_id_++; kf.cloud_ptr = cloud; kf.T_world_kf = T_world_kf; kf.optimized_T_world_kf = T_world_kf;
+        local_map_.PushKeyframe(kf);
+    }
+    void Rebuild() { local_map_.BuildCloudFromData(); icp_sequence_.setMap(local_map_.Cloud()); rebuilds_++; }
+    LocalMap<T> local_map_;
+    TransformationPtr rigid_transformation_;
+    DataPointsFilters input_filters_;
+    ICPSequence icp_sequence_;
+    Matrix T_refkf_robot_, T_world_robot_, last_input_T_world_robot_;
+    T overlap_threshold_, last_overlap_ = T(0);
+    size_t next_id_;
+    int rebuilds_;
 };
 
 template <typename T>

@@ -127,6 +127,46 @@ void run(const char *name)
         CHECK(pose_diff(icp2(reading, bare, guess), P) < 1e-2);
     }
 
+    // --- StreamingLocalizer: ProcessData + graph-free UpdateAfterIcp on a sliding LocalMap
+    {
+        // the robot walks through the corner scene; every scan is the scene seen from its true pose, the
+        // odometry reports the true increments with a small error
+        std::vector<Matrix> truth;
+        for (int s = 0; s < 7; s++) truth.push_back(pose<T>(0.25 * s, 0.1 * s, 0.0, 0.03 * s));
+        auto scan_at = [&](int s) { return std::make_shared<DP>(rigid->compute(make_corner<T>(2500, 40 + s, 0.004), truth[s].inverse())); };
+        std::vector<Matrix> odom(truth);
+        for (int s = 1; s < 7; s++) odom[s] = odom[s - 1] * (truth[s - 1].inverse() * truth[s]) * pose<T>(0.01, -0.008, 0.0, 0.004);
+        // threshold above what the trimmed filter can ever report (0.85): every scan becomes a keyframe
+        pgslam::StreamingLocalizer<T> every(3);
+        every.SetIcpConfigFromString(kIcpYaml);
+        every.SetOverlapThreshold(T(0.9));
+        for (int s = 0; s < 7; s++) {
+            const Matrix Tw = every.ProcessData(odom[s], Matrix::Identity(4, 4), scan_at(s));
+            CHECK(pose_diff(Tw, truth[s]) < 2e-2);                          // odometry alone would be ~6 cm off by the end
+        }
+        CHECK(every.local_map().Data().size() == 3 && every.rebuilds() == 7);
+        CHECK(every.local_map().Data()[0].id == 4 && every.local_map().ReferenceKeyframe().id == 6);
+        CHECK(every.local_map().Cloud().getNbPoints() == 3 * scan_at(0)->getNbPoints());
+        // threshold the filter always meets: one keyframe, no rebuild after the first, pose still tracked
+        pgslam::StreamingLocalizer<T> never(3);
+        never.SetIcpConfigFromString(kIcpYaml);
+        never.SetOverlapThreshold(T(0.5));
+        for (int s = 0; s < 7; s++) CHECK(pose_diff(never.ProcessData(odom[s], Matrix::Identity(4, 4), scan_at(s)), truth[s]) < 2e-2);
+        CHECK(never.local_map().Data().size() == 1 && never.rebuilds() == 1 && never.last_overlap() >= T(0.84));
+        // case #2: with two keyframes in the window, walking back towards the older one makes it the reference
+        pgslam::StreamingLocalizer<T> back(3);
+        back.SetIcpConfigFromString(kIcpYaml);
+        back.SetOverlapThreshold(T(0.9));
+        back.ProcessData(truth[0], Matrix::Identity(4, 4), scan_at(0));
+        back.ProcessData(truth[4], Matrix::Identity(4, 4), scan_at(4));      // second keyframe (ids 0, 1), reference = 1
+        back.SetOverlapThreshold(T(0.5));
+        back.ProcessData(truth[3], Matrix::Identity(4, 4), scan_at(3));
+        CHECK(back.local_map().ReferenceKeyframe().id == 1);
+        const Matrix Tb = back.ProcessData(truth[1], Matrix::Identity(4, 4), scan_at(1));
+        CHECK(back.local_map().ReferenceKeyframe().id == 0 && back.local_map().Data().size() == 2);
+        CHECK(pose_diff(Tb, truth[1]) < 2e-2);
+    }
+
     // --- ConvergenceError propagates like libpointmatcher's
     bool threw = false;
     try { seq(reading, pose<T>(500, 0, 0, 0)); } catch (const typename PM::ConvergenceError &) { threw = true; }
