@@ -285,6 +285,12 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
  * resolved because their existence was unknown, [2] resolved because their lower bound was
  * within the trim threshold, [3] reserved. */
 int pgicp_debug_counters(pgicp_ctx *ctx, int out[4]);
+/* Diagnostics: the correspondences the LAST iteration of problem `problem` of the last align call
+ * ended with, in reading order (host buffers of n entries).  ids: reference index, -1 = no neighbour
+ * within maxDist, -2 = a neighbour exists but was not located (lazy resolution: its distance is an
+ * upper bound and lies beyond the trim threshold).  Kept pairs carry exact ids and distances. */
+int pgicp_debug_last_matches_f32(pgicp_ctx *ctx, int problem, int32_t *ids, float *dist2);
+int pgicp_debug_last_matches_f64(pgicp_ctx *ctx, int problem, int32_t *ids, double *dist2);
 int pgicp_profile_enable(pgicp_ctx *ctx, int on);
 int pgicp_profile_reset(pgicp_ctx *ctx);
 int pgicp_profile_get(pgicp_ctx *ctx, int kernel_id, long long *launches, double *total_ms,

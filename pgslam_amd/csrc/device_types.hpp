@@ -64,6 +64,7 @@ struct ProblemDev {
     int n_finite, n_kept, rank;
     int n_refined;           // queued queries the slow path resolved since the last threshold selection
     double limit;            // last trim threshold (squared distance)
+    double prev_limit;       // the threshold the last fast matcher pass derived its search cap from
     double sys[kSys];        // final sums of the last iteration
     Checker chk;
 };

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_centroid_bbox(const T *__restrict__ xyz
             const double v = (double)xyz[i * stride + a];
             s[a] += __double2ll_rn(v * 16777216.0);
             mn[a] = fmin(mn[a], v);
-            mx[a] = fmax(mx[a], v);
+            mx[a] = v == v ? fmax(mx[a], v) : HUGE_VAL;      // fmax would hide a NaN: let it surface as a non-finite box
         }
     }
 #pragma unroll
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_unpermute(const MapDev<T> *__restrict__
     if (j >= n) return;
     const int i = order[j];
     const int s = slot[j];
-    ids_out[i] = s < 0 ? -1 : Bits<T>::unpack_idx(maps[map].pts[s].w);
+    ids_out[i] = s < 0 ? s : Bits<T>::unpack_idx(maps[map].pts[s].w);     // -1 none, -2 exists but not located (lazy)
     d2_out[i] = d2[j];
 }
 
@@ -505,6 +505,8 @@ struct Best {
 };
 
 #ifdef PGICP_KNN_STATS
+__device__ int g_trace_i = -1;          // diagnostics: sorted index of one query of problem 0 to narrate
+#define KNN_TRACE(prob_, i_, ...) do { if ((prob_) == 0 && (i_) == g_trace_i) printf(__VA_ARGS__); } while (0)
 __device__ unsigned long long g_knn_stats[48];   // [16..31] histogram of own-row, [32..47] of flat-walk candidates per lane (log2 bins)
 #define KNN_STAT_WAVE_ADD(slot_, v_)                                                              \
     do {                                                                                          \
@@ -518,6 +520,8 @@ __device__ unsigned long long g_knn_stats[48];   // [16..31] histogram of own-ro
         for (int o_ = 32; o_ > 0; o_ >>= 1) s_ = max(s_, __shfl_xor(s_, o_, 64));                  \
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_stats[slot_], (unsigned long long)s_);      \
     } while (0)
+#else
+#define KNN_TRACE(prob_, i_, ...) do { } while (0)
 #endif
 
 template <typename T>
@@ -940,6 +944,7 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
     KNN_STAT_WAVE_MAX(8, best.cnt - cnt_a);
     KNN_STAT_WAVE_MAX(9, best.cnt);
 #endif
+    KNN_TRACE(prob, i, "[fast] i=%d use_seed=%d capped=%d cap2=%g best=(%g,%d) seed=(%g,%d) resolved=%d gr=%g r_next=%d\n", i, use_seed, (int)capped, (double)cap2, (double)best.d2, best.slot, (double)seed.d2, seed.slot, (int)resolved, (double)gr, r_next);
     T lb_override = (T)-1;
     if (capped && best.slot < 0) {
         // nothing within the cap: that is not "no neighbour", only "farther than the cap"
@@ -964,7 +969,8 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
                                                  const T *__restrict__ rd, int *__restrict__ slot_io, T *__restrict__ d2_out,
                                                  ChainDev<T> ch, int *__restrict__ slow_count,
                                                  const int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
-                                                 int *__restrict__ slow_ring, int *__restrict__ slow2_idx, int med_rings)
+                                                 int *__restrict__ slow_ring, int *__restrict__ slow2_idx, int med_rings,
+                                                 int use_seed)
 {
     const int count = *slow_count;
     const int lane = threadIdx.x;
@@ -992,9 +998,16 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
             eval_point<T>(M.pts[prev], prev, qx, qy, qz, seed);
             if (seed.d2 <= best.d2) best = seed;
         }
+        // The rings below slow_ring[k] were examined by the fast pass under ITS bound (the cap derived from the
+        // previous threshold, or maxDist); rows beyond that bound were skipped.  If this pass has to look
+        // farther than that -- the threshold grew, or only a far seed is known -- it starts over from ring 0.
+        const T fast_cap2 = use_seed ? (T)(1.21 * P.prev_limit) : Bits<T>::inf();
+        const T fast_bound = fast_cap2 < ch.max_dist2 ? fast_cap2 : ch.max_dist2;
+        const int r_begin = best.d2 > fast_bound ? 0 : slow_ring[k];
         T gr;
         int r_next;
-        bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, slow_ring[k], med_rings, cap2, best, gr, r_next);
+        bool resolved = grid_nn<T>(M, qx, qy, qz, ch.max_dist, r_begin, med_rings, cap2, best, gr, r_next);
+        KNN_TRACE(e.x, i, "[med] i=%d lb=%g limit=%g cap2=%g ring=%d -> resolved=%d best=(%g,%d) gr=%g r_next=%d prev=%d\n", i, (double)lb, (double)limit, (double)cap2, r_begin, (int)resolved, (double)best.d2, best.slot, (double)gr, r_next, prev);
         if (capped && best.slot < 0) {
             // nothing within 1.1x the threshold: irrelevant for the filter, keep it queued beyond reach
             const bool seed_ok = seed.slot >= 0 && seed.d2 <= ch.max_dist2;
@@ -1079,6 +1092,7 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
         // and its distance stays in d2 as an upper bound like any other unresolved entry's.
         const T lbk = slow_lb[k];
         const bool exist_only = !exact_all && lbk < (T)0 && (-lbk - (T)1) > (T)P.limit;
+        if (lane == 0) KNN_TRACE(e.x, i, "[slow] i=%d lbk=%g limit=%g exist_only=%d prev=%d\n", i, (double)lbk, (double)P.limit, (int)exist_only, prev);
 #ifdef PGICP_KNN_STATS
         const long long t_begin = clock64();
         int st_sc = 0, st_rows = 0, st_trips = 0, st_R = 0;
@@ -1522,6 +1536,7 @@ __global__ __launch_bounds__(kSelectBlock) void k_trim_select(ProblemDev *__rest
     int nf;
     trim_select_block<T>(d2 + P.off, P.n, ch.trim_ratio, limit, nf);
     if (threadIdx.x == 0) {
+        if (!second) P.prev_limit = P.limit;      // the fast pass of this iteration capped its search with it
         P.limit = (double)limit;
         P.n_finite = nf;
     }
@@ -1796,6 +1811,16 @@ __global__ __launch_bounds__(1024) void k_compact_active(const ProblemDev *__res
     (void)n_live_total;
 }
 
+int knn_trace_set(int sorted_index)
+{
+#ifdef PGICP_KNN_STATS
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_i), &sorted_index, sizeof(int)) == hipSuccess ? 0 : -1;
+#else
+    (void)sorted_index;
+    return -1;
+#endif
+}
+
 int knn_stats_read(unsigned long long out[48], int reset)
 {
 #ifdef PGICP_KNN_STATS
@@ -1986,10 +2011,10 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                     const ChainDev<T> &ch, int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring, int *slow2_idx,
-                    int med_rings)
+                    int med_rings, int use_seed)
 {
     hipLaunchKernelGGL(k_knn_med<T>, dim3(8192), dim3(64), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list, slow_lb,
-                       slow_ring, slow2_idx, med_rings);
+                       slow_ring, slow2_idx, med_rings, use_seed);
 }
 
 // resolves the queries the fast path queued: all of them (exact_all, public matcher
@@ -2094,7 +2119,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
                                 const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *);         \
     template void launch_knn_med<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                  \
-                                    const ChainDev<T> &, int *, const int2 *, T *, int *, int *, int);                    \
+                                    const ChainDev<T> &, int *, const int2 *, T *, int *, int *, int, int);               \
     template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \
                                      const ChainDev<T> &, const int *, const int2 *, const T *, const int *, int);        \
     template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int, int, const int *); \

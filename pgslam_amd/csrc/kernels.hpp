@@ -27,7 +27,7 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                     const ChainDev<T> &ch, int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring, int *slow2_idx,
-                    int med_rings);
+                    int med_rings, int use_seed);
 template <typename T>
 void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                      const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb,
@@ -35,7 +35,8 @@ void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, c
 template <typename T>
 void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second,
                         const int *active);
-int knn_stats_read(unsigned long long out[48], int reset);   // diagnostics build (-DPGICP_KNN_STATS) only
+int knn_stats_read(unsigned long long out[48], int reset);
+int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
 void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active);
 template <typename T>
 int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m, int knn, T max_dist, T eps_rank, T *out_nrm,

@@ -530,6 +530,12 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     }
     // hs/hp must outlive the async copies
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (const char *e = std::getenv("PGICP_TRACE_ORIG")) {     // diagnostics build: narrate one query of problem 0
+        std::vector<int> ord(hp[0].n);
+        (void)hipMemcpy(ord.data(), c->order.as<int>(), sizeof(int) * ord.size(), hipMemcpyDeviceToHost);
+        const int want = std::atoi(e);
+        for (int j = 0; j < (int)ord.size(); j++) if (ord[j] == want) { (void)knn_trace_set(j); break; }
+    }
     return PGICP_OK;
 }
 
@@ -561,7 +567,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
             ProfScope ps(c, PGICP_PROF_KNN_SLOW, act_units, act_probs);
             launch_knn_med<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
                               ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), c->slow_ring.as<int>(),
-                              c->slow2.as<int>(), c->med_rings);
+                              c->slow2.as<int>(), c->med_rings, use_seed);
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
                                c->slow2.as<int>(), 0);
@@ -1036,6 +1042,25 @@ int map_create_batch_abi(pgicp_ctx *c, int n, const T *const *xyz, const int *xs
     return map_create_batch<T>(c, n, src.data(), mem, center, ids);
 }
 template <typename T>
+int debug_last_matches(pgicp_ctx *c, int problem, int32_t *ids, T *dist2)
+{
+    if (!c || problem < 0 || !ids || !dist2) return PGICP_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    State<T> &S = state<T>(c);
+    ProblemDev D;
+    HIPC(c, hipMemcpy(&D, c->probs.as<ProblemDev>() + problem, sizeof D, hipMemcpyDeviceToHost));
+    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)D.n));
+    HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)D.n));
+    // `order` holds positions in the batch-wide sorted arrays: point the kernel at this problem's slice
+    launch_unpermute<T>(c->stream, S.d_maps.template as<MapDev<T>>(), D.map, c->order.as<int>() + D.off,
+                        S.slot.template as<int>() + D.off, S.d2.template as<T>() + D.off, D.n, c->tmp_a.as<int>(), c->tmp_b.as<T>());
+    HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * (size_t)D.n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * (size_t)D.n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return PGICP_OK;
+}
+
+template <typename T>
 int map_transfer_impl(pgicp_ctx *from, int id, pgicp_ctx *to, int *new_id)
 {
     MapHost<T> *src = get_map<T>(from, id);
@@ -1348,6 +1373,9 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
     }
     return PGICP_OK;
 }
+
+int pgicp_debug_last_matches_f32(pgicp_ctx *c, int problem, int32_t *ids, float *dist2) { return debug_last_matches<float>(c, problem, ids, dist2); }
+int pgicp_debug_last_matches_f64(pgicp_ctx *c, int problem, int32_t *ids, double *dist2) { return debug_last_matches<double>(c, problem, ids, dist2); }
 
 int pgicp_profile_enable(pgicp_ctx *c, int on)
 {

@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpgicp.so")
+LIB_PATH = os.environ.get("PGICP_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libpgicp.so")
 
 OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID = range(7)
 HOST, DEVICE = 0, 1
@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "pgicp_partial_chain_batch_f64", "pgicp_transform_f32", "pgicp_transform_f64",
     "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_surface_normals_f32", "pgicp_surface_normals_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
     "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters",
+    "pgicp_debug_last_matches_f32", "pgicp_debug_last_matches_f64",
 ]
 
 
@@ -429,6 +430,14 @@ class Context:
         out = (C.c_int * 4)()
         self._check(self.lib.pgicp_debug_counters(self.h, out))
         return list(out)
+
+    def debug_last_matches(self, n, problem=0, dtype=np.float32):
+        """Correspondences of the last iteration of the last align call (diagnostics; see pgicp.h)."""
+        ids = np.empty(n, dtype=np.int32)
+        d2 = np.empty(n, dtype=dtype)
+        fn = getattr(self.lib, "pgicp_debug_last_matches" + self._sfx(dtype))
+        self._check(fn(self.h, C.c_int(problem), C.c_void_p(ids.ctypes.data), C.c_void_p(d2.ctypes.data)))
+        return ids, d2
 
     def profile_reset(self):
         self._check(self.lib.pgicp_profile_reset(self.h))

@@ -1,0 +1,153 @@
+"""Edge cases of the drop-in boundary on the GPU: ragged batches, tiny and degenerate clouds,
+strided / homogeneous inputs, bad arguments.  Every result is checked against the oracle."""
+import numpy as np
+import pytest
+
+from pgslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01,
+             smooth_length=3, sensor_std_dev=0.01)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pgslam_amd import icp
+    c = icp.Context(0, **CHAIN)
+    yield c
+    c.close()
+
+
+def pose_error(Ta, Tb):
+    dT = np.linalg.inv(Ta) @ Tb
+    return np.linalg.norm(dT[:3, 3]), np.arccos(np.clip((np.trace(dT[:3, :3]) - 1) / 2, -1, 1))
+
+
+def test_ragged_batch_of_different_maps_and_sizes(ctx, oracle32):
+    """One device batch mixing reading sizes (not multiples of 64) and maps of different density."""
+    a = synth.make_two_scans(6000, rings=16)
+    b = synth.make_two_scans(2500, rings=16)
+    m_a = ctx.set_map(a["ref_xyz"], a["ref_nrm"])
+    m_b = ctx.set_map(b["ref_xyz"][:1777], b["ref_nrm"][:1777])
+    readings = [a["reading_xyz"][:5999], b["reading_xyz"][:1001], a["reading_xyz"][:63], b["reading_xyz"][:2500], a["reading_xyz"][:1]]
+    maps = [m_a, m_b, m_a, m_b, m_a]
+    refs = [(a["ref_xyz"], a["ref_nrm"]), (b["ref_xyz"][:1777], b["ref_nrm"][:1777])] * 3
+    T0 = [a["T_init"], b["T_init"], a["T_init"], b["T_init"], a["T_init"]]
+    Ts, st = ctx.align_batch(maps, readings, T0, raise_on_error=False)
+    for k in range(5):
+        o = oracle32.icp(readings[k], refs[k % 2][0], refs[k % 2][1], T0[k], **CHAIN)
+        assert st[k]["status"] == o["status"], k
+        if o["status"] == 0:
+            dt, dr = pose_error(o["T"], Ts[k])
+            assert dt < 1e-5 and dr < 1e-5, (k, dt, dr)
+            assert st[k]["iterations"] == o["iterations"] and st[k]["n_finite"] == o["n_finite"]
+        # each problem alone gives the same answer as inside the batch (the reading-sort bins, and with them
+        # the order of the double-precision sums, are chosen per batch: equal to rounding, not bit for bit)
+        T1, s1 = ctx.align_batch([maps[k]], [readings[k]], [T0[k]], raise_on_error=False)
+        assert s1[0]["status"] == st[k]["status"]
+        if st[k]["status"] == 0:
+            np.testing.assert_allclose(T1[0], Ts[k], rtol=0, atol=1e-12)
+            assert s1[0]["iterations"] == st[k]["iterations"]
+    ctx.destroy_map(m_a); ctx.destroy_map(m_b)
+
+
+def test_tiny_and_degenerate_maps(ctx, oracle32):
+    one = np.array([[1.0, 2.0, 3.0]], dtype=np.float32)
+    nrm = np.array([[0.0, 0.0, 1.0]], dtype=np.float32)
+    m = ctx.set_map(one, nrm, center=False)
+    q = np.array([[1.0, 2.0, 3.5], [50.0, 0.0, 0.0], [1.0, 2.0, 3.0]], dtype=np.float32)
+    ids, d2 = ctx.match(m, q)
+    oi, od = oracle32.knn_brute(q, one, 2.0)
+    np.testing.assert_array_equal(ids, oi)
+    np.testing.assert_array_equal(d2, od)
+    ctx.destroy_map(m)
+    # all points identical: every query ties on distance, the smallest index wins
+    same = np.tile(one, (300, 1))
+    m = ctx.set_map(same, np.tile(nrm, (300, 1)), center=False)
+    ids, d2 = ctx.match(m, q)
+    np.testing.assert_array_equal(ids, [0, -1, 0])
+    ctx.destroy_map(m)
+    # a line of points (flat bounding box in two axes)
+    line = np.stack([np.linspace(-5, 5, 777), np.zeros(777), np.zeros(777)], 1).astype(np.float32)
+    m = ctx.set_map(line, np.tile(nrm, (777, 1)), center=True)
+    rng = np.random.default_rng(3)
+    qq = (line[rng.integers(0, 777, 500)] + rng.normal(0, 0.3, (500, 3))).astype(np.float32)
+    ids, d2 = ctx.match(m, qq)
+    mean = oracle32.centroid(line)
+    oi, od = oracle32.knn_brute((qq - mean).astype(np.float32), (line - mean).astype(np.float32), 2.0)
+    np.testing.assert_array_equal(ids, oi)
+    ctx.destroy_map(m)
+
+
+def test_homogeneous_and_strided_inputs(ctx, oracle32):
+    """libpointmatcher `features` are 4xN column-major = (N,4) rows with pad 1: stride 4, same result as (N,3)."""
+    t = synth.make_two_scans(3000, rings=16)
+    ref4 = np.concatenate([t["ref_xyz"], np.ones((3000, 1), np.float32)], 1)
+    rd4 = np.concatenate([t["reading_xyz"], np.ones((3000, 1), np.float32)], 1)
+    m3 = ctx.set_map(t["ref_xyz"], t["ref_nrm"])
+    m4 = ctx.set_map(ref4, t["ref_nrm"])
+    T3, s3 = ctx.align(m3, t["reading_xyz"], t["T_init"])
+    T4, s4 = ctx.align(m4, rd4, t["T_init"])
+    np.testing.assert_array_equal(T3, T4)
+    assert s3["iterations"] == s4["iterations"]
+    ctx.destroy_map(m3); ctx.destroy_map(m4)
+
+
+def test_bad_arguments_are_reported_not_computed(ctx):
+    from pgslam_amd import icp
+    t = synth.make_two_scans(500, rings=16)
+    bad = t["ref_xyz"].copy()
+    bad[7, 1] = np.nan
+    with pytest.raises(icp.PgicpError):
+        ctx.set_map(bad, t["ref_nrm"])
+    m = ctx.set_map(t["ref_xyz"], None)                       # match-only map: no normals
+    with pytest.raises(icp.PgicpError):
+        ctx.align(m, t["reading_xyz"], t["T_init"])            # point-to-plane needs them
+    ids, _ = ctx.match(m, t["reading_xyz"])
+    assert ids.shape == (500,)
+    ctx.destroy_map(m)
+    with pytest.raises(icp.PgicpError):
+        ctx.align(12345, t["reading_xyz"], t["T_init"])        # unknown map id
+    shear = np.eye(4); shear[0, 1] = 0.3
+    with pytest.raises(icp.PgicpError):
+        ctx.transform(shear, t["ref_xyz"])                     # RigidTransformation refuses a non-rigid matrix
+
+
+def test_reading_with_points_far_outside_the_map(ctx, oracle32):
+    """Queries far outside the grid's bounding box (clamped cells) and beyond maxDist keep the sentinels."""
+    t = synth.make_two_scans(3000, rings=16)
+    rd = t["reading_xyz"].copy()
+    rd[::7] += np.float32(500.0)                               # far away: no neighbour within maxDist
+    rd[3::11] *= np.float32(1.02)
+    m = ctx.set_map(t["ref_xyz"], t["ref_nrm"])
+    T, st = ctx.align(m, rd, t["T_init"])
+    o = oracle32.icp(rd, t["ref_xyz"], t["ref_nrm"], t["T_init"], **CHAIN)
+    dt, dr = pose_error(o["T"], T)
+    assert dt < 1e-5 and dr < 1e-5 and st["n_finite"] == o["n_finite"] and st["iterations"] == o["iterations"]
+    ctx.destroy_map(m)
+
+
+def test_lazy_matcher_state_equals_oracle_every_iteration(ctx, oracle32):
+    """Regression (sparse map, threshold that grows past the previous search cap): after every iteration
+    count the kept pairs are the oracle's, id for id and bit for bit, and 'has a neighbour within maxDist'
+    agrees for every point -- the quantities the lazily-exact matcher promises."""
+    b = synth.make_two_scans(2500, rings=16)
+    ref, nrm, rd, T0 = b["ref_xyz"][:1777], b["ref_nrm"][:1777], b["reading_xyz"], b["T_init"]
+    m = ctx.set_map(ref, nrm)
+    for it in (1, 2, 3, 4, 6):
+        ctx.set_params(**dict(CHAIN, max_iters=it))
+        T, st = ctx.align(m, rd, T0)
+        gi, gd = ctx.debug_last_matches(rd.shape[0])
+        o = oracle32.icp(rd, ref, nrm, T0, **dict(CHAIN, max_iters=it))
+        assert st["iterations"] == o["iterations"] and st["n_finite"] == o["n_finite"] and st["n_kept"] == o["n_kept"]
+        assert st["trim_limit"] == o["trim_limit"]
+        np.testing.assert_array_equal(np.isfinite(gd), np.isfinite(o["last_d2"]))
+        kept = o["last_d2"] <= o["trim_limit"]
+        np.testing.assert_array_equal(gi[kept], o["last_ids"][kept])
+        np.testing.assert_array_equal(gd[kept], o["last_d2"][kept])
+        # whatever is not exact is an upper bound beyond the threshold
+        loose = np.isfinite(gd) & ~kept
+        assert np.all(gd[loose] >= o["last_d2"][loose]) and np.all(gd[loose] > o["trim_limit"])
+    ctx.set_params(**CHAIN)
+    ctx.destroy_map(m)
