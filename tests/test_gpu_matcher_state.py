@@ -1,0 +1,97 @@
+"""Per-point matcher state against the oracle after every iteration, on every workload shape.
+
+The lazily-exact matcher promises: kept pairs (distance <= trim threshold) carry the oracle's ids and
+distances bit for bit; "has a neighbour within maxDist" agrees for every point; everything else is an
+upper bound beyond the threshold.  pgicp_debug_last_matches exposes that state."""
+import numpy as np
+import pytest
+
+from pgslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01,
+             smooth_length=3, sensor_std_dev=0.01)
+
+
+def check_state(ctx, oracle, reading, ref, nrm, T0, iters, chain=CHAIN, dtype=np.float32, mid=None, rtol=0.0):
+    """rtol = 0: bit for bit (float32 chain: the transforms are rounded to float before they meet a point).
+    The float64 chain sees the last ulp of the device's vs the host's sin/cos/sqrt in the transforms, so it
+    is compared to rounding instead."""
+    own = mid is None
+    if own:
+        mid = ctx.set_map(ref, nrm, dtype=dtype)
+    for it in iters:
+        prm = dict(chain, max_iters=it)
+        ctx.set_params(**prm)
+        T, st = ctx.align(mid, reading, T0, dtype=dtype)
+        gi, gd = ctx.debug_last_matches(reading.shape[0], dtype=dtype)
+        o = oracle.icp(reading, ref, nrm, T0, **prm)
+        assert st["iterations"] == o["iterations"], it
+        assert st["n_finite"] == o["n_finite"] and st["n_kept"] == o["n_kept"], it
+        np.testing.assert_array_equal(np.isfinite(gd), np.isfinite(o["last_d2"]))
+        kept = o["last_d2"] <= o["trim_limit"]
+        np.testing.assert_array_equal(gi[kept], o["last_ids"][kept])
+        if rtol == 0.0:
+            assert st["trim_limit"] == o["trim_limit"], it
+            np.testing.assert_array_equal(gd[kept], o["last_d2"][kept])
+        else:
+            assert st["trim_limit"] == pytest.approx(o["trim_limit"], rel=rtol)
+            np.testing.assert_allclose(gd[kept], o["last_d2"][kept], rtol=rtol, atol=1e-18)
+        loose = np.isfinite(gd) & ~kept
+        assert np.all(gd[loose] >= o["last_d2"][loose] * (1 - rtol)) and np.all(gd[loose] > o["trim_limit"] * (1 - rtol))
+    ctx.set_params(**chain)
+    if own:
+        ctx.destroy_map(mid)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pgslam_amd import icp
+    c = icp.Context(0, **CHAIN)
+    yield c
+    c.close()
+
+
+def test_dense_scan_to_map(ctx, oracle32):
+    w = synth.make_scan_to_map(n_scan=6000, n_map=50_000, n_queries=2, n_map_poses=4, rings=16)
+    for b in range(2):
+        check_state(ctx, oracle32, w.scans_xyz[b], w.map_xyz, w.map_nrm, w.T_init[b], (1, 2, 3, 5, 30))
+
+
+def test_partial_overlap_pairs(ctx, oracle32):
+    ps = synth.make_pairs(3, n_pts=8000, n_keyframes=6, rings=16)
+    for k in range(3):
+        check_state(ctx, oracle32, ps.reading_xyz[k], ps.ref_xyz[k], ps.ref_nrm[k], ps.T_init[k], (1, 2, 4, 30))
+
+
+def test_large_initial_error_and_small_max_dist(ctx, oracle32):
+    """A guess 0.8 m / 6 degrees off and maxDist 0.5 m: most points start without a neighbour, the
+    threshold moves a lot between iterations."""
+    t = synth.make_two_scans(8000, rings=16)
+    T0 = t["T_truth"] @ synth.se3(x=0.8, y=-0.5, z=0.2, yaw=np.deg2rad(6.0))
+    chain = dict(CHAIN, max_dist=0.5)
+    check_state(ctx, oracle32, t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], T0, (1, 2, 3, 5, 8), chain=chain)
+
+
+def test_unbounded_max_dist_and_full_trim_ratio(ctx, oracle32):
+    t = synth.make_two_scans(5000, rings=16)
+    check_state(ctx, oracle32, t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], t["T_init"], (1, 2, 5),
+                chain=dict(CHAIN, max_dist=float("inf")))
+    check_state(ctx, oracle32, t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], t["T_init"], (1, 3),
+                chain=dict(CHAIN, trim_ratio=1.0))
+    check_state(ctx, oracle32, t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], t["T_init"], (1, 3),
+                chain=dict(CHAIN, trim_ratio=0.3))
+
+
+def test_double_precision_state(ctx, oracle64):
+    t = synth.make_two_scans(4000, rings=16)
+    check_state(ctx, oracle64, t["reading_xyz"].astype(np.float64), t["ref_xyz"].astype(np.float64),
+                t["ref_nrm"].astype(np.float64), t["T_init"], (1, 2, 4), dtype=np.float64, rtol=1e-11)
+
+
+def test_full_size_state(ctx, oracle32):
+    """BASELINE configs[1] sizes, two iterations (the oracle's kd-tree needs ~10 s per call)."""
+    from bench import build_workload
+    w = build_workload(100_000, 1_000_000, 16)
+    check_state(ctx, oracle32, w.scans_xyz[3], w.map_xyz, w.map_nrm, w.T_init[3], (2, 4))
