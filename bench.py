@@ -346,8 +346,44 @@ def main_stream(args):
             self.m.close()
             self.new()
 
-    vehicles = [Vehicle() for _ in range(args.streams)]
     per_step = (n_total - first - 1) * args.streams
+
+    class Fleet:
+        """--fleet: all vehicles stepped together, one device batch per time step (StreamingFleet)."""
+        def __init__(self):
+            from pgslam_amd.local_mapper import StreamingFleet
+            self.ctx = icp.Context(local_rank, **CHAIN)
+            self.builder = None
+            self.StreamingFleet = StreamingFleet
+            self.new()
+
+        def new(self):
+            cfg = LocalMapperConfig(capacity=args.capacity, overlap_threshold=0.8, chain=dict(CHAIN))
+            self.f = self.StreamingFleet(self.ctx, args.streams, cfg)
+            for m in self.f.mappers:
+                for k in range(n_prime):
+                    s = k * args.prime_stride
+                    m.window.append(Keyframe(m.next_kf_id, d_xyz[s], d_nrm[s], odom[s].copy()))
+                    m.next_kf_id += 1
+            self.f.step([odom[first]] * args.streams, [d_xyz[first]] * args.streams, [d_nrm[first]] * args.streams)
+            self.m = self.f.mappers[0]
+
+        def run(self, out):
+            its, conv = 0, 0
+            for s in range(first + 1, n_total):
+                self.f.step([odom[s]] * args.streams, [d_xyz[s]] * args.streams, [d_nrm[s]] * args.streams)
+                for m in self.f.mappers:
+                    its += m.last_stats["iterations"]
+                    conv += int(m.last_stats["status"] == 0 and m.last_stats["converged"])
+            m = self.f.mappers[0]
+            out.append((its, conv, len(m.keyframe_scans) - 1, m.rebuilds,
+                        float(np.linalg.norm((np.linalg.inv(poses[n_total - 1]) @ m.T_world_robot)[:3, 3]))))
+
+        def reset(self):
+            self.f.close()
+            self.new()
+
+    vehicles = [Fleet()] if args.fleet else [Vehicle() for _ in range(args.streams)]
 
     def step():
         outs = [[] for _ in vehicles]
@@ -383,6 +419,8 @@ def main_stream(args):
     if rank == 0:
         its = sum(r[0] for r in res)
         conv = sum(r[1] for r in res)
+        mode = ("one device batch per time step (fleet)" if args.fleet else
+                ("synchronous" if args.sync_rebuild else "background") + " map rebuild, one host thread per vehicle")
         print(json.dumps({
             "metric": "streamed scans/sec through the local mapper (100k-pt scans, sliding 2M-pt device-resident map)",
             "value": args.steps * per_step * world / elapsed, "unit": "scans/s", "n_gpus": world, "steps": args.steps,
@@ -390,7 +428,7 @@ def main_stream(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"streaming local mapper, {args.stream_scans - 1} timed scans of {args.n_scan} pts per vehicle, "
                                    f"{args.capacity}-keyframe sliding map ({args.capacity * args.n_scan} pts, BASELINE.json configs[2]), "
-                                   f"{args.streams} vehicle(s) per GPU, {'synchronous' if args.sync_rebuild else 'background'} map rebuild",
+                                   f"{args.streams} vehicle(s) per GPU, {mode}",
                        "parallelism": f"{world} GPU(s) x {args.streams} independent vehicles (replicas)"},
             "ms_per_scan_per_vehicle": elapsed * 1e3 / (args.steps * (n_total - first - 1)),
             "mean_iterations": its / per_step, "converged_fraction": conv / per_step,
@@ -428,6 +466,7 @@ def main():
     ap.add_argument("--stream-step", type=float, default=0.35, help="stream: metres travelled between scans (10 Hz at 3.5 m/s)")
     ap.add_argument("--prime-stride", type=int, default=3, help="stream: earlier scans between the keyframes that pre-fill the window")
     ap.add_argument("--sync-rebuild", action="store_true", help="stream: rebuild the map in line, as the reference does")
+    ap.add_argument("--fleet", action="store_true", help="stream: step all vehicles together, one device batch per time step")
     ap.add_argument("--workload", choices=["scan2map", "loopclosure", "stream"], default="scan2map",
                     help="scan2map = BASELINE configs[1] (the headline metric); loopclosure = configs[4]: --pairs candidate "
                          "scan pairs (100k vs 100k) sharded over the ranks, all-gather of the SE(3) edges")
@@ -583,6 +622,23 @@ def main():
                 kern[name] = dict(launches=v["launches"], total_ms=round(v["total_ms"], 4),
                                   avg_us=round(v["total_ms"] * 1e3 / v["launches"], 2))
 
+    # ---- workload-stable companion figure: the same step with the Differential
+    #      checker disabled, i.e. exactly 30 iterations per scan; reported next to the metric, never as `value`
+    fixed30 = None
+    if not args.fixed_iters and not args.no_profile:
+        for c in ctxs:
+            c.set_params(min_diff_rot=0.0, min_diff_trans=0.0, check_every=args.check_every)
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, st30 = step()
+        torch.cuda.synchronize()
+        dt30 = time.perf_counter() - t0
+        fixed30 = dict(scans_per_s=sum(1 for s in st30 if s["status"] == 0) / dt30, ms_per_step=dt30 * 1e3,
+                       iterations=float(np.mean([s["iterations"] for s in st30])))
+        for c in ctxs:
+            c.set_params(min_diff_rot=chain["min_diff_rot"], min_diff_trans=chain["min_diff_trans"])
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, args.cpu_sample, os.cpu_count() or 1)
@@ -610,6 +666,7 @@ def main():
                        "parallelism": f"{world} independent replica(s), one process per GPU"},
             "scans_total": scans_all,
             "scans_converged": converged_all,
+            "fixed_30_iterations": fixed30,
             "mean_iterations": iters_all / max(1, scans_all),
             "set_map_ms": t_setmap * 1e3,
             "median_translation_error_m": float(np.median(err_t)) if err_t else None,

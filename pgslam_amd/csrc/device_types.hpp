@@ -29,7 +29,8 @@ struct MapDev {
     const typename Vec4<T>::type *pts;   // (x, y, z, bit-cast original index) cell-sorted, centred
     const typename Vec4<T>::type *nrm;   // (nx, ny, nz, 0) same order; may be null
     const int *cell_start;               // ncells + 1 exclusive prefix sums
-    const int *sc_count;                 // points per 8x8x8 super-cell (coarse occupancy)
+    const int *sc_count;                 // occupancy flag per 8x8x8 super-cell
+    const int *sc_dist;                  // Chebyshev distance (in super-cells, capped at kScReach + 1) to the nearest occupied one
     const int *slot_of;                  // original index -> position in pts / nrm
     const int *near;                     // per cell: a nearby occupied cell (itself when occupied), -1 if none within kNearReach
     GridDesc<T> g;
@@ -82,6 +83,7 @@ constexpr int kReduceBlock = 256;
 constexpr int kReduceItems = 4;      // queries per thread in the reduce kernels
 constexpr int kSelectBlock = 1024;
 constexpr int kCovTerms = 42;
-constexpr int kNearReach = 8;     // cells searched per axis for MapDev::near        // 21 (H upper) + 21 (G upper)
+constexpr int kNearReach = 8;
+constexpr int kScReach = 15;      // super-cells searched per axis for MapDev::sc_dist     // cells searched per axis for MapDev::near        // 21 (H upper) + 21 (G upper)
 
 }  // namespace pgicp

@@ -231,6 +231,48 @@ __global__ __launch_bounds__(256) void k_near_z(const int *__restrict__ in, int 
     out[c] = best;
 }
 
+// MapDev::sc_dist -- Chebyshev distance, in super-cells, from every super-cell to the nearest occupied
+// one (separable: distance along x, then min over y of max(|dy|, .), then the same over z), capped at
+// kScReach + 1.  A query whose super-cell is d super-cells from anything has no point closer than
+// (d - 1) * 8h: the matcher answers "no neighbour within maxDist" from this one look-up.
+__device__ __forceinline__ void scdist_cell(const int *__restrict__ in, int nsx, int nsy, int nsz, int axis, int first,
+                                            int *__restrict__ out, int c)
+{
+    const int x = c % nsx, y = (c / nsx) % nsy, z = c / (nsx * nsy);
+    const int pos = axis == 0 ? x : (axis == 1 ? y : z), len = axis == 0 ? nsx : (axis == 1 ? nsy : nsz);
+    const int stride = axis == 0 ? 1 : (axis == 1 ? nsx : nsx * nsy);
+    int best = kScReach + 1;
+    for (int d = -kScReach; d <= kScReach; ++d) {
+        const int p = pos + d;
+        if (p < 0 || p >= len) continue;
+        const int v = in[c + d * stride];
+        // first pass reads occupancy flags (occupied = distance 0), the others read distances
+        const int dv = first ? (v > 0 ? 0 : kScReach + 1) : v;
+        best = min(best, max(abs(d), dv));
+    }
+    out[c] = best;
+}
+
+__global__ __launch_bounds__(256) void k_scdist(const int *__restrict__ in, int nsx, int nsy, int nsz, int axis, int first,
+                                                 int *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nsx * nsy * nsz) scdist_cell(in, nsx, nsy, nsz, axis, first, out, c);
+}
+
+// all three sweeps in one launch for the usual small super-cell grid (one block; a block-wide barrier
+// orders the global writes of one sweep before the reads of the next)
+__global__ __launch_bounds__(1024) void k_scdist_fused(const int *__restrict__ flags, int nsx, int nsy, int nsz,
+                                                        int *__restrict__ tmp_a, int *__restrict__ tmp_b, int *__restrict__ out)
+{
+    const int n = nsx * nsy * nsz;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(flags, nsx, nsy, nsz, 0, 1, tmp_a, c);
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(tmp_a, nsx, nsy, nsz, 1, 0, tmp_b, c);
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(tmp_b, nsx, nsy, nsz, 2, 0, out, c);
+}
+
 // three-phase exclusive scan over `n` ints (n up to 2^27)
 constexpr int kScanChunk = 4096;   // elements per block (1024 threads x 4)
 
@@ -803,7 +845,7 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
     const int lane = threadIdx.x;
     const int i = tile * kFastBlock + lane;
     if (tile * kFastBlock >= P.n) return;
-    const bool live = i < P.n;
+    bool live = i < P.n;
     const MapDev<T> M = maps[P.map];
     const GridDesc<T> g = M.g;
     T qx = 0, qy = 0, qz = 0;
@@ -832,6 +874,19 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
     }
     const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
     const int cx = clamp_cell<T>(ux, g.inv_h, g.nx), cy = clamp_cell<T>(uy, g.inv_h, g.ny), cz = clamp_cell<T>(uz, g.inv_h, g.nz);
+
+    // Far from everything: the nearest occupied super-cell is d super-cells away, so no point is closer than
+    // (d - 1) * 8h (measured from the query's own super-cell, in which it lies or to which it was clamped
+    // from farther out).  Beyond maxDist that settles "no neighbour" with one look-up -- scan points ahead
+    // of a streaming map would otherwise each walk the queue, the medium and the slow path every iteration.
+    if (live) {
+        const int dsc = as_global(M.sc_dist)[(cx >> 3) + M.nsx * ((cy >> 3) + M.nsy * (cz >> 3))];
+        if ((T)(dsc - 1) * (g.h * (T)8) - g.margin > ch.max_dist) {
+            slot_io[P.off + i] = -1;
+            d2_out[P.off + i] = Bits<T>::inf();
+            live = false;
+        }
+    }
 
     // no previous match (first iteration, or nothing located last time): a query that starts in an empty
     // cell takes the points of a nearby occupied cell as first candidates, so every later row test prunes
@@ -1020,10 +1075,11 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
             slot_io[P.off + i] = best.slot;
             d2_out[P.off + i] = best.d2;
             slow_lb[k] = Bits<T>::inf();                      // finished: later passes skip it
-            P.n_refined = 1;                                  // a flag: every writer stores the same value
+            if (P.n_refined == 0) P.n_refined = 1;            // a flag; stored only while it reads 0: thousands of
+                                                              // stores to one address serialise at the memory side
         } else {
             // still open: keep the better upper bound (if a real candidate exists) and the larger lower bound
-            if (best.slot >= 0) { slot_io[P.off + i] = best.slot; d2_out[P.off + i] = best.d2; P.n_refined = 1; }
+            if (best.slot >= 0) { slot_io[P.off + i] = best.slot; d2_out[P.off + i] = best.d2; if (P.n_refined == 0) P.n_refined = 1; }
             T nlb = lb;
             const T reached = gr > (T)0 ? gr * gr : (T)0;
             if (lb >= (T)0 || best.slot >= 0) { nlb = reached; slow_lb[k] = nlb; }
@@ -1072,7 +1128,7 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
         // (a plain flag store: contended atomics on one address serialise the waves, and on gfx9 every
         // later load of the wave waits behind them)
         if (!exact_all && lane == 0) {
-            P.n_refined = 1;
+            if (P.n_refined == 0) P.n_refined = 1;
 #ifdef PGICP_KNN_STATS
             atomicAdd(const_cast<int *>(slow_count) + (slow_lb[k] < (T)0 ? 1 : 2), 1);     // diagnostics: forced / bound-hit
 #endif
@@ -1094,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
         const bool exist_only = !exact_all && lbk < (T)0 && (-lbk - (T)1) > (T)P.limit;
         if (lane == 0) KNN_TRACE(e.x, i, "[slow] i=%d lbk=%g limit=%g exist_only=%d prev=%d\n", i, (double)lbk, (double)P.limit, (int)exist_only, prev);
 #ifdef PGICP_KNN_STATS
-        const long long t_begin = clock64();
+        const long long t_begin = wall_clock64();
         int st_sc = 0, st_rows = 0, st_trips = 0, st_R = 0;
 #endif
         bool found = exist_only && prev >= 0 && best.slot >= 0;
@@ -1197,7 +1253,7 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
             slot_io[P.off + i] = best.slot;
             d2_out[P.off + i] = best.d2;
 #ifdef PGICP_KNN_STATS
-            const unsigned long long dt = (unsigned long long)(clock64() - t_begin);
+            const unsigned long long dt = (unsigned long long)(wall_clock64() - t_begin);   // 100 MHz ticks
             atomicAdd(&g_knn_stats[10], 1ULL);
             atomicAdd(&g_knn_stats[11], dt);
             const unsigned long long old = atomicMax(&g_knn_stats[12], dt);
@@ -1927,7 +1983,7 @@ template <typename T>
 void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, int nstride, int m, const T mean[3],
                        const GridDesc<T> &g, int *cell_of, int *counts, int *block_sums, int *cell_start, int *cursor,
                        int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of,
-                       int *sc_count, int *near, int near_reach)
+                       int *sc_count, int *near, int near_reach, int *sc_dist)
 {
     const long long ncells = (long long)g.nx * g.ny * g.nz;
     const long long nsc = (long long)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
@@ -1950,6 +2006,16 @@ void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, i
     hipLaunchKernelGGL(k_near_x, dim3(nbc), dim3(256), 0, st, (const int *)cell_start, g.nx, ncells, reach, counts);
     hipLaunchKernelGGL(k_near_y, dim3(nbc), dim3(256), 0, st, (const int *)counts, g.nx, g.ny, ncells, reach, cursor);
     hipLaunchKernelGGL(k_near_z, dim3(nbc), dim3(256), 0, st, (const int *)cursor, g.nx, g.ny, g.nz, ncells, reach, near);
+    // super-cell distance map (tiny grid): x sweep from the flags, then y, then z
+    const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3, nsz = (g.nz + 7) >> 3;
+    const int nbs = cdiv(nsc, 256);
+    if (nsc <= 32768) {
+        hipLaunchKernelGGL(k_scdist_fused, dim3(1), dim3(1024), 0, st, (const int *)sc_count, nsx, nsy, nsz, counts, cursor, sc_dist);
+    } else {
+        hipLaunchKernelGGL(k_scdist, dim3(nbs), dim3(256), 0, st, (const int *)sc_count, nsx, nsy, nsz, 0, 1, counts);
+        hipLaunchKernelGGL(k_scdist, dim3(nbs), dim3(256), 0, st, (const int *)counts, nsx, nsy, nsz, 1, 0, cursor);
+        hipLaunchKernelGGL(k_scdist, dim3(nbs), dim3(256), 0, st, (const int *)cursor, nsx, nsy, nsz, 2, 0, sc_dist);
+    }
 }
 
 // once per scan: order every problem's pre-transformed reading by (map row, x)
@@ -2111,7 +2177,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_centroid_bbox<T>(hipStream_t, const T *, int, int, unsigned long long *);                        \
     template void launch_grid_build<T>(hipStream_t, const T *, int, const T *, int, int, const T[3], const GridDesc<T> &, \
                                        int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,                \
-                                       typename Vec4<T>::type *, int *, int *, int *, int);                               \
+                                       typename Vec4<T>::type *, int *, int *, int *, int, int *);                        \
     template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *,         \
                                        unsigned long long *, int *, int *, int *, int *, int *, int, int, int, int);      \
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \

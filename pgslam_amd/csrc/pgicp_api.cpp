@@ -50,6 +50,7 @@ struct MapHost {
     int *slot_of = nullptr;
     int *sc_count = nullptr;
     int *near = nullptr;
+    int *sc_dist = nullptr;
     char *block = nullptr;          // the one device allocation holding all of the above
     size_t block_bytes = 0;
     GridDesc<T> g{};
@@ -87,6 +88,7 @@ struct pgicp_ctx {
     std::multimap<size_t, char *> block_pool;
     size_t pooled_bytes = 0;
     int fast_rings_seeded = 1, fast_rings_unseeded = 3;
+    double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
     std::vector<ProfEvent> prof_events;
@@ -236,6 +238,7 @@ int sync_maps_table(pgicp_ctx *c)
         h[i].sc_count = m.sc_count;
         h[i].slot_of = m.slot_of;
         h[i].near = m.near;
+        h[i].sc_dist = m.sc_dist;
         h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
     }
     HIPC(c, hipMemcpyAsync(S.d_maps.p, h.data(), sizeof(MapDev<T>) * n, hipMemcpyHostToDevice, c->stream));
@@ -384,7 +387,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         const size_t b_pts = up(sizeof(V4) * (size_t)m), b_nrm = M.has_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (ncells + 1)),
                      b_slot = up(sizeof(int) * (size_t)m), b_sc = up(sizeof(int) * nsc), b_near = up(sizeof(int) * ncells);
         char *base = nullptr;
-        { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + b_sc + b_near, &base, &M.block_bytes); if (ast) return ast; }
+        { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near, &base, &M.block_bytes); if (ast) return ast; }
         M.block = base;
         M.pts = (V4 *)base;
         M.nrm = M.has_nrm ? (V4 *)(base + b_pts) : nullptr;
@@ -392,13 +395,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         M.slot_of = (int *)(base + b_pts + b_nrm + b_cs);
         M.sc_count = (int *)(base + b_pts + b_nrm + b_cs + b_slot);
         M.near = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc);
+        M.sc_dist = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc + b_near);
         // a first candidate farther than ~a third of maxDist prunes little: do not look for one beyond that
-        const double reach_len = std::isfinite(c->prm.max_dist) ? 0.35 * c->prm.max_dist : 1e30;
+        const double reach_len = std::isfinite(c->prm.max_dist) ? c->near_frac * c->prm.max_dist : 1e30;
         const int near_reach = (int)std::min((double)kNearReach, std::max(2.0, std::ceil(reach_len / (double)g.h)));
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
         launch_grid_build<T>(c->stream, d_xyz[k], src[k].xyz_stride, d_nrm[k], src[k].nrm_stride, m, M.mean, g, c->tmp_a.as<int>(),
                              c->tmp_b.as<int>(), c->tmp_c.as<int>(), M.cell_start, c->tmp_d.as<int>(), c->tmp_e.as<int>(), M.pts, M.nrm,
-                             M.slot_of, M.sc_count, M.near, near_reach);
+                             M.slot_of, M.sc_count, M.near, near_reach, M.sc_dist);
     }
     HIPC(c, hipGetLastError());
     // ---- phase 3: register ----
@@ -1120,6 +1124,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     c->device = device;
     pgicp_default_params(&c->prm);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_SEEDED")) c->fast_rings_seeded = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PGICP_NEAR_FRAC")) c->near_frac = std::atof(e);
     if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||

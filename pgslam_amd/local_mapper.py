@@ -96,6 +96,7 @@ class StreamingLocalMapper:
         self.rebuilds = 0
         self.last_stats = None
         self._pending = None                 # (thread, result holder, window snapshot)
+        self._job = None                     # scan between prepare() and complete()
 
     # ---- map (re)building ---------------------------------------------------------------
     def _build(self, ctx, window):
@@ -146,6 +147,16 @@ class StreamingLocalMapper:
     # ---- per scan -----------------------------------------------------------------------
     def process(self, odom_T_world_robot, scan_xyz, scan_nrm):
         """One scan (already in the robot frame).  Returns T_world_robot."""
+        job = self.prepare(odom_T_world_robot, scan_xyz, scan_nrm)
+        if job is not None:
+            T, stats = self.be.align(job[0], job[1], job[2])                  # Localizer.hpp:126
+            self.complete(T, stats)
+        return self.T_world_robot.copy()
+
+    def prepare(self, odom_T_world_robot, scan_xyz, scan_nrm):
+        """First half of ProcessData: everything up to the ICP call.  Returns (map_id, reading, T_init) for
+        the caller to align -- alone or as one problem of a device batch (StreamingFleet) -- or None when
+        the scan was consumed as the first keyframe."""
         odom = np.asarray(odom_T_world_robot, dtype=np.float64).reshape(4, 4)
         self.count += 1
         if self.map_id is None and self._pending is None:
@@ -157,19 +168,22 @@ class StreamingLocalMapper:
             self.T_refkf_robot = np.eye(4)
             self.T_world_robot = odom.copy()
             self.last_odom = odom.copy()
-            return self.T_world_robot.copy()
+            return None
         self._finish_pending(wait=False)
         d_odom = _inv(self.last_odom) @ odom                                   # Localizer.hpp:119
         T_init = self.T_refkf_robot @ d_odom                                   # :123
-        dev_xyz = self.to_device(scan_xyz)
-        T, stats = self.be.align(self.map_id, dev_xyz, T_init)                 # :126
+        self._job = (odom, self.to_device(scan_xyz), scan_nrm)
+        return self.map_id, self._job[1], T_init
+
+    def complete(self, T, stats):
+        """Second half of ProcessData: the ICP result, the world pose, UpdateAfterIcp."""
+        odom, dev_xyz, scan_nrm = self._job
+        self._job = None
         self.last_stats = stats
-        self.T_refkf_robot = T
-        ref_served = self.map_window[-1]
-        self.T_world_robot = ref_served.T_world_kf @ T                         # :127
+        self.T_refkf_robot = np.asarray(T, dtype=np.float64).reshape(4, 4)
+        self.T_world_robot = self.map_window[-1].T_world_kf @ self.T_refkf_robot   # :127
         self._update_after_icp(stats["overlap"], dev_xyz, scan_nrm)
         self.last_odom = odom.copy()
-        return self.T_world_robot.copy()
 
     def _update_after_icp(self, overlap, dev_xyz, scan_nrm):
         if self._pending is not None:
@@ -199,3 +213,29 @@ class StreamingLocalMapper:
         if self.map_id is not None:
             self.be.destroy_map(self.map_id)
             self.map_id = None
+
+
+class StreamingFleet:
+    """Several independent vehicles on one GPU, stepped together: the scans of one time step are aligned
+    as ONE device batch against each vehicle's own map (pgicp_align_batch), which fills the GPU where a
+    single 100k-point scan cannot (a chain of small kernels).  Every vehicle keeps its own mapper state
+    and takes exactly the decisions it would take alone; only the ICP calls are shared."""
+
+    def __init__(self, backend, n_vehicles, cfg: LocalMapperConfig, builder=None, to_device=None):
+        if cfg.async_rebuild:
+            raise ValueError("StreamingFleet rebuilds maps in line (one context serves all vehicles)")
+        self.be = backend
+        self.mappers = [StreamingLocalMapper(backend, cfg, builder=builder, to_device=to_device) for _ in range(n_vehicles)]
+
+    def step(self, odoms, scans_xyz, scans_nrm):
+        jobs = [m.prepare(o, x, n) for m, o, x, n in zip(self.mappers, odoms, scans_xyz, scans_nrm)]
+        live = [k for k, j in enumerate(jobs) if j is not None]
+        if live:
+            Ts, stats = self.be.align_batch([jobs[k][0] for k in live], [jobs[k][1] for k in live], [jobs[k][2] for k in live])
+            for n, k in enumerate(live):
+                self.mappers[k].complete(Ts[n], stats[n])
+        return [m.T_world_robot.copy() for m in self.mappers]
+
+    def close(self):
+        for m in self.mappers:
+            m.close()

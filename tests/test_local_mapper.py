@@ -138,3 +138,32 @@ def test_gpu_async_rebuild_tracks_like_sync(drive):
         assert dt < 0.15 and dr < 0.03, (s, dt, dr)
     for s, T in enumerate(res[True]):
         assert pose_err(drive.poses_true[s], T)[0] < 0.15
+
+
+@pytest.mark.gpu
+def test_gpu_fleet_equals_vehicles_stepped_alone(drive):
+    """StreamingFleet shares only the ICP calls: every vehicle ends where it would have ended alone."""
+    import torch
+    from pgslam_amd import icp
+    from pgslam_amd.local_mapper import StreamingFleet
+    dev = torch.device("cuda", 0)
+    up = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ctx = icp.Context(0, **CHAIN)
+    cfg = LocalMapperConfig(capacity=3, overlap_threshold=0.8, chain=CHAIN)
+    S = len(drive.odom)
+    # vehicle v starts v scans into the drive (different maps, different keyframe times)
+    starts = [0, 2, 5]
+    fleet = StreamingFleet(ctx, len(starts), cfg, to_device=up)
+    solo = [StreamingLocalMapper(ctx, cfg, to_device=up) for _ in starts]
+    for t in range(S - max(starts)):
+        idx = [s + t for s in starts]
+        Tf = fleet.step([drive.odom[i] for i in idx], [drive.scans_xyz[i] for i in idx], [drive.scans_nrm[i] for i in idx])
+        for v, i in enumerate(idx):
+            Ts = solo[v].process(drive.odom[i], drive.scans_xyz[i], drive.scans_nrm[i])
+            np.testing.assert_allclose(Tf[v], Ts, rtol=0, atol=1e-9)       # batch vs single: equal to rounding
+    for v in range(len(starts)):
+        assert fleet.mappers[v].keyframe_scans == solo[v].keyframe_scans
+    fleet.close()
+    for m in solo:
+        m.close()
+    ctx.close()
