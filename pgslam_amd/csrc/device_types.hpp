@@ -61,6 +61,7 @@ struct ProblemDev {
     double T_prev[16];       // T_iter used for the last matching
     double dT[16];           // last increment
     double Tcur[12];         // T_iter as 3x4 for the kernels (cast to T when applied)
+    double Tcur_prev[12];    // the Tcur the previous matcher pass ran with (how far each query moved since)
     int done, status, iters, converged, max_iter_reached;
     int n_finite, n_kept, rank;
     int n_refined;           // queued queries the slow path resolved since the last threshold selection

@@ -755,13 +755,14 @@ template <typename T>
 __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<T> &g, const ChainDev<T> &ch, bool resolved, T gr,
                                              Best<T> best, T qx, T qy, T qz, T ux, T uy, T uz, int cx, int cy, int cz, int prob,
                                              int i, long long pos, int r_next, T lb_override, int *__restrict__ slot_io,
-                                             T *__restrict__ d2_out,
+                                             T *__restrict__ d2_out, T *__restrict__ none_r,
                                              int *__restrict__ slow_count, int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
                                              int *__restrict__ slow_ring)
 {
     // ---- phase C: bookkeeping for the lazy slow path ----
     if (resolved) {
-        if (best.slot < 0) best.d2 = Bits<T>::inf();
+        // (the search pruned with maxDist: it proves nothing beyond it, so no radius is cached here)
+        if (best.slot < 0) { best.d2 = Bits<T>::inf(); none_r[pos] = (T)0; }
     } else {
         T lb = lb_override >= (T)0 ? lb_override : (gr > (T)0 ? gr * gr : (T)0);
         if (best.slot < 0) {
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
                                                   T *__restrict__ d2_out, ChainDev<T> ch, int use_seed, int fast_rings,
                                                   int *__restrict__ slow_count, int2 *__restrict__ slow_list,
                                                   T *__restrict__ slow_lb, int *__restrict__ slow_ring,
-                                                  const int *__restrict__ active)
+                                                  const int *__restrict__ active, T *__restrict__ none_r)
 {
     using V4 = typename Vec4<T>::type;
     constexpr int NR = (2 * R + 1) * (2 * R + 1);
@@ -856,6 +857,7 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
     // iteration's threshold exceed the cap, the lazy medium/slow path resolves it exactly.
     const T cap2 = use_seed ? (T)(1.21 * P.limit) : Bits<T>::inf();
     const bool capped = cap2 < ch.max_dist2;
+    bool still_none = false;
     Best<T> best, seed;
     best.d2 = capped ? cap2 : ch.max_dist2;            // anything farther is useless
     best.idx = 0x7FFFFFFF;
@@ -869,9 +871,24 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
             if (prev >= 0) {
                 eval_point<T>(M.pts[prev], prev, qx, qy, qz, seed);
                 if (seed.d2 <= best.d2) best = seed;
+            } else if (prev == -1) {
+                // Last pass proved that no map point lies within none_r of where the query was; it has
+                // moved by |dq| since, so none lies within none_r - |dq| now.  While that still exceeds
+                // maxDist the answer stays "no neighbour" without any search (points outside the map's
+                // reach would otherwise walk the queue and the slow path in every iteration).
+                T px, py, pz;
+                apply_T<T>(P.Tcur_prev, q[0], q[1], q[2], px, py, pz);
+                const T mx = qx - px, my = qy - py, mz = qz - pz;
+                const T left = none_r[P.off + i] - sqrt((mx * mx + my * my) + mz * mz) - g.margin;
+                if (left > ch.max_dist) {
+                    none_r[P.off + i] = left;
+                    d2_out[P.off + i] = Bits<T>::inf();        // slot_io already holds -1
+                    still_none = true;
+                }
             }
         }
     }
+    if (still_none) live = false;
     const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
     const int cx = clamp_cell<T>(ux, g.inv_h, g.nx), cy = clamp_cell<T>(uy, g.inv_h, g.ny), cz = clamp_cell<T>(uz, g.inv_h, g.nz);
 
@@ -881,9 +898,11 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
     // of a streaming map would otherwise each walk the queue, the medium and the slow path every iteration.
     if (live) {
         const int dsc = as_global(M.sc_dist)[(cx >> 3) + M.nsx * ((cy >> 3) + M.nsy * (cz >> 3))];
-        if ((T)(dsc - 1) * (g.h * (T)8) - g.margin > ch.max_dist) {
+        const T empty_r = (T)(dsc - 1) * (g.h * (T)8) - g.margin;
+        if (empty_r > ch.max_dist) {
             slot_io[P.off + i] = -1;
             d2_out[P.off + i] = Bits<T>::inf();
+            none_r[P.off + i] = empty_r;
             live = false;
         }
     }
@@ -1010,7 +1029,7 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
         else best.d2 = ch.max_dist2;
     }
     finish_query<T>(M, g, ch, resolved, gr, best, qx, qy, qz, ux, uy, uz, cx, cy, cz, prob, i, P.off + i, r_next, lb_override,
-                    slot_io, d2_out, slow_count, slow_list, slow_lb, slow_ring);
+                    slot_io, d2_out, none_r, slow_count, slow_list, slow_lb, slow_ring);
 }
 
 // Medium path: the queued queries that can still matter (lower bound within the threshold just
@@ -1025,7 +1044,7 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
                                                  ChainDev<T> ch, int *__restrict__ slow_count,
                                                  const int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
                                                  int *__restrict__ slow_ring, int *__restrict__ slow2_idx, int med_rings,
-                                                 int use_seed)
+                                                 int use_seed, T *__restrict__ none_r)
 {
     const int count = *slow_count;
     const int lane = threadIdx.x;
@@ -1071,7 +1090,7 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
             if (seed_ok) best = seed;
         }
         if (resolved) {
-            if (best.slot < 0) best.d2 = Bits<T>::inf();
+            if (best.slot < 0) { best.d2 = Bits<T>::inf(); none_r[P.off + i] = (T)0; }
             slot_io[P.off + i] = best.slot;
             d2_out[P.off + i] = best.d2;
             slow_lb[k] = Bits<T>::inf();                      // finished: later passes skip it
@@ -1112,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
                                                    T *__restrict__ d2_out, ChainDev<T> ch,
                                                    const int *__restrict__ slow_count, const int2 *__restrict__ slow_list,
                                                    const T *__restrict__ slow_lb, const int *__restrict__ slow2_idx,
-                                                   int exact_all)
+                                                   int exact_all, T *__restrict__ none_r)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1139,8 +1158,14 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
         const MapDev<T> M = maps[P.map];
         const GridDesc<T> g = M.g;
         const T H = g.h * (T)8;
+        // The search prunes with a radius 15 % beyond maxDist (candidates out there are found but not accepted):
+        // when the answer is "none" it then knows how far the nearest point really is, or that nothing lies
+        // within that larger radius -- the empty radius the fast pass subtracts the query's movement from in
+        // later iterations instead of searching again.
+        const T prune_dist = ch.max_dist * (T)1.15;
+        const T prune2 = prune_dist * prune_dist;
         Best<T> best;
-        best.d2 = ch.max_dist2; best.idx = 0x7FFFFFFF; best.slot = -1;
+        best.d2 = prune2; best.idx = 0x7FFFFFFF; best.slot = -1;
         const int prev = slot_io[P.off + i];
         if (prev >= 0) eval_point<T>(M.pts[prev], prev, qx, qy, qz, best);
         // An entry whose neighbour -- if it has one -- is already proven farther than the threshold only
@@ -1153,10 +1178,11 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
         const long long t_begin = wall_clock64();
         int st_sc = 0, st_rows = 0, st_trips = 0, st_R = 0;
 #endif
-        bool found = exist_only && prev >= 0 && best.slot >= 0;
+        bool found = exist_only && prev >= 0 && best.slot >= 0 && best.d2 <= ch.max_dist2;
         const T ux = qx - g.ox, uy = qy - g.oy, uz = qz - g.oz;
         const int Cx = clamp_cell<T>(ux, g.inv_h, g.nx) >> 3, Cy = clamp_cell<T>(uy, g.inv_h, g.ny) >> 3,
                   Cz = clamp_cell<T>(uz, g.inv_h, g.nz) >> 3;
+        T empty_r = (T)0;                                     // radius proven free of points when the answer is "none"
         for (int R = 0; !found; ++R) {
             const int side = 2 * R + 1, total = side * side * side;
             for (int base = 0; base < total && !found; base += 64) {
@@ -1222,7 +1248,7 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
                         for (int o = 32; o > 0; o >>= 1) wmin = fmin(wmin, __shfl_xor(wmin, o, 64));
                         if (wmin < best.d2) { best.d2 = wmin; best.idx = 0x7FFFFFFF; best.slot = -1; }
                     }
-                    if (exist_only && best.d2 < ch.max_dist2) { found = true; break; }    // wave-uniform
+                    if (exist_only && best.d2 <= ch.max_dist2) { found = true; break; }   // wave-uniform
                 }
             }
             // every super-cell outside ring R is at least this far away (wave-uniform)
@@ -1233,12 +1259,13 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
             if (Cy + R + 1 <= M.nsy - 1) gr = fmin(gr, slab_dist(uy, Cy + R + 1, H));
             if (Cz - R - 1 >= 0) gr = fmin(gr, slab_dist(uz, Cz - R - 1, H));
             if (Cz + R + 1 <= M.nsz - 1) gr = fmin(gr, slab_dist(uz, Cz + R + 1, H));
-            if (!(gr < Bits<T>::inf())) break;
+            if (!(gr < Bits<T>::inf())) { empty_r = gr; break; }           // the whole grid was covered
             gr = gr - g.margin;
+            empty_r = gr;
             T wbest = best.d2;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) wbest = fmin(wbest, __shfl_xor(wbest, o, 64));
-            if (gr > (T)0 && (wbest < gr * gr || gr > ch.max_dist)) break;
+            if (gr > (T)0 && (wbest < gr * gr || gr > prune_dist)) break;
         }
         // lexicographic (d2, idx) minimum over the wave; lanes whose bound was only borrowed hold slot -1
 #pragma unroll
@@ -1249,6 +1276,13 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
             if (od < best.d2 || (od == best.d2 && oi < best.idx)) { best.d2 = od; best.idx = oi; best.slot = os; }
         }
         if (lane == 0) {
+            if (best.slot >= 0 && best.d2 > ch.max_dist2) {
+                // the nearest point lies beyond maxDist: no neighbour, and nothing closer than that point
+                none_r[P.off + i] = sqrt(best.d2) * (T)0.9999;
+                best.slot = -1;
+            } else if (best.slot < 0) {
+                none_r[P.off + i] = fmin(empty_r, prune_dist);
+            }
             if (best.slot < 0) best.d2 = Bits<T>::inf();
             slot_io[P.off + i] = best.slot;
             d2_out[P.off + i] = best.d2;
@@ -1816,7 +1850,7 @@ __global__ __launch_bounds__(256) void k_solve_update(ProblemDev *__restrict__ p
         for (int i = 0; i < 16; i++) { P.T_prev[i] = P.T_iter[i]; P.dT[i] = dT[i]; }
         mat4_mul(dT, P.T_iter, Tn);
         for (int i = 0; i < 16; i++) P.T_iter[i] = Tn[i];
-        for (int i = 0; i < 12; i++) P.Tcur[i] = Tn[i];
+        for (int i = 0; i < 12; i++) { P.Tcur_prev[i] = P.Tcur[i]; P.Tcur[i] = Tn[i]; }
         P.n_kept = (int)sys[28];
         P.iters += 1;
         const int f = checker_check(P.chk, Tn, ch.max_iters, ch.min_rot, ch.min_trans, ch.smooth);
@@ -2059,7 +2093,7 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active)
+                int *slow_ring, int fast_rings, const int *active, T *none_r)
 {
     if (matcher == 1) {
         hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot, d2,
@@ -2071,16 +2105,16 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
     // R = 1 in both cases: measured, a 5x5x5 collected block on the unseeded first iteration costs
     // 2.5x the ring-by-ring continuation (nothing prunes it until the own row has a hit)
     hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, kFastBlock)), P), dim3(kFastBlock), 0, st, probs, maps, rd, slot, d2, ch,
-                       use_seed, fast_rings, slow_count, slow_list, slow_lb, slow_ring, active);
+                       use_seed, fast_rings, slow_count, slow_list, slow_lb, slow_ring, active, none_r);
 }
 
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                     const ChainDev<T> &ch, int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring, int *slow2_idx,
-                    int med_rings, int use_seed)
+                    int med_rings, int use_seed, T *none_r)
 {
     hipLaunchKernelGGL(k_knn_med<T>, dim3(8192), dim3(64), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list, slow_lb,
-                       slow_ring, slow2_idx, med_rings, use_seed);
+                       slow_ring, slow2_idx, med_rings, use_seed, none_r);
 }
 
 // resolves the queries the fast path queued: all of them (exact_all, public matcher
@@ -2090,10 +2124,10 @@ constexpr int kSlowBlocks = 2048;
 template <typename T>
 void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                      const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb,
-                     const int *slow2_idx, int exact_all)
+                     const int *slow2_idx, int exact_all, T *none_r)
 {
     hipLaunchKernelGGL(k_knn_slow<T>, dim3(kSlowBlocks), dim3(256), 0, st, probs, maps, rd, slot, d2, ch, slow_count, slow_list,
-                       slow_lb, slow2_idx, exact_all);
+                       slow_lb, slow2_idx, exact_all, none_r);
 }
 
 template <typename T>
@@ -2183,11 +2217,11 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
-                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *);         \
+                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *, T *);    \
     template void launch_knn_med<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                  \
-                                    const ChainDev<T> &, int *, const int2 *, T *, int *, int *, int, int);               \
+                                    const ChainDev<T> &, int *, const int2 *, T *, int *, int *, int, int, T *);          \
     template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \
-                                     const ChainDev<T> &, const int *, const int2 *, const T *, const int *, int);        \
+                                     const ChainDev<T> &, const int *, const int2 *, const T *, const int *, int, T *);   \
     template void launch_trim_select<T>(hipStream_t, ProblemDev *, const T *, const ChainDev<T> &, int, int, const int *); \
     template void launch_reduce<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, const int *, const T *, \
                                    double *, int, int, const int *);                                                      \

@@ -23,15 +23,15 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active);
+                int *slow_ring, int fast_rings, const int *active, T *none_r);
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                     const ChainDev<T> &ch, int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring, int *slow2_idx,
-                    int med_rings, int use_seed);
+                    int med_rings, int use_seed, T *none_r);
 template <typename T>
 void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                      const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb,
-                     const int *slow2_idx, int exact_all);
+                     const int *slow2_idx, int exact_all, T *none_r);
 template <typename T>
 void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second,
                         const int *active);

@@ -61,7 +61,7 @@ struct State {
     std::vector<MapHost<T>> maps;
     DevBuf d_maps;                  // MapDev<T>[capacity]
     int d_maps_cap = 0;
-    DevBuf rd_pre, rd_sorted, slot, d2, staging, stage_aux;
+    DevBuf rd_pre, rd_sorted, slot, d2, none_r, staging, stage_aux;
 };
 
 struct ProfEvent {
@@ -491,6 +491,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     }
     HIPC(c, S.slot.ensure(sizeof(int) * (size_t)L.total));
     HIPC(c, S.d2.ensure(sizeof(T) * (size_t)L.total));
+    HIPC(c, S.none_r.ensure(sizeof(T) * (size_t)L.total));
     HIPC(c, c->probs.ensure(sizeof(ProblemDev) * (size_t)P));
     HIPC(c, c->src.ensure(sizeof(SrcDesc) * (size_t)P));
     HIPC(c, c->partials.ensure(sizeof(double) * (size_t)P * reduce_blocks(L.max_n) * kCovTerms));
@@ -557,7 +558,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
-                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active);
+                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active, S.none_r.template as<T>());
     }
     {
         ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
@@ -571,10 +572,10 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
             ProfScope ps(c, PGICP_PROF_KNN_SLOW, act_units, act_probs);
             launch_knn_med<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
                               ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(), c->slow_ring.as<int>(),
-                              c->slow2.as<int>(), c->med_rings, use_seed);
+                              c->slow2.as<int>(), c->med_rings, use_seed, S.none_r.template as<T>());
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                               c->slow2.as<int>(), 0);
+                               c->slow2.as<int>(), 0, S.none_r.template as<T>());
         }
         ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
         launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, 1, active);
@@ -728,12 +729,12 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>());
+                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>());
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                               c->slow2.as<int>(), 1);
+                               c->slow2.as<int>(), 1, S.none_r.template as<T>());
     }
     return PGICP_OK;
 }
@@ -1150,7 +1151,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
-                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active})
+                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->f32.none_r, &c->f64.none_r})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
