@@ -452,6 +452,9 @@ def main():
     ap.add_argument("--n-scan", type=int, default=100_000)
     ap.add_argument("--n-map", type=int, default=1_000_000)
     ap.add_argument("--fixed-iters", action="store_true", help="disable the Differential checker: exactly 30 iterations")
+    ap.add_argument("--with-fixed30", action="store_true",
+                    help="after the timed run, also time one step with the Differential checker disabled and report it as "
+                         "`fixed_30_iterations` (off by default so that a kernel trace of the default command holds only the metric's launches)")
     ap.add_argument("--matcher", choices=["grid", "brute"], default="grid")
     ap.add_argument("--grid-cell", type=float, default=0.0)
     ap.add_argument("--check-every", type=int, default=1)
@@ -625,7 +628,7 @@ def main():
     # ---- workload-stable companion figure: the same step with the Differential
     #      checker disabled, i.e. exactly 30 iterations per scan; reported next to the metric, never as `value`
     fixed30 = None
-    if not args.fixed_iters and not args.no_profile:
+    if args.with_fixed30 and not args.fixed_iters:
         for c in ctxs:
             c.set_params(min_diff_rot=0.0, min_diff_trans=0.0, check_every=args.check_every)
         step()

@@ -7,10 +7,12 @@ mkdir -p $OUT
 python3 bench.py --prepare-only > /dev/null 2>&1
 python3 bench.py --workload stream --prepare-only > /dev/null 2>&1
 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench_n1.json
-python3 bench.py --fixed-iters --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_n1_fixed30.json
+python3 bench.py --with-fixed30 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_n1_with_fixed30.json
 python3 bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_loopclosure.json
 python3 bench.py --workload stream --streams 1 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_1.json
 python3 bench.py --workload stream --streams 4 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_4.json
+python3 bench.py --workload stream --streams 16 --fleet --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_fleet16.json
+python3 tools/bench_normals.py 2>/dev/null | grep -v amdgpu > $OUT/bench_normals.json
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace -o t -- python3 $REPO/bench.py > $REPO/$OUT/trace.log 2>&1
