@@ -38,6 +38,19 @@ struct MapDev {
     int nsx, nsy, nsz;                   // super-cell grid dims
 };
 
+// One cloud of a batched index build.  All clouds of the batch share concatenated arrays: points of
+// cloud k live at [pbase, pbase + m), its cells (plus one sentinel slot) at [cbase, cbase + ncells],
+// its super-cells at [sbase, sbase + nsc).
+template <typename T>
+struct BuildDesc {
+    const T *xyz; const T *nrm;
+    int xstride, nstride, m, near_reach;
+    T mean[3];
+    GridDesc<T> g;
+    long long pbase, cbase, sbase;
+    int ncells, nsc;
+};
+
 // Chain parameters as the kernels need them.
 template <typename T>
 struct ChainDev {

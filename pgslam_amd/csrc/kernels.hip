@@ -78,40 +78,6 @@ __device__ __forceinline__ unsigned long long ordered_key(double v)
     return (unsigned long long)(i >= 0 ? (i ^ (long long)0x8000000000000000LL) : ~i);
 }
 
-// stats[0..2] = fixed-point sums (int64), stats[3..5] = min keys, stats[6..8] = max keys
-template <typename T>
-__global__ __launch_bounds__(256) void k_centroid_bbox(const T *__restrict__ xyz, int stride, int m,
-                                                        unsigned long long *__restrict__ stats)
-{
-    long long s[3] = {0, 0, 0};
-    double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const double v = (double)xyz[i * stride + a];
-            s[a] += __double2ll_rn(v * 16777216.0);
-            mn[a] = fmin(mn[a], v);
-            mx[a] = v == v ? fmax(mx[a], v) : HUGE_VAL;      // fmax would hide a NaN: let it surface as a non-finite box
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        long long sv = s[a];
-        double lo = mn[a], hi = mx[a];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            sv += __shfl_down(sv, o, 64);
-            lo = fmin(lo, __shfl_down(lo, o, 64));
-            hi = fmax(hi, __shfl_down(hi, o, 64));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats[a], (unsigned long long)sv);
-            atomicMin(&stats[3 + a], ordered_key(lo));
-            atomicMax(&stats[6 + a], ordered_key(hi));
-        }
-    }
-}
-
 template <typename T>
 __device__ __forceinline__ int build_cell(const GridDesc<T> &g, T x, T y, T z)
 {
@@ -148,89 +114,6 @@ __device__ __forceinline__ int wave_bucket_add(int *__restrict__ counts, int key
     return pos;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_cell_count(const T *__restrict__ xyz, int stride, int m, T mx, T my, T mz,
-                                                     GridDesc<T> g, int *__restrict__ cell_of, int *__restrict__ counts,
-                                                     int *__restrict__ sc_count, int *__restrict__ arrival)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < m;
-    int c = 0;
-    if (live) {
-        const T x = xyz[(long long)i * stride] - mx, y = xyz[(long long)i * stride + 1] - my,
-                z = xyz[(long long)i * stride + 2] - mz;
-        c = build_cell(g, x, y, z);
-        cell_of[i] = c;
-    }
-    const int pos = wave_bucket_add(counts, c, live);
-    if (!live) return;
-    arrival[i] = pos;
-    // occupancy flag of the 8x8x8 super-cell (used by the wave-cooperative slow path): set by the first
-    // point of every fine cell with a plain store -- a contended atomic per point serialises on dense maps
-    if (pos == 0) {
-        const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
-        const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3;
-        sc_count[(cx >> 3) + nsx * ((cy >> 3) + nsy * (cz >> 3))] = 1;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// MapDev::near -- for every cell a nearby OCCUPIED cell (three separable sweeps: nearest occupied
-// cell of the row, then the best of the neighbouring rows' answers in y, then in z).  The answer is
-// a heuristic, not a nearest-cell guarantee: the matcher only uses it to give a query that starts
-// in empty space a first candidate, so that its exact ring search prunes from the first row on.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_near_x(const int *__restrict__ cell_start, int nx, long long ncells, int reach, int *__restrict__ out)
-{
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells) return;
-    const int x = (int)(c % nx);
-    int found = -1;
-    for (int d = 0; d <= reach && found < 0; ++d) {
-        if (x - d >= 0 && cell_start[c - d + 1] > cell_start[c - d]) found = x - d;
-        else if (x + d < nx && cell_start[c + d + 1] > cell_start[c + d]) found = x + d;
-    }
-    out[c] = found;
-}
-
-// in: nearest occupied x of each row cell; out: (x', y') packed x' | y' << 16, or -1
-__global__ __launch_bounds__(256) void k_near_y(const int *__restrict__ in, int nx, int ny, long long ncells, int reach, int *__restrict__ out)
-{
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells) return;
-    const int x = (int)(c % nx), y = (int)((c / nx) % ny);
-    int best = -1, bd = 0x7FFFFFFF;
-    for (int d = -reach; d <= reach; ++d) {
-        const int yy = y + d;
-        if (yy < 0 || yy >= ny) continue;
-        const int xx = in[c + (long long)d * nx];
-        if (xx < 0) continue;
-        const int dist = (xx - x) * (xx - x) + d * d;
-        if (dist < bd) { bd = dist; best = xx | (yy << 16); }
-    }
-    out[c] = best;
-}
-
-// in: (x', y') of each cell's xy-plane answer; out: linear index of the chosen occupied cell, or -1
-__global__ __launch_bounds__(256) void k_near_z(const int *__restrict__ in, int nx, int ny, int nz, long long ncells, int reach, int *__restrict__ out)
-{
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells) return;
-    const long long plane = (long long)nx * ny;
-    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / plane);
-    int best = -1, bd = 0x7FFFFFFF;
-    for (int d = -reach; d <= reach; ++d) {
-        const int zz = z + d;
-        if (zz < 0 || zz >= nz) continue;
-        const int v = in[c + d * plane];
-        if (v < 0) continue;
-        const int xx = v & 0xFFFF, yy = v >> 16;
-        const int dist = (xx - x) * (xx - x) + (yy - y) * (yy - y) + d * d;
-        if (dist < bd) { bd = dist; best = (int)(xx + (long long)nx * (yy + (long long)ny * zz)); }
-    }
-    out[c] = best;
-}
-
 // MapDev::sc_dist -- Chebyshev distance, in super-cells, from every super-cell to the nearest occupied
 // one (separable: distance along x, then min over y of max(|dy|, .), then the same over z), capped at
 // kScReach + 1.  A query whose super-cell is d super-cells from anything has no point closer than
@@ -251,26 +134,6 @@ __device__ __forceinline__ void scdist_cell(const int *__restrict__ in, int nsx,
         best = min(best, max(abs(d), dv));
     }
     out[c] = best;
-}
-
-__global__ __launch_bounds__(256) void k_scdist(const int *__restrict__ in, int nsx, int nsy, int nsz, int axis, int first,
-                                                 int *__restrict__ out)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < nsx * nsy * nsz) scdist_cell(in, nsx, nsy, nsz, axis, first, out, c);
-}
-
-// all three sweeps in one launch for the usual small super-cell grid (one block; a block-wide barrier
-// orders the global writes of one sweep before the reads of the next)
-__global__ __launch_bounds__(1024) void k_scdist_fused(const int *__restrict__ flags, int nsx, int nsy, int nsz,
-                                                        int *__restrict__ tmp_a, int *__restrict__ tmp_b, int *__restrict__ out)
-{
-    const int n = nsx * nsy * nsz;
-    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(flags, nsx, nsy, nsz, 0, 1, tmp_a, c);
-    __syncthreads();
-    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(tmp_a, nsx, nsy, nsz, 1, 0, tmp_b, c);
-    __syncthreads();
-    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(tmp_b, nsx, nsy, nsz, 2, 0, out, c);
 }
 
 // three-phase exclusive scan over `n` ints (n up to 2^27)
@@ -366,16 +229,88 @@ __global__ __launch_bounds__(256) void k_scatter_idx(int m, const int *__restric
     order_tmp[cell_start[cell_of[i]] + arrival[i]] = i;      // arrival position from k_cell_count: no second atomic
 }
 
+// ---------------------------------------------------------------------------
+// Batched index build: n clouds in one set of launches (blockIdx.y = cloud).  Counting, the prefix scan
+// and the scatter run on the concatenation of all clouds' points and cells, so a batch of loop-closure
+// candidate maps costs a dozen launches instead of a dozen per map.
+// ---------------------------------------------------------------------------
+// per cloud: stats[0..2] = fixed-point coordinate sums (int64), stats[3..5] = min keys, stats[6..8] = max keys
 template <typename T>
-__global__ __launch_bounds__(256) void k_rank_place(const T *__restrict__ xyz, int stride, const T *__restrict__ nrm,
-                                                     int nstride, int m, T mx, T my, T mz, const int *__restrict__ cell_of,
-                                                     const int *__restrict__ cell_start, const int *__restrict__ order_tmp,
-                                                     typename Vec4<T>::type *__restrict__ pts,
-                                                     typename Vec4<T>::type *__restrict__ nrm_out, int *__restrict__ slot_of)
+__global__ __launch_bounds__(256) void k_centroid_bbox_b(const BuildDesc<T> *__restrict__ descs, unsigned long long *__restrict__ stats)
 {
+    const BuildDesc<T> &d = descs[blockIdx.y];
+    const T *xyz = d.xyz;
+    const int stride = d.xstride, m = d.m;
+    unsigned long long *st = stats + 9 * (long long)blockIdx.y;
+    long long s[3] = {0, 0, 0};
+    double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double v = (double)xyz[i * stride + a];
+            s[a] += __double2ll_rn(v * 16777216.0);
+            mn[a] = fmin(mn[a], v);
+            mx[a] = v == v ? fmax(mx[a], v) : HUGE_VAL;
+        }
+    }
+    if ((long long)blockIdx.x * blockDim.x >= m) return;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        long long sv = s[a];
+        double lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sv += __shfl_down(sv, o, 64);
+            lo = fmin(lo, __shfl_down(lo, o, 64));
+            hi = fmax(hi, __shfl_down(hi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&st[a], (unsigned long long)sv);
+            atomicMin(&st[3 + a], ordered_key(lo));
+            atomicMax(&st[6 + a], ordered_key(hi));
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_cell_count_b(const BuildDesc<T> *__restrict__ descs, int *__restrict__ cell_of,
+                                                       int *__restrict__ counts, int *__restrict__ sc_count, int *__restrict__ arrival)
+{
+    const BuildDesc<T> &d = descs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= d.m) return;
+    const bool live = i < d.m;
+    const GridDesc<T> g = d.g;
+    int c = 0, cl = 0;
+    if (live) {
+        const T x = d.xyz[(long long)i * d.xstride] - d.mean[0], y = d.xyz[(long long)i * d.xstride + 1] - d.mean[1],
+                z = d.xyz[(long long)i * d.xstride + 2] - d.mean[2];
+        cl = build_cell(g, x, y, z);
+        c = (int)(d.cbase + cl);
+        cell_of[d.pbase + i] = c;
+    }
+    const int pos = wave_bucket_add(counts, c, live);
+    if (!live) return;
+    arrival[d.pbase + i] = pos;
+    if (pos == 0) {
+        const int cx = cl % g.nx, cy = (cl / g.nx) % g.ny, cz = cl / (g.nx * g.ny);
+        const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3;
+        sc_count[d.sbase + (cx >> 3) + nsx * ((cy >> 3) + nsy * (cz >> 3))] = 1;
+    }
+}
+
+// rank inside the cell by original index, placement, slot map; then the cell table of this cloud is made
+// local (offsets into ITS points) by k_localise_b
+template <typename T>
+__global__ __launch_bounds__(256) void k_rank_place_b(const BuildDesc<T> *__restrict__ descs, const int *__restrict__ cell_of,
+                                                       const int *__restrict__ cell_start, const int *__restrict__ order_tmp,
+                                                       typename Vec4<T>::type *__restrict__ pts,
+                                                       typename Vec4<T>::type *__restrict__ nrm_out, int *__restrict__ slot_of)
+{
+    const BuildDesc<T> &d = descs[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const int i = order_tmp[j];
+    if (j >= d.m) return;
+    const int i = order_tmp[d.pbase + j];                    // global point index
     const int c = cell_of[i];
     const int a = cell_start[c], b = cell_start[c + 1];
     int rank = 0;
@@ -386,13 +321,104 @@ __global__ __launch_bounds__(256) void k_rank_place(const T *__restrict__ xyz, i
 #pragma unroll
         for (int u = 0; u < 8; ++u) rank += (k + u < b && w[u] < i) ? 1 : 0;
     }
-    const int pos = a + rank;
-    const T x = xyz[(long long)i * stride] - mx, y = xyz[(long long)i * stride + 1] - my,
-            z = xyz[(long long)i * stride + 2] - mz;
-    pts[pos] = make_v4(x, y, z, Bits<T>::pack_idx(i));
-    if (nrm) nrm_out[pos] = make_v4(nrm[(long long)i * nstride], nrm[(long long)i * nstride + 1],
-                                    nrm[(long long)i * nstride + 2], (T)0);
-    slot_of[i] = pos;
+    const int pos = a + rank;                                // global slot
+    const int li = (int)(i - d.pbase);
+    const T x = d.xyz[(long long)li * d.xstride] - d.mean[0], y = d.xyz[(long long)li * d.xstride + 1] - d.mean[1],
+            z = d.xyz[(long long)li * d.xstride + 2] - d.mean[2];
+    pts[pos] = make_v4(x, y, z, Bits<T>::pack_idx(li));
+    if (d.nrm) nrm_out[pos] = make_v4(d.nrm[(long long)li * d.nstride], d.nrm[(long long)li * d.nstride + 1],
+                                      d.nrm[(long long)li * d.nstride + 2], (T)0);
+    slot_of[i] = (int)(pos - d.pbase);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_localise_b(const BuildDesc<T> *__restrict__ descs, int *__restrict__ cell_start)
+{
+    const BuildDesc<T> &d = descs[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= d.ncells) cell_start[d.cbase + c] -= (int)d.pbase;
+}
+
+// MapDev::near -- for every cell a nearby OCCUPIED cell (three separable sweeps: nearest occupied cell of
+// the row (pass 0), then the best of the neighbouring rows' answers in y (pass 1), then in z (pass 2)).  A
+// heuristic, not a nearest-cell guarantee: the matcher only uses it to give a query that starts in empty
+// space a first candidate, so that its exact ring search prunes from the first row on.
+template <typename T>
+__global__ __launch_bounds__(256) void k_near_b(const BuildDesc<T> *__restrict__ descs, int pass, const int *__restrict__ cell_start,
+                                                 int *__restrict__ tmp_a, int *__restrict__ tmp_b, int *__restrict__ near)
+{
+    const BuildDesc<T> &d = descs[blockIdx.y];
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.ncells) return;
+    const int nx = d.g.nx, ny = d.g.ny, nz = d.g.nz;
+    const int reach = d.near_reach < 1 ? 1 : (d.near_reach > kNearReach ? kNearReach : d.near_reach);
+    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((long long)nx * ny));
+    if (pass == 0) {
+        const int *cs = cell_start + d.cbase;
+        int found = -1;
+        for (int t = 0; t <= reach && found < 0; ++t) {
+            if (x - t >= 0 && cs[c - t + 1] > cs[c - t]) found = x - t;
+            else if (x + t < nx && cs[c + t + 1] > cs[c + t]) found = x + t;
+        }
+        tmp_a[d.cbase + c] = found;
+    } else if (pass == 1) {
+        const int *in = tmp_a + d.cbase;
+        int best = -1, bd = 0x7FFFFFFF;
+        for (int t = -reach; t <= reach; ++t) {
+            const int yy = y + t;
+            if (yy < 0 || yy >= ny) continue;
+            const int xx = in[c + (long long)t * nx];
+            if (xx < 0) continue;
+            const int dist = (xx - x) * (xx - x) + t * t;
+            if (dist < bd) { bd = dist; best = xx | (yy << 16); }
+        }
+        tmp_b[d.cbase + c] = best;
+    } else {
+        const int *in = tmp_b + d.cbase;
+        const long long plane = (long long)nx * ny;
+        int best = -1, bd = 0x7FFFFFFF;
+        for (int t = -reach; t <= reach; ++t) {
+            const int zz = z + t;
+            if (zz < 0 || zz >= nz) continue;
+            const int v = in[c + t * plane];
+            if (v < 0) continue;
+            const int xx = v & 0xFFFF, yy = v >> 16;
+            const int dist = (xx - x) * (xx - x) + (yy - y) * (yy - y) + t * t;
+            if (dist < bd) { bd = dist; best = (int)(xx + (long long)nx * (yy + (long long)ny * zz)); }
+        }
+        near[d.cbase + c] = best;
+    }
+}
+
+// super-cell distance maps: one block per cloud, three sweeps separated by block barriers
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scdist_b(const BuildDesc<T> *__restrict__ descs, const int *__restrict__ sc_count,
+                                                    int *__restrict__ tmp_a, int *__restrict__ tmp_b, int *__restrict__ sc_dist)
+{
+    const BuildDesc<T> &d = descs[blockIdx.x];
+    const int nsx = (d.g.nx + 7) >> 3, nsy = (d.g.ny + 7) >> 3, nsz = (d.g.nz + 7) >> 3;
+    const int n = d.nsc;
+    int *ta = tmp_a + d.cbase, *tb = tmp_b + d.cbase;         // ncells >= nsc: the cell scratch is large enough
+    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(sc_count + d.sbase, nsx, nsy, nsz, 0, 1, ta, c);
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(ta, nsx, nsy, nsz, 1, 0, tb, c);
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += blockDim.x) scdist_cell(tb, nsx, nsy, nsz, 2, 0, sc_dist + d.sbase, c);
+}
+
+// the same sweeps one launch each, for clouds whose super-cell grid is too large for one block
+template <typename T>
+__global__ __launch_bounds__(256) void k_scdist_pass_b(const BuildDesc<T> *__restrict__ descs, int pass, const int *__restrict__ sc_count,
+                                                        int *__restrict__ tmp_a, int *__restrict__ tmp_b, int *__restrict__ sc_dist)
+{
+    const BuildDesc<T> &d = descs[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nsc) return;
+    const int nsx = (d.g.nx + 7) >> 3, nsy = (d.g.ny + 7) >> 3, nsz = (d.g.nz + 7) >> 3;
+    int *ta = tmp_a + d.cbase, *tb = tmp_b + d.cbase;
+    if (pass == 0) scdist_cell(sc_count + d.sbase, nsx, nsy, nsz, 0, 1, ta, c);
+    else if (pass == 1) scdist_cell(ta, nsx, nsy, nsz, 1, 0, tb, c);
+    else scdist_cell(tb, nsx, nsy, nsz, 2, 0, sc_dist + d.sbase, c);
 }
 
 // ---------------------------------------------------------------------------
@@ -2005,50 +2031,43 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 static inline int round8(int x) { return (x + 7) & ~7; }
 
 template <typename T>
-void launch_centroid_bbox(hipStream_t st, const T *xyz, int stride, int m, unsigned long long *stats)
+void launch_centroid_bbox_batch(hipStream_t st, const BuildDesc<T> *descs, int n, int max_m, unsigned long long *stats)
 {
-    int nb = cdiv(m, 256 * 8);
+    int nb = cdiv(max_m, 256 * 8);
     if (nb < 1) nb = 1;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_centroid_bbox<T>, dim3(nb), dim3(256), 0, st, xyz, stride, m, stats);
+    hipLaunchKernelGGL(k_centroid_bbox_b<T>, dim3(nb, n), dim3(256), 0, st, descs, stats);
 }
 
+// descs: device array; totals over the batch: points, cells (incl. one sentinel slot per cloud), super-cells
 template <typename T>
-void launch_grid_build(hipStream_t st, const T *xyz, int stride, const T *nrm, int nstride, int m, const T mean[3],
-                       const GridDesc<T> &g, int *cell_of, int *counts, int *block_sums, int *cell_start, int *cursor,
-                       int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out, int *slot_of,
-                       int *sc_count, int *near, int near_reach, int *sc_dist)
+void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_c, long long tot_s,
+                             int max_m, int max_cells, int max_nsc, int *cell_of, int *counts, int *block_sums, int *cell_start,
+                             int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
+                             int *slot_of, int *sc_count, int *near, int *sc_dist)
 {
-    const long long ncells = (long long)g.nx * g.ny * g.nz;
-    const long long nsc = (long long)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
-    (void)hipMemsetAsync(counts, 0, sizeof(int) * ncells, st);
-    (void)hipMemsetAsync(sc_count, 0, sizeof(int) * nsc, st);
-    hipLaunchKernelGGL(k_cell_count<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, m, mean[0], mean[1], mean[2], g,
-                       cell_of, counts, sc_count, slot_of /* arrival positions until k_rank_place overwrites it */);
-    const int nb = cdiv(ncells, kScanChunk);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)ncells, block_sums);
+    (void)hipMemsetAsync(counts, 0, sizeof(int) * tot_c, st);
+    (void)hipMemsetAsync(sc_count, 0, sizeof(int) * tot_s, st);
+    hipLaunchKernelGGL(k_cell_count_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, cell_of, counts, sc_count, slot_of);
+    const int nb = cdiv(tot_c, kScanChunk);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_c, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)ncells, (const int *)block_sums,
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_c, (const int *)block_sums,
                        cell_start, cursor);
-    hipLaunchKernelGGL(k_scatter_idx, dim3(cdiv(m, 256)), dim3(256), 0, st, m, (const int *)cell_of, (const int *)cell_start,
-                       (const int *)slot_of, order_tmp);
-    hipLaunchKernelGGL(k_rank_place<T>, dim3(cdiv(m, 256)), dim3(256), 0, st, xyz, stride, nrm, nstride, m, mean[0], mean[1],
-                       mean[2], (const int *)cell_of, (const int *)cell_start, (const int *)order_tmp, pts, nrm_out, slot_of);
-    // counts / cursor are free again: scratch of the three sweeps
-    const int nbc = cdiv(ncells, 256);
-    const int reach = near_reach < 1 ? 1 : (near_reach > kNearReach ? kNearReach : near_reach);
-    hipLaunchKernelGGL(k_near_x, dim3(nbc), dim3(256), 0, st, (const int *)cell_start, g.nx, ncells, reach, counts);
-    hipLaunchKernelGGL(k_near_y, dim3(nbc), dim3(256), 0, st, (const int *)counts, g.nx, g.ny, ncells, reach, cursor);
-    hipLaunchKernelGGL(k_near_z, dim3(nbc), dim3(256), 0, st, (const int *)cursor, g.nx, g.ny, g.nz, ncells, reach, near);
-    // super-cell distance map (tiny grid): x sweep from the flags, then y, then z
-    const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3, nsz = (g.nz + 7) >> 3;
-    const int nbs = cdiv(nsc, 256);
-    if (nsc <= 32768) {
-        hipLaunchKernelGGL(k_scdist_fused, dim3(1), dim3(1024), 0, st, (const int *)sc_count, nsx, nsy, nsz, counts, cursor, sc_dist);
+    hipLaunchKernelGGL(k_scatter_idx, dim3(cdiv(tot_m, 256)), dim3(256), 0, st, (int)tot_m, (const int *)cell_of,
+                       (const int *)cell_start, (const int *)slot_of, order_tmp);
+    hipLaunchKernelGGL(k_rank_place_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, (const int *)cell_of,
+                       (const int *)cell_start, (const int *)order_tmp, pts, nrm_out, slot_of);
+    hipLaunchKernelGGL(k_localise_b<T>, dim3(cdiv(max_cells + 1, 256), n), dim3(256), 0, st, descs, cell_start);
+    for (int pass = 0; pass < 3; pass++)
+        hipLaunchKernelGGL(k_near_b<T>, dim3(cdiv(max_cells, 256), n), dim3(256), 0, st, descs, pass, (const int *)cell_start, counts,
+                           cursor, near);
+    if (max_nsc <= 4096) {
+        hipLaunchKernelGGL(k_scdist_b<T>, dim3(n), dim3(1024), 0, st, descs, (const int *)sc_count, counts, cursor, sc_dist);
     } else {
-        hipLaunchKernelGGL(k_scdist, dim3(nbs), dim3(256), 0, st, (const int *)sc_count, nsx, nsy, nsz, 0, 1, counts);
-        hipLaunchKernelGGL(k_scdist, dim3(nbs), dim3(256), 0, st, (const int *)counts, nsx, nsy, nsz, 1, 0, cursor);
-        hipLaunchKernelGGL(k_scdist, dim3(nbs), dim3(256), 0, st, (const int *)cursor, nsx, nsy, nsz, 2, 0, sc_dist);
+        for (int pass = 0; pass < 3; pass++)
+            hipLaunchKernelGGL(k_scdist_pass_b<T>, dim3(cdiv(max_nsc, 256), n), dim3(256), 0, st, descs, pass, (const int *)sc_count,
+                               counts, cursor, sc_dist);
     }
 }
 
@@ -2208,10 +2227,10 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
 }
 
 #define INSTANTIATE(T)                                                                                                   \
-    template void launch_centroid_bbox<T>(hipStream_t, const T *, int, int, unsigned long long *);                        \
-    template void launch_grid_build<T>(hipStream_t, const T *, int, const T *, int, int, const T[3], const GridDesc<T> &, \
-                                       int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,                \
-                                       typename Vec4<T>::type *, int *, int *, int *, int, int *);                        \
+    template void launch_centroid_bbox_batch<T>(hipStream_t, const BuildDesc<T> *, int, int, unsigned long long *);       \
+    template void launch_grid_build_batch<T>(hipStream_t, const BuildDesc<T> *, int, long long, long long, long long, int, \
+                                             int, int, int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,      \
+                                             typename Vec4<T>::type *, int *, int *, int *, int *);                       \
     template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *,         \
                                        unsigned long long *, int *, int *, int *, int *, int *, int, int, int, int);      \
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \

@@ -16,6 +16,7 @@
 #include <numeric>
 #include <string>
 #include <map>
+#include <memory>
 #include <vector>
 
 using namespace pgicp;
@@ -38,6 +39,8 @@ struct DevBuf {
     template <typename U> U *as() const { return (U *)p; }
 };
 
+struct SharedBlock { char *p = nullptr; size_t bytes = 0; };
+
 template <typename T>
 struct MapHost {
     bool used = false;
@@ -51,8 +54,9 @@ struct MapHost {
     int *sc_count = nullptr;
     int *near = nullptr;
     int *sc_dist = nullptr;
-    char *block = nullptr;          // the one device allocation holding all of the above
-    size_t block_bytes = 0;
+    // the one device allocation holding all of the above -- shared by the maps of one batched build and
+    // returned to the pool (or freed) by whoever drops the last reference
+    std::shared_ptr<SharedBlock> block;
     GridDesc<T> g{};
 };
 
@@ -80,7 +84,7 @@ struct pgicp_ctx {
     pgicp_params prm{};
     State<float> f32;
     State<double> f64;
-    DevBuf probs, src, partials, sums, small, stats, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
+    DevBuf probs, src, partials, sums, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
     DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     // Freed map blocks are kept for reuse: hipFree synchronises the device, and loop closing creates
@@ -267,12 +271,13 @@ int block_alloc(pgicp_ctx *c, size_t bytes, char **out, size_t *got)
 template <typename T>
 void free_map(pgicp_ctx *c, MapHost<T> &m)
 {
-    if (m.block) {
-        if (c && c->pooled_bytes + m.block_bytes <= kPoolLimitBytes) {
-            c->block_pool.emplace(m.block_bytes, m.block);
-            c->pooled_bytes += m.block_bytes;
+    if (m.block && m.block.use_count() == 1 && m.block->p) {
+        if (c && c->pooled_bytes + m.block->bytes <= kPoolLimitBytes) {
+            c->block_pool.emplace(m.block->bytes, m.block->p);
+            c->pooled_bytes += m.block->bytes;
         } else
-            (void)hipFree(m.block);
+            (void)hipFree(m.block->p);
+        m.block->p = nullptr;
     }
     m = MapHost<T>();
 }
@@ -320,23 +325,36 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         unsigned long long *s = h_stats.data() + 9 * k;
         s[0] = s[1] = s[2] = 0; s[3] = s[4] = s[5] = ~0ULL; s[6] = s[7] = s[8] = 0;
     }
-    HIPC(c, c->stats.ensure(sizeof(unsigned long long) * 9 * (size_t)n));
-    HIPC(c, hipMemcpyAsync(c->stats.p, h_stats.data(), sizeof(unsigned long long) * 9 * n, hipMemcpyHostToDevice, c->stream));
+    std::vector<BuildDesc<T>> descs(n);
+    int max_m = 0;
     for (int k = 0; k < n; k++) {
-        ProfScope ps(c, PGICP_PROF_GRID_BUILD, src[k].m);
-        launch_centroid_bbox<T>(c->stream, d_xyz[k], src[k].xyz_stride, src[k].m, c->stats.as<unsigned long long>() + 9 * k);
+        BuildDesc<T> &d = descs[k];
+        std::memset(&d, 0, sizeof d);
+        d.xyz = d_xyz[k]; d.nrm = d_nrm[k]; d.xstride = src[k].xyz_stride; d.nstride = src[k].nrm_stride; d.m = src[k].m;
+        max_m = std::max(max_m, src[k].m);
+    }
+    HIPC(c, c->stats.ensure(sizeof(unsigned long long) * 9 * (size_t)n));
+    HIPC(c, c->bdesc.ensure(sizeof(BuildDesc<T>) * (size_t)n));
+    HIPC(c, hipMemcpyAsync(c->stats.p, h_stats.data(), sizeof(unsigned long long) * 9 * n, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, PGICP_PROF_GRID_BUILD, max_m, n);
+        launch_centroid_bbox_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, max_m, c->stats.as<unsigned long long>());
     }
     HIPC(c, hipMemcpyAsync(h_stats.data(), c->stats.p, sizeof(unsigned long long) * 9 * n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
 
-    // ---- phase 2: grids ----
+    // ---- phase 2: grids; every cloud gets its slice of ONE allocation and ONE set of build launches ----
     std::vector<MapHost<T>> Ms(n);
-    size_t max_m = 0, max_cells = 0;
+    long long tot_m = 0, tot_c = 0, tot_s = 0;
+    int max_cells = 0, max_nsc = 0;
+    bool any_nrm = false;
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
         const int m = src[k].m;
         const unsigned long long *st = h_stats.data() + 9 * k;
         M.used = true; M.m = m; M.has_nrm = src[k].nrm != nullptr;
+        any_nrm = any_nrm || M.has_nrm;
         double lo[3], hi[3];
         for (int a = 0; a < 3; a++) {
             const double mean_d = ((double)(long long)st[a] / 16777216.0) / (double)m;
@@ -368,42 +386,63 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         g.ox = (T)lo[0]; g.oy = (T)lo[1]; g.oz = (T)lo[2];
         g.nx = (int)std::floor(ex / (double)g.h) + 1; g.ny = (int)std::floor(ey / (double)g.h) + 1;
         g.nz = (int)std::floor(ez / (double)g.h) + 1;
-        max_m = std::max(max_m, (size_t)m);
-        max_cells = std::max(max_cells, (size_t)g.nx * g.ny * g.nz);
+        BuildDesc<T> &d = descs[k];
+        d.g = g;
+        for (int a = 0; a < 3; a++) d.mean[a] = M.mean[a];
+        d.ncells = g.nx * g.ny * g.nz;
+        d.nsc = ((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
+        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s;
+        // a first candidate farther than a fraction of maxDist prunes little: do not look for one beyond that
+        const double reach_len = std::isfinite(c->prm.max_dist) ? c->near_frac * c->prm.max_dist : 1e30;
+        d.near_reach = (int)std::min((double)kNearReach, std::max(2.0, std::ceil(reach_len / (double)g.h)));
+        tot_m += m; tot_c += (long long)d.ncells + 1; tot_s += d.nsc;
+        max_cells = std::max(max_cells, d.ncells);
+        max_nsc = std::max(max_nsc, d.nsc);
     }
-    // scratch sized for the largest map BEFORE any build is queued (a later grow would free buffers in use)
-    HIPC(c, c->tmp_a.ensure(sizeof(int) * max_m));                                  // cell_of
-    HIPC(c, c->tmp_b.ensure(sizeof(int) * max_cells));                              // counts
-    HIPC(c, c->tmp_c.ensure(sizeof(int) * (max_cells / kScanChunkHost + 2)));       // block sums
-    HIPC(c, c->tmp_d.ensure(sizeof(int) * max_cells));                              // cursor
-    HIPC(c, c->tmp_e.ensure(sizeof(int) * max_m));                                  // order_tmp
+    if (tot_m > 0x7FFFFFF0LL || tot_c > 0x7FFFFFF0LL) {
+        // the concatenated index space must fit an int: build the clouds of an oversized batch one by one
+        if (n == 1) return fail(c, PGICP_ERR_ARG, "pgicp_map_create: cloud too large");
+        for (int k = 0; k < n; k++) {
+            const int st1 = map_create_batch<T>(c, 1, src + k, mem, center, map_ids + k);
+            if (st1) return st1;
+        }
+        return PGICP_OK;
+    }
+    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)tot_m));                               // cell_of
+    HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)tot_c));                               // counts, then sweep scratch
+    HIPC(c, c->tmp_c.ensure(sizeof(int) * ((size_t)tot_c / kScanChunkHost + 2)));        // block sums
+    HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)tot_c));                               // cursor, then sweep scratch
+    HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)tot_m));                               // order_tmp
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
+                 b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c);
+    auto blk = std::make_shared<SharedBlock>();
+    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near, &blk->p, &blk->bytes); if (ast) return ast; }
+    char *base = blk->p;
+    V4 *g_pts = (V4 *)base, *g_nrm = any_nrm ? (V4 *)(base + b_pts) : nullptr;
+    int *g_cs = (int *)(base + b_pts + b_nrm), *g_slot = (int *)(base + b_pts + b_nrm + b_cs),
+        *g_sc = (int *)(base + b_pts + b_nrm + b_cs + b_slot), *g_near = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc),
+        *g_scd = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc + b_near);
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
-        const GridDesc<T> &g = M.g;
-        const int m = M.m;
-        const size_t ncells = (size_t)g.nx * g.ny * g.nz;
-        const size_t nsc = (size_t)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
-        const size_t b_pts = up(sizeof(V4) * (size_t)m), b_nrm = M.has_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (ncells + 1)),
-                     b_slot = up(sizeof(int) * (size_t)m), b_sc = up(sizeof(int) * nsc), b_near = up(sizeof(int) * ncells);
-        char *base = nullptr;
-        { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near, &base, &M.block_bytes); if (ast) return ast; }
-        M.block = base;
-        M.pts = (V4 *)base;
-        M.nrm = M.has_nrm ? (V4 *)(base + b_pts) : nullptr;
-        M.cell_start = (int *)(base + b_pts + b_nrm);
-        M.slot_of = (int *)(base + b_pts + b_nrm + b_cs);
-        M.sc_count = (int *)(base + b_pts + b_nrm + b_cs + b_slot);
-        M.near = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc);
-        M.sc_dist = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc + b_near);
-        // a first candidate farther than ~a third of maxDist prunes little: do not look for one beyond that
-        const double reach_len = std::isfinite(c->prm.max_dist) ? c->near_frac * c->prm.max_dist : 1e30;
-        const int near_reach = (int)std::min((double)kNearReach, std::max(2.0, std::ceil(reach_len / (double)g.h)));
-        ProfScope ps(c, PGICP_PROF_GRID_BUILD, m);
-        launch_grid_build<T>(c->stream, d_xyz[k], src[k].xyz_stride, d_nrm[k], src[k].nrm_stride, m, M.mean, g, c->tmp_a.as<int>(),
-                             c->tmp_b.as<int>(), c->tmp_c.as<int>(), M.cell_start, c->tmp_d.as<int>(), c->tmp_e.as<int>(), M.pts, M.nrm,
-                             M.slot_of, M.sc_count, M.near, near_reach, M.sc_dist);
+        const BuildDesc<T> &d = descs[k];
+        M.block = blk;
+        M.pts = g_pts + d.pbase;
+        M.nrm = M.has_nrm ? g_nrm + d.pbase : nullptr;
+        M.cell_start = g_cs + d.cbase;
+        M.slot_of = g_slot + d.pbase;
+        M.sc_count = g_sc + d.sbase;
+        M.near = g_near + d.cbase;
+        M.sc_dist = g_scd + d.sbase;
     }
+    HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
+        launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_c, tot_s, max_m, max_cells, max_nsc, c->tmp_a.as<int>(),
+                                   c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, c->tmp_d.as<int>(), c->tmp_e.as<int>(), g_pts, g_nrm,
+                                   g_slot, g_sc, g_near, g_scd);
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));          // `descs` (host) feeds an async copy
     HIPC(c, hipGetLastError());
     // ---- phase 3: register ----
     for (int k = 0; k < n; k++) {
@@ -1149,7 +1188,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     c->block_pool.clear();
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
-                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
+                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
                       &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->f32.none_r, &c->f64.none_r})
         b->release();
