@@ -154,6 +154,11 @@ public:
     //! findClosests + outlier weights + error elements -> weightedPointUsedRatio, as ONE device pass
     T ComputeOverlapWith(const DP &candidate_map_in_world_frame)
     {
+        return ComputeOverlapOf(*input_cloud_ptr_, T_world_robot_, candidate_map_in_world_frame);
+    }
+    //! the same partial chain for an explicit (reading in robot frame, robot pose, map in world frame) triple
+    T ComputeOverlapOf(const DP &reading_in, const Matrix &T_world_robot, const DP &candidate_map_in_world_frame)
+    {
         typename PM::ICP temp_icp;
         std::istringstream iss(icp_config_buffer_);
         temp_icp.loadFromYaml(iss);
@@ -161,11 +166,11 @@ public:
         temp_icp.referenceDataPointsFilters.init();
         temp_icp.referenceDataPointsFilters.apply(reference);
         temp_icp.matcher->init(reference);
-        DP reading(*input_cloud_ptr_);
+        DP reading(reading_in);
         temp_icp.readingDataPointsFilters.init();
         temp_icp.readingDataPointsFilters.apply(reading);
         double Tm[16], ratio = 0, residual = 0;
-        pgslam_amd::to_row_major16(T_world_robot_, Tm);
+        pgslam_amd::to_row_major16(T_world_robot, Tm);
         temp_icp.pushParams();
         PM::check(temp_icp.ctx, pgslam_amd::Abi<T>::partial(temp_icp.ctx, temp_icp.matcher->mapId, reading.xyzPtr(), reading.xyzStride(),
                                                            (int)reading.getNbPoints(), Tm, &ratio, &residual));

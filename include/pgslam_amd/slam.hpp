@@ -1,0 +1,805 @@
+// slam.hpp -- the host side of pgslam around the GPU hot path: keyframe graph, map manager, pose-graph
+// optimiser, candidate searches and the PoseGraphSlam facade.
+//
+// Everything here is CPU code by design (north_star keeps the pose-graph back end on the host); it
+// restates, without Boost.Graph and GTSAM (neither exists in this image):
+//   * Types<T>::Graph (undirected, Keyframe vertices, Constraint edges)       reference types.h:24-57
+//   * MapManager                                                             MapManager.hpp:36-158
+//   * Optimizer (BetweenFactor / PriorFactor least squares, LM)              Optimizer.hpp:25-157
+//   * LoopCloser::FindLocalMapCandidate / ProcessVertex / CheckIcpResult     LoopCloser.hpp:83-110,193-305,308-340
+//   * Localizer::ProcessData / UpdateAfterIcp / FindNeighborLocalMapComposition  Localizer.hpp:91-268,393-483
+//   * PoseGraphSlam::AddData / SetIcpConfig / WriteGraphviz                   PoseGraphSlam.hpp:21-76
+// [EXT] GTSAM's LevenbergMarquardtOptimizer is replaced by a dependency-free LM on SE(3) that minimises the
+// same cost (whitened Logmap residuals of between factors, rotation-first tangent order as
+// Optimizer::PmCovToGtsamCov prepares it); the prior of sigma 1e-6 on the fixed vertex is imposed as a hard
+// constraint.  The optimum is the same to solver tolerance; the iteration path is not GTSAM's.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <functional>
+#include <limits>
+#include <queue>
+#include <set>
+
+#include "pgslam.hpp"
+
+namespace pgslam {
+
+// ------------------------------------------------------------------ graph
+template <typename T>
+class PoseGraph {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    struct EdgeRec { size_t from, to; Constraint c; };
+    size_t AddVertex(const Keyframe &kf) { v_.push_back(kf); adj_.emplace_back(); return v_.size() - 1; }
+    //! undirected, at most one edge per vertex pair (boost::add_edge on a setS-less list graph would allow
+    //! parallel edges; pgslam treats a second one as a logic error, MapManager.hpp:97,127)
+    size_t AddEdge(size_t from, size_t to, const Constraint &c)
+    {
+        for (size_t id : adj_[from]) if (Other(id, from) == to) throw std::logic_error("PoseGraph: edge already exists");
+        e_.push_back(EdgeRec{from, to, c});
+        adj_[from].push_back(e_.size() - 1);
+        adj_[to].push_back(e_.size() - 1);
+        return e_.size() - 1;
+    }
+    size_t NumVertices() const { return v_.size(); }
+    size_t NumEdges() const { return e_.size(); }
+    Keyframe &operator[](size_t v) { return v_[v]; }
+    const Keyframe &operator[](size_t v) const { return v_[v]; }
+    const EdgeRec &Edge(size_t id) const { return e_[id]; }
+    const std::vector<size_t> &IncidentEdges(size_t v) const { return adj_[v]; }
+    size_t Other(size_t edge, size_t v) const { return e_[edge].from == v ? e_[edge].to : e_[edge].from; }
+
+    //! Dijkstra over Constraint::weight from `src` on the sub-graph the filters keep.  `examine` is called
+    //! for every vertex when it is settled (boost's on_examine_vertex), in non-decreasing distance; it may
+    //! return false to stop the search (the reference throws StopSearch, LoopCloser.hpp:160-175).
+    std::vector<double> Dijkstra(size_t src, const std::function<bool(size_t)> &keep_vertex,
+                                 const std::function<bool(size_t)> &keep_edge, const std::function<bool(size_t)> &examine) const
+    {
+        const double inf = std::numeric_limits<double>::infinity();
+        std::vector<double> dist(v_.size(), inf);
+        if (keep_vertex && !keep_vertex(src)) return dist;
+        using QE = std::pair<double, size_t>;
+        std::priority_queue<QE, std::vector<QE>, std::greater<QE>> pq;
+        std::vector<char> done(v_.size(), 0);
+        dist[src] = 0.0;
+        pq.push({0.0, src});
+        while (!pq.empty()) {
+            const auto [d, u] = pq.top();
+            pq.pop();
+            if (done[u]) continue;
+            done[u] = 1;
+            if (examine && !examine(u)) break;
+            for (size_t id : adj_[u]) {
+                if (keep_edge && !keep_edge(id)) continue;
+                const size_t w = Other(id, u);
+                if (done[w] || (keep_vertex && !keep_vertex(w))) continue;
+                const double nd = d + (double)e_[id].c.weight;
+                if (nd < dist[w]) { dist[w] = nd; pq.push({nd, w}); }
+            }
+        }
+        return dist;
+    }
+
+private:
+    std::vector<Keyframe> v_;
+    std::vector<EdgeRec> e_;
+    std::vector<std::vector<size_t>> adj_;
+};
+
+inline double TranslationDistance(const double *A16, const double *B16)
+{
+    const double dx = B16[3] - A16[3], dy = B16[7] - A16[7], dz = B16[11] - A16[11];
+    return std::sqrt(dx * dx + dy * dy + dz * dz);
+}
+template <typename M>
+double PoseDistance(const M &A, const M &B)          // Metrics<T>::Distance, metrics.hpp:7-12
+{
+    double s = 0;
+    for (int k = 0; k < 3; k++) { const double d = (double)B(k, 3) - (double)A(k, 3); s += d * d; }
+    return std::sqrt(s);
+}
+template <typename M>
+double PoseWeight(const M &T_meas)                   // Metrics<T>::Weight, metrics.hpp:21-24
+{
+    return std::sqrt((double)T_meas(0, 3) * T_meas(0, 3) + (double)T_meas(1, 3) * T_meas(1, 3) + (double)T_meas(2, 3) * T_meas(2, 3));
+}
+
+// ------------------------------------------------------------------ SE(3) helpers (double, row-major 4x4)
+namespace se3 {
+struct Pose { double R[9]; double t[3]; };
+inline Pose identity() { return Pose{{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}}; }
+inline Pose mul(const Pose &a, const Pose &b)
+{
+    Pose o;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) o.R[3 * i + j] = a.R[3 * i] * b.R[j] + a.R[3 * i + 1] * b.R[3 + j] + a.R[3 * i + 2] * b.R[6 + j];
+        o.t[i] = a.R[3 * i] * b.t[0] + a.R[3 * i + 1] * b.t[1] + a.R[3 * i + 2] * b.t[2] + a.t[i];
+    }
+    return o;
+}
+inline Pose inv(const Pose &a)
+{
+    Pose o;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) o.R[3 * i + j] = a.R[3 * j + i];
+    for (int i = 0; i < 3; i++) o.t[i] = -(o.R[3 * i] * a.t[0] + o.R[3 * i + 1] * a.t[1] + o.R[3 * i + 2] * a.t[2]);
+    return o;
+}
+//! Expmap of the twist [w (rotation), v (translation)] -- GTSAM's Pose3 tangent order
+inline Pose exp(const double xi[6])
+{
+    const double wx = xi[0], wy = xi[1], wz = xi[2];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
+    double A, B, C;                               // sin(th)/th, (1-cos)/th^2, (th-sin)/th^3
+    if (th < 1e-5) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; C = 1.0 / 6.0 - th2 / 120.0; }
+    else { A = std::sin(th) / th; B = (1.0 - std::cos(th)) / th2; C = (th - std::sin(th)) / (th2 * th); }
+    const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double K2[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    Pose o;
+    double V[9];
+    for (int i = 0; i < 9; i++) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        o.R[i] = I + A * K[i] + B * K2[i];
+        V[i] = I + B * K[i] + C * K2[i];
+    }
+    for (int i = 0; i < 3; i++) o.t[i] = V[3 * i] * xi[3] + V[3 * i + 1] * xi[4] + V[3 * i + 2] * xi[5];
+    return o;
+}
+//! Logmap, inverse of exp above
+inline void log(const Pose &p, double xi[6])
+{
+    const double tr = p.R[0] + p.R[4] + p.R[8];
+    double c = 0.5 * (tr - 1.0);
+    c = std::max(-1.0, std::min(1.0, c));
+    const double th = std::acos(c);
+    double w[3] = {p.R[7] - p.R[5], p.R[2] - p.R[6], p.R[3] - p.R[1]};
+    double k;
+    if (th < 1e-5) k = 0.5 + th * th / 12.0;
+    else if (M_PI - th < 1e-4) {                  // near pi: axis from the symmetric part
+        double ax[3];
+        for (int i = 0; i < 3; i++) ax[i] = std::sqrt(std::max(0.0, (p.R[4 * i] - c) / (1.0 - c)));
+        if (w[0] < 0) ax[0] = -ax[0];
+        if (w[1] < 0) ax[1] = -ax[1];
+        if (w[2] < 0) ax[2] = -ax[2];
+        for (int i = 0; i < 3; i++) xi[i] = th * ax[i];
+        k = 0;
+    } else k = th / (2.0 * std::sin(th));
+    if (k != 0) for (int i = 0; i < 3; i++) xi[i] = k * w[i];
+    const double wx = xi[0], wy = xi[1], wz = xi[2], th2 = wx * wx + wy * wy + wz * wz;
+    const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double K2[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    // V^-1 = I - K/2 + D K^2,  D = (1 - th*sin/(2(1-cos)))/th^2
+    double D;
+    const double t = std::sqrt(th2);
+    if (t < 1e-5) D = 1.0 / 12.0 + th2 / 720.0;
+    else D = (1.0 - 0.5 * t * std::sin(t) / (1.0 - std::cos(t))) / th2;
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int j = 0; j < 3; j++) {
+            const double Vi = ((i == j) ? 1.0 : 0.0) - 0.5 * K[3 * i + j] + D * K2[3 * i + j];
+            s += Vi * p.t[j];
+        }
+        xi[3 + i] = s;
+    }
+}
+template <typename M>
+Pose from_matrix(const M &m)
+{
+    Pose p;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) p.R[3 * i + j] = (double)m(i, j); p.t[i] = (double)m(i, 3); }
+    return p;
+}
+template <typename M>
+M to_matrix(const Pose &p)
+{
+    M m = M::Identity(4, 4);
+    using S = typename std::decay<decltype(m(0, 0))>::type;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) m(i, j) = (S)p.R[3 * i + j]; m(i, 3) = (S)p.t[i]; }
+    return m;
+}
+}  // namespace se3
+
+//! Gauss-Jordan inverse of a 6x6 with partial pivoting; false if singular
+inline bool invert6(const double A[36], double Ai[36])
+{
+    double M[6][12];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { M[i][j] = A[6 * i + j]; M[i][6 + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++) if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+        if (!(std::fabs(M[piv][c]) > 0)) return false;
+        if (piv != c) for (int j = 0; j < 12; j++) std::swap(M[c][j], M[piv][j]);
+        const double d = 1.0 / M[c][c];
+        for (int j = 0; j < 12; j++) M[c][j] *= d;
+        for (int r = 0; r < 6; r++) if (r != c) { const double f = M[r][c]; if (f != 0) for (int j = 0; j < 12; j++) M[r][j] -= f * M[c][j]; }
+    }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Ai[6 * i + j] = M[i][6 + j];
+    return true;
+}
+
+// ------------------------------------------------------------------ pose-graph least squares
+//! min sum_k || L_k * Log( Z_k^-1 * X_from^-1 * X_to ) ||^2  with one pose held fixed; LM with GTSAM's default
+//! parameters (lambda 1e-5, factor 10, upper bound 1e5, 100 iterations, relative / absolute error tolerance 1e-5).
+class PoseGraphLeastSquares {
+public:
+    struct Between { size_t from, to; se3::Pose Z; double L[36]; };       // L: upper Cholesky factor of the information
+    std::vector<se3::Pose> X;
+    std::vector<Between> factors;
+    size_t fixed = 0;
+    int iterations = 0;
+    double initial_error = 0, final_error = 0;
+
+    //! cov6 row-major, order [rot, trans]; returns false if it is not positive definite
+    static bool InformationFactor(const double cov6[36], double L[36])
+    {
+        double C[36], Ci[36];
+        std::copy(cov6, cov6 + 36, C);
+        // Cholesky C = G G^T, invert, then information = C^-1 = U^T U with U = G^-1 ... computed via explicit inverse
+        double G[36] = {0};
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j <= i; j++) {
+                double s = C[6 * i + j];
+                for (int k = 0; k < j; k++) s -= G[6 * i + k] * G[6 * j + k];
+                if (i == j) { if (!(s > 0)) return false; G[6 * i + i] = std::sqrt(s); }
+                else G[6 * i + j] = s / G[6 * j + j];
+            }
+        // W = G^-1 (lower triangular); then r^T C^-1 r = |W r|^2
+        double W[36] = {0};
+        for (int c = 0; c < 6; c++) {
+            for (int i = 0; i < 6; i++) {
+                double s = (i == c) ? 1.0 : 0.0;
+                for (int k = 0; k < i; k++) s -= G[6 * i + k] * W[6 * k + c];
+                W[6 * i + c] = s / G[6 * i + i];
+            }
+        }
+        std::copy(W, W + 36, L);
+        (void)Ci;
+        return true;
+    }
+    void Residual(const Between &f, const se3::Pose &Xi, const se3::Pose &Xj, double r[6]) const
+    {
+        double xi[6];
+        se3::log(se3::mul(se3::inv(f.Z), se3::mul(se3::inv(Xi), Xj)), xi);
+        for (int a = 0; a < 6; a++) { double s = 0; for (int b = 0; b < 6; b++) s += f.L[6 * a + b] * xi[b]; r[a] = s; }
+    }
+    double Error(const std::vector<se3::Pose> &P) const
+    {
+        double e = 0;
+        for (const auto &f : factors) { double r[6]; Residual(f, P[f.from], P[f.to], r); for (int a = 0; a < 6; a++) e += r[a] * r[a]; }
+        return 0.5 * e;
+    }
+    void Optimize()
+    {
+        const size_t N = X.size();
+        double lambda = 1e-5;
+        double err = Error(X);
+        initial_error = err;
+        iterations = 0;
+        for (int it = 0; it < 100; it++) {
+            Linearize();
+            bool improved = false;
+            double new_err = err;
+            std::vector<se3::Pose> cand;
+            while (lambda <= 1e5) {
+                std::vector<double> delta = SolveDamped(lambda);
+                cand = X;
+                for (size_t v = 0; v < N; v++) if (v != fixed) cand[v] = se3::mul(X[v], se3::exp(delta.data() + 6 * v));
+                new_err = Error(cand);
+                if (new_err < err) { improved = true; lambda = std::max(lambda / 10.0, 1e-20); break; }
+                lambda *= 10.0;
+            }
+            iterations = it + 1;
+            if (!improved) break;
+            const double dec = err - new_err;
+            X.swap(cand);
+            const double prev = err;
+            err = new_err;
+            if (dec < 1e-5 || dec / std::max(prev, 1e-300) < 1e-5) break;
+        }
+        final_error = err;
+    }
+
+private:
+    std::vector<double> J_;        // per factor: 6 x 12 (d r / d delta_from | d r / d delta_to)
+    std::vector<double> r_;        // per factor: 6
+    void Linearize()
+    {
+        const size_t F = factors.size();
+        J_.assign(F * 72, 0.0);
+        r_.assign(F * 6, 0.0);
+        const double h = 1e-6;
+        for (size_t k = 0; k < F; k++) {
+            const Between &f = factors[k];
+            Residual(f, X[f.from], X[f.to], &r_[6 * k]);
+            for (int side = 0; side < 2; side++)
+                for (int a = 0; a < 6; a++) {
+                    double d[6] = {0, 0, 0, 0, 0, 0}, rp[6], rm[6];
+                    d[a] = h;
+                    const se3::Pose Pp = se3::mul(side == 0 ? X[f.from] : X[f.to], se3::exp(d));
+                    d[a] = -h;
+                    const se3::Pose Pm = se3::mul(side == 0 ? X[f.from] : X[f.to], se3::exp(d));
+                    if (side == 0) { Residual(f, Pp, X[f.to], rp); Residual(f, Pm, X[f.to], rm); }
+                    else { Residual(f, X[f.from], Pp, rp); Residual(f, X[f.from], Pm, rm); }
+                    for (int b = 0; b < 6; b++) J_[72 * k + 12 * b + 6 * side + a] = (rp[b] - rm[b]) / (2 * h);
+                }
+        }
+    }
+    // y = (J^T J + lambda I) x on the free variables
+    void Apply(const std::vector<double> &x, double lambda, std::vector<double> &y) const
+    {
+        std::fill(y.begin(), y.end(), 0.0);
+        for (size_t k = 0; k < factors.size(); k++) {
+            const Between &f = factors[k];
+            double Jx[6];
+            for (int b = 0; b < 6; b++) {
+                double s = 0;
+                for (int a = 0; a < 6; a++) s += J_[72 * k + 12 * b + a] * x[6 * f.from + a] + J_[72 * k + 12 * b + 6 + a] * x[6 * f.to + a];
+                Jx[b] = s;
+            }
+            for (int a = 0; a < 6; a++) {
+                double s0 = 0, s1 = 0;
+                for (int b = 0; b < 6; b++) { s0 += J_[72 * k + 12 * b + a] * Jx[b]; s1 += J_[72 * k + 12 * b + 6 + a] * Jx[b]; }
+                y[6 * f.from + a] += s0;
+                y[6 * f.to + a] += s1;
+            }
+        }
+        for (size_t i = 0; i < x.size(); i++) y[i] += lambda * x[i];
+        for (int a = 0; a < 6; a++) y[6 * fixed + a] = 0.0;
+    }
+    //! preconditioned conjugate gradients with the 6x6 diagonal blocks as preconditioner
+    std::vector<double> SolveDamped(double lambda) const
+    {
+        const size_t N = X.size(), n = 6 * N;
+        std::vector<double> b(n, 0.0), D(N * 36, 0.0);
+        for (size_t k = 0; k < factors.size(); k++) {
+            const Between &f = factors[k];
+            for (int a = 0; a < 6; a++) {
+                double s0 = 0, s1 = 0;
+                for (int c = 0; c < 6; c++) { s0 += J_[72 * k + 12 * c + a] * r_[6 * k + c]; s1 += J_[72 * k + 12 * c + 6 + a] * r_[6 * k + c]; }
+                b[6 * f.from + a] -= s0;
+                b[6 * f.to + a] -= s1;
+                for (int a2 = 0; a2 < 6; a2++) {
+                    double d0 = 0, d1 = 0;
+                    for (int c = 0; c < 6; c++) { d0 += J_[72 * k + 12 * c + a] * J_[72 * k + 12 * c + a2]; d1 += J_[72 * k + 12 * c + 6 + a] * J_[72 * k + 12 * c + 6 + a2]; }
+                    D[36 * f.from + 6 * a + a2] += d0;
+                    D[36 * f.to + 6 * a + a2] += d1;
+                }
+            }
+        }
+        for (int a = 0; a < 6; a++) b[6 * fixed + a] = 0.0;
+        // invert the damped diagonal blocks
+        std::vector<double> Dinv(N * 36, 0.0);
+        for (size_t v = 0; v < N; v++) {
+            double A[36], Ai[36];
+            for (int i = 0; i < 36; i++) A[i] = D[36 * v + i];
+            for (int i = 0; i < 6; i++) A[7 * i] += lambda + 1e-12;
+            if (!invert6(A, Ai)) { for (int i = 0; i < 36; i++) Ai[i] = (i % 7 == 0) ? 1.0 / std::max(A[i], 1e-12) : 0.0; }
+            for (int i = 0; i < 36; i++) Dinv[36 * v + i] = Ai[i];
+        }
+        auto precond = [&](const std::vector<double> &r, std::vector<double> &z) {
+            for (size_t v = 0; v < N; v++)
+                for (int a = 0; a < 6; a++) { double s = 0; for (int c = 0; c < 6; c++) s += Dinv[36 * v + 6 * a + c] * r[6 * v + c]; z[6 * v + a] = s; }
+            for (int a = 0; a < 6; a++) z[6 * fixed + a] = 0.0;
+        };
+        std::vector<double> x(n, 0.0), r = b, z(n), p(n), Ap(n);
+        precond(r, z);
+        p = z;
+        double rz = 0, b2 = 0;
+        for (size_t i = 0; i < n; i++) { rz += r[i] * z[i]; b2 += b[i] * b[i]; }
+        if (b2 == 0) return x;
+        const int max_it = (int)std::min<size_t>(20 * n + 100, 200000);
+        for (int it = 0; it < max_it; it++) {
+            Apply(p, lambda, Ap);
+            double pAp = 0;
+            for (size_t i = 0; i < n; i++) pAp += p[i] * Ap[i];
+            if (!(pAp > 0)) break;
+            const double alpha = rz / pAp;
+            double r2 = 0;
+            for (size_t i = 0; i < n; i++) { x[i] += alpha * p[i]; r[i] -= alpha * Ap[i]; r2 += r[i] * r[i]; }
+            if (r2 <= 1e-24 * b2) break;
+            precond(r, z);
+            double rz_new = 0;
+            for (size_t i = 0; i < n; i++) rz_new += r[i] * z[i];
+            const double beta = rz_new / rz;
+            rz = rz_new;
+            for (size_t i = 0; i < n; i++) p[i] = z[i] + beta * p[i];
+        }
+        return x;
+    }
+};
+
+template <typename T> class GraphLocalizer;
+template <typename T> class GraphLoopCloser;
+
+// ------------------------------------------------------------------ MapManager (MapManager.hpp)
+template <typename T>
+class MapManager {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    using Ptr = std::shared_ptr<MapManager<T>>;
+    PoseGraph<T> &GetGraph() { return graph_; }
+    size_t GetFixedVertex() const { return fixed_vertex_; }
+    void SetLocalizer(std::shared_ptr<GraphLocalizer<T>> p) { localizer_ = p; }
+    void SetLoopCloser(std::shared_ptr<GraphLoopCloser<T>> p) { loop_closer_ = p; }
+    size_t AddFirstKeyframe(DPPtr cloud, const Matrix &T_world_kf)
+    {
+        const size_t v = graph_.AddVertex(MakeKeyframe(cloud, T_world_kf));
+        fixed_vertex_ = v;                                  // kept fixed during optimisation (MapManager.hpp:56-58)
+        return v;
+    }
+    size_t AddNewKeyframe(size_t from, const Matrix &T_world_newkf, const Matrix &meas_T_from_newkf, const Matrix &meas_cov, DPPtr cloud);
+    void AddLoopClosingConstraint(size_t from, size_t to, const Matrix &T_from_to, const Matrix &cov)
+    {
+        Constraint c;
+        c.type = Constraint::kLoopConstraint; c.T_from_to = T_from_to; c.cov_from_to = cov; c.weight = (T)PoseWeight(T_from_to);
+        graph_.AddEdge(from, to, c);
+    }
+    void UpdateKeyframeTransform(size_t v, const Matrix &updated, typename Types<T>::Time t) { graph_[v].optimized_T_world_kf = updated; graph_[v].update_time = t; }
+    void NotifyKeyframeUpdate();
+    void WriteGraphviz(const std::string &path)
+    {
+        std::ofstream ofs(path);
+        ofs << "graph G {\n";
+        for (size_t v = 0; v < graph_.NumVertices(); v++) ofs << graph_[v].id << " [label=" << graph_[v].id << "];\n";
+        for (size_t e = 0; e < graph_.NumEdges(); e++) ofs << graph_[graph_.Edge(e).from].id << "--" << graph_[graph_.Edge(e).to].id << " ;\n";
+        ofs << "}\n";
+    }
+
+private:
+    Keyframe MakeKeyframe(DPPtr cloud, const Matrix &T_world_kf)
+    {
+        Keyframe kf;
+        kf.id = graph_.NumVertices(); kf.cloud_ptr = cloud; kf.T_world_kf = T_world_kf; kf.optimized_T_world_kf = T_world_kf;
+        kf.update_time = std::chrono::high_resolution_clock::now();
+        return kf;
+    }
+    PoseGraph<T> graph_;
+    size_t fixed_vertex_ = 0;
+    std::weak_ptr<GraphLocalizer<T>> localizer_;
+    std::weak_ptr<GraphLoopCloser<T>> loop_closer_;
+};
+
+// ------------------------------------------------------------------ Optimizer (Optimizer.hpp)
+template <typename T>
+class Optimizer {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    using Ptr = std::shared_ptr<Optimizer<T>>;
+    using InputData = std::tuple<size_t, size_t, Matrix, Matrix>;       // from, to, T_from_to, COV_from_to (Optimizer.h:22)
+    explicit Optimizer(typename MapManager<T>::Ptr mm) : map_manager_(mm) {}
+    void AddNewData(size_t from, size_t to, const Matrix &T_from_to, const Matrix &cov)
+    {
+        data_buffer_.clear();
+        data_buffer_.push_back(std::make_tuple(from, to, T_from_to, cov));
+        ProcessData();
+    }
+    //! OptimizerMT::Main drains its whole buffer into one solve (OptimizerMT.hpp:59-65); the batched loop-closing
+    //! dispatcher feeds the gathered edges through this
+    void AddNewDataBatch(const std::vector<InputData> &batch) { data_buffer_ = batch; if (!batch.empty()) ProcessData(); }
+    int last_iterations() const { return last_iterations_; }
+    double last_initial_error() const { return e0_; }
+    double last_final_error() const { return e1_; }
+
+private:
+    //! [x y z rx ry rz] -> [rx ry rz x y z] (Optimizer.hpp:32-42), row-major double
+    static void PmCovToRotFirst(const Matrix &m, double out[36])
+    {
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) out[6 * i + j] = (double)m((i + 3) % 6, (j + 3) % 6);
+    }
+    void AddFactor(PoseGraphLeastSquares &ls, size_t from, size_t to, const Matrix &Tm, const Matrix &cov)
+    {
+        PoseGraphLeastSquares::Between f;
+        f.from = from; f.to = to; f.Z = se3::from_matrix(Tm);
+        double c[36];
+        PmCovToRotFirst(cov, c);
+        if (!PoseGraphLeastSquares::InformationFactor(c, f.L)) throw std::runtime_error("[Optimizer] constraint covariance is not positive definite");
+        ls.factors.push_back(f);
+    }
+    void ProcessData()
+    {
+        auto &g = map_manager_->GetGraph();
+        PoseGraphLeastSquares ls;
+        for (size_t e = 0; e < g.NumEdges(); e++) AddFactor(ls, g.Edge(e).from, g.Edge(e).to, g.Edge(e).c.T_from_to, g.Edge(e).c.cov_from_to);
+        for (auto &d : data_buffer_) AddFactor(ls, std::get<0>(d), std::get<1>(d), std::get<2>(d), std::get<3>(d));
+        for (size_t v = 0; v < g.NumVertices(); v++) ls.X.push_back(se3::from_matrix(g[v].optimized_T_world_kf));
+        ls.fixed = map_manager_->GetFixedVertex();                         // prior with sigma 1e-6 (Optimizer.hpp:122-130)
+        ls.Optimize();
+        last_iterations_ = ls.iterations; e0_ = ls.initial_error; e1_ = ls.final_error;
+        const auto now = std::chrono::high_resolution_clock::now();
+        for (size_t v = 0; v < g.NumVertices(); v++) map_manager_->UpdateKeyframeTransform(v, se3::to_matrix<Matrix>(ls.X[v]), now);
+        for (auto &d : data_buffer_) map_manager_->AddLoopClosingConstraint(std::get<0>(d), std::get<1>(d), std::get<2>(d), std::get<3>(d));
+        map_manager_->NotifyKeyframeUpdate();
+    }
+    typename MapManager<T>::Ptr map_manager_;
+    std::vector<InputData> data_buffer_;
+    int last_iterations_ = 0;
+    double e0_ = 0, e1_ = 0;
+};
+
+// ------------------------------------------------------------------ loop closer with its candidate search
+template <typename T>
+class GraphLoopCloser {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    using Ptr = std::shared_ptr<GraphLoopCloser<T>>;
+    GraphLoopCloser(typename MapManager<T>::Ptr mm, typename Optimizer<T>::Ptr opt) : map_manager_(mm), optimizer_(opt) {}
+    void SetTopologicalDistanceThreshold(T v) { topo_dist_threshold_ = v; }
+    void SetGeometricalDistanceThreshold(T v) { geom_dist_threshold_ = v; }
+    void SetOverlapThreshold(T v) { overlap_threshold_ = v; if (closer_) closer_->SetOverlapThreshold(v); }
+    void SetResidualErrorThreshold(T v) { residual_error_threshold_ = v; if (closer_) closer_->SetResidualErrorThreshold(v); }
+    void SetIcpConfigFromString(const std::string &yaml) { closer().SetIcpConfigFromString(yaml); }
+    void AddNewVertex(size_t v) { ProcessVertex(v); }
+    int loops_closed() const { return loops_closed_; }
+    int candidates_tried() const { return candidates_tried_; }
+
+    //! LoopCloser.hpp:193-305: vertices geometrically close (<= geom threshold) and topologically far (> topo
+    //! threshold) from input_v, nearest first; around the first one that admits it, the `capacity` vertices a
+    //! Dijkstra on the graph without loop edges and without the topologically close vertices settles first.
+    bool FindLocalMapCandidate(size_t input_v, std::vector<size_t> &composition) const
+    {
+        auto &g = map_manager_->GetGraph();
+        const auto topo = g.Dijkstra(input_v, nullptr, nullptr, nullptr);
+        std::vector<double> geom(g.NumVertices());
+        for (size_t v = 0; v < g.NumVertices(); v++) geom[v] = PoseDistance(g[v].optimized_T_world_kf, g[input_v].optimized_T_world_kf);
+        std::vector<size_t> cand;
+        for (size_t v = 0; v < g.NumVertices(); v++)
+            if (geom[v] <= (double)geom_dist_threshold_ && topo[v] > (double)topo_dist_threshold_) cand.push_back(v);
+        std::stable_sort(cand.begin(), cand.end(), [&](size_t a, size_t b) { return geom[a] < geom[b]; });
+        auto keep_v = [&](size_t v) { return topo[v] > (double)topo_dist_threshold_; };
+        auto keep_e = [&](size_t e) { return g.Edge(e).c.type != Constraint::kLoopConstraint; };
+        for (size_t cv : cand) {
+            std::deque<size_t> comp;
+            g.Dijkstra(cv, keep_v, keep_e, [&](size_t v) { comp.push_front(v); return comp.size() < capacity_; });   // record_n_and_stop
+            if (comp.size() == capacity_) { composition.assign(comp.begin(), comp.end()); return true; }
+        }
+        return false;
+    }
+    void ProcessVertex(size_t input_v)
+    {
+        auto &g = map_manager_->GetGraph();
+        if (g.NumVertices() < 2) return;
+        std::vector<size_t> comp;
+        if (!FindLocalMapCandidate(input_v, comp)) return;
+        candidates_tried_++;
+        // candidate local map: composition order, reference = back (LocalMap::UpdateToNewComposition)
+        LocalMap<T> lm(capacity_);
+        for (size_t v : comp) lm.PushKeyframe(g[v]);
+        lm.BuildCloudFromData();
+        const size_t ref_v = comp.back();
+        const Matrix guess = g[ref_v].optimized_T_world_kf.inverse() * g[input_v].optimized_T_world_kf;      // LoopCloser.hpp:95
+        auto r = closer().ProcessCandidate(*g[input_v].cloud_ptr, lm.Cloud(), guess);                         // :98 + CheckIcpResult
+        if (r.accepted) {
+            loops_closed_++;
+            optimizer_->AddNewData(ref_v, input_v, r.T_refkf_kf, r.cov);                              // :104-108
+        }
+    }
+
+private:
+    typename MapManager<T>::Ptr map_manager_;
+    //! the ICP object (and with it the device context) is created on first use: the graph searches need no GPU
+    LoopCloser<T> &closer()
+    {
+        if (!closer_) {
+            closer_.reset(new LoopCloser<T>());
+            closer_->SetOverlapThreshold(overlap_threshold_);
+            closer_->SetResidualErrorThreshold(residual_error_threshold_);
+        }
+        return *closer_;
+    }
+    typename Optimizer<T>::Ptr optimizer_;
+    std::unique_ptr<LoopCloser<T>> closer_;
+    T topo_dist_threshold_ = T(3), geom_dist_threshold_ = T(3);               // LoopCloser.hpp:16-17
+    T overlap_threshold_ = T(0.8), residual_error_threshold_ = T(5000);       // :18-19
+    size_t capacity_ = 3;                                                     // :20
+    int loops_closed_ = 0, candidates_tried_ = 0;
+};
+
+// ------------------------------------------------------------------ localizer on the graph
+template <typename T>
+class GraphLocalizer {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    using Ptr = std::shared_ptr<GraphLocalizer<T>>;
+    explicit GraphLocalizer(typename MapManager<T>::Ptr mm, size_t capacity = 3)
+        : map_manager_(mm), capacity_(capacity), rigid_(PM::get().REG(Transformation).create("RigidTransformation")),
+          T_refkf_robot_(Matrix::Identity(4, 4)), T_world_robot_(Matrix::Identity(4, 4)), last_input_(Matrix::Identity(4, 4)) {}
+    void SetOverlapThreshold(T v) { overlap_threshold_ = v; }
+    void SetIcpConfigFromString(const std::string &yaml) { icp_yaml_ = yaml; std::istringstream iss(yaml); icp_sequence_.loadFromYaml(iss); }
+    void SetInputFiltersConfigFromString(const std::string &yaml) { std::istringstream iss(yaml); input_filters_ = DataPointsFilters(iss); }
+    const Matrix &T_world_robot() const { return T_world_robot_; }
+    const std::vector<size_t> &composition() const { return comp_; }
+    int rebuilds() const { return rebuilds_; }
+
+    void AddNewData(unsigned long long, const std::string &, const Matrix &T_world_robot, const Matrix &T_robot_sensor, DPPtr cloud)
+    {
+        ProcessData(T_world_robot, T_robot_sensor, cloud);
+    }
+    void ProcessData(const Matrix &input_T_world_robot, const Matrix &input_T_robot_sensor, DPPtr cloud)
+    {
+        input_cloud_ = cloud;
+        input_filters_.apply(*cloud);
+        (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
+        auto &g = map_manager_->GetGraph();
+        if (comp_.empty()) {                                                 // ProcessFirstCloud
+            comp_.push_back(map_manager_->AddFirstKeyframe(cloud, input_T_world_robot));
+            Rebuild();
+            T_refkf_robot_ = Matrix::Identity(4, 4);
+            T_world_robot_ = input_T_world_robot;
+            last_input_ = input_T_world_robot;
+            return;
+        }
+        const Matrix d = last_input_.inverse() * input_T_world_robot;
+        T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);
+        T_world_robot_ = g[comp_.back()].optimized_T_world_kf * T_refkf_robot_;
+        UpdateAfterIcp();
+        last_input_ = input_T_world_robot;
+    }
+    //! MapManager::NotifyKeyframeUpdate -> Localizer::UpdateFromGraph (Localizer.hpp:155-176): after an
+    //! optimisation the local map is rebuilt from the corrected poses and the world pose follows the reference
+    void UpdateFromGraph()
+    {
+        if (comp_.empty()) return;
+        Rebuild();
+        T_world_robot_ = map_manager_->GetGraph()[comp_.back()].optimized_T_world_kf * T_refkf_robot_;
+    }
+
+private:
+    void Rebuild()
+    {
+        auto &g = map_manager_->GetGraph();
+        LocalMap<T> lm(capacity_);
+        for (size_t v : comp_) lm.PushKeyframe(g[v]);
+        lm.BuildCloudFromData();
+        icp_sequence_.setMap(lm.Cloud());
+        rebuilds_++;
+    }
+    T OverlapWith(const std::vector<size_t> &comp)                          // ComputeOverlapWith, Localizer.hpp:282-348
+    {
+        auto &g = map_manager_->GetGraph();
+        LocalMap<T> lm(capacity_);
+        for (size_t v : comp) lm.PushKeyframe(g[v]);
+        lm.BuildCloudFromData();
+        Localizer<T> probe;
+        probe.SetIcpConfigFromString(icp_yaml_);
+        const DP world_map = rigid_->compute(lm.Cloud(), g[comp.back()].optimized_T_world_kf);
+        return probe.ComputeOverlapOf(*input_cloud_, T_world_robot_, world_map);
+    }
+    //! Localizer.hpp:393-483
+    bool FindNeighborComposition(std::vector<size_t> &out)
+    {
+        auto &g = map_manager_->GetGraph();
+        std::set<size_t> adj;
+        for (size_t v : comp_)
+            for (size_t e : g.IncidentEdges(v)) { const size_t w = g.Other(e, v); if (std::find(comp_.begin(), comp_.end(), w) == comp_.end()) adj.insert(w); }
+        if (adj.empty()) return false;
+        size_t closest = *adj.begin();
+        double cd = PoseDistance(g[closest].optimized_T_world_kf, T_world_robot_);
+        for (size_t v : adj) { const double d = PoseDistance(g[v].optimized_T_world_kf, T_world_robot_); if (d < cd) { cd = d; closest = v; } }
+        std::vector<size_t> ext(comp_.begin(), comp_.end());
+        ext.push_back(closest);
+        auto keep_v = [&](size_t v) { return std::find(ext.begin(), ext.end(), v) != ext.end(); };
+        const auto topo = g.Dijkstra(closest, keep_v, nullptr, nullptr);
+        // decreasing topological distance from the new vertex (sort on reverse iterators, :455-457)
+        std::stable_sort(ext.begin(), ext.end(), [&](size_t a, size_t b) { return topo[a] > topo[b]; });
+        std::deque<size_t> comp;
+        auto push = [&](size_t v) { comp.push_back(v); if (comp.size() > capacity_) comp.pop_front(); };
+        for (size_t i = 0; i + 2 < ext.size(); i++) push(ext[i]);
+        const size_t last = ext[ext.size() - 1], before = ext[ext.size() - 2];
+        const double dl = PoseDistance(g[last].optimized_T_world_kf, T_world_robot_), db = PoseDistance(g[before].optimized_T_world_kf, T_world_robot_);
+        if (db < dl) { push(last); push(before); } else { push(before); push(last); }
+        out.assign(comp.begin(), comp.end());
+        return true;
+    }
+    void UpdateAfterIcp()                                                   // Localizer.hpp:178-268
+    {
+        auto &g = map_manager_->GetGraph();
+        const T overlap = icp_sequence_.errorMinimizer->getOverlap();
+        std::vector<size_t> next = comp_, neigh;
+        const bool enough = overlap >= overlap_threshold_;
+        bool took_neighbor = false;
+        if (FindNeighborComposition(neigh) && OverlapWith(neigh) > overlap) { next = neigh; took_neighbor = true; }   // IsBetterComposition :363-372
+        if (!took_neighbor) {
+            if (enough) {
+                size_t best = 0;
+                double bd = PoseDistance(g[comp_[0]].optimized_T_world_kf, T_world_robot_);
+                for (size_t i = 1; i < comp_.size(); i++) { const double d = PoseDistance(g[comp_[i]].optimized_T_world_kf, T_world_robot_); if (d < bd) { bd = d; best = i; } }
+                if (best != comp_.size() - 1) std::swap(next[best], next[next.size() - 1]);
+            } else {
+                const size_t v = map_manager_->AddNewKeyframe(comp_.back(), T_world_robot_, T_refkf_robot_, icp_sequence_.errorMinimizer->getCovariance(), input_cloud_);
+                // the loop closer may have optimised the graph inside AddNewKeyframe: comp_ poses are re-read below
+                next = comp_;
+                next.push_back(v);
+                if (next.size() > capacity_) next.erase(next.begin());
+            }
+        }
+        const bool same_set = std::set<size_t>(next.begin(), next.end()) == std::set<size_t>(comp_.begin(), comp_.end());
+        if (!(same_set && next.back() == comp_.back())) {
+            const size_t old_ref = comp_.back();
+            comp_ = next;
+            Rebuild();
+            if (comp_.back() != old_ref) T_refkf_robot_ = g[comp_.back()].optimized_T_world_kf.inverse() * T_world_robot_;
+        }
+    }
+    typename MapManager<T>::Ptr map_manager_;
+    size_t capacity_;
+    TransformationPtr rigid_;
+    DataPointsFilters input_filters_;
+    ICPSequence icp_sequence_;
+    std::string icp_yaml_;
+    DPPtr input_cloud_;
+    std::vector<size_t> comp_;                       // local map composition, reference keyframe last
+    Matrix T_refkf_robot_, T_world_robot_, last_input_;
+    T overlap_threshold_ = T(0.8);
+    int rebuilds_ = 0;
+};
+
+template <typename T>
+size_t MapManager<T>::AddNewKeyframe(size_t from, const Matrix &T_world_newkf, const Matrix &meas_T_from_newkf, const Matrix &meas_cov, DPPtr cloud)
+{
+    if (from >= graph_.NumVertices()) throw std::logic_error("MapManager<T>::AddNewKeyframe(): Vertex 'from' must exist in the graph");
+    const size_t v = graph_.AddVertex(MakeKeyframe(cloud, T_world_newkf));
+    Constraint c;
+    c.type = Constraint::kOdomConstraint; c.T_from_to = meas_T_from_newkf; c.cov_from_to = meas_cov; c.weight = (T)PoseWeight(meas_T_from_newkf);
+    graph_.AddEdge(from, v, c);
+    if (auto lc = loop_closer_.lock()) lc->AddNewVertex(v);                  // MapManager.hpp:107-111
+    return v;
+}
+template <typename T>
+void MapManager<T>::NotifyKeyframeUpdate()
+{
+    if (auto l = localizer_.lock()) l->UpdateFromGraph();
+}
+
+// ------------------------------------------------------------------ facade (PoseGraphSlam.h:17-68, single-thread flavour)
+template <typename T>
+class PoseGraphSlam {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    PoseGraphSlam()
+        : map_manager_ptr_(std::make_shared<MapManager<T>>()), optimizer_ptr_(std::make_shared<Optimizer<T>>(map_manager_ptr_)),
+          loop_closer_ptr_(std::make_shared<GraphLoopCloser<T>>(map_manager_ptr_, optimizer_ptr_)),
+          localizer_ptr_(std::make_shared<GraphLocalizer<T>>(map_manager_ptr_))
+    {
+        map_manager_ptr_->SetLocalizer(localizer_ptr_);
+        map_manager_ptr_->SetLoopCloser(loop_closer_ptr_);
+    }
+    //! the reference takes three file paths (PoseGraphSlam.hpp:38-48); the YAML texts are accepted as well
+    void SetIcpConfigFromStrings(const std::string &input_filters_yaml, const std::string &localizer_icp_yaml, const std::string &loop_closer_icp_yaml)
+    {
+        localizer_ptr_->SetInputFiltersConfigFromString(input_filters_yaml);
+        localizer_ptr_->SetIcpConfigFromString(localizer_icp_yaml);
+        loop_closer_ptr_->SetIcpConfigFromString(loop_closer_icp_yaml);
+    }
+    void SetIcpConfig(const std::string &input_filters_path, const std::string &localizer_icp_path, const std::string &loop_closer_icp_path)
+    {
+        auto slurp = [](const std::string &p) {
+            std::ifstream ifs(p);
+            if (!ifs) throw std::runtime_error("[PoseGraphSlam] cannot open " + p);
+            std::stringstream ss;
+            ss << ifs.rdbuf();
+            return ss.str();
+        };
+        SetIcpConfigFromStrings(slurp(input_filters_path), slurp(localizer_icp_path), slurp(loop_closer_icp_path));
+    }
+    void AddData(unsigned long long timestamp, std::string world_frame_id, Matrix T_world_robot, Matrix T_robot_sensor, DPPtr cloud_ptr)
+    {
+        localizer_ptr_->AddNewData(timestamp, world_frame_id, T_world_robot, T_robot_sensor, cloud_ptr);
+    }
+    void WriteGraphviz(const std::string &path) { map_manager_ptr_->WriteGraphviz(path); }
+    MapManager<T> &map_manager() { return *map_manager_ptr_; }
+    GraphLocalizer<T> &localizer() { return *localizer_ptr_; }
+    GraphLoopCloser<T> &loop_closer() { return *loop_closer_ptr_; }
+    Optimizer<T> &optimizer() { return *optimizer_ptr_; }
+
+protected:
+    typename MapManager<T>::Ptr map_manager_ptr_;
+    typename Optimizer<T>::Ptr optimizer_ptr_;
+    typename GraphLoopCloser<T>::Ptr loop_closer_ptr_;
+    typename GraphLocalizer<T>::Ptr localizer_ptr_;
+};
+
+}  // namespace pgslam

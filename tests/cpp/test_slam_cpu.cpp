@@ -1,0 +1,130 @@
+// CPU checks of include/pgslam_amd/slam.hpp (no GPU): graph search, SE(3) maps, pose-graph least squares,
+// loop-closure candidate search.  The least-squares problem and its solution are printed so that the Python
+// side can solve the same cost with scipy and compare (tests/test_slam.py).
+#include "common.hpp"
+#include <pgslam_amd/slam.hpp>
+
+using namespace pgslam;
+
+static Types<double>::Keyframe kf_at(size_t id, double x, double y, double yaw)
+{
+    Types<double>::Keyframe k;
+    k.id = id; k.T_world_kf = pose<double>(x, y, 0, yaw); k.optimized_T_world_kf = k.T_world_kf;
+    return k;
+}
+static Types<double>::Constraint edge_of(const pgslam_amd::Mat<double> &Tm, bool loop = false)
+{
+    Types<double>::Constraint c;
+    c.type = loop ? Types<double>::Constraint::kLoopConstraint : Types<double>::Constraint::kOdomConstraint;
+    c.T_from_to = Tm;
+    c.cov_from_to = pgslam_amd::Mat<double>::Identity(6, 6);
+    c.weight = PoseWeight(Tm);
+    return c;
+}
+
+int main()
+{
+    // ---- SE(3): exp/log round trips, small and large angles
+    Lcg g(7);
+    for (int k = 0; k < 200; k++) {
+        double xi[6], back[6];
+        const double scale = k < 50 ? 1e-7 : (k < 150 ? 1.0 : 3.0);
+        for (int a = 0; a < 6; a++) xi[a] = scale * (g.next() - 0.5);
+        se3::log(se3::exp(xi), back);
+        for (int a = 0; a < 6; a++) CHECK(std::fabs(back[a] - xi[a]) < 1e-9 * (1 + scale));
+        const se3::Pose P = se3::exp(xi), I = se3::mul(P, se3::inv(P));
+        for (int a = 0; a < 9; a++) CHECK(std::fabs(I.R[a] - (a % 4 == 0 ? 1.0 : 0.0)) < 1e-12);
+    }
+
+    // ---- graph: a chain 0-1-2-3-4 with unit steps plus a long edge 0-4; Dijkstra settles by distance
+    PoseGraph<double> G;
+    for (int i = 0; i < 5; i++) G.AddVertex(kf_at(i, i, 0, 0));
+    for (int i = 0; i < 4; i++) G.AddEdge(i, i + 1, edge_of(pose<double>(1, 0, 0, 0)));
+    G.AddEdge(0, 4, edge_of(pose<double>(2.5, 0, 0, 0), true));
+    std::vector<size_t> order;
+    auto dist = G.Dijkstra(0, nullptr, nullptr, [&](size_t v) { order.push_back(v); return true; });
+    CHECK(order.size() == 5 && order[0] == 0 && order[1] == 1 && order[2] == 2 && order[3] == 4 && order[4] == 3);
+    CHECK(dist[4] == 2.5 && dist[3] == 3.0);
+    // without loop edges the far end is 4 away; a stopping visitor records the first three
+    std::vector<size_t> first3;
+    dist = G.Dijkstra(0, nullptr, [&](size_t e) { return G.Edge(e).c.type != Types<double>::Constraint::kLoopConstraint; },
+                      [&](size_t v) { first3.push_back(v); return first3.size() < 3; });
+    CHECK(first3.size() == 3 && first3[2] == 2);
+    bool threw = false;
+    try { G.AddEdge(1, 0, edge_of(pose<double>(1, 0, 0, 0))); } catch (const std::logic_error &) { threw = true; }
+    CHECK(threw);
+
+    // ---- pose-graph least squares: a square loop with drifting odometry and one loop-closing edge
+    const int N = 16;
+    std::vector<pgslam_amd::Mat<double>> truth, est;
+    for (int i = 0; i < N; i++) {
+        const double a = 2 * M_PI * i / N;
+        truth.push_back(pose<double>(3 * std::cos(a), 3 * std::sin(a), 0.1 * std::sin(2 * a), a + M_PI / 2, 0.02 * std::cos(a), 0.01 * a));
+    }
+    PoseGraphLeastSquares ls;
+    est.push_back(truth[0]);
+    std::printf("PROBLEM %d\n", N);
+    for (int i = 0; i + 1 <= N; i++) {
+        const int j = (i + 1) % N;
+        const bool loop = j == 0;
+        auto Z = truth[i].inverse() * truth[j];
+        // measurement = truth composed with a deterministic error; loop edge is accurate
+        const double s = loop ? 0.002 : 0.03;
+        Z = Z * pose<double>(s * (g.next() - 0.5), s * (g.next() - 0.5), s * (g.next() - 0.5), s * (g.next() - 0.5), 0.3 * s * (g.next() - 0.5), 0.3 * s * (g.next() - 0.5));
+        if (!loop) est.push_back(est.back() * Z);
+        PoseGraphLeastSquares::Between f;
+        f.from = i; f.to = j; f.Z = se3::from_matrix(Z);
+        double cov[36] = {0};
+        for (int a = 0; a < 6; a++) cov[7 * a] = (a < 3 ? 1e-4 : 4e-4) * (loop ? 0.01 : 1.0) * (1 + 0.1 * a);
+        cov[1] = cov[6] = 2e-5 * (loop ? 0.01 : 1.0);
+        CHECK(PoseGraphLeastSquares::InformationFactor(cov, f.L));
+        ls.factors.push_back(f);
+        std::printf("EDGE %d %d", i, j);
+        for (int a = 0; a < 9; a++) std::printf(" %.17g", f.Z.R[a]);
+        for (int a = 0; a < 3; a++) std::printf(" %.17g", f.Z.t[a]);
+        for (int a = 0; a < 36; a++) std::printf(" %.17g", cov[a]);
+        std::printf("\n");
+    }
+    for (int i = 0; i < N; i++) ls.X.push_back(se3::from_matrix(est[i]));
+    ls.fixed = 0;
+    for (int i = 0; i < N; i++) {
+        std::printf("INIT %d", i);
+        for (int a = 0; a < 9; a++) std::printf(" %.17g", ls.X[i].R[a]);
+        for (int a = 0; a < 3; a++) std::printf(" %.17g", ls.X[i].t[a]);
+        std::printf("\n");
+    }
+    const double drift_before = pose_diff(est[N - 1], truth[N - 1]);
+    ls.Optimize();
+    CHECK(ls.final_error < ls.initial_error * 0.2 && ls.iterations >= 2 && ls.iterations < 100);
+    const double drift_after = pose_diff(se3::to_matrix<pgslam_amd::Mat<double>>(ls.X[N - 1]), truth[N - 1]);
+    CHECK(drift_after < 0.5 * drift_before);
+    CHECK(pose_diff(se3::to_matrix<pgslam_amd::Mat<double>>(ls.X[0]), truth[0]) == 0.0);          // the fixed vertex did not move
+    std::printf("COST %.17g %.17g ITER %d\n", ls.initial_error, ls.final_error, ls.iterations);
+    for (int i = 0; i < N; i++) {
+        std::printf("SOL %d", i);
+        for (int a = 0; a < 9; a++) std::printf(" %.17g", ls.X[i].R[a]);
+        for (int a = 0; a < 3; a++) std::printf(" %.17g", ls.X[i].t[a]);
+        std::printf("\n");
+    }
+
+    // ---- loop-closure candidate search (LoopCloser.hpp:193-305) on a trajectory that comes back to its start
+    auto mm = std::make_shared<MapManager<double>>();
+    auto opt = std::make_shared<Optimizer<double>>(mm);
+    GraphLoopCloser<double> lc(mm, opt);
+    auto &PG = mm->GetGraph();
+    const int L = 14;                                         // an out-and-back line: 0..7 out, 8..13 back next to 5..0
+    for (int i = 0; i < L; i++) {
+        const double x = i <= 7 ? i : 14 - i, y = i <= 7 ? 0.0 : 0.4;
+        PG.AddVertex(kf_at(i, x, y, 0));
+        if (i > 0) PG.AddEdge(i - 1, i, edge_of(PG[i - 1].optimized_T_world_kf.inverse() * PG[i].optimized_T_world_kf));
+    }
+    std::vector<size_t> comp;
+    CHECK(!lc.FindLocalMapCandidate(7, comp));                // at the turning point everything near is also topologically near
+    CHECK(lc.FindLocalMapCandidate(13, comp));                // vertex 13 sits at (1, 0.4): next to vertex 1
+    CHECK(comp.size() == 3 && comp.back() == 1);              // the closest candidate is the reference (settled first, pushed front)
+    for (size_t v : comp) CHECK(v <= 4);                      // built from old vertices only (topologically far from 13)
+    lc.SetGeometricalDistanceThreshold(0.1);
+    CHECK(!lc.FindLocalMapCandidate(13, comp));
+    std::puts("slam cpu tests ok");
+    return 0;
+}

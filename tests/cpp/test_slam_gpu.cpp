@@ -1,0 +1,55 @@
+// PoseGraphSlam facade end to end on the GPU: a robot drives a closed loop through the room-corner scene;
+// every scan becomes a keyframe (overlap threshold above what the trimmed filter can report), the loop
+// closer finds the first keyframes again, the loop ICP is accepted and the pose graph is optimised.
+#include "common.hpp"
+#include <pgslam_amd/slam.hpp>
+
+template <typename T>
+void run(const char *name)
+{
+    IMPORT_PGSLAM_TYPES(T)
+    pgslam::PoseGraphSlam<T> slam;
+    slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+    slam.localizer().SetOverlapThreshold(T(0.9));
+    slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
+    slam.loop_closer().SetGeometricalDistanceThreshold(T(0.3));
+    TransformationPtr rigid = PM::get().REG(Transformation).create("RigidTransformation");
+    const int S = 15;
+    std::vector<Matrix> truth, odom;
+    for (int s = 0; s < S; s++) {
+        const double a = 2 * M_PI * s / (S - 1);                        // last pose = first pose
+        truth.push_back(pose<T>(1.5 + 0.5 * std::cos(a), 1.5 + 0.5 * std::sin(a), 0.0, a * 0.2));
+    }
+    odom.push_back(truth[0]);
+    for (int s = 1; s < S; s++) odom.push_back(odom[s - 1] * (truth[s - 1].inverse() * truth[s]) * pose<T>(0.012, -0.009, 0.0, 0.005));
+    for (int s = 0; s < S; s++) {
+        auto cloud = std::make_shared<DP>(rigid->compute(make_corner<T>(2000, 70 + s, 0.004), truth[s].inverse()));
+        slam.AddData((unsigned long long)s, "world", odom[s], Matrix::Identity(4, 4), cloud);
+        CHECK(pose_diff(slam.localizer().T_world_robot(), truth[s]) < 3e-2);
+    }
+    auto &g = slam.map_manager().GetGraph();
+    CHECK(g.NumVertices() == (size_t)S);                                // one keyframe per scan
+    int loops = 0;
+    for (size_t e = 0; e < g.NumEdges(); e++) loops += g.Edge(e).c.type == Constraint::kLoopConstraint;
+    CHECK(loops >= 1 && loops == slam.loop_closer().loops_closed());
+    CHECK(slam.optimizer().last_iterations() >= 1 && slam.optimizer().last_final_error() <= slam.optimizer().last_initial_error());
+    // the optimised keyframe poses sit on the true trajectory (odometry alone ends ~10 cm off)
+    double worst = 0;
+    for (size_t v = 0; v < g.NumVertices(); v++) worst = std::max(worst, pose_diff(g[v].optimized_T_world_kf, truth[v]));
+    CHECK(worst < 3e-2);
+    CHECK(pose_diff(odom[S - 1], truth[S - 1]) > 5e-2);
+    slam.WriteGraphviz("/tmp/pgslam_amd_graph.dot");
+    std::ifstream dot("/tmp/pgslam_amd_graph.dot");
+    std::string text((std::istreambuf_iterator<char>(dot)), std::istreambuf_iterator<char>());
+    CHECK(text.find("graph G") != std::string::npos && text.find("--") != std::string::npos);
+    std::printf("%s: ok  (%zu keyframes, %d loop edges, %d optimiser iterations, worst keyframe error %.2e)\n", name, g.NumVertices(), loops,
+                slam.optimizer().last_iterations(), worst);
+}
+
+int main()
+{
+    run<float>("PoseGraphSlam<float>");
+    run<double>("PoseGraphSlam<double>");
+    std::puts("slam gpu tests ok");
+    return 0;
+}
