@@ -12,6 +12,11 @@
 #ifndef PGICP_FAST_BLOCK
 #define PGICP_FAST_BLOCK 64
 #endif
+// The fast matcher kernel keeps ~100 scalars live; capping its SGPR allocation at 80 (the rest spill into
+// lanes of one VGPR) admits 7 waves per SIMD instead of 6 (800 SGPRs per SIMD: MI355X_MICROARCH.md).
+#ifndef PGICP_FAST_ATTR
+#define PGICP_FAST_ATTR __attribute__((amdgpu_num_sgpr(80)))
+#endif
 
 namespace pgicp {
 
@@ -478,6 +483,10 @@ __device__ __forceinline__ int clamp_cell(T u, T inv_h, int n)
 // each distinct bin are counted with ONE atomic (up to 8 leader rounds, then plain per-lane atomics
 // for incoherent input).  The value the atomic returns is the point's arrival position inside its
 // bin, so the scatter pass needs no second round of atomics.
+// hardware square root (1 ulp): only where the result feeds a conservative bound with a margin
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_qbin(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                const T *__restrict__ rd_pre, int max_bins, int bin_shift,
@@ -853,7 +862,7 @@ __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<
 constexpr int kFastBlock = PGICP_FAST_BLOCK;
 
 template <typename T, int R>
-__global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
+__global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                   const T *__restrict__ rd, int *__restrict__ slot_io,
                                                   T *__restrict__ d2_out, ChainDev<T> ch, int use_seed, int fast_rings,
                                                   int *__restrict__ slow_count, int2 *__restrict__ slow_list,
@@ -864,7 +873,6 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
     constexpr int NR = (2 * R + 1) * (2 * R + 1);
     __shared__ int rng_a[NR - 1][kFastBlock];      // column `lane` is private to that lane: no barrier needed
     __shared__ int rng_b[NR - 1][kFastBlock];
-    __shared__ T rng_l[NR - 1][kFastBlock];
     const int prob = active[blockIdx.y];           // only problems still iterating are launched
     const ProblemDev &P = probs[prob];
     if (P.done) return;
@@ -961,38 +969,48 @@ __global__ __launch_bounds__(kFastBlock) void k_knn_grid(const ProblemDev *__res
 #endif
     {
     // ---- phase A.2: collect the ranges of the other rows of the (2R+1)^3 block with that bound ----
-    int ra[NR - 1], rb[NR - 1];
-    T rl[NR - 1];
+    // Straight-line code: the slab terms of the 2R+1 offsets per axis are computed once, every row then
+    // costs a handful of selects (a row that is out of the grid, pruned or empty in x loads entry 0 and
+    // yields an empty range).  The x-range uses the fast square root: its rounding is far below the margin.
+    constexpr int W = 2 * R + 1;
+    T ly2[W], lz2[W];
+    bool oky[W], okz[W];
 #pragma unroll
-    for (int t = 0; t < NR - 1; ++t) {
-        const int tt = (t < R * (2 * R + 1) + R) ? t : t + 1;      // skip the centre (own) row
-        const int dy = tt % (2 * R + 1) - R, dz = tt / (2 * R + 1) - R;
-        const int y = cy + dy, z = cz + dz;
-        ra[t] = 0; rb[t] = 0; rl[t] = (T)0;
-        if (live && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-            const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
-            const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
-            const T lb2 = ly * ly + lz * lz;
-            if (!(lb2 > best.d2)) {
-                int xlo = max(cx - R, 0), xhi = min(cx + R, g.nx - 1);
-                if (best.d2 < Bits<T>::inf()) {
-                    const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + g.margin;
-                    xlo = max(xlo, clamp_cell<T>(ux - rad, g.inv_h, g.nx));
-                    xhi = min(xhi, clamp_cell<T>(ux + rad, g.inv_h, g.nx));
-                }
-                if (xlo <= xhi) {
-                    const int row = g.nx * (y + g.ny * z);
-                    ra[t] = as_global(M.cell_start)[row + xlo];
-                    rb[t] = as_global(M.cell_start)[row + xhi + 1];
-                    rl[t] = lb2;
-                }
-            }
-        }
+    for (int d = 0; d < W; ++d) {
+        const int y = cy + d - R, z = cz + d - R;
+        oky[d] = y >= 0 && y < g.ny;
+        okz[d] = z >= 0 && z < g.nz;
+        const T l = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0), m = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
+        ly2[d] = l * l;
+        lz2[d] = m * m;
     }
+    const int row0 = g.nx * (cy + g.ny * cz), sy = g.nx, sz = g.nx * g.ny;
+    const int xlo0 = max(cx - R, 0), xhi0 = min(cx + R, g.nx - 1);
+    const T bound = best.d2;
     int nr = 0;
+    // two groups of rows: all look-ups of a group are in flight together, and only half of them are live
+    // in registers at a time (the kernel sits at the edge of a register-allocation step)
 #pragma unroll
-    for (int t = 0; t < NR - 1; ++t)
-        if (ra[t] < rb[t]) { rng_a[nr][lane] = ra[t]; rng_b[nr][lane] = rb[t]; rng_l[nr][lane] = rl[t]; ++nr; }
+    for (int grp = 0; grp < 2; ++grp) {
+        constexpr int H = (NR - 1) / 2;
+        int ra[H], rb[H];
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            const int t = grp * H + u;
+            const int tt = (t < R * W + R) ? t : t + 1;            // skip the centre (own) row
+            const int dy = tt % W, dz = tt / W;
+            const T lb2 = ly2[dy] + lz2[dz];
+            const T rad = fast_sqrt(fmax(bound - lb2, (T)0)) * (T)1.000001 + g.margin;
+            const int xlo = max(xlo0, clamp_cell<T>(ux - rad, g.inv_h, g.nx)), xhi = min(xhi0, clamp_cell<T>(ux + rad, g.inv_h, g.nx));
+            const bool need = live && oky[dy] && okz[dz] && !(lb2 > bound) && xlo <= xhi;
+            const int row = row0 + (dy - R) * sy + (dz - R) * sz;
+            ra[u] = as_global(M.cell_start)[need ? row + xlo : 0];
+            rb[u] = as_global(M.cell_start)[need ? row + xhi + 1 : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < H; ++u)
+            if (ra[u] < rb[u]) { rng_a[nr][lane] = ra[u]; rng_b[nr][lane] = rb[u]; ++nr; }
+    }
     // ---- flat walk over the concatenated ranges (LDS is only read by the lane that wrote it) ----
     {
         int k = 0, j = 0, e = 0;
