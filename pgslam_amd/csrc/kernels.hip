@@ -844,20 +844,21 @@ __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<
 // Fast path: one query per lane, 64 consecutive queries of the 3-D-compact sorted
 // reading per wave (workgroup = one wave; LDS is wave private).
 //
-// Phase A -- block of (2R+1)^3 cells around the query's own cell, R = 1 when the
-// previous iteration's match seeds the bound, R = 2 on the first iteration.  The
-// lane first COLLECTS the point ranges of every row of the block it cannot prune
-// (all cell-offset loads are independent, so they are in flight together), then
-// walks the concatenation of its non-empty ranges in ONE flat loop with the next
-// candidate's load issued before the current one is evaluated.  A wave therefore
-// iterates max-over-lanes(total candidates) times, not sum-over-rows(max-over-
-// lanes), which is what lock-step row loops cost on divergent data.
-// Phase B -- lanes not resolved within radius R continue ring by ring.
-// Phase C -- what is still unresolved is queued with a lower bound LB on its true
-// squared distance while d2 keeps an UPPER bound (partial best, or a certificate
-// that a non-empty super-cell lies wholly within maxDist).  The trimmed-distance
-// filter only needs exact values up to its threshold, so k_knn_slow resolves
-// just the queued queries with LB <= threshold (normally none): kept pairs,
+// Start -- previous match as seed (or, without one, the points of MapDev::near's cell); "no neighbour"
+// settled without a search where the super-cell distance map or the empty radius of the previous pass
+// allows it.
+// Phase A -- the 3x3x3 cells around the query's own cell: own row first (it usually holds the neighbour
+// and shrinks the bound), then the lane COLLECTS the point ranges of the other eight rows it cannot
+// prune (straight-line code, all cell-table look-ups in flight together) and walks the concatenation
+// of its non-empty ranges in ONE flat loop.  A wave therefore iterates max-over-lanes(total
+// candidates) times, not sum-over-rows(max-over-lanes), which is what lock-step row loops cost on
+// divergent data.
+// Phase B -- lanes not resolved within that block continue ring by ring (1 ring more when seeded, 3 on
+// the first iteration), never beyond 1.21x the previous trim threshold.
+// Phase C -- what is still unresolved is queued with a lower bound LB on its true squared distance
+// while d2 keeps an UPPER bound (partial best, or a certificate that a non-empty super-cell lies
+// wholly within maxDist).  The trimmed-distance filter only needs exact values up to its threshold,
+// so k_knn_med / k_knn_slow resolve just the queued queries with LB <= threshold: kept pairs,
 // threshold and n_finite stay exact.
 constexpr int kFastBlock = PGICP_FAST_BLOCK;
 
