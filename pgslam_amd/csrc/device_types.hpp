@@ -29,6 +29,8 @@ struct MapDev {
     const typename Vec4<T>::type *pts;   // (x, y, z, bit-cast original index) cell-sorted, centred
     const typename Vec4<T>::type *nrm;   // (nx, ny, nz, 0) same order; may be null
     const int *cell_start;               // ncells + 1 exclusive prefix sums
+    const int *cell_start_f;             // the same prefix sums on cells kx times finer in x (== cell_start when kx == 1)
+    int kx;                              // points of a cell are ordered by fine x cell, so fine ranges are contiguous too
     const int *sc_count;                 // occupancy flag per 8x8x8 super-cell
     const int *sc_dist;                  // Chebyshev distance (in super-cells, capped at kScReach + 1) to the nearest occupied one
     const int *slot_of;                  // original index -> position in pts / nrm
@@ -47,8 +49,8 @@ struct BuildDesc {
     int xstride, nstride, m, near_reach;
     T mean[3];
     GridDesc<T> g;
-    long long pbase, cbase, sbase;
-    int ncells, nsc;
+    long long pbase, cbase, sbase, fbase;   // fbase: offset of this cloud's FINE cells (+1 sentinel) in the fine table
+    int ncells, nsc, kx, ncells_f;
 };
 
 // Chain parameters as the kernels need them.

@@ -83,6 +83,15 @@ __device__ __forceinline__ unsigned long long ordered_key(double v)
     return (unsigned long long)(i >= 0 ? (i ^ (long long)0x8000000000000000LL) : ~i);
 }
 
+// cell index of coordinate offset u on a grid of n cells of width 1 / inv_h (clamped; shared by the build
+// and every query so that both sides round identically)
+template <typename T>
+__device__ __forceinline__ int clamp_cell(T u, T inv_h, int n)
+{
+    const T lim = (T)16777216.0;
+    return min(max((int)fmin(fmax(floor(u * inv_h), -lim), lim), 0), n - 1);
+}
+
 template <typename T>
 __device__ __forceinline__ int build_cell(const GridDesc<T> &g, T x, T y, T z)
 {
@@ -286,21 +295,24 @@ __global__ __launch_bounds__(256) void k_cell_count_b(const BuildDesc<T> *__rest
     if (blockIdx.x * blockDim.x >= d.m) return;
     const bool live = i < d.m;
     const GridDesc<T> g = d.g;
-    int c = 0, cl = 0;
+    int c = 0, fx = 0, cy = 0, cz = 0;
+    const int kx = d.kx, nxf = g.nx * kx;
     if (live) {
         const T x = d.xyz[(long long)i * d.xstride] - d.mean[0], y = d.xyz[(long long)i * d.xstride + 1] - d.mean[1],
                 z = d.xyz[(long long)i * d.xstride + 2] - d.mean[2];
-        cl = build_cell(g, x, y, z);
-        c = (int)(d.cbase + cl);
+        // the fine x cell with exactly the expression the matcher narrows with (clamp_cell on inv_h * kx)
+        fx = clamp_cell<T>(x - g.ox, g.inv_h * (T)kx, nxf);
+        cy = min(max((int)floor((y - g.oy) * g.inv_h), 0), g.ny - 1);
+        cz = min(max((int)floor((z - g.oz) * g.inv_h), 0), g.nz - 1);
+        c = (int)(d.fbase + fx + (long long)nxf * (cy + g.ny * cz));
         cell_of[d.pbase + i] = c;
     }
     const int pos = wave_bucket_add(counts, c, live);
     if (!live) return;
     arrival[d.pbase + i] = pos;
     if (pos == 0) {
-        const int cx = cl % g.nx, cy = (cl / g.nx) % g.ny, cz = cl / (g.nx * g.ny);
         const int nsx = (g.nx + 7) >> 3, nsy = (g.ny + 7) >> 3;
-        sc_count[d.sbase + (cx >> 3) + nsx * ((cy >> 3) + nsy * (cz >> 3))] = 1;
+        sc_count[d.sbase + ((fx / kx) >> 3) + nsx * ((cy >> 3) + nsy * (cz >> 3))] = 1;
     }
 }
 
@@ -336,12 +348,26 @@ __global__ __launch_bounds__(256) void k_rank_place_b(const BuildDesc<T> *__rest
     slot_of[i] = (int)(pos - d.pbase);
 }
 
+// the fine table of this cloud becomes local (offsets into ITS points); the table of the search cells is
+// every kx-th entry of it
 template <typename T>
-__global__ __launch_bounds__(256) void k_localise_b(const BuildDesc<T> *__restrict__ descs, int *__restrict__ cell_start)
+__global__ __launch_bounds__(256) void k_localise_b(const BuildDesc<T> *__restrict__ descs, int *__restrict__ cell_start_f)
 {
     const BuildDesc<T> &d = descs[blockIdx.y];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= d.ncells) cell_start[d.cbase + c] -= (int)d.pbase;
+    if (c <= d.ncells_f) cell_start_f[d.fbase + c] -= (int)d.pbase;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_coarse_table_b(const BuildDesc<T> *__restrict__ descs, const int *__restrict__ cell_start_f,
+                                                         int *__restrict__ cell_start)
+{
+    const BuildDesc<T> &d = descs[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > d.ncells) return;
+    const int nx = d.g.nx;
+    // cell (cx, row) starts at fine cell (cx * kx, row); the sentinel maps to the fine sentinel
+    const long long f = c == d.ncells ? (long long)d.ncells_f : (long long)(c % nx) * d.kx + (long long)nx * d.kx * (c / nx);
+    cell_start[d.cbase + c] = cell_start_f[d.fbase + f];
 }
 
 // MapDev::near -- for every cell a nearby OCCUPIED cell (three separable sweeps: nearest occupied cell of
@@ -353,11 +379,12 @@ __global__ __launch_bounds__(256) void k_near_b(const BuildDesc<T> *__restrict__
                                                  int *__restrict__ tmp_a, int *__restrict__ tmp_b, int *__restrict__ near)
 {
     const BuildDesc<T> &d = descs[blockIdx.y];
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;         // ncells <= 2^26: 32-bit index arithmetic
     if (c >= d.ncells) return;
     const int nx = d.g.nx, ny = d.g.ny, nz = d.g.nz;
     const int reach = d.near_reach < 1 ? 1 : (d.near_reach > kNearReach ? kNearReach : d.near_reach);
-    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((long long)nx * ny));
+    const int row = c / nx;
+    const int x = c - row * nx, z = row / ny, y = row - z * ny;
     if (pass == 0) {
         const int *cs = cell_start + d.cbase;
         int found = -1;
@@ -372,7 +399,7 @@ __global__ __launch_bounds__(256) void k_near_b(const BuildDesc<T> *__restrict__
         for (int t = -reach; t <= reach; ++t) {
             const int yy = y + t;
             if (yy < 0 || yy >= ny) continue;
-            const int xx = in[c + (long long)t * nx];
+            const int xx = in[c + t * nx];
             if (xx < 0) continue;
             const int dist = (xx - x) * (xx - x) + t * t;
             if (dist < bd) { bd = dist; best = xx | (yy << 16); }
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(256) void k_near_b(const BuildDesc<T> *__restrict__
         tmp_b[d.cbase + c] = best;
     } else {
         const int *in = tmp_b + d.cbase;
-        const long long plane = (long long)nx * ny;
+        const int plane = nx * ny;
         int best = -1, bd = 0x7FFFFFFF;
         for (int t = -reach; t <= reach; ++t) {
             const int zz = z + t;
@@ -389,7 +416,7 @@ __global__ __launch_bounds__(256) void k_near_b(const BuildDesc<T> *__restrict__
             if (v < 0) continue;
             const int xx = v & 0xFFFF, yy = v >> 16;
             const int dist = (xx - x) * (xx - x) + (yy - y) * (yy - y) + t * t;
-            if (dist < bd) { bd = dist; best = (int)(xx + (long long)nx * (yy + (long long)ny * zz)); }
+            if (dist < bd) { bd = dist; best = xx + nx * (yy + ny * zz); }
         }
         near[d.cbase + c] = best;
     }
@@ -463,26 +490,17 @@ __global__ __launch_bounds__(256) void k_pretransform(const ProblemDev *__restri
     o[0] = ox; o[1] = oy; o[2] = oz;
 }
 
-// ---------------------------------------------------------------------------
-// reading sort: once per scan the (pre-transformed) reading is put in a
-// 3-D-compact order: by 4x4x4-cell block of the map grid (blocks x-fastest),
-// then by cell inside the block, then by original index.  A rigid correction
-// keeps neighbours neighbours, so for every later iteration the 64 queries of a
-// wave share one small neighbourhood of the cell-sorted map: the wave can stage
-// that neighbourhood in LDS once instead of every lane pulling its own cache
-// lines.
-// ---------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ int clamp_cell(T u, T inv_h, int n)
-{
-    const T lim = (T)16777216.0;
-    return min(max((int)fmin(fmax(floor(u * inv_h), -lim), lim), 0), n - 1);
-}
 
 // Readings arrive in scan order, so the lanes of a wave fall into a handful of bins: the lanes of
 // each distinct bin are counted with ONE atomic (up to 8 leader rounds, then plain per-lane atomics
 // for incoherent input).  The value the atomic returns is the point's arrival position inside its
 // bin, so the scatter pass needs no second round of atomics.
+// ---------------------------------------------------------------------------
+// reading sort: once per scan the (pre-transformed) reading is put in a 3-D-compact order: by block of
+// map cells (blocks x-fastest), then by cell inside the block, then by original index.  A rigid
+// correction keeps neighbours neighbours, so for every later iteration the 64 queries of a wave share one
+// small neighbourhood of the cell-sorted map (L1 locality).
+// ---------------------------------------------------------------------------
 // hardware square root (1 ulp): only where the result feeds a conservative bound with a margin
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
@@ -681,17 +699,23 @@ __device__ __forceinline__ T slab_dist(T u, int c, T h)
 // contiguous in memory, and only those within sqrt(best - rowdist^2) of the
 // query in x can hold a better point.
 template <typename T>
-__device__ __forceinline__ void scan_row(const MapDev<T> &M, int row_base, int xa, int xb, T ux, T lb2, T qx, T qy, T qz,
+__device__ __forceinline__ void scan_row(const MapDev<T> &M, int row_id, int xa, int xb, T ux, T lb2, T qx, T qy, T qz,
                                          Best<T> &best)
 {
+    // [xa, xb] are cells of the search structure; the range actually read is cut down on the kx-times
+    // finer x grid the points are ordered by (every candidate is a 16-byte gather: fewer is faster)
+    const int kx = M.kx, nxf = M.g.nx * kx;
+    int fa = xa * kx, fb = xb * kx + kx - 1;
     if (best.d2 < Bits<T>::inf()) {
         const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + M.g.margin;
-        xa = max(xa, clamp_cell<T>(ux - rad, M.g.inv_h, M.g.nx));
-        xb = min(xb, clamp_cell<T>(ux + rad, M.g.inv_h, M.g.nx));
-        if (xa > xb) return;
+        const T inv_hx = M.g.inv_h * (T)kx;
+        fa = max(fa, clamp_cell<T>(ux - rad, inv_hx, nxf));
+        fb = min(fb, clamp_cell<T>(ux + rad, inv_hx, nxf));
+        if (fa > fb) return;
     }
-    const auto *cs = as_global(M.cell_start);
-    scan_range<T>(M.pts, cs[row_base + xa], cs[row_base + xb + 1], qx, qy, qz, best);
+    const auto *cs = as_global(M.cell_start_f);
+    const int row = nxf * row_id;
+    scan_range<T>(M.pts, cs[row + fa], cs[row + fb + 1], qx, qy, qz, best);
 }
 
 // guaranteed radius after ring r: every cell outside Chebyshev ring r around c0 is at
@@ -744,7 +768,7 @@ __device__ __forceinline__ bool grid_nn(const MapDev<T> &M, T qx, T qy, T qz, T 
                 const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
                 const T lb2 = ly * ly + lz * lz;
                 if (lb2 > best.d2) continue;
-                const int row = g.nx * (y + g.ny * z);
+                const int row = y + g.ny * z;
                 if (zo || (y - c0y == r) || (c0y - y == r)) {
                     scan_row<T>(M, row, xa, xb, ux, lb2, qx, qy, qz, best);
                 } else {                         // inner row of the shell: only its two end cells are new
@@ -957,7 +981,7 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
         }
     }
     // ---- phase A.1: own row first -- it usually holds the neighbour and shrinks the bound ----
-    if (live) scan_row<T>(M, g.nx * (cy + g.ny * cz), max(cx - R, 0), min(cx + R, g.nx - 1), ux, (T)0, qx, qy, qz, best);
+    if (live) scan_row<T>(M, cy + g.ny * cz, max(cx - R, 0), min(cx + R, g.nx - 1), ux, (T)0, qx, qy, qz, best);
 #ifdef PGICP_KNN_STATS
     KNN_STAT_WAVE_ADD(0, (threadIdx.x & 63) == 0 ? 1 : 0);
     KNN_STAT_WAVE_MAX(1, best.cnt);
@@ -985,8 +1009,10 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
         ly2[d] = l * l;
         lz2[d] = m * m;
     }
-    const int row0 = g.nx * (cy + g.ny * cz), sy = g.nx, sz = g.nx * g.ny;
-    const int xlo0 = max(cx - R, 0), xhi0 = min(cx + R, g.nx - 1);
+    const int kx = M.kx, nxf = g.nx * kx;
+    const T inv_hx = g.inv_h * (T)kx;
+    const int row0 = nxf * (cy + g.ny * cz), sy = nxf, sz = nxf * g.ny;
+    const int xlo0 = max(cx - R, 0) * kx, xhi0 = min(cx + R, g.nx - 1) * kx + kx - 1;
     const T bound = best.d2;
     int nr = 0;
     // two groups of rows: all look-ups of a group are in flight together, and only half of them are live
@@ -1002,11 +1028,11 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
             const int dy = tt % W, dz = tt / W;
             const T lb2 = ly2[dy] + lz2[dz];
             const T rad = fast_sqrt(fmax(bound - lb2, (T)0)) * (T)1.000001 + g.margin;
-            const int xlo = max(xlo0, clamp_cell<T>(ux - rad, g.inv_h, g.nx)), xhi = min(xhi0, clamp_cell<T>(ux + rad, g.inv_h, g.nx));
+            const int xlo = max(xlo0, clamp_cell<T>(ux - rad, inv_hx, nxf)), xhi = min(xhi0, clamp_cell<T>(ux + rad, inv_hx, nxf));
             const bool need = live && oky[dy] && okz[dz] && !(lb2 > bound) && xlo <= xhi;
             const int row = row0 + (dy - R) * sy + (dz - R) * sz;
-            ra[u] = as_global(M.cell_start)[need ? row + xlo : 0];
-            rb[u] = as_global(M.cell_start)[need ? row + xhi + 1 : 0];
+            ra[u] = as_global(M.cell_start_f)[need ? row + xlo : 0];
+            rb[u] = as_global(M.cell_start_f)[need ? row + xhi + 1 : 0];
         }
 #pragma unroll
         for (int u = 0; u < H; ++u)
@@ -2060,24 +2086,27 @@ void launch_centroid_bbox_batch(hipStream_t st, const BuildDesc<T> *descs, int n
 
 // descs: device array; totals over the batch: points, cells (incl. one sentinel slot per cloud), super-cells
 template <typename T>
-void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_c, long long tot_s,
-                             int max_m, int max_cells, int max_nsc, int *cell_of, int *counts, int *block_sums, int *cell_start,
-                             int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
+void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_f, long long tot_s,
+                             int max_m, int max_cells, int max_cells_f, int max_nsc, int *cell_of, int *counts, int *block_sums,
+                             int *cell_start, int *cell_start_f, int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
                              int *slot_of, int *sc_count, int *near, int *sc_dist)
 {
-    (void)hipMemsetAsync(counts, 0, sizeof(int) * tot_c, st);
+    (void)hipMemsetAsync(counts, 0, sizeof(int) * tot_f, st);
     (void)hipMemsetAsync(sc_count, 0, sizeof(int) * tot_s, st);
     hipLaunchKernelGGL(k_cell_count_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, cell_of, counts, sc_count, slot_of);
-    const int nb = cdiv(tot_c, kScanChunk);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_c, block_sums);
+    const int nb = cdiv(tot_f, kScanChunk);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_f, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_c, (const int *)block_sums,
-                       cell_start, cursor);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_f, (const int *)block_sums,
+                       cell_start_f, cursor);
     hipLaunchKernelGGL(k_scatter_idx, dim3(cdiv(tot_m, 256)), dim3(256), 0, st, (int)tot_m, (const int *)cell_of,
-                       (const int *)cell_start, (const int *)slot_of, order_tmp);
+                       (const int *)cell_start_f, (const int *)slot_of, order_tmp);
     hipLaunchKernelGGL(k_rank_place_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, (const int *)cell_of,
-                       (const int *)cell_start, (const int *)order_tmp, pts, nrm_out, slot_of);
-    hipLaunchKernelGGL(k_localise_b<T>, dim3(cdiv(max_cells + 1, 256), n), dim3(256), 0, st, descs, cell_start);
+                       (const int *)cell_start_f, (const int *)order_tmp, pts, nrm_out, slot_of);
+    hipLaunchKernelGGL(k_localise_b<T>, dim3(cdiv(max_cells_f + 1, 256), n), dim3(256), 0, st, descs, cell_start_f);
+    if (cell_start != cell_start_f)
+        hipLaunchKernelGGL(k_coarse_table_b<T>, dim3(cdiv(max_cells + 1, 256), n), dim3(256), 0, st, descs, (const int *)cell_start_f,
+                           cell_start);
     for (int pass = 0; pass < 3; pass++)
         hipLaunchKernelGGL(k_near_b<T>, dim3(cdiv(max_cells, 256), n), dim3(256), 0, st, descs, pass, (const int *)cell_start, counts,
                            cursor, near);
@@ -2248,7 +2277,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
 #define INSTANTIATE(T)                                                                                                   \
     template void launch_centroid_bbox_batch<T>(hipStream_t, const BuildDesc<T> *, int, int, unsigned long long *);       \
     template void launch_grid_build_batch<T>(hipStream_t, const BuildDesc<T> *, int, long long, long long, long long, int, \
-                                             int, int, int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,      \
+                                             int, int, int, int *, int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,      \
                                              typename Vec4<T>::type *, int *, int *, int *, int *);                       \
     template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *,         \
                                        unsigned long long *, int *, int *, int *, int *, int *, int, int, int, int);      \

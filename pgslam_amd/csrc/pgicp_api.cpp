@@ -50,6 +50,8 @@ struct MapHost {
     typename Vec4<T>::type *pts = nullptr;
     typename Vec4<T>::type *nrm = nullptr;
     int *cell_start = nullptr;
+    int *cell_start_f = nullptr;
+    int kx = 1;
     int *slot_of = nullptr;
     int *sc_count = nullptr;
     int *near = nullptr;
@@ -92,6 +94,7 @@ struct pgicp_ctx {
     std::multimap<size_t, char *> block_pool;
     size_t pooled_bytes = 0;
     int fast_rings_seeded = 1, fast_rings_unseeded = 3;
+    int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
@@ -239,6 +242,7 @@ int sync_maps_table(pgicp_ctx *c)
     for (int i = 0; i < n; i++) {
         const MapHost<T> &m = S.maps[i];
         h[i].pts = m.pts; h[i].nrm = m.nrm; h[i].cell_start = m.cell_start; h[i].g = m.g; h[i].m = m.used ? m.m : 0;
+        h[i].cell_start_f = m.cell_start_f; h[i].kx = m.kx;
         h[i].sc_count = m.sc_count;
         h[i].slot_of = m.slot_of;
         h[i].near = m.near;
@@ -346,8 +350,9 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
 
     // ---- phase 2: grids; every cloud gets its slice of ONE allocation and ONE set of build launches ----
     std::vector<MapHost<T>> Ms(n);
-    long long tot_m = 0, tot_c = 0, tot_s = 0;
-    int max_cells = 0, max_nsc = 0;
+    long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0;
+    int max_cells = 0, max_nsc = 0, max_cells_f = 0;
+    const int kx = std::max(1, std::min(8, c->grid_kx));
     bool any_nrm = false;
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
@@ -391,15 +396,18 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         for (int a = 0; a < 3; a++) d.mean[a] = M.mean[a];
         d.ncells = g.nx * g.ny * g.nz;
         d.nsc = ((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
-        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s;
+        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s; d.fbase = tot_f;
+        d.kx = kx; d.ncells_f = d.ncells * kx;
+        M.kx = kx;
         // a first candidate farther than a fraction of maxDist prunes little: do not look for one beyond that
         const double reach_len = std::isfinite(c->prm.max_dist) ? c->near_frac * c->prm.max_dist : 1e30;
         d.near_reach = (int)std::min((double)kNearReach, std::max(2.0, std::ceil(reach_len / (double)g.h)));
-        tot_m += m; tot_c += (long long)d.ncells + 1; tot_s += d.nsc;
+        tot_m += m; tot_c += (long long)d.ncells + 1; tot_s += d.nsc; tot_f += (long long)d.ncells_f + 1;
         max_cells = std::max(max_cells, d.ncells);
+        max_cells_f = std::max(max_cells_f, d.ncells_f);
         max_nsc = std::max(max_nsc, d.nsc);
     }
-    if (tot_m > 0x7FFFFFF0LL || tot_c > 0x7FFFFFF0LL) {
+    if (tot_m > 0x7FFFFFF0LL || tot_f > 0x7FFFFFF0LL) {
         // the concatenated index space must fit an int: build the clouds of an oversized batch one by one
         if (n == 1) return fail(c, PGICP_ERR_ARG, "pgicp_map_create: cloud too large");
         for (int k = 0; k < n; k++) {
@@ -409,20 +417,22 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         return PGICP_OK;
     }
     HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)tot_m));                               // cell_of
-    HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)tot_c));                               // counts, then sweep scratch
-    HIPC(c, c->tmp_c.ensure(sizeof(int) * ((size_t)tot_c / kScanChunkHost + 2)));        // block sums
-    HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)tot_c));                               // cursor, then sweep scratch
+    HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)tot_f));                               // counts (fine cells), then sweep scratch
+    HIPC(c, c->tmp_c.ensure(sizeof(int) * ((size_t)tot_f / kScanChunkHost + 2)));        // block sums
+    HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)tot_f));                               // cursor, then sweep scratch
     HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)tot_m));                               // order_tmp
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
-                 b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c);
+                 b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c),
+                 b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0;
     auto blk = std::make_shared<SharedBlock>();
-    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near, &blk->p, &blk->bytes); if (ast) return ast; }
+    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near + b_csf, &blk->p, &blk->bytes); if (ast) return ast; }
     char *base = blk->p;
     V4 *g_pts = (V4 *)base, *g_nrm = any_nrm ? (V4 *)(base + b_pts) : nullptr;
     int *g_cs = (int *)(base + b_pts + b_nrm), *g_slot = (int *)(base + b_pts + b_nrm + b_cs),
         *g_sc = (int *)(base + b_pts + b_nrm + b_cs + b_slot), *g_near = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc),
-        *g_scd = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc + b_near);
+        *g_scd = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc + b_near),
+        *g_csf = kx > 1 ? (int *)(base + b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near) : g_cs;
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
         const BuildDesc<T> &d = descs[k];
@@ -430,6 +440,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         M.pts = g_pts + d.pbase;
         M.nrm = M.has_nrm ? g_nrm + d.pbase : nullptr;
         M.cell_start = g_cs + d.cbase;
+        M.cell_start_f = g_csf + d.fbase;
         M.slot_of = g_slot + d.pbase;
         M.sc_count = g_sc + d.sbase;
         M.near = g_near + d.cbase;
@@ -438,8 +449,8 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
-        launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_c, tot_s, max_m, max_cells, max_nsc, c->tmp_a.as<int>(),
-                                   c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, c->tmp_d.as<int>(), c->tmp_e.as<int>(), g_pts, g_nrm,
+        launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_f, tot_s, max_m, max_cells, max_cells_f, max_nsc, c->tmp_a.as<int>(),
+                                   c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), g_pts, g_nrm,
                                    g_slot, g_sc, g_near, g_scd);
     }
     HIPC(c, hipStreamSynchronize(c->stream));          // `descs` (host) feeds an async copy
@@ -1164,6 +1175,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     c->device = device;
     pgicp_default_params(&c->prm);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_SEEDED")) c->fast_rings_seeded = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PGICP_KX")) c->grid_kx = std::atoi(e);
     if (const char *e = std::getenv("PGICP_NEAR_FRAC")) c->near_frac = std::atof(e);
     if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
