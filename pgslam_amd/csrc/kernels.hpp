@@ -33,9 +33,10 @@ void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, c
                      const ChainDev<T> &ch, const int *slow_count, const int2 *slow_list, const T *slow_lb,
                      const int *slow2_idx, int exact_all, T *none_r);
 template <typename T>
-void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int second,
-                        const int *active);
-int knn_stats_read(unsigned long long out[48], int reset);
+void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int max_n, int second,
+                        const int *active, int *tables, void *keys);
+size_t trim_select_table_bytes(int P);
+int knn_stats_read(unsigned long long out[56], int reset);
 int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
 void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active);
 template <typename T>

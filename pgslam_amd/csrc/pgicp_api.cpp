@@ -87,7 +87,7 @@ struct pgicp_ctx {
     State<float> f32;
     State<double> f64;
     DevBuf probs, src, partials, sums, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
-    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active;
+    DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active, sel_tables;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     // Freed map blocks are kept for reuse: hipFree synchronises the device, and loop closing creates
     // and destroys one index per candidate pair.
@@ -547,6 +547,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     HIPC(c, c->partials.ensure(sizeof(double) * (size_t)P * reduce_blocks(L.max_n) * kCovTerms));
     HIPC(c, c->sums.ensure(sizeof(double) * (size_t)P * kCovTerms));
     HIPC(c, c->small.ensure(256));
+    HIPC(c, c->sel_tables.ensure(trim_select_table_bytes(P)));
     if (stage_total) HIPC(c, S.staging.ensure(stage_total));
 
     hp.assign(P, ProblemDev());
@@ -574,6 +575,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     std::iota(ident.begin(), ident.end(), 0);
     HIPC(c, hipMemcpyAsync(c->active.p, ident.data(), sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
+    HIPC(c, hipMemsetAsync(c->sel_tables.p, 0, trim_select_table_bytes(P), c->stream));
     {
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
         launch_pretransform<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.rd_pre.template as<T>(), P, L.max_n);
@@ -612,7 +614,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
     }
     {
         ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, 0, active);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 0, active, c->sel_tables.as<int>(), c->qtmp.p);
     }
     if (c->prm.matcher == PGICP_MATCHER_GRID) {
         // lazy resolution: only queued queries whose lower bound is within the threshold just
@@ -628,7 +630,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
                                c->slow2.as<int>(), 0, S.none_r.template as<T>());
         }
         ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, 1, active);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 1, active, c->sel_tables.as<int>(), c->qtmp.p);
     }
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
@@ -1202,7 +1204,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
-                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->f32.none_r, &c->f64.none_r})
+                      &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->sel_tables, &c->f32.none_r, &c->f64.none_r})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1414,13 +1416,14 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
     if (!c || !out) return PGICP_ERR_ARG;
     HIPC(c, hipMemcpy(out, c->small.as<int>() + 16, 4 * sizeof(int), hipMemcpyDeviceToHost));
     if (std::getenv("PGICP_KNN_STATS_DUMP")) {          // diagnostics build only
-        unsigned long long s[48];
+        unsigned long long s[56];
         (void)hipDeviceSynchronize();
         if (knn_stats_read(s, 1) == 0) {
             std::fprintf(stderr, "knn_stats waves=%llu a1_max=%llu a1_sum=%llu flat_iters_max=%llu a2_sum=%llu b_cand=%llu unresolved=%llu b_lanes=%llu b_max=%llu tot_max=%llu\n",
                          s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9]);
             std::fprintf(stderr, "  slow: entries=%llu cycles_sum=%llu cycles_max=%llu (worst: supercells=%llu rows=%llu trips=%llu exist_only=%llu found=%llu) trips_sum=%llu\n",
                          s[10], s[11], s[12], s[13] >> 40, (s[13] >> 20) & 0xFFFFF, s[13] & 0xFFFFF, s[14] >> 32, s[14] & 1, s[15]);
+            std::fprintf(stderr, "  med: searched=%llu existence_unknown=%llu resolved=%llu candidates=%llu; wave ticks(100MHz) max=%llu sum=%llu waves=%llu\n", s[44], s[45], s[46], s[47], s[48], s[49], s[50]);
             std::fprintf(stderr, "  own-row hist (0,1,2-3,4-7,...):");
             for (int i = 0; i < 12; i++) std::fprintf(stderr, " %llu", s[16 + i]);
             std::fprintf(stderr, "\n  flat hist:");

@@ -5,7 +5,7 @@ import numpy as np, torch
 from bench import build_drive, CHAIN
 from pgslam_amd import icp
 from pgslam_amd.local_mapper import Keyframe, LocalMapperConfig, StreamingLocalMapper
-cap, stride, nscan = 20, 3, 8
+cap, stride, nscan = 20, 3, int(os.environ.get("NSCAN", "8"))
 n_total = (cap - 1) * stride + nscan
 poses, odom, xyz, nrm = build_drive((cap - 1) * stride + 41, 100000, 0.35)
 dev = torch.device('cuda', 0)
