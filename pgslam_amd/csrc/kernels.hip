@@ -1216,6 +1216,15 @@ __global__ __launch_bounds__(64) void k_knn_med(ProblemDev *__restrict__ probs, 
 // whole wave, one lane per (y,z) row of it.  Empty space costs one table look-up
 // per super-cell, so proving "nothing within maxDist" stays cheap.  A
 // lexicographic (d2, index) wave reduction picks the winner.
+#ifndef PGICP_SLOW_PRIVATE
+#define PGICP_SLOW_PRIVATE 4
+#endif
+#ifndef PGICP_SLOW_GROUP
+#define PGICP_SLOW_GROUP 1
+#endif
+constexpr int kSlowPrivate = PGICP_SLOW_PRIVATE;   // rows of at most this many points are scanned by their own lane
+constexpr int kSlowGroup = PGICP_SLOW_GROUP;       // surviving super-cells looked up together
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs, const MapDev<T> *__restrict__ maps,
                                                    const T *__restrict__ rd, int *__restrict__ slot_io,
@@ -1290,54 +1299,90 @@ __global__ __launch_bounds__(256) void k_knn_slow(ProblemDev *__restrict__ probs
                 }
                 unsigned long long mask = __ballot(need);
                 while (mask) {
-                    const int src = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const int SX = __shfl(X, src, 64), SY = __shfl(Y, src, 64), SZ = __shfl(Z, src, 64);
-                    // lane r looks up row r of the super-cell (bound, x-range, point range) ...
-                    const int y = 8 * SY + (lane & 7), z = 8 * SZ + (lane >> 3);
-                    int ra = 0, rb = 0;
-                    T rlb = (T)0;
-                    if (y < g.ny && z < g.nz) {
-                        const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
-                        const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
-                        const T lb2 = ly * ly + lz * lz;
-                        if (!(lb2 > best.d2)) {
-                            int xa = 8 * SX, xb = min(8 * SX + 7, g.nx - 1);
-                            if (best.d2 < Bits<T>::inf()) {
-                                const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + g.margin;
-                                xa = max(xa, clamp_cell<T>(ux - rad, g.inv_h, g.nx));
-                                xb = min(xb, clamp_cell<T>(ux + rad, g.inv_h, g.nx));
-                            }
-                            if (xa <= xb) {
-                                const int row = g.nx * (y + g.ny * z);
-                                ra = as_global(M.cell_start)[row + xa];
-                                rb = as_global(M.cell_start)[row + xb + 1];
-                                rlb = lb2;
+                    // lane r looks up row r of the super-cell (bound, x-range on the fine table, point range);
+                    // kSlowGroup super-cells per trip (looking two up together measured no gain)
+                    int srcs[kSlowGroup];
+#pragma unroll
+                    for (int u = 0; u < kSlowGroup; ++u) {
+                        srcs[u] = -1;
+                        if (mask) { srcs[u] = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+                    }
+                    int ra[kSlowGroup], rb[kSlowGroup];
+                    T rlb[kSlowGroup];
+#pragma unroll
+                    for (int u = 0; u < kSlowGroup; ++u) { ra[u] = 0; rb[u] = 0; rlb[u] = (T)0; }
+#pragma unroll
+                    for (int u = 0; u < kSlowGroup; ++u) {
+                        if (srcs[u] < 0) continue;                         // wave-uniform
+                        const int SX = __shfl(X, srcs[u], 64), SY = __shfl(Y, srcs[u], 64), SZ = __shfl(Z, srcs[u], 64);
+                        const int y = 8 * SY + (lane & 7), z = 8 * SZ + (lane >> 3);
+                        if (y < g.ny && z < g.nz) {
+                            const T ly = fmax(slab_dist(uy, y, g.h) - g.margin, (T)0);
+                            const T lz = fmax(slab_dist(uz, z, g.h) - g.margin, (T)0);
+                            const T lb2 = ly * ly + lz * lz;
+                            if (!(lb2 > best.d2)) {
+                                const int kx = M.kx, nxf = g.nx * kx;
+                                int fa = 8 * SX * kx, fb = min(8 * SX + 7, g.nx - 1) * kx + kx - 1;
+                                if (best.d2 < Bits<T>::inf()) {
+                                    const T rad = sqrt(fmax(best.d2 - lb2, (T)0)) + g.margin;
+                                    const T inv_hx = g.inv_h * (T)kx;
+                                    fa = max(fa, clamp_cell<T>(ux - rad, inv_hx, nxf));
+                                    fb = min(fb, clamp_cell<T>(ux + rad, inv_hx, nxf));
+                                }
+                                if (fa <= fb) {
+                                    const int row = nxf * (y + g.ny * z);
+                                    ra[u] = as_global(M.cell_start_f)[row + fa];
+                                    rb[u] = as_global(M.cell_start_f)[row + fb + 1];
+                                    rlb[u] = lb2;
+                                }
                             }
                         }
                     }
-                    // ... then the WHOLE wave scans each non-empty row, 64 consecutive points per trip: the
-                    // rows of a dense super-cell hold thousands of points in a few rows (ground near the
-                    // sensor), which one lane per row would walk serially
-                    unsigned long long rows = __ballot(ra < rb);
 #ifdef PGICP_KNN_STATS
-                    st_sc++; st_rows += __popcll(rows);
+                    for (int u = 0; u < kSlowGroup; ++u) { st_sc += srcs[u] >= 0 ? 1 : 0; st_rows += __popcll(__ballot(ra[u] < rb[u])); }
 #endif
-                    while (rows) {
-                        const int r = __ffsll((long long)rows) - 1;
-                        rows &= rows - 1;
-                        const int pa = __shfl(ra, r, 64), pb = __shfl(rb, r, 64);
-                        const T l2 = __shfl(rlb, r, 64);
-                        if (l2 > best.d2) continue;                     // best.d2 is wave-uniform here
-                        for (int s = pa + lane; s < pb; s += 64) eval_point<T>(load_rec<T>(M.pts, s), s, qx, qy, qz, best);
-#ifdef PGICP_KNN_STATS
-                        st_trips += (pb - pa + 63) / 64;
-#endif
-                        // share the tightest bound (pruning only; the winner is reduced at the end)
+                    // short rows (the sparse fringe of a map: a few points per row) are read by their own lane,
+                    // all lanes at once; ...
+                    if constexpr (kSlowPrivate > 0) {
+#pragma unroll
+                        for (int u = 0; u < kSlowGroup; ++u) {
+                            const int len = rb[u] - ra[u];
+                            if (len > 0 && len <= kSlowPrivate) {
+                                typename Vec4<T>::type v[kSlowPrivate > 0 ? kSlowPrivate : 1];
+#pragma unroll
+                                for (int w = 0; w < kSlowPrivate; ++w) v[w] = load_rec<T>(M.pts, ra[u] + min(w, len - 1));
+#pragma unroll
+                                for (int w = 0; w < kSlowPrivate; ++w)
+                                    if (w < len) eval_point<T>(v[w], ra[u] + w, qx, qy, qz, best);
+                            }
+                        }
                         T wmin = best.d2;
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) wmin = fmin(wmin, __shfl_xor(wmin, o, 64));
                         if (wmin < best.d2) { best.d2 = wmin; best.idx = 0x7FFFFFFF; best.slot = -1; }
+                    }
+                    // ... long rows by the WHOLE wave, 64 consecutive points per trip: the rows of a dense
+                    // super-cell hold thousands of points in a few rows (ground near the sensor), which one
+                    // lane per row would walk serially
+#pragma unroll
+                    for (int u = 0; u < kSlowGroup; ++u) {
+                        unsigned long long rows = __ballot(rb[u] - ra[u] > kSlowPrivate);
+                        while (rows) {
+                            const int r = __ffsll((long long)rows) - 1;
+                            rows &= rows - 1;
+                            const int pa = __shfl(ra[u], r, 64), pb = __shfl(rb[u], r, 64);
+                            const T l2 = __shfl(rlb[u], r, 64);
+                            if (l2 > best.d2) continue;                     // best.d2 is wave-uniform here
+                            for (int q = pa + lane; q < pb; q += 64) eval_point<T>(load_rec<T>(M.pts, q), q, qx, qy, qz, best);
+#ifdef PGICP_KNN_STATS
+                            st_trips += (pb - pa + 63) / 64;
+#endif
+                            // share the tightest bound (pruning only; the winner is reduced at the end)
+                            T wmin = best.d2;
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) wmin = fmin(wmin, __shfl_xor(wmin, o, 64));
+                            if (wmin < best.d2) { best.d2 = wmin; best.idx = 0x7FFFFFFF; best.slot = -1; }
+                        }
                     }
                     if (exist_only && best.d2 <= ch.max_dist2) { found = true; break; }   // wave-uniform
                 }
@@ -2086,7 +2131,16 @@ __global__ __launch_bounds__(64) void k_sum_partials(const double *__restrict__ 
     }
     if ((int)threadIdx.x < nt) {
         double s = 0.0;
-        for (int b = 0; b < nb; b++) s += partials[((long long)p * max_blocks + b) * nt + threadIdx.x];
+        const double *src = partials + (long long)p * max_blocks * nt + threadIdx.x;
+        int b = 0;
+        for (; b + 8 <= nb; b += 8) {                     // eight loads in flight, added in block order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(long long)(b + u) * nt];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nb; b++) s += src[(long long)b * nt];
         out[(long long)p * nt + threadIdx.x] = s;
     }
 }
@@ -2161,7 +2215,8 @@ __global__ __launch_bounds__(256) void k_solve_update(ProblemDev *__restrict__ p
 
 // active[] = ids of the problems still iterating, followed by the finished ones (so a stale, larger
 // launch count only adds blocks that exit at once).  One block; P is at most a few thousand.
-__global__ __launch_bounds__(1024) void k_compact_active(const ProblemDev *__restrict__ probs, int P, int *__restrict__ active)
+__global__ __launch_bounds__(1024) void k_compact_active(const ProblemDev *__restrict__ probs, int P, int *__restrict__ active,
+                                                         int *host_flag, int stamp)
 {
     __shared__ int lds[32];
     __shared__ int base_live, base_done;
@@ -2190,6 +2245,11 @@ __global__ __launch_bounds__(1024) void k_compact_active(const ProblemDev *__res
         __syncthreads();
     }
     (void)n_live_total;
+    // the host polls this pair in pinned memory instead of waiting for a copy: {problems done, iteration stamp}
+    if (host_flag && threadIdx.x == 0) {
+        __hip_atomic_store(host_flag, P - n_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_flag + 1, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 int knn_trace_set(int sorted_index)
@@ -2214,9 +2274,9 @@ int knn_stats_read(unsigned long long out[56], int reset)
 #endif
 }
 
-void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active)
+void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp)
 {
-    hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, st, probs, P, active);
+    hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, st, probs, P, active, host_flag, stamp);
 }
 
 // ---------------------------------------------------------------------------

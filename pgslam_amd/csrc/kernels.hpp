@@ -38,7 +38,7 @@ void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const Ch
 size_t trim_select_table_bytes(int P);
 int knn_stats_read(unsigned long long out[56], int reset);
 int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
-void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active);
+void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp);
 template <typename T>
 int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m, int knn, T max_dist, T eps_rank, T *out_nrm,
                            int out_stride, T *out_eig, int *out_ids, T *out_d2);
