@@ -2216,8 +2216,10 @@ __global__ __launch_bounds__(256) void k_solve_update(ProblemDev *__restrict__ p
 // active[] = ids of the problems still iterating, followed by the finished ones (so a stale, larger
 // launch count only adds blocks that exit at once).  One block; P is at most a few thousand.
 __global__ __launch_bounds__(1024) void k_compact_active(const ProblemDev *__restrict__ probs, int P, int *__restrict__ active,
-                                                         int *host_flag, int stamp)
+                                                         int *host_flag, int stamp, int *__restrict__ queue_counters)
 {
+    // the matcher's queue counters are cleared here for the next iteration (their last values stay readable 8 ints on)
+    if (queue_counters && threadIdx.x < 4) { queue_counters[8 + threadIdx.x] = queue_counters[threadIdx.x]; queue_counters[threadIdx.x] = 0; }
     __shared__ int lds[32];
     __shared__ int base_live, base_done;
     if (threadIdx.x == 0) { base_live = 0; base_done = 0; }
@@ -2274,9 +2276,10 @@ int knn_stats_read(unsigned long long out[56], int reset)
 #endif
 }
 
-void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp)
+void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp,
+                           int *queue_counters)
 {
-    hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, st, probs, P, active, host_flag, stamp);
+    hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, st, probs, P, active, host_flag, stamp, queue_counters);
 }
 
 // ---------------------------------------------------------------------------
@@ -2440,15 +2443,14 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active, T *none_r)
+                int *slow_ring, int fast_rings, const int *active, T *none_r, int counters_clean)
 {
+    if (!counters_clean) (void)hipMemsetAsync(slow_count, 0, 4 * sizeof(int), st);
     if (matcher == 1) {
         hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot, d2,
                            ch, active);
-        (void)hipMemsetAsync(slow_count, 0, 4 * sizeof(int), st);
         return;
     }
-    (void)hipMemsetAsync(slow_count, 0, 4 * sizeof(int), st);
     // R = 1 in both cases: measured, a 5x5x5 collected block on the unseeded first iteration costs
     // 2.5x the ring-by-ring continuation (nothing prunes it until the own row has a hit)
     hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, kFastBlock)), P), dim3(kFastBlock), 0, st, probs, maps, rd, slot, d2, ch,
@@ -2574,7 +2576,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
-                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *, T *);    \
+                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *, T *, int); \
     template void launch_knn_med<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                  \
                                     const ChainDev<T> &, int *, const int2 *, T *, int *, int *, int, int, T *);          \
     template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \

@@ -23,7 +23,7 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active, T *none_r);
+                int *slow_ring, int fast_rings, const int *active, T *none_r, int counters_clean);
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
                     const ChainDev<T> &ch, int *slow_count, const int2 *slow_list, T *slow_lb, int *slow_ring, int *slow2_idx,
@@ -38,7 +38,8 @@ void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const Ch
 size_t trim_select_table_bytes(int P);
 int knn_stats_read(unsigned long long out[56], int reset);
 int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
-void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp);
+void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp,
+                           int *queue_counters);
 template <typename T>
 int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m, int knn, T max_dist, T eps_rank, T *out_nrm,
                            int out_stride, T *out_eig, int *out_ids, T *out_d2);

@@ -93,7 +93,8 @@ struct pgicp_ctx {
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     int *h_flag = nullptr;          // coherent pinned pair {problems done, stamp} the last kernel of an iteration writes
     int flag_stamp = 0;
-    int poll_us = 2000;             // how long the host polls h_flag before it blocks on the stream instead
+    int counters_clean = 0;         // the matcher's queue counters were zeroed by the last kernel of the previous iteration
+    int poll_us = 400;              // how long the host polls h_flag before it blocks on the stream instead
     // Freed map blocks are kept for reuse: hipFree synchronises the device, and loop closing creates
     // and destroys one index per candidate pair.
     std::multimap<size_t, char *> block_pool;
@@ -580,6 +581,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     std::iota(ident.begin(), ident.end(), 0);
     HIPC(c, hipMemcpyAsync(c->active.p, ident.data(), sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
+    c->counters_clean = 1;
     HIPC(c, hipMemsetAsync(c->sel_tables.p, 0, trim_select_table_bytes(P), c->stream));
     {
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
@@ -615,7 +617,9 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
-                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active, S.none_r.template as<T>());
+                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active, S.none_r.template as<T>(),
+                      c->counters_clean);
+        c->counters_clean = 0;
     }
     {
         ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
@@ -645,7 +649,8 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
     if (with_solve) {
         ProfScope ps(c, PGICP_PROF_SOLVE, act_units, act_probs);
         launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), nA, L.max_n, active);
-        launch_compact_active(c->stream, probs, L.P, c->active.as<int>(), c->h_flag, ++c->flag_stamp);
+        launch_compact_active(c->stream, probs, L.P, c->active.as<int>(), c->h_flag, ++c->flag_stamp, c->small.as<int>() + 16);
+        c->counters_clean = 1;
     }
 }
 
@@ -806,7 +811,7 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>());
+                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 0);
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
@@ -1443,7 +1448,7 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
 int pgicp_debug_counters(pgicp_ctx *c, int out[4])
 {
     if (!c || !out) return PGICP_ERR_ARG;
-    HIPC(c, hipMemcpy(out, c->small.as<int>() + 16, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPC(c, hipMemcpy(out, c->small.as<int>() + (c->counters_clean ? 24 : 16), 4 * sizeof(int), hipMemcpyDeviceToHost));
     if (std::getenv("PGICP_KNN_STATS_DUMP")) {          // diagnostics build only
         unsigned long long s[56];
         (void)hipDeviceSynchronize();
