@@ -34,7 +34,7 @@ struct MapDev {
     const int *sc_count;                 // occupancy flag per 8x8x8 super-cell
     const int *sc_dist;                  // Chebyshev distance (in super-cells, capped at kScReach + 1) to the nearest occupied one
     const int *slot_of;                  // original index -> position in pts / nrm
-    const int *near;                     // per cell: a nearby occupied cell (itself when occupied), -1 if none within kNearReach
+    const int *near;                     // per 2x2x2 block of cells: a nearby occupied cell, -1 if none within kNearReach
     GridDesc<T> g;
     int m;
     int nsx, nsy, nsz;                   // super-cell grid dims

@@ -370,55 +370,80 @@ __global__ __launch_bounds__(256) void k_coarse_table_b(const BuildDesc<T> *__re
     cell_start[d.cbase + c] = cell_start_f[d.fbase + f];
 }
 
-// MapDev::near -- for every cell a nearby OCCUPIED cell (three separable sweeps: nearest occupied cell of
-// the row (pass 0), then the best of the neighbouring rows' answers in y (pass 1), then in z (pass 2)).  A
-// heuristic, not a nearest-cell guarantee: the matcher only uses it to give a query that starts in empty
-// space a first candidate, so that its exact ring search prunes from the first row on.
+// MapDev::near -- for every 2x2x2 BLOCK of cells a nearby OCCUPIED cell.  Pass -1 picks an occupied cell of
+// the block itself; three separable sweeps over blocks follow (nearest answer along x, then the best of the
+// neighbouring answers in y, then in z).  Answers travel as 6-bit cell offsets from the block's first cell.
+// A heuristic, not a nearest-cell guarantee: the matcher only uses it to give a query that starts in empty
+// space a first candidate, so that its exact ring search prunes from the first row on.  (Per cell this table
+// cost three sweeps over a grid that is 99 % empty: 1.7 ms of a 4.2 ms map build.)
+__device__ __forceinline__ int near_pack(int dx, int dy, int dz) { return (dx + 32) | ((dy + 32) << 6) | ((dz + 32) << 12); }
+__device__ __forceinline__ int near_dist(int v, int ax, int ay, int az)
+{
+    // squared distance (in half cells) from the block's centre to the centre of the cell at offset v + (ax, ay, az)
+    const int dx = 2 * ((v & 63) - 32 + ax) - 1, dy = 2 * (((v >> 6) & 63) - 32 + ay) - 1, dz = 2 * (((v >> 12) & 63) - 32 + az) - 1;
+    return dx * dx + dy * dy + dz * dz;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_near_b(const BuildDesc<T> *__restrict__ descs, int pass, const int *__restrict__ cell_start,
                                                  int *__restrict__ tmp_a, int *__restrict__ tmp_b, int *__restrict__ near)
 {
     const BuildDesc<T> &d = descs[blockIdx.y];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;         // ncells <= 2^26: 32-bit index arithmetic
-    if (c >= d.ncells) return;
     const int nx = d.g.nx, ny = d.g.ny, nz = d.g.nz;
-    const int reach = d.near_reach < 1 ? 1 : (d.near_reach > kNearReach ? kNearReach : d.near_reach);
-    const int row = c / nx;
-    const int x = c - row * nx, z = row / ny, y = row - z * ny;
-    if (pass == 0) {
+    const int nbx = (nx + 1) >> 1, nby = (ny + 1) >> 1, nbz = (nz + 1) >> 1;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;         // blocks <= cells <= 2^26: 32-bit index arithmetic
+    if (b >= nbx * nby * nbz) return;
+    const int reach_c = d.near_reach < 1 ? 1 : (d.near_reach > kNearReach ? kNearReach : d.near_reach);
+    const int reach = (reach_c + 1) >> 1;                        // in blocks
+    const int brow = b / nbx;
+    const int bx = b - brow * nbx, bz = brow / nby, by = brow - bz * nby;
+    if (pass < 0) {
         const int *cs = cell_start + d.cbase;
         int found = -1;
+        for (int k = 0; k < 2 && found < 0; ++k)
+            for (int j = 0; j < 2 && found < 0; ++j) {
+                const int y = 2 * by + j, z = 2 * bz + k;
+                if (y >= ny || z >= nz) continue;
+                const int c0 = 2 * bx + nx * (y + ny * z);
+                const int s0 = cs[c0], s1 = cs[c0 + 1];
+                if (s1 > s0) found = near_pack(0, j, k);
+                else if (2 * bx + 1 < nx && cs[c0 + 2] > s1) found = near_pack(1, j, k);
+            }
+        near[d.cbase + b] = found;                                // (sweep input; overwritten by the last pass)
+    } else if (pass == 0) {
+        const int *in = near + d.cbase;
+        int found = -1;
         for (int t = 0; t <= reach && found < 0; ++t) {
-            if (x - t >= 0 && cs[c - t + 1] > cs[c - t]) found = x - t;
-            else if (x + t < nx && cs[c + t + 1] > cs[c + t]) found = x + t;
+            if (bx - t >= 0 && in[b - t] >= 0) found = in[b - t] - 2 * t;             // the x offset sits in the low bits
+            else if (bx + t < nbx && in[b + t] >= 0) found = in[b + t] + 2 * t;
         }
-        tmp_a[d.cbase + c] = found;
+        tmp_a[d.cbase + b] = found;
     } else if (pass == 1) {
         const int *in = tmp_a + d.cbase;
         int best = -1, bd = 0x7FFFFFFF;
         for (int t = -reach; t <= reach; ++t) {
-            const int yy = y + t;
-            if (yy < 0 || yy >= ny) continue;
-            const int xx = in[c + t * nx];
-            if (xx < 0) continue;
-            const int dist = (xx - x) * (xx - x) + t * t;
-            if (dist < bd) { bd = dist; best = xx | (yy << 16); }
+            if (by + t < 0 || by + t >= nby) continue;
+            const int v = in[b + t * nbx];
+            if (v < 0) continue;
+            const int dist = near_dist(v, 0, 2 * t, 0);
+            if (dist < bd) { bd = dist; best = v + 2 * t * 64; }
         }
-        tmp_b[d.cbase + c] = best;
+        tmp_b[d.cbase + b] = best;
     } else {
         const int *in = tmp_b + d.cbase;
-        const int plane = nx * ny;
+        const int plane = nbx * nby;
         int best = -1, bd = 0x7FFFFFFF;
         for (int t = -reach; t <= reach; ++t) {
-            const int zz = z + t;
-            if (zz < 0 || zz >= nz) continue;
-            const int v = in[c + t * plane];
+            if (bz + t < 0 || bz + t >= nbz) continue;
+            const int v = in[b + t * plane];
             if (v < 0) continue;
-            const int xx = v & 0xFFFF, yy = v >> 16;
-            const int dist = (xx - x) * (xx - x) + (yy - y) * (yy - y) + t * t;
-            if (dist < bd) { bd = dist; best = xx + nx * (yy + ny * zz); }
+            const int dist = near_dist(v, 0, 0, 2 * t);
+            if (dist < bd) { bd = dist; best = v + 2 * t * 4096; }
         }
-        near[d.cbase + c] = best;
+        int out = -1;
+        if (best >= 0)
+            out = (2 * bx + (best & 63) - 32) + nx * ((2 * by + ((best >> 6) & 63) - 32) + ny * (2 * bz + ((best >> 12) & 63) - 32));
+        near[d.cbase + b] = out;
     }
 }
 
@@ -971,7 +996,7 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
     // against a finite bound and "a neighbour exists within maxDist" is settled by a real candidate
     if (live && seed.slot < 0) {
         const int c = cx + g.nx * (cy + g.ny * cz);
-        const int nc = as_global(M.near)[c];
+        const int nc = as_global(M.near)[(cx >> 1) + ((g.nx + 1) >> 1) * ((cy >> 1) + ((g.ny + 1) >> 1) * (cz >> 1))];
         // (the own cell is scanned by phase A.1 anyway -- but under the cap, which hides what lies beyond it)
         if (nc >= 0 && (nc != c || capped)) {
             Best<T> ns;
@@ -2370,7 +2395,7 @@ void launch_centroid_bbox_batch(hipStream_t st, const BuildDesc<T> *descs, int n
 // descs: device array; totals over the batch: points, cells (incl. one sentinel slot per cloud), super-cells
 template <typename T>
 void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_f, long long tot_s,
-                             int max_m, int max_cells, int max_cells_f, int max_nsc, int *cell_of, int *counts, int *block_sums,
+                             int max_m, int max_cells, int max_cells_f, int max_nsc, int max_blocks, int *cell_of, int *counts, int *block_sums,
                              int *cell_start, int *cell_start_f, int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
                              int *slot_of, int *sc_count, int *near, int *sc_dist)
 {
@@ -2390,8 +2415,8 @@ void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, l
     if (cell_start != cell_start_f)
         hipLaunchKernelGGL(k_coarse_table_b<T>, dim3(cdiv(max_cells + 1, 256), n), dim3(256), 0, st, descs, (const int *)cell_start_f,
                            cell_start);
-    for (int pass = 0; pass < 3; pass++)
-        hipLaunchKernelGGL(k_near_b<T>, dim3(cdiv(max_cells, 256), n), dim3(256), 0, st, descs, pass, (const int *)cell_start, counts,
+    for (int pass = -1; pass < 3; pass++)
+        hipLaunchKernelGGL(k_near_b<T>, dim3(cdiv(max_blocks, 256), n), dim3(256), 0, st, descs, pass, (const int *)cell_start, counts,
                            cursor, near);
     if (max_nsc <= 4096) {
         hipLaunchKernelGGL(k_scdist_b<T>, dim3(n), dim3(1024), 0, st, descs, (const int *)sc_count, counts, cursor, sc_dist);
@@ -2569,7 +2594,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
 #define INSTANTIATE(T)                                                                                                   \
     template void launch_centroid_bbox_batch<T>(hipStream_t, const BuildDesc<T> *, int, int, unsigned long long *);       \
     template void launch_grid_build_batch<T>(hipStream_t, const BuildDesc<T> *, int, long long, long long, long long, int, \
-                                             int, int, int, int *, int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,      \
+                                             int, int, int, int, int *, int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,      \
                                              typename Vec4<T>::type *, int *, int *, int *, int *);                       \
     template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *,         \
                                        unsigned long long *, int *, int *, int *, int *, int *, int, int, int, int);      \

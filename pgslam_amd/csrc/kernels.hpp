@@ -8,7 +8,7 @@ template <typename T>
 void launch_centroid_bbox_batch(hipStream_t st, const BuildDesc<T> *descs, int n, int max_m, unsigned long long *stats);
 template <typename T>
 void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_f, long long tot_s,
-                             int max_m, int max_cells, int max_cells_f, int max_nsc, int *cell_of, int *counts, int *block_sums,
+                             int max_m, int max_cells, int max_cells_f, int max_nsc, int max_blocks, int *cell_of, int *counts, int *block_sums,
                              int *cell_start, int *cell_start_f, int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
                              int *slot_of, int *sc_count, int *near, int *sc_dist);
 template <typename T>

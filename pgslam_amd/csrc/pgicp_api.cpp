@@ -357,7 +357,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     // ---- phase 2: grids; every cloud gets its slice of ONE allocation and ONE set of build launches ----
     std::vector<MapHost<T>> Ms(n);
     long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0;
-    int max_cells = 0, max_nsc = 0, max_cells_f = 0;
+    int max_cells = 0, max_nsc = 0, max_cells_f = 0, max_blocks = 0;
     const int kx = std::max(1, std::min(8, c->grid_kx));
     bool any_nrm = false;
     for (int k = 0; k < n; k++) {
@@ -412,6 +412,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         max_cells = std::max(max_cells, d.ncells);
         max_cells_f = std::max(max_cells_f, d.ncells_f);
         max_nsc = std::max(max_nsc, d.nsc);
+        max_blocks = std::max(max_blocks, ((g.nx + 1) >> 1) * ((g.ny + 1) >> 1) * ((g.nz + 1) >> 1));
     }
     if (tot_m > 0x7FFFFFF0LL || tot_f > 0x7FFFFFF0LL) {
         // the concatenated index space must fit an int: build the clouds of an oversized batch one by one
@@ -455,7 +456,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
-        launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_f, tot_s, max_m, max_cells, max_cells_f, max_nsc, c->tmp_a.as<int>(),
+        launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_f, tot_s, max_m, max_cells, max_cells_f, max_nsc, max_blocks, c->tmp_a.as<int>(),
                                    c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), g_pts, g_nrm,
                                    g_slot, g_sc, g_near, g_scd);
     }
