@@ -225,7 +225,7 @@ __global__ __launch_bounds__(1024) void k_scan_final(const int *__restrict__ in,
     int ex = block_exclusive_scan_1024(s, lds, total) + block_offs[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (base + k < n) { out[base + k] = ex; cursor[base + k] = ex; }
+        if (base + k < n) { out[base + k] = ex; if (cursor) cursor[base + k] = ex; }
         ex += v[k];
     }
     if (base <= n - 1 && n - 1 < base + 4) out[n] = ex;    // the thread holding the last element
@@ -268,6 +268,11 @@ __global__ __launch_bounds__(256) void k_centroid_bbox_b(const BuildDesc<T> *__r
         }
     }
     if ((long long)blockIdx.x * blockDim.x >= m) return;
+    // wave results meet in LDS; ONE wave per block then issues the nine atomics (every wave doing so cost
+    // 370 us on a 2M-point cloud: ~4000 contended 64-bit atomics per address)
+    __shared__ long long w_sum[4][3];
+    __shared__ double w_lo[4][3], w_hi[4][3];
+    const int wid = threadIdx.x >> 6;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         long long sv = s[a];
@@ -278,11 +283,17 @@ __global__ __launch_bounds__(256) void k_centroid_bbox_b(const BuildDesc<T> *__r
             lo = fmin(lo, __shfl_down(lo, o, 64));
             hi = fmax(hi, __shfl_down(hi, o, 64));
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&st[a], (unsigned long long)sv);
-            atomicMin(&st[3 + a], ordered_key(lo));
-            atomicMax(&st[6 + a], ordered_key(hi));
-        }
+        if ((threadIdx.x & 63) == 0) { w_sum[wid][a] = sv; w_lo[wid][a] = lo; w_hi[wid][a] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        long long sv = 0;
+        double lo = HUGE_VAL, hi = -HUGE_VAL;
+        for (int w = 0; w < 4; w++) { sv += w_sum[w][a]; lo = fmin(lo, w_lo[w][a]); hi = fmax(hi, w_hi[w][a]); }
+        atomicAdd(&st[a], (unsigned long long)sv);
+        atomicMin(&st[3 + a], ordered_key(lo));
+        atomicMax(&st[6 + a], ordered_key(hi));
     }
 }
 
@@ -2388,7 +2399,7 @@ void launch_centroid_bbox_batch(hipStream_t st, const BuildDesc<T> *descs, int n
 {
     int nb = cdiv(max_m, 256 * 8);
     if (nb < 1) nb = 1;
-    if (nb > 2048) nb = 2048;
+    if (nb > 512) nb = 512;
     hipLaunchKernelGGL(k_centroid_bbox_b<T>, dim3(nb, n), dim3(256), 0, st, descs, stats);
 }
 
@@ -2406,12 +2417,13 @@ void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, l
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_f, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_f, (const int *)block_sums,
-                       cell_start_f, cursor);
+                       cell_start_f, (int *)nullptr);
     hipLaunchKernelGGL(k_scatter_idx, dim3(cdiv(tot_m, 256)), dim3(256), 0, st, (int)tot_m, (const int *)cell_of,
                        (const int *)cell_start_f, (const int *)slot_of, order_tmp);
     hipLaunchKernelGGL(k_rank_place_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, (const int *)cell_of,
                        (const int *)cell_start_f, (const int *)order_tmp, pts, nrm_out, slot_of);
-    hipLaunchKernelGGL(k_localise_b<T>, dim3(cdiv(max_cells_f + 1, 256), n), dim3(256), 0, st, descs, cell_start_f);
+    if (n > 1)       // a single cloud's offsets are local already
+        hipLaunchKernelGGL(k_localise_b<T>, dim3(cdiv(max_cells_f + 1, 256), n), dim3(256), 0, st, descs, cell_start_f);
     if (cell_start != cell_start_f)
         hipLaunchKernelGGL(k_coarse_table_b<T>, dim3(cdiv(max_cells + 1, 256), n), dim3(256), 0, st, descs, (const int *)cell_start_f,
                            cell_start);
@@ -2441,7 +2453,7 @@ void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> 
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, (const int *)block_sums,
-                       qstart, cursor);
+                       qstart, (int *)nullptr);
     // `order` carries the arrival positions until k_qrank overwrites it with the final permutation
     hipLaunchKernelGGL(k_qscatter, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, (const int *)qstart, (const int *)order, qtmp);
     hipLaunchKernelGGL(k_qrank<T>, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, (const int *)qstart,
