@@ -213,10 +213,18 @@ __global__ __launch_bounds__(1024) void k_scan_sums_inplace(int *__restrict__ bl
 }
 
 __global__ __launch_bounds__(1024) void k_scan_final(const int *__restrict__ in, int n, const int *__restrict__ block_offs,
-                                                      int *__restrict__ out /* n+1 */, int *__restrict__ cursor)
+                                                      int *__restrict__ out /* n+1 */, int *__restrict__ cursor, int skip_empty)
 {
     __shared__ int lds[32];
     const long long base = (long long)blockIdx.x * kScanChunk + threadIdx.x * 4;
+    if (skip_empty && blockIdx.x + 1 < gridDim.x && block_offs[blockIdx.x + 1] == block_offs[blockIdx.x]) {
+        // nothing counted in this chunk: every entry is the running offset (block-uniform branch)
+        const int ex0 = block_offs[blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (base + k < n) { out[base + k] = ex0; if (cursor) cursor[base + k] = ex0; }
+        return;
+    }
     int v[4];
     int s = 0;
 #pragma unroll
@@ -299,7 +307,8 @@ __global__ __launch_bounds__(256) void k_centroid_bbox_b(const BuildDesc<T> *__r
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_cell_count_b(const BuildDesc<T> *__restrict__ descs, int *__restrict__ cell_of,
-                                                       int *__restrict__ counts, int *__restrict__ sc_count, int *__restrict__ arrival)
+                                                       int *__restrict__ counts, int *__restrict__ sc_count, int *__restrict__ arrival,
+                                                       int *__restrict__ chunk_sums)
 {
     const BuildDesc<T> &d = descs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,6 +328,9 @@ __global__ __launch_bounds__(256) void k_cell_count_b(const BuildDesc<T> *__rest
         cell_of[d.pbase + i] = c;
     }
     const int pos = wave_bucket_add(counts, c, live);
+    // the per-chunk sums of the prefix scan are taken here (a wave's points fall into one or two chunks):
+    // the cell table of a range scan is 99 % zeros, which the scan then neither sums nor re-reads
+    (void)wave_bucket_add(chunk_sums, c / kScanChunk, live);
     if (!live) return;
     arrival[d.pbase + i] = pos;
     if (pos == 0) {
@@ -2412,12 +2424,12 @@ void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, l
 {
     (void)hipMemsetAsync(counts, 0, sizeof(int) * tot_f, st);
     (void)hipMemsetAsync(sc_count, 0, sizeof(int) * tot_s, st);
-    hipLaunchKernelGGL(k_cell_count_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, cell_of, counts, sc_count, slot_of);
     const int nb = cdiv(tot_f, kScanChunk);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_f, block_sums);
+    (void)hipMemsetAsync(block_sums, 0, sizeof(int) * (size_t)nb, st);
+    hipLaunchKernelGGL(k_cell_count_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, cell_of, counts, sc_count, slot_of, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_f, (const int *)block_sums,
-                       cell_start_f, (int *)nullptr);
+                       cell_start_f, (int *)nullptr, 1);
     hipLaunchKernelGGL(k_scatter_idx, dim3(cdiv(tot_m, 256)), dim3(256), 0, st, (int)tot_m, (const int *)cell_of,
                        (const int *)cell_start_f, (const int *)slot_of, order_tmp);
     hipLaunchKernelGGL(k_rank_place_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, (const int *)cell_of,
@@ -2453,7 +2465,7 @@ void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> 
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, block_sums);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)nbins, (const int *)block_sums,
-                       qstart, (int *)nullptr);
+                       qstart, (int *)nullptr, 0);
     // `order` carries the arrival positions until k_qrank overwrites it with the final permutation
     hipLaunchKernelGGL(k_qscatter, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, (const int *)qstart, (const int *)order, qtmp);
     hipLaunchKernelGGL(k_qrank<T>, grid, dim3(256), 0, st, probs, max_rows, (const int *)qrow, (const int *)qstart,
