@@ -104,6 +104,19 @@ __device__ __forceinline__ int build_cell(const GridDesc<T> &g, T x, T y, T z)
     return cx + g.nx * (cy + g.ny * cz);
 }
 
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 // One atomic per distinct key among the lanes of a wave (clouds arrive in scan order, so neighbouring
 // lanes mostly share a cell); falls back to per-lane atomics after 8 leader rounds.  Returns the
 // lane's arrival position inside its key's bucket.
@@ -586,9 +599,10 @@ __global__ __launch_bounds__(256) void k_qscatter(const ProblemDev *__restrict__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     const int key = qbin[P.off + i];
-    // (cell-in-block key, index) packed: the rank kernel compares these words straight from the bin segment
+    // (bin, cell-in-block key, index) packed: the rank kernel compares these words straight from the bin
+    // segment and needs no second look-up of the bin (bin < 2^25)
     qtmp[qstart[(long long)blockIdx.y * max_bins + (key >> 6)] + qpos[P.off + i]] =
-        ((unsigned long long)(unsigned int)(key & 63) << 32) | (unsigned int)i;
+        ((unsigned long long)(unsigned int)key << 32) | (unsigned int)i;
 }
 
 template <typename T>
@@ -597,23 +611,39 @@ __global__ __launch_bounds__(256) void k_qrank(const ProblemDev *__restrict__ pr
                                                 const unsigned long long *__restrict__ qtmp, const T *__restrict__ rd_pre,
                                                 T *__restrict__ rd_sorted, int *__restrict__ order)
 {
+    (void)qbin;
     const ProblemDev &P = probs[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.n) return;
-    const unsigned long long me = qtmp[P.off + j];
-    const int i = (int)(unsigned int)(me & 0xFFFFFFFFu);
-    const long long bin = (long long)blockIdx.y * max_bins + (qbin[P.off + i] >> 6);
-    const int a = qstart[bin], b = qstart[bin + 1];
-    int rank = 0;
-    // (cell-in-block, index) order; 8 independent contiguous reads in flight per trip
-    for (int k = a; k < b; k += 8) {
-        unsigned long long w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = qtmp[min(k + u, b - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) rank += (k + u < b && w[u] < me) ? 1 : 0;
+    if (blockIdx.x * blockDim.x >= P.n) return;
+    const bool live = j < P.n;
+    const int lane = threadIdx.x & 63;
+    // The 64 words of a wave are consecutive in bin order, so the segments of their bins form one contiguous
+    // span [lo, hi).  The wave reads that span once, 64 words per trip, and every lane counts the words below
+    // its own through lane broadcasts -- no lane walks its bin through memory (that loop was the cost of the
+    // reading sort: O(bin population) cached reads per point).  All words of earlier bins are smaller and all
+    // words of later bins larger, so (words below mine in the span) - (words before my bin) is the rank.
+    unsigned long long me = ~0ULL;
+    int a = 0x7FFFFFFF, b = 0;
+    if (live) {
+        me = qtmp[P.off + j];
+        const long long bin = (long long)blockIdx.y * max_bins + (long long)(me >> 38);
+        a = qstart[bin]; b = qstart[bin + 1];
     }
-    const int f = a + rank;                                 // global position (the scan runs over all problems)
+    const int lo = wave_min_i(a), hi = wave_max_i(b);
+    int below = 0;
+    for (int t = lo; t < hi; t += 64) {
+        const unsigned long long w = t + lane < hi ? qtmp[t + lane] : ~0ULL;
+        const unsigned int wl = (unsigned int)w, wh = (unsigned int)(w >> 32);
+#pragma unroll 16
+        for (int u = 0; u < 64; ++u) {
+            const unsigned long long wu = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)wh, u) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readlane((int)wl, u);
+            below += wu < me ? 1 : 0;
+        }
+    }
+    if (!live) return;
+    const int i = (int)(unsigned int)(me & 0xFFFFFFFFu);
+    const int f = a + (below - (a - lo));                   // global position (the scan runs over all problems)
     order[f] = i;
     const T *src = rd_pre + 3 * (P.off + i);
     T *dst = rd_sorted + 3 * (long long)f;
@@ -841,19 +871,6 @@ template <typename T>
 __device__ __forceinline__ T slab_far(T u, T lo, T hi)
 {
     return fmax(fabs(u - lo), fabs(hi - u));
-}
-
-__device__ __forceinline__ int wave_min_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
 }
 
 // Phase C of the fast path (shared by both fast kernels): store a resolved result, or queue the
