@@ -12,6 +12,7 @@ python3 bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 2>/dev/
 python3 bench.py --workload stream --streams 1 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_1.json
 python3 bench.py --workload stream --streams 4 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_4.json
 python3 bench.py --workload stream --streams 16 --fleet --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_fleet16.json
+python3 bench.py --workload stream --streams 64 --fleet --steps 1 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_fleet64.json
 python3 tools/bench_normals.py 2>/dev/null | grep -v amdgpu > $OUT/bench_normals.json
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
