@@ -151,3 +151,63 @@ def test_lazy_matcher_state_equals_oracle_every_iteration(ctx, oracle32):
         assert np.all(gd[loose] >= o["last_d2"][loose]) and np.all(gd[loose] > o["trim_limit"])
     ctx.set_params(**CHAIN)
     ctx.destroy_map(m)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 2047, 2048, 2049, 4097, 30011])
+def test_outlier_selection_sizes_and_ratios(ctx, oracle32, n):
+    """The chip-wide trimmed-distance selection (histogram -> filter -> finish) at sizes around its 2048-point
+    tiles and with several ratios, in one ragged batch: threshold, kept and finite counts equal the oracle's."""
+    t = synth.make_two_scans(max(n, 3000), rings=16)
+    ref, nrm, T0 = t["ref_xyz"], t["ref_nrm"], t["T_init"]
+    rd = t["reading_xyz"][:n].copy()
+    if n > 10:
+        rd[::9] += np.float32(300.0)                          # some points without any neighbour
+    m = ctx.set_map(ref, nrm)
+    for ratio in (0.85, 0.5, 0.999, 1.0, 0.01):
+        prm = dict(CHAIN, max_iters=2, trim_ratio=ratio)
+        ctx.set_params(**prm)
+        Ts, st = ctx.align_batch([m, m], [rd, t["reading_xyz"][:777]], [T0, T0], raise_on_error=False)
+        o = oracle32.icp(rd, ref, nrm, T0, **prm)
+        assert st[0]["status"] == o["status"], (n, ratio)
+        if o["status"] == 0:
+            assert st[0]["trim_limit"] == o["trim_limit"], (n, ratio)
+            assert st[0]["n_kept"] == o["n_kept"] and st[0]["n_finite"] == o["n_finite"], (n, ratio)
+    ctx.set_params(**CHAIN)
+    ctx.destroy_map(m)
+
+
+def test_outlier_selection_with_equal_distances(ctx, oracle32):
+    """Every distance in ONE histogram bin (a plane of points matched from a parallel plane): the compact list
+    of the selection is the whole reading."""
+    g = np.arange(70, dtype=np.float32) * np.float32(0.125)
+    xx, yy = np.meshgrid(g, g, indexing="ij")
+    ref = np.stack([xx.ravel(), yy.ravel(), np.zeros(xx.size, dtype=np.float32)], 1).astype(np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (ref.shape[0], 1))
+    rd = ref.copy()
+    rd[:, 2] = np.float32(0.0625)                                # exactly representable: d2 = 2^-8 for every point
+    m = ctx.set_map(ref, nrm, center=False)
+    prm = dict(CHAIN, max_iters=1)
+    ctx.set_params(**prm)
+    T, st = ctx.align_batch([m], [rd], [np.eye(4)], raise_on_error=False)
+    o = oracle32.icp(rd, ref, nrm, np.eye(4), **prm)
+    assert st[0]["status"] == o["status"]
+    assert st[0]["trim_limit"] == o["trim_limit"] == np.float32(0.0625) ** 2
+    assert st[0]["n_kept"] == o["n_kept"] and st[0]["n_finite"] == o["n_finite"] == rd.shape[0]
+    ctx.set_params(**CHAIN)
+    ctx.destroy_map(m)
+
+
+def test_outlier_selection_f64(ctx, oracle64):
+    """Double precision: the selection finishes 52 remaining key bits on the compact list (five levels)."""
+    t = synth.make_two_scans(5000, rings=16)
+    ref, nrm, rd = t["ref_xyz"].astype(np.float64), t["ref_nrm"].astype(np.float64), t["reading_xyz"].astype(np.float64)
+    m = ctx.set_map(ref, nrm)
+    for ratio in (0.85, 0.3):
+        prm = dict(CHAIN, max_iters=3, trim_ratio=ratio)
+        ctx.set_params(**prm)
+        T, st = ctx.align(m, rd, t["T_init"])
+        o = oracle64.icp(rd, ref, nrm, t["T_init"], **prm)
+        assert st["n_kept"] == o["n_kept"] and st["n_finite"] == o["n_finite"]
+        np.testing.assert_allclose(st["trim_limit"], o["trim_limit"], rtol=1e-11)   # device vs host libm in the transforms
+    ctx.set_params(**CHAIN)
+    ctx.destroy_map(m)
