@@ -93,6 +93,8 @@ struct pgicp_ctx {
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     int *h_flag = nullptr;          // coherent pinned pair {problems done, stamp} the last kernel of an iteration writes
     int flag_stamp = 0;
+    std::vector<SrcDesc> h_src;     // host copies of per-batch descriptors (uploaded asynchronously)
+    std::vector<int> h_ident;
     int counters_clean = 0;         // the matcher's queue counters were zeroed by the last kernel of the previous iteration
     int poll_us = 400;              // how long the host polls h_flag before it blocks on the stream instead
     // Freed map blocks are kept for reuse: hipFree synchronises the device, and loop closing creates
@@ -558,7 +560,8 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     if (stage_total) HIPC(c, S.staging.ensure(stage_total));
 
     hp.assign(P, ProblemDev());
-    std::vector<SrcDesc> hs(P);
+    std::vector<SrcDesc> &hs = c->h_src;        // context members: they outlive the async uploads below
+    hs.assign(P, SrcDesc());
     size_t soff = 0;
     long long off = 0;
     for (int p = 0; p < P; p++) {
@@ -578,7 +581,8 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     }
     HIPC(c, hipMemcpyAsync(c->probs.p, hp.data(), sizeof(ProblemDev) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->src.p, hs.data(), sizeof(SrcDesc) * P, hipMemcpyHostToDevice, c->stream));
-    std::vector<int> ident(P);
+    std::vector<int> &ident = c->h_ident;
+    ident.resize(P);
     std::iota(ident.begin(), ident.end(), 0);
     HIPC(c, hipMemcpyAsync(c->active.p, ident.data(), sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
@@ -593,9 +597,10 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
                              c->order.as<int>(), c->qcounts.as<int>(), c->qblock.as<int>(), c->qstart.as<int>(),
                              c->qcursor.as<int>(), P, L.max_n, L.max_rows, L.bin_shift);
     }
-    // hs/hp must outlive the async copies
-    HIPC(c, hipStreamSynchronize(c->stream));
+    // (no synchronisation here: hp is the caller's, hs / ident are context members, and every caller ends with
+    // a stream synchronisation before it returns -- a wait at this point idles the GPU for ~25 us per scan)
     if (const char *e = std::getenv("PGICP_TRACE_ORIG")) {     // diagnostics build: narrate one query of problem 0
+        HIPC(c, hipStreamSynchronize(c->stream));
         std::vector<int> ord(hp[0].n);
         (void)hipMemcpy(ord.data(), c->order.as<int>(), sizeof(int) * ord.size(), hipMemcpyDeviceToHost);
         const int want = std::atoi(e);
