@@ -1,0 +1,27 @@
+"""The tuning knobs only move work between the matcher's paths: the edge-case parity
+tests must pass unchanged for every setting.  Each setting runs in its own process (the knobs are read once, at
+context creation)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SETTINGS = [
+    {"PGICP_KX": "1"},
+    {"PGICP_MED_RINGS": "1", "PGICP_FAST_RINGS_SEEDED": "3", "PGICP_FAST_RINGS_UNSEEDED": "1"},
+    {"PGICP_KX": "7", "PGICP_MED_RINGS": "8", "PGICP_POLL_US": "0", "PGICP_NEAR_FRAC": "0.05"},
+]
+
+
+@pytest.mark.parametrize("setting", SETTINGS, ids=lambda s: ",".join(f"{k[6:]}={v}" for k, v in s.items()))
+def test_parity_holds_for_every_knob_setting(setting):
+    env = dict(os.environ, **setting)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_edge_cases.py", "tests/test_gpu_matcher_state.py",
+                        "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
