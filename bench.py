@@ -448,7 +448,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=128, help="independent scans aligned per step")
-    ap.add_argument("--queries", type=int, default=16, help="distinct query scans generated (cycled to fill the batch)")
+    ap.add_argument("--queries", type=int, default=64, help="distinct query scans generated (cycled to fill the batch)")
     ap.add_argument("--n-scan", type=int, default=100_000)
     ap.add_argument("--n-map", type=int, default=1_000_000)
     ap.add_argument("--fixed-iters", action="store_true", help="disable the Differential checker: exactly 30 iterations")
