@@ -285,6 +285,79 @@ struct PointMatcher {
             if (c.descriptors.rows()) c.descriptors.conservativeResize(c.descriptors.rows(), k);
         }
     };
+    //! keeps the columns for which `keep(j)` holds, in order (features and descriptors)
+    template <typename Pred>
+    static void compactColumns(DataPoints &c, Pred keep)
+    {
+        const int n = (int)c.features.cols();
+        int k = 0;
+        for (int j = 0; j < n; j++) {
+            if (!keep(j)) continue;
+            if (k != j) {
+                for (int i = 0; i < c.features.rows(); i++) c.features(i, k) = c.features(i, j);
+                for (int i = 0; i < c.descriptors.rows(); i++) c.descriptors(i, k) = c.descriptors(i, j);
+            }
+            k++;
+        }
+        c.features.conservativeResize(c.features.rows(), k);
+        if (c.descriptors.rows()) c.descriptors.conservativeResize(c.descriptors.rows(), k);
+    }
+    //! [EXT] BoundingBoxDataPointsFilter{xMin..zMax, removeInside}: a point is inside when every coordinate lies
+    //! strictly between its bounds; removeInside = 1 (the default) drops the inside, 0 keeps only the inside
+    struct BoundingBoxDataPointsFilter : DataPointsFilter {
+        T lo[3], hi[3]; bool removeInside;
+        BoundingBoxDataPointsFilter(const T l[3], const T h[3], bool rm) : removeInside(rm) { for (int a = 0; a < 3; a++) { lo[a] = l[a]; hi[a] = h[a]; } }
+        void inPlaceFilter(DataPoints &c) override
+        {
+            compactColumns(c, [&](int j) {
+                bool in = true;
+                for (int a = 0; a < 3; a++) in = in && lo[a] < c.features(a, j) && c.features(a, j) < hi[a];
+                return in != removeInside;
+            });
+        }
+    };
+    //! [EXT] RemoveNaNDataPointsFilter: drops points with a NaN coordinate
+    struct RemoveNaNDataPointsFilter : DataPointsFilter {
+        void inPlaceFilter(DataPoints &c) override
+        {
+            compactColumns(c, [&](int j) {
+                for (int i = 0; i < c.features.rows(); i++) if (c.features(i, j) != c.features(i, j)) return false;
+                return true;
+            });
+        }
+    };
+    //! [EXT] ObservationDirectionDataPointsFilter{x, y, z}: descriptor observationDirections = sensor position - point
+    struct ObservationDirectionDataPointsFilter : DataPointsFilter {
+        T c0[3];
+        ObservationDirectionDataPointsFilter(T x, T y, T z) { c0[0] = x; c0[1] = y; c0[2] = z; }
+        void inPlaceFilter(DataPoints &c) override
+        {
+            const int n = (int)c.features.cols();
+            Matrix d(3, n);
+            for (int j = 0; j < n; j++)
+                for (int a = 0; a < 3; a++) d(a, j) = c0[a] - c.features(a, j);
+            c.addDescriptor("observationDirections", d);
+        }
+    };
+    //! [EXT] OrientNormalsDataPointsFilter{towardCenter}: flips every normal that points away from (towardCenter = 1)
+    //! or toward (0) the sensor; needs the normals and observationDirections descriptors
+    struct OrientNormalsDataPointsFilter : DataPointsFilter {
+        bool towardCenter;
+        explicit OrientNormalsDataPointsFilter(bool t) : towardCenter(t) {}
+        void inPlaceFilter(DataPoints &c) override
+        {
+            if (!c.descriptorExists("normals")) throw std::runtime_error("OrientNormalsDataPointsFilter: cannot find normals in descriptors");
+            if (!c.descriptorExists("observationDirections")) throw std::runtime_error("OrientNormalsDataPointsFilter: cannot find observation directions in descriptors");
+            const int rn = c.getDescriptorStartingRow("normals"), ro = c.getDescriptorStartingRow("observationDirections");
+            const int n = (int)c.features.cols();
+            for (int j = 0; j < n; j++) {
+                T dot = 0;
+                for (int a = 0; a < 3; a++) dot += c.descriptors(rn + a, j) * c.descriptors(ro + a, j);
+                if (towardCenter ? dot < 0 : dot > 0)
+                    for (int a = 0; a < 3; a++) c.descriptors(rn + a, j) = -c.descriptors(rn + a, j);
+            }
+        }
+    };
     //! [EXT] SurfaceNormalDataPointsFilter{knn, maxDist, epsilon, keepNormals, keepEigenValues}: normals (and,
     //! on request, eigenvalues) of every point from its knn neighbours, computed on the device by
     //! pgicp_surface_normals_*; the descriptors are appended as libpointmatcher appends them.
@@ -340,9 +413,22 @@ struct PointMatcher {
                     this->push_back(std::make_shared<SurfaceNormalDataPointsFilter>(knn, (T)to_double(get("maxDist", "inf"), m.name),
                                                                                      to_double(get("keepNormals", "1"), m.name) != 0.0,
                                                                                      to_double(get("keepEigenValues", "0"), m.name) != 0.0));
+                } else if (m.name == "BoundingBoxDataPointsFilter") {
+                    auto get = [&](const char *k, const char *def) { return (T)to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
+                    const T lo[3] = {get("xMin", "-1"), get("yMin", "-1"), get("zMin", "-1")}, hi[3] = {get("xMax", "1"), get("yMax", "1"), get("zMax", "1")};
+                    this->push_back(std::make_shared<BoundingBoxDataPointsFilter>(lo, hi, get("removeInside", "1") != (T)0));
+                } else if (m.name == "RemoveNaNDataPointsFilter") {
+                    this->push_back(std::make_shared<RemoveNaNDataPointsFilter>());
+                } else if (m.name == "ObservationDirectionDataPointsFilter") {
+                    auto get = [&](const char *k) { return (T)to_double(m.params.count(k) ? m.params.at(k) : std::string("0"), m.name); };
+                    this->push_back(std::make_shared<ObservationDirectionDataPointsFilter>(get("x"), get("y"), get("z")));
+                } else if (m.name == "OrientNormalsDataPointsFilter") {
+                    this->push_back(std::make_shared<OrientNormalsDataPointsFilter>(
+                        to_double(m.params.count("towardCenter") ? m.params.at("towardCenter") : std::string("1"), m.name) != 0.0));
                 } else
                     throw std::runtime_error("DataPointsFilters: unsupported filter '" + m.name +
-                                             "' (supported: Identity, MinDist, MaxDist, SurfaceNormal)");
+                                             "' (supported: Identity, MinDist, MaxDist, BoundingBox, RemoveNaN, SurfaceNormal, "
+                                             "ObservationDirection, OrientNormals; the sampling filters draw from rand() upstream and are not restated)");
             }
         }
         void init() { for (auto &f : *this) f->init(); }

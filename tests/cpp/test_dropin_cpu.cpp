@@ -3,6 +3,7 @@
 // test, tests/instantiation.cpp), DataPoints / YAML / matrix semantics, and the
 // "no CPU fallback" rule: constructing an ICP object without a GPU must throw.
 #include "common.hpp"
+#include <limits>
 
 template <typename T>
 void type_spelling()
@@ -75,6 +76,36 @@ void yaml_and_matrix()
     auto dp = PointMatcher<float>::DataPoints::fromXYZ(xyz, 3);
     f.init(); f.apply(dp);
     CHECK(f.size() == 2 && dp.getNbPoints() == 2 && dp.features(1, 1) == 1.0f);
+    {   // the deterministic host-side filters: bounding box, NaN removal, observation directions, normal orientation
+        std::istringstream bs("- BoundingBoxDataPointsFilter:\n    xMin: -0.5\n    xMax: 0.5\n    yMin: -0.5\n    yMax: 0.5\n    zMin: -0.5\n    zMax: 0.5\n    removeInside: 1\n"
+                              "- RemoveNaNDataPointsFilter\n"
+                              "- ObservationDirectionDataPointsFilter:\n    x: 0\n    y: 0\n    z: 2\n"
+                              "- OrientNormalsDataPointsFilter:\n    towardCenter: 1\n");
+        PointMatcher<float>::DataPointsFilters g(bs);
+        CHECK(g.size() == 4);
+        const float nan = std::numeric_limits<float>::quiet_NaN();
+        const float pts[] = {0.1f, 0.2f, 0.3f,  3, 0, 0,  nan, 1, 1,  0, 3, 0,  0.5f, 0, 0};
+        auto c = PointMatcher<float>::DataPoints::fromXYZ(pts, 5);
+        PointMatcher<float>::Matrix nrm(3, 5);
+        for (int j = 0; j < 5; j++) { nrm(0, j) = 0; nrm(1, j) = 0; nrm(2, j) = j % 2 ? 1.0f : -1.0f; }
+        c.addDescriptor("normals", nrm);
+        g.apply(c);
+        // point 0 is inside the box (removed), point 2 has a NaN (removed), point 4 sits ON the box (kept: strict bounds)
+        CHECK(c.getNbPoints() == 3 && c.features(0, 0) == 3.0f && c.features(1, 1) == 3.0f && c.features(0, 2) == 0.5f);
+        const int ro = c.getDescriptorStartingRow("observationDirections"), rn = c.getDescriptorStartingRow("normals");
+        CHECK(c.descriptors(ro, 0) == -3.0f && c.descriptors(ro + 2, 0) == 2.0f && c.descriptors(ro + 1, 1) == -3.0f);
+        for (int j = 0; j < 3; j++) CHECK(c.descriptors(rn + 2, j) == 1.0f);       // all normals now face the sensor at z = 2
+        std::istringstream ks("- BoundingBoxDataPointsFilter:\n    removeInside: 0\n");
+        PointMatcher<float>::DataPointsFilters keepIn(ks);
+        auto c2 = PointMatcher<float>::DataPoints::fromXYZ(pts, 5);
+        keepIn.apply(c2);
+        CHECK(c2.getNbPoints() == 2 && c2.features(0, 0) == 0.1f && c2.features(0, 1) == 0.5f);   // default box is (-1, 1)^3
+        std::istringstream os("- OrientNormalsDataPointsFilter\n");
+        PointMatcher<float>::DataPointsFilters orient(os);
+        threw = false;
+        try { orient.apply(c2); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);                                                          // no normals: refused like upstream
+    }
     // anything outside the supported set is refused at load time, never ignored
     for (const char *txt : {"- RandomSamplingDataPointsFilter:\n    prob: 0.5\n",
                             "- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: 3.16\n",
