@@ -761,7 +761,12 @@ __device__ __forceinline__ void scan_range(const typename Vec4<T>::type *__restr
         eval_point<T>(v2, s + 2, qx, qy, qz, best);
         eval_point<T>(v3, s + 3, qx, qy, qz, best);
     }
-    for (; s < b; ++s) eval_point<T>(load_rec<T>(pts, s), s, qx, qy, qz, best);
+    if (s < b) {                                 // the 1..3 left over: one round trip, not one each
+        const auto v0 = load_rec<T>(pts, s), v1 = load_rec<T>(pts, min(s + 1, b - 1)), v2 = load_rec<T>(pts, min(s + 2, b - 1));
+        eval_point<T>(v0, s, qx, qy, qz, best);
+        eval_point_if<T>(s + 1 < b, v1, s + 1, qx, qy, qz, best);
+        eval_point_if<T>(s + 2 < b, v2, s + 2, qx, qy, qz, best);
+    }
 }
 
 // distance from coordinate offset u (= x - origin) to the slab of cell c
@@ -987,9 +992,15 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
     best.idx = 0x7FFFFFFF;
     best.slot = -1;
     seed.d2 = Bits<T>::inf(); seed.idx = 0x7FFFFFFF; seed.slot = -1;
+    int dsc = 0;
     if (live) {
         const T *q = rd + 3 * (P.off + i);
         apply_T<T>(P.Tcur, q[0], q[1], q[2], qx, qy, qz);
+        {   // the super-cell distance look-up (used below) is requested together with the seed
+            const int sx = clamp_cell<T>(qx - g.ox, g.inv_h, g.nx) >> 3, sy8 = clamp_cell<T>(qy - g.oy, g.inv_h, g.ny) >> 3,
+                      sz8 = clamp_cell<T>(qz - g.oz, g.inv_h, g.nz) >> 3;
+            dsc = as_global(M.sc_dist)[sx + M.nsx * (sy8 + M.nsy * sz8)];
+        }
         if (use_seed) {
             const int prev = slot_io[P.off + i];
             if (prev >= 0) {
@@ -1021,7 +1032,6 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
     // from farther out).  Beyond maxDist that settles "no neighbour" with one look-up -- scan points ahead
     // of a streaming map would otherwise each walk the queue, the medium and the slow path every iteration.
     if (live) {
-        const int dsc = as_global(M.sc_dist)[(cx >> 3) + M.nsx * ((cy >> 3) + M.nsy * (cz >> 3))];
         const T empty_r = (T)(dsc - 1) * (g.h * (T)8) - g.margin;
         if (empty_r > ch.max_dist) {
             slot_io[P.off + i] = -1;
@@ -1104,25 +1114,41 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
             if (ra[u] < rb[u]) { rng_a[nr][lane] = ra[u]; rng_b[nr][lane] = rb[u]; ++nr; }
     }
     // ---- flat walk over the concatenated ranges (LDS is only read by the lane that wrote it) ----
+    // Four candidates per trip, as two pairs; the second pair may already belong to the lane's next range, so
+    // four gathers per lane are in flight per L1 round trip whatever the range lengths are.  (Carrying a
+    // requested pair across the loop edge instead does not work: the register copy on the back edge waits for
+    // the data.)
     {
         int k = 0, j = 0, e = 0;
         bool valid = nr > 0;
         if (valid) { j = rng_a[0][lane]; e = rng_b[0][lane]; }
-        while (__any(valid)) {
-            // two candidates per trip (the second only if it is still inside the current range)
-            const bool two = valid & (j + 1 < e);
-            const V4 v0 = load_rec<T>(M.pts, valid ? j : 0);
-            const V4 v1 = load_rec<T>(M.pts, two ? j + 1 : 0);
-            eval_point_if<T>(valid, v0, j, qx, qy, qz, best);
-            eval_point_if<T>(two, v1, j + 1, qx, qy, qz, best);
+        auto advance = [&]() {
             j += 2;
             if (valid & (j >= e)) {                                   // next non-empty range of this lane
                 ++k;
                 valid = k < nr;
                 if (valid) { j = rng_a[k][lane]; e = rng_b[k][lane]; }
             }
+        };
+        while (__any(valid)) {
+#ifndef PGICP_FLAT_PAIRS
+#define PGICP_FLAT_PAIRS 2
+#endif
+            constexpr int NP = PGICP_FLAT_PAIRS;
+            bool pv[NP], pt[NP];
+            int pj[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { pv[u] = valid; pt[u] = valid & (j + 1 < e); pj[u] = j; advance(); }
+            V4 c0[NP], c1[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { c0[u] = load_rec<T>(M.pts, pv[u] ? pj[u] : 0); c1[u] = load_rec<T>(M.pts, pt[u] ? pj[u] + 1 : 0); }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                eval_point_if<T>(pv[u], c0[u], pj[u], qx, qy, qz, best);
+                eval_point_if<T>(pt[u], c1[u], pj[u] + 1, qx, qy, qz, best);
+            }
 #ifdef PGICP_KNN_STATS
-            flat_iters++;
+            flat_iters += 2;
 #endif
         }
     }
