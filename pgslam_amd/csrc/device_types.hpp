@@ -94,9 +94,14 @@ struct ProblemDev {
 struct Mat34 { double v[12]; };                    // row-major 3x4, kernel argument
 struct SrcDesc { const void *ptr; int stride; int pad_; };   // where a problem's reading lives (device)
 
+#ifndef PGICP_REDUCE_ROUNDS
+#define PGICP_REDUCE_ROUNDS 2
+#endif
 constexpr int kKnnBlock = 256;
 constexpr int kReduceBlock = 256;
-constexpr int kReduceItems = 4;      // queries per thread in the reduce kernels
+constexpr int kReduceItems = 4;      // queries per thread and round in the reduce kernels (loads of one round in flight together)
+constexpr int kReduceRounds = PGICP_REDUCE_ROUNDS;   // rounds per block: one 30-double block reduction per kReduceSpan queries
+constexpr int kReduceSpan = kReduceBlock * kReduceItems * kReduceRounds;
 constexpr int kSelectBlock = 1024;
 constexpr int kCovTerms = 42;
 constexpr int kNearReach = 8;

@@ -2134,7 +2134,7 @@ __global__ __launch_bounds__(kReduceBlock) void k_p2plane_reduce(const ProblemDe
     const ProblemDev &P = probs[prob];
     if (P.done) return;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    if (tile * (kReduceBlock * kReduceItems) >= P.n) return;      // whole block past the end: partial stays unused
+    if (tile * kReduceSpan >= P.n) return;      // whole block past the end: partial stays unused
     const MapDev<T> M = maps[P.map];
     const T limit = (T)P.limit;
     double acc[kSys];
@@ -2143,11 +2143,14 @@ __global__ __launch_bounds__(kReduceBlock) void k_p2plane_reduce(const ProblemDe
     // three load stages, each with kReduceItems independent loads in flight per lane:
     // (slot, d2) -> gathered (point, normal, reading) -> arithmetic
     using V4 = typename Vec4<T>::type;
+    for (int rnd = 0; rnd < kReduceRounds; ++rnd) {
+    const int base = tile * kReduceSpan + rnd * (kReduceBlock * kReduceItems);
+    if (base >= P.n) break;
     int ss[kReduceItems];
     bool keep[kReduceItems];
 #pragma unroll
     for (int it = 0; it < kReduceItems; it++) {
-        const int i = tile * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
+        const int i = base + it * kReduceBlock + threadIdx.x;
         ss[it] = -1;
         T dd = Bits<T>::inf();
         if (i < P.n) { dd = d2[P.off + i]; ss[it] = slot[P.off + i]; }
@@ -2157,7 +2160,7 @@ __global__ __launch_bounds__(kReduceBlock) void k_p2plane_reduce(const ProblemDe
     T qv[kReduceItems][3];
 #pragma unroll
     for (int it = 0; it < kReduceItems; it++) {
-        const int i = tile * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
+        const int i = base + it * kReduceBlock + threadIdx.x;
         const int s = keep[it] ? ss[it] : 0;
         mp[it] = M.pts[s];
         mn[it] = M.nrm[s];
@@ -2172,6 +2175,7 @@ __global__ __launch_bounds__(kReduceBlock) void k_p2plane_reduce(const ProblemDe
             accumulate_pair(acc, 1.0, (double)px, (double)py, (double)pz, (double)mp[it].x, (double)mp[it].y, (double)mp[it].z,
                             (double)mn[it].x, (double)mn[it].y, (double)mn[it].z);
         }
+    }
     }
     block_reduce_store<kSys>(acc, partials + ((long long)prob * max_blocks + tile) * kSys);
 }
@@ -2189,8 +2193,8 @@ __global__ __launch_bounds__(kReduceBlock) void k_error_stats(const MapDev<T> *_
     double acc[kSys];
 #pragma unroll
     for (int k = 0; k < kSys; k++) acc[k] = 0.0;
-    for (int it = 0; it < kReduceItems; it++) {
-        const int i = blockIdx.x * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
+    for (int it = 0; it < kReduceItems * kReduceRounds; it++) {
+        const int i = blockIdx.x * kReduceSpan + it * kReduceBlock + threadIdx.x;
         if (i < n) {
             const T wi = w[i];
             const int id = ids[i];
@@ -2217,7 +2221,7 @@ __global__ __launch_bounds__(64) void k_sum_partials(const double *__restrict__ 
     const int p = blockIdx.x;
     int nb = nb_uniform;
     if (probs) {
-        nb = (probs[p].n + kReduceBlock * kReduceItems - 1) / (kReduceBlock * kReduceItems);
+        nb = (probs[p].n + kReduceSpan - 1) / kReduceSpan;
         if (probs[p].status != PGICP_ST_OK) nb = 0;       // partials were never written
     }
     if ((int)threadIdx.x < nt) {
@@ -2269,7 +2273,7 @@ __global__ __launch_bounds__(256) void k_solve_update(ProblemDev *__restrict__ p
     if (P.done) return;
     __shared__ double sys[kSys];
     __shared__ double red[8][32];
-    const int nb = (P.n + kReduceBlock * kReduceItems - 1) / (kReduceBlock * kReduceItems);
+    const int nb = (P.n + kReduceSpan - 1) / kReduceSpan;
     const double tot = sum_partials_256(partials + (long long)prob * max_blocks * kSys, nb, kSys, red);
     if (threadIdx.x < kSys) {
         sys[threadIdx.x] = tot;
@@ -2386,7 +2390,7 @@ __global__ __launch_bounds__(kReduceBlock) void k_cov_reduce(const ProblemDev *_
 {
     const ProblemDev &P = probs[blockIdx.y];
     if (P.status != PGICP_ST_OK) return;
-    if (blockIdx.x * (kReduceBlock * kReduceItems) >= P.n) return;
+    if (blockIdx.x * kReduceSpan >= P.n) return;
     const MapDev<T> M = maps[P.map];
     const T limit = (T)P.limit;
     // small-angle parameters of the last increment
@@ -2400,8 +2404,8 @@ __global__ __launch_bounds__(kReduceBlock) void k_cov_reduce(const ProblemDev *_
     double acc[kCovTerms];
 #pragma unroll
     for (int k = 0; k < kCovTerms; k++) acc[k] = 0.0;
-    for (int it = 0; it < kReduceItems; it++) {
-        const int i = blockIdx.x * (kReduceBlock * kReduceItems) + it * kReduceBlock + threadIdx.x;
+    for (int it = 0; it < kReduceItems * kReduceRounds; it++) {
+        const int i = blockIdx.x * kReduceSpan + it * kReduceBlock + threadIdx.x;
         if (i >= P.n) continue;
         const T dd = d2[P.off + i];
         const int s = slot[P.off + i];
@@ -2600,7 +2604,7 @@ int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m
     return 0;
 }
 
-int reduce_blocks(int max_n) { return round8(cdiv(max_n, kReduceBlock * kReduceItems)); }
+int reduce_blocks(int max_n) { return round8(cdiv(max_n, kReduceSpan)); }
 
 template <typename T>
 void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
@@ -2644,7 +2648,7 @@ template <typename T>
 void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const int *slot_of, const T *rd, int stride,
                         const int *ids, const T *w, int n, const T mean[3], double *partials, double *out)
 {
-    const int nb = cdiv(n, kReduceBlock * kReduceItems);
+    const int nb = cdiv(n, kReduceSpan);
     hipLaunchKernelGGL(k_error_stats<T>, dim3(nb), dim3(kReduceBlock), 0, st, maps, map, slot_of, rd, stride, ids, w, n,
                        mean[0], mean[1], mean[2], partials);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, (const double *)partials, nb, kSys,

@@ -958,7 +958,7 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         d_ids = c->tmp_a.as<int>();
         d_w = c->tmp_b.as<T>();
     }
-    const int nb = (n + kReduceBlock * kReduceItems - 1) / (kReduceBlock * kReduceItems);
+    const int nb = (n + kReduceSpan - 1) / kReduceSpan;
     HIPC(c, c->partials.ensure(sizeof(double) * (size_t)nb * kSys));
     HIPC(c, c->sums.ensure(sizeof(double) * kCovTerms));
     {
