@@ -33,6 +33,7 @@ struct MapDev {
     int kx;                              // points of a cell are ordered by fine x cell, so fine ranges are contiguous too
     const int *sc_count;                 // occupancy flag per 8x8x8 super-cell
     const int *sc_dist;                  // Chebyshev distance (in super-cells, capped at kScReach + 1) to the nearest occupied one
+    const int *sc_wit;                   // slot of a point in a nearest occupied super-cell (within kWitReach), else -1
     const int *slot_of;                  // original index -> position in pts / nrm
     const int *near;                     // per 2x2x2 block of cells: a nearby occupied cell, -1 if none within kNearReach
     GridDesc<T> g;
@@ -105,6 +106,7 @@ constexpr int kReduceSpan = kReduceBlock * kReduceItems * kReduceRounds;
 constexpr int kSelectBlock = 1024;
 constexpr int kCovTerms = 42;
 constexpr int kNearReach = 8;
+constexpr int kWitReach = 6;      // super-cells searched for MapDev::sc_wit
 constexpr int kScReach = 15;      // super-cells searched per axis for MapDev::sc_dist     // cells searched per axis for MapDev::near        // 21 (H upper) + 21 (G upper)
 
 }  // namespace pgicp

@@ -141,6 +141,24 @@ __device__ __forceinline__ int wave_bucket_add(int *__restrict__ counts, int key
     return pos;
 }
 
+// The same grouping without the arrival positions: the atomics return nothing, so the wave does not wait for them.
+__device__ __forceinline__ void wave_bucket_count(int *__restrict__ counts, int key, bool live)
+{
+    const int lane = threadIdx.x & 63;
+    bool todo = live;
+    for (int round = 0; round < 4; ++round) {
+        const unsigned long long pending = __ballot(todo);
+        if (pending == 0ULL) break;
+        const int leader = __ffsll((long long)pending) - 1;
+        const int lkey = __builtin_amdgcn_readlane(key, leader);
+        const bool mine = todo && key == lkey;
+        const unsigned long long grp = __ballot(mine);
+        if (lane == leader) atomicAdd(&counts[lkey], __popcll(grp));
+        if (mine) todo = false;
+    }
+    if (todo) atomicAdd(&counts[key], 1);
+}
+
 // MapDev::sc_dist -- Chebyshev distance, in super-cells, from every super-cell to the nearest occupied
 // one (separable: distance along x, then min over y of max(|dy|, .), then the same over z), capped at
 // kScReach + 1.  A query whose super-cell is d super-cells from anything has no point closer than
@@ -205,6 +223,15 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(const int *__restrict_
     int total;
     block_exclusive_scan_1024(s, lds, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_sum_copies(int *__restrict__ sums, int nb, int ncopies)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    int v = 0;
+    for (int r = 0; r < ncopies; ++r) v += sums[(long long)r * nb + i];
+    sums[i] = v;
 }
 
 __global__ __launch_bounds__(1024) void k_scan_sums_inplace(int *__restrict__ block_sums, int nb)
@@ -321,7 +348,7 @@ __global__ __launch_bounds__(256) void k_centroid_bbox_b(const BuildDesc<T> *__r
 template <typename T>
 __global__ __launch_bounds__(256) void k_cell_count_b(const BuildDesc<T> *__restrict__ descs, int *__restrict__ cell_of,
                                                        int *__restrict__ counts, int *__restrict__ sc_count, int *__restrict__ arrival,
-                                                       int *__restrict__ chunk_sums)
+                                                       int *__restrict__ chunk_sums, int n_chunks)
 {
     const BuildDesc<T> &d = descs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -343,7 +370,9 @@ __global__ __launch_bounds__(256) void k_cell_count_b(const BuildDesc<T> *__rest
     const int pos = wave_bucket_add(counts, c, live);
     // the per-chunk sums of the prefix scan are taken here (a wave's points fall into one or two chunks):
     // the cell table of a range scan is 99 % zeros, which the scan then neither sums nor re-reads
-    (void)wave_bucket_add(chunk_sums, c / kScanChunk, live);
+    // (one copy of the sums per XCD -- blocks b and b+8 share one: neighbouring chunks share cache lines, and
+    // atomics from eight L2s on one line were the whole kernel)
+    wave_bucket_count(chunk_sums + (long long)(blockIdx.x & 7) * n_chunks, c / kScanChunk, live);
     if (!live) return;
     arrival[d.pbase + i] = pos;
     if (pos == 0) {
@@ -481,6 +510,69 @@ __global__ __launch_bounds__(256) void k_near_b(const BuildDesc<T> *__restrict__
             out = (2 * bx + (best & 63) - 32) + nx * ((2 * by + ((best >> 6) & 63) - 32) + ny * (2 * bz + ((best >> 12) & 63) - 32));
         near[d.cbase + b] = out;
     }
+}
+
+// MapDev::sc_wit -- for every super-cell the slot of one point of a nearest occupied super-cell (Chebyshev, as
+// sc_dist; the first point of that super-cell in layout order), or -1 beyond kWitReach.  A query the matcher
+// could give no candidate at all -- a scan point over ground the map does not hold yet -- tests this one point:
+// if it lies within maxDist, "a neighbour exists" is settled and the point is the seed of the next iteration;
+// without it every such query walked super-cell rings in the wave-per-query path (70 % of that kernel's time
+// in a fleet's first iterations).
+template <typename T>
+__global__ __launch_bounds__(256) void k_sc_first_b(const BuildDesc<T> *__restrict__ descs, const int *__restrict__ sc_count,
+                                                     const int *__restrict__ cell_start, int *__restrict__ sc_first)
+{
+    const BuildDesc<T> &d = descs[blockIdx.y];
+    const int C = blockIdx.x * blockDim.x + threadIdx.x;
+    if (C >= d.nsc) return;
+    const int nx = d.g.nx, ny = d.g.ny, nz = d.g.nz;
+    const int nsx = (nx + 7) >> 3, nsy = (ny + 7) >> 3;
+    int first = -1;
+    if (sc_count[d.sbase + C] > 0) {
+        const int X = C % nsx, Y = (C / nsx) % nsy, Z = C / (nsx * nsy);
+        const int *cs = cell_start + d.cbase;
+        const int xa = 8 * X, xb = min(8 * X + 8, nx);
+        for (int r = 0; r < 64 && first < 0; ++r) {
+            const int y = 8 * Y + (r & 7), z = 8 * Z + (r >> 3);
+            if (y >= ny || z >= nz) continue;
+            const int row = nx * (y + ny * z);
+            const int a = cs[row + xa], b = cs[row + xb];
+            if (b > a) first = a;
+        }
+    }
+    sc_first[d.sbase + C] = first;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_sc_wit_b(const BuildDesc<T> *__restrict__ descs, const int *__restrict__ sc_dist,
+                                                   const int *__restrict__ sc_first, int *__restrict__ sc_wit)
+{
+    const BuildDesc<T> &d = descs[blockIdx.y];
+    const int C = blockIdx.x * blockDim.x + threadIdx.x;
+    if (C >= d.nsc) return;
+    const int nsx = (d.g.nx + 7) >> 3, nsy = (d.g.ny + 7) >> 3, nsz = (d.g.nz + 7) >> 3;
+    const int X = C % nsx, Y = (C / nsx) % nsy, Z = C / (nsx * nsy);
+    const int r = sc_dist[d.sbase + C];
+    int wit = -1;
+    if (r == 0) wit = sc_first[d.sbase + C];
+    else if (r <= kWitReach) {
+        // some super-cell of the shell at Chebyshev distance r is occupied: the first in (z, y, x) order wins
+        for (int dz = -r; dz <= r && wit < 0; ++dz) {
+            const int z = Z + dz;
+            if (z < 0 || z >= nsz) continue;
+            for (int dy = -r; dy <= r && wit < 0; ++dy) {
+                const int y = Y + dy;
+                if (y < 0 || y >= nsy) continue;
+                const bool face = dz == r || dz == -r || dy == r || dy == -r;
+                for (int dx = -r; dx <= r && wit < 0; dx += face ? 1 : 2 * r) {
+                    const int x = X + dx;
+                    if (x < 0 || x >= nsx) continue;
+                    wit = sc_first[d.sbase + x + nsx * (y + nsy * z)];
+                }
+            }
+        }
+    }
+    sc_wit[d.sbase + C] = wit;
 }
 
 // super-cell distance maps: one block per cloud, three sweeps separated by block barriers
@@ -895,7 +987,19 @@ __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<
     } else {
         T lb = lb_override >= (T)0 ? lb_override : (gr > (T)0 ? gr * gr : (T)0);
         if (best.slot < 0) {
-            // no candidate yet: look for a certificate that a neighbour within maxDist exists
+            // no candidate yet: one point of a nearest occupied super-cell (MapDev::sc_wit) -- within maxDist it
+            // settles that a neighbour exists, and it is a real candidate: the seed of the next iteration
+            const int Cx = cx >> 3, Cy = cy >> 3, Cz = cz >> 3;
+            const int wslot = as_global(M.sc_wit)[Cx + M.nsx * (Cy + M.nsy * Cz)];
+            if (wslot >= 0) {
+                Best<T> wb;
+                wb.d2 = ch.max_dist2; wb.idx = 0x7FFFFFFF; wb.slot = -1;
+                eval_point<T>(M.pts[wslot], wslot, qx, qy, qz, wb);
+                if (wb.slot >= 0) best = wb;
+            }
+        }
+        if (best.slot < 0) {
+            // still none: look for a certificate that a neighbour within maxDist exists
             const T H = g.h * (T)8;
             const int Cx = cx >> 3, Cy = cy >> 3, Cz = cz >> 3;
             T ub = Bits<T>::inf();
@@ -2467,13 +2571,14 @@ template <typename T>
 void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_f, long long tot_s,
                              int max_m, int max_cells, int max_cells_f, int max_nsc, int max_blocks, int *cell_of, int *counts, int *block_sums,
                              int *cell_start, int *cell_start_f, int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
-                             int *slot_of, int *sc_count, int *near, int *sc_dist)
+                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit)
 {
     (void)hipMemsetAsync(counts, 0, sizeof(int) * tot_f, st);
     (void)hipMemsetAsync(sc_count, 0, sizeof(int) * tot_s, st);
     const int nb = cdiv(tot_f, kScanChunk);
-    (void)hipMemsetAsync(block_sums, 0, sizeof(int) * (size_t)nb, st);
-    hipLaunchKernelGGL(k_cell_count_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, cell_of, counts, sc_count, slot_of, block_sums);
+    (void)hipMemsetAsync(block_sums, 0, sizeof(int) * (size_t)nb * 8, st);
+    hipLaunchKernelGGL(k_cell_count_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, cell_of, counts, sc_count, slot_of, block_sums, nb);
+    hipLaunchKernelGGL(k_sum_copies, dim3(cdiv(nb, 256)), dim3(256), 0, st, block_sums, nb, 8);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_f, (const int *)block_sums,
                        cell_start_f, (int *)nullptr, 1);
@@ -2496,6 +2601,9 @@ void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, l
             hipLaunchKernelGGL(k_scdist_pass_b<T>, dim3(cdiv(max_nsc, 256), n), dim3(256), 0, st, descs, pass, (const int *)sc_count,
                                counts, cursor, sc_dist);
     }
+    // (`counts` is scratch by now: the first point of every occupied super-cell, then the witness table)
+    hipLaunchKernelGGL(k_sc_first_b<T>, dim3(cdiv(max_nsc, 256), n), dim3(256), 0, st, descs, (const int *)sc_count, (const int *)cell_start, counts);
+    hipLaunchKernelGGL(k_sc_wit_b<T>, dim3(cdiv(max_nsc, 256), n), dim3(256), 0, st, descs, (const int *)sc_dist, (const int *)counts, sc_wit);
 }
 
 // once per scan: order every problem's pre-transformed reading by (map row, x)
@@ -2666,7 +2774,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_centroid_bbox_batch<T>(hipStream_t, const BuildDesc<T> *, int, int, unsigned long long *);       \
     template void launch_grid_build_batch<T>(hipStream_t, const BuildDesc<T> *, int, long long, long long, long long, int, \
                                              int, int, int, int, int *, int *, int *, int *, int *, int *, int *, typename Vec4<T>::type *,      \
-                                             typename Vec4<T>::type *, int *, int *, int *, int *);                       \
+                                             typename Vec4<T>::type *, int *, int *, int *, int *, int *);                \
     template void launch_query_sort<T>(hipStream_t, const ProblemDev *, const MapDev<T> *, const T *, T *, int *,         \
                                        unsigned long long *, int *, int *, int *, int *, int *, int, int, int, int);      \
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \

@@ -58,6 +58,7 @@ struct MapHost {
     int *sc_count = nullptr;
     int *near = nullptr;
     int *sc_dist = nullptr;
+    int *sc_wit = nullptr;
     // the one device allocation holding all of the above -- shared by the maps of one batched build and
     // returned to the pool (or freed) by whoever drops the last reference
     std::shared_ptr<SharedBlock> block;
@@ -255,6 +256,7 @@ int sync_maps_table(pgicp_ctx *c)
         h[i].slot_of = m.slot_of;
         h[i].near = m.near;
         h[i].sc_dist = m.sc_dist;
+        h[i].sc_wit = m.sc_wit;
         h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
     }
     HIPC(c, hipMemcpyAsync(S.d_maps.p, h.data(), sizeof(MapDev<T>) * n, hipMemcpyHostToDevice, c->stream));
@@ -427,7 +429,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     }
     HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)tot_m));                               // cell_of
     HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)tot_f));                               // counts (fine cells), then sweep scratch
-    HIPC(c, c->tmp_c.ensure(sizeof(int) * ((size_t)tot_f / kScanChunkHost + 2)));        // block sums
+    HIPC(c, c->tmp_c.ensure(sizeof(int) * 8 * ((size_t)tot_f / kScanChunkHost + 2)));    // block sums (8 partial copies)
     HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)tot_f));                               // cursor, then sweep scratch
     HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)tot_m));                               // order_tmp
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -435,13 +437,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
                  b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c),
                  b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0;
     auto blk = std::make_shared<SharedBlock>();
-    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near + b_csf, &blk->p, &blk->bytes); if (ast) return ast; }
+    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf, &blk->p, &blk->bytes); if (ast) return ast; }
     char *base = blk->p;
     V4 *g_pts = (V4 *)base, *g_nrm = any_nrm ? (V4 *)(base + b_pts) : nullptr;
     int *g_cs = (int *)(base + b_pts + b_nrm), *g_slot = (int *)(base + b_pts + b_nrm + b_cs),
         *g_sc = (int *)(base + b_pts + b_nrm + b_cs + b_slot), *g_near = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc),
         *g_scd = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc + b_near),
-        *g_csf = kx > 1 ? (int *)(base + b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near) : g_cs;
+        *g_wit = (int *)(base + b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near),
+        *g_csf = kx > 1 ? (int *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near) : g_cs;
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
         const BuildDesc<T> &d = descs[k];
@@ -454,13 +457,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         M.sc_count = g_sc + d.sbase;
         M.near = g_near + d.cbase;
         M.sc_dist = g_scd + d.sbase;
+        M.sc_wit = g_wit + d.sbase;
     }
     HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
         launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_f, tot_s, max_m, max_cells, max_cells_f, max_nsc, max_blocks, c->tmp_a.as<int>(),
                                    c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), g_pts, g_nrm,
-                                   g_slot, g_sc, g_near, g_scd);
+                                   g_slot, g_sc, g_near, g_scd, g_wit);
     }
     HIPC(c, hipStreamSynchronize(c->stream));          // `descs` (host) feeds an async copy
     HIPC(c, hipGetLastError());
