@@ -182,6 +182,10 @@ __device__ __forceinline__ void scdist_cell(const int *__restrict__ in, int nsx,
 }
 
 // three-phase exclusive scan over `n` ints (n up to 2^27)
+#ifndef PGICP_CHUNK_COPIES
+#define PGICP_CHUNK_COPIES 32
+#endif
+constexpr int kChunkCopies = PGICP_CHUNK_COPIES;   // partial copies of the scan's chunk sums (a multiple of the 8 XCDs)
 constexpr int kScanChunk = 4096;   // elements per block (1024 threads x 4)
 
 __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *lds /*>=17 ints*/, int &total)
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void k_cell_count_b(const BuildDesc<T> *__rest
     // the cell table of a range scan is 99 % zeros, which the scan then neither sums nor re-reads
     // (one copy of the sums per XCD -- blocks b and b+8 share one: neighbouring chunks share cache lines, and
     // atomics from eight L2s on one line were the whole kernel)
-    wave_bucket_count(chunk_sums + (long long)(blockIdx.x & 7) * n_chunks, c / kScanChunk, live);
+    wave_bucket_count(chunk_sums + (long long)(blockIdx.x & (kChunkCopies - 1)) * n_chunks, c / kScanChunk, live);
     if (!live) return;
     arrival[d.pbase + i] = pos;
     if (pos == 0) {
@@ -2576,9 +2580,9 @@ void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, l
     (void)hipMemsetAsync(counts, 0, sizeof(int) * tot_f, st);
     (void)hipMemsetAsync(sc_count, 0, sizeof(int) * tot_s, st);
     const int nb = cdiv(tot_f, kScanChunk);
-    (void)hipMemsetAsync(block_sums, 0, sizeof(int) * (size_t)nb * 8, st);
+    (void)hipMemsetAsync(block_sums, 0, sizeof(int) * (size_t)nb * kChunkCopies, st);
     hipLaunchKernelGGL(k_cell_count_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, cell_of, counts, sc_count, slot_of, block_sums, nb);
-    hipLaunchKernelGGL(k_sum_copies, dim3(cdiv(nb, 256)), dim3(256), 0, st, block_sums, nb, 8);
+    hipLaunchKernelGGL(k_sum_copies, dim3(cdiv(nb, 256)), dim3(256), 0, st, block_sums, nb, kChunkCopies);
     hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(1024), 0, st, block_sums, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(1024), 0, st, (const int *)counts, (int)tot_f, (const int *)block_sums,
                        cell_start_f, (int *)nullptr, 1);

@@ -429,7 +429,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     }
     HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)tot_m));                               // cell_of
     HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)tot_f));                               // counts (fine cells), then sweep scratch
-    HIPC(c, c->tmp_c.ensure(sizeof(int) * 8 * ((size_t)tot_f / kScanChunkHost + 2)));    // block sums (8 partial copies)
+    HIPC(c, c->tmp_c.ensure(sizeof(int) * 32 * ((size_t)tot_f / kScanChunkHost + 2)));   // block sums (up to 32 partial copies)
     HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)tot_f));                               // cursor, then sweep scratch
     HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)tot_m));                               // order_tmp
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
