@@ -186,6 +186,7 @@ __device__ __forceinline__ void scdist_cell(const int *__restrict__ in, int nsx,
 #define PGICP_CHUNK_COPIES 32
 #endif
 constexpr int kChunkCopies = PGICP_CHUNK_COPIES;   // partial copies of the scan's chunk sums (a multiple of the 8 XCDs)
+constexpr int kQueueCounterStride = 32;            // ints between the queue counters of two segments: one 128-byte line each
 constexpr int kScanChunk = 4096;   // elements per block (1024 threads x 4)
 
 __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *lds /*>=17 ints*/, int &total)
@@ -982,7 +983,7 @@ __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<
                                              int i, long long pos, int r_next, T lb_override, int *__restrict__ slot_io,
                                              T *__restrict__ d2_out, T *__restrict__ none_r,
                                              int *__restrict__ slow_count, int2 *__restrict__ slow_list, T *__restrict__ slow_lb,
-                                             int *__restrict__ slow_ring)
+                                             int *__restrict__ slow_ring, int q_cap)
 {
     // ---- phase C: bookkeeping for the lazy slow path ----
     if (resolved) {
@@ -1026,14 +1027,18 @@ __device__ __forceinline__ void finish_query(const MapDev<T> &M, const GridDesc<
             if (ub < Bits<T>::inf()) { best.d2 = ub; best.slot = -2; }   // exists, not located
             else { best.d2 = ch.max_dist2; best.slot = -2; lb = (T)-1; } // existence unknown: always resolved later
         }
-        // one atomic per wave: the unresolved lanes of the wave reserve consecutive queue slots
+        // One atomic per wave: the unresolved lanes of the wave reserve consecutive queue slots -- in the queue
+        // SEGMENT of (problem, XCD), whose counter has a cache line of its own.  Nearly every wave queues
+        // something (the ~10 % of a scan beyond the search cap), and with one counter for the whole launch
+        // those returning atomics, from eight L2s on one line, serialised the kernel: half of its time.
         const unsigned long long m = __ballot(1);
         const int lane = threadIdx.x & 63;
         const int leader = __ffsll((long long)m) - 1;
+        const int seg = prob * 8 + (blockIdx.x & 7);
         int base = 0;
-        if (lane == leader) base = atomicAdd(slow_count, __popcll(m));
+        if (lane == leader) base = atomicAdd(slow_count + kQueueCounterStride * seg, __popcll(m));
         base = __shfl(base, leader, 64);
-        const int k = base + __popcll(m & ((1ULL << lane) - 1ULL));
+        const long long k = (long long)seg * q_cap + base + __popcll(m & ((1ULL << lane) - 1ULL));
         slow_list[k] = make_int2(prob, i);
         slow_lb[k] = lb;
         slow_ring[k] = r_next;
@@ -1070,7 +1075,7 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
                                                   T *__restrict__ d2_out, ChainDev<T> ch, int use_seed, int fast_rings,
                                                   int *__restrict__ slow_count, int2 *__restrict__ slow_list,
                                                   T *__restrict__ slow_lb, int *__restrict__ slow_ring,
-                                                  const int *__restrict__ active, T *__restrict__ none_r)
+                                                  const int *__restrict__ active, T *__restrict__ none_r, int q_cap)
 {
     using V4 = typename Vec4<T>::type;
     constexpr int NR = (2 * R + 1) * (2 * R + 1);
@@ -1299,7 +1304,47 @@ __global__ __launch_bounds__(kFastBlock) PGICP_FAST_ATTR void k_knn_grid(const P
         else best.d2 = ch.max_dist2;
     }
     finish_query<T>(M, g, ch, resolved, gr, best, qx, qy, qz, ux, uy, uz, cx, cy, cz, prob, i, P.off + i, r_next, lb_override,
-                    slot_io, d2_out, none_r, slow_count, slow_list, slow_lb, slow_ring);
+                    slot_io, d2_out, none_r, slow_count, slow_list, slow_lb, slow_ring, q_cap);
+}
+
+// The fast pass queues per (problem, XCD) segment; the medium and slow paths want one dense list.
+// k_queue_offsets: exclusive scan of the segment counts (total -> counters[0], survivors counter cleared);
+// k_queue_compact: every segment's entries are copied behind those of the segments before it.
+__global__ __launch_bounds__(1024) void k_queue_offsets(const int *__restrict__ seg_count, int nseg, int *__restrict__ seg_start,
+                                                         int *__restrict__ counters)
+{
+    __shared__ int lds[32];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nseg; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nseg ? seg_count[kQueueCounterStride * i] : 0;
+        int total;
+        const int ex = block_exclusive_scan_1024(v, lds, total);
+        if (i < nseg) seg_start[i] = ex + carry;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counters[0] = carry; counters[1] = 0; counters[2] = 0; counters[3] = 0; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_queue_compact(const int *__restrict__ seg_count, const int *__restrict__ seg_start, int q_cap,
+                                                        const int2 *__restrict__ seg_list, const T *__restrict__ seg_lb,
+                                                        const int *__restrict__ seg_ring, int2 *__restrict__ list,
+                                                        T *__restrict__ lb, int *__restrict__ ring)
+{
+    const int seg = blockIdx.y;
+    const int cnt = seg_count[kQueueCounterStride * seg];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cnt) return;
+    const long long src = (long long)seg * q_cap + j;
+    const int dst = seg_start[seg] + j;
+    list[dst] = seg_list[src];
+    lb[dst] = seg_lb[src];
+    ring[dst] = seg_ring[src];
 }
 
 // Medium path: the queued queries that can still matter (lower bound within the threshold just
@@ -2648,21 +2693,39 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
     hipLaunchKernelGGL(k_pretransform<T>, dim3(cdiv(max_n, 256), P), dim3(256), 0, st, probs, src, rd_pre);
 }
 
+size_t knn_queue_bytes(int n_problems, int max_n, size_t elem)
+{
+    const size_t nseg = (size_t)n_problems * 8, q_cap = (size_t)(round8(cdiv(max_n, kFastBlock)) / 8) * kFastBlock;
+    return nseg * kQueueCounterStride * sizeof(int) + nseg * sizeof(int) + nseg * q_cap * (sizeof(int2) + elem + sizeof(int)) + 1024;
+}
+
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active, T *none_r, int counters_clean)
+                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf)
 {
-    if (!counters_clean) (void)hipMemsetAsync(slow_count, 0, 4 * sizeof(int), st);
     if (matcher == 1) {
+        (void)hipMemsetAsync(slow_count, 0, 4 * sizeof(int), st);
         hipLaunchKernelGGL(k_knn_brute<T>, dim3(cdiv(max_n, kKnnBlock), P), dim3(kKnnBlock), 0, st, probs, maps, rd, slot, d2,
                            ch, active);
         return;
     }
+    // segmented queue of this pass (see finish_query): [counters | starts | list | lb | ring]
+    const int nseg = n_problems * 8, q_cap = (round8(cdiv(max_n, kFastBlock)) / 8) * kFastBlock;
+    char *qb = (char *)queue_buf;
+    int *seg_count = (int *)qb;                 qb += sizeof(int) * (size_t)nseg * kQueueCounterStride;
+    int *seg_start = (int *)qb;                 qb += (sizeof(int) * (size_t)nseg + 255) & ~(size_t)255;
+    int2 *seg_list = (int2 *)qb;                qb += sizeof(int2) * (size_t)nseg * q_cap;
+    T *seg_lb = (T *)qb;                        qb += sizeof(T) * (size_t)nseg * q_cap;
+    int *seg_ring = (int *)qb;
+    (void)hipMemsetAsync(seg_count, 0, sizeof(int) * (size_t)nseg * kQueueCounterStride, st);
     // R = 1 in both cases: measured, a 5x5x5 collected block on the unseeded first iteration costs
     // 2.5x the ring-by-ring continuation (nothing prunes it until the own row has a hit)
     hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, kFastBlock)), P), dim3(kFastBlock), 0, st, probs, maps, rd, slot, d2, ch,
-                       use_seed, fast_rings, slow_count, slow_list, slow_lb, slow_ring, active, none_r);
+                       use_seed, fast_rings, seg_count, seg_list, seg_lb, seg_ring, active, none_r, q_cap);
+    hipLaunchKernelGGL(k_queue_offsets, dim3(1), dim3(1024), 0, st, (const int *)seg_count, nseg, seg_start, slow_count);
+    hipLaunchKernelGGL(k_queue_compact<T>, dim3(cdiv(q_cap, 256), nseg), dim3(256), 0, st, (const int *)seg_count, (const int *)seg_start,
+                       q_cap, (const int2 *)seg_list, (const T *)seg_lb, (const int *)seg_ring, slow_list, slow_lb, slow_ring);
 }
 
 template <typename T>
@@ -2784,7 +2847,7 @@ void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int 
     template void launch_transform<T>(hipStream_t, const T *, int, T *, int, int, const double *, int);                   \
     template void launch_pretransform<T>(hipStream_t, const ProblemDev *, const SrcDesc *, T *, int, int);                \
     template void launch_knn<T>(hipStream_t, int, const ProblemDev *, const MapDev<T> *, const T *, int *, T *,           \
-                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *, T *, int); \
+                                const ChainDev<T> &, int, int, int, int *, int2 *, T *, int *, int, const int *, T *, int, void *); \
     template void launch_knn_med<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                  \
                                     const ChainDev<T> &, int *, const int2 *, T *, int *, int *, int, int, T *);          \
     template void launch_knn_slow<T>(hipStream_t, ProblemDev *, const MapDev<T> *, const T *, int *, T *,                 \
