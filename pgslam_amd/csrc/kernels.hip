@@ -1336,9 +1336,9 @@ __global__ __launch_bounds__(256) void k_queue_compact(const int *__restrict__ s
                                                         const int *__restrict__ seg_ring, int2 *__restrict__ list,
                                                         T *__restrict__ lb, int *__restrict__ ring)
 {
-    const int seg = blockIdx.y;
+    const int seg = blockIdx.x;                      // (segments along x: a batch may have more than 8191 problems)
     const int cnt = seg_count[kQueueCounterStride * seg];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
     if (j >= cnt) return;
     const long long src = (long long)seg * q_cap + j;
     const int dst = seg_start[seg] + j;
@@ -2724,7 +2724,7 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
     hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, kFastBlock)), P), dim3(kFastBlock), 0, st, probs, maps, rd, slot, d2, ch,
                        use_seed, fast_rings, seg_count, seg_list, seg_lb, seg_ring, active, none_r, q_cap);
     hipLaunchKernelGGL(k_queue_offsets, dim3(1), dim3(1024), 0, st, (const int *)seg_count, nseg, seg_start, slow_count);
-    hipLaunchKernelGGL(k_queue_compact<T>, dim3(cdiv(q_cap, 256), nseg), dim3(256), 0, st, (const int *)seg_count, (const int *)seg_start,
+    hipLaunchKernelGGL(k_queue_compact<T>, dim3(nseg, cdiv(q_cap, 256)), dim3(256), 0, st, (const int *)seg_count, (const int *)seg_start,
                        q_cap, (const int2 *)seg_list, (const T *)seg_lb, (const int *)seg_ring, slow_list, slow_lb, slow_ring);
 }
 

@@ -507,6 +507,7 @@ struct BatchLayout {
 template <typename T, typename F>
 int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLayout &L, std::vector<ProblemDev> &hp)
 {
+    if (P > 65535) return fail(c, PGICP_ERR_ARG, "pgicp: at most 65535 problems per batch (the problem index is a launch-grid dimension)");
     State<T> &S = state<T>(c);
     L.P = P; L.max_n = 0; L.max_rows = 1; L.total = 0;
     size_t stage_total = 0;
@@ -1135,6 +1136,7 @@ int map_create_batch_abi(pgicp_ctx *c, int n, const T *const *xyz, const int *xs
                                 const int *m, int mem, int center, int *ids)
 {
     if (!c || n <= 0 || !xyz || !xs || !m || !ids || (nrm && !ns)) return fail(c, PGICP_ERR_ARG, "pgicp_map_create_batch: bad argument");
+    if (n > 65535) return fail(c, PGICP_ERR_ARG, "pgicp_map_create_batch: at most 65535 clouds per call");
     std::vector<MapSrc<T>> src(n);
     for (int k = 0; k < n; k++) src[k] = MapSrc<T>{xyz[k], xs[k], nrm ? nrm[k] : nullptr, nrm ? ns[k] : 0, m[k]};
     return map_create_batch<T>(c, n, src.data(), mem, center, ids);
