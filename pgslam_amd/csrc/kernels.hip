@@ -1334,9 +1334,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_queue_compact(const int *__restrict__ seg_count, const int *__restrict__ seg_start, int q_cap,
                                                         const int2 *__restrict__ seg_list, const T *__restrict__ seg_lb,
                                                         const int *__restrict__ seg_ring, int2 *__restrict__ list,
-                                                        T *__restrict__ lb, int *__restrict__ ring)
+                                                        T *__restrict__ lb, int *__restrict__ ring, const int *__restrict__ active)
 {
-    const int seg = blockIdx.x;                      // (segments along x: a batch may have more than 8191 problems)
+    // (segments along x: a batch may have more than 8191 problems; only the launched problems' segments hold anything)
+    const int seg = active[blockIdx.x >> 3] * 8 + (blockIdx.x & 7);
     const int cnt = seg_count[kQueueCounterStride * seg];
     const int j = blockIdx.y * blockDim.x + threadIdx.x;
     if (j >= cnt) return;
@@ -2724,8 +2725,8 @@ void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapD
     hipLaunchKernelGGL((k_knn_grid<T, 1>), dim3(round8(cdiv(max_n, kFastBlock)), P), dim3(kFastBlock), 0, st, probs, maps, rd, slot, d2, ch,
                        use_seed, fast_rings, seg_count, seg_list, seg_lb, seg_ring, active, none_r, q_cap);
     hipLaunchKernelGGL(k_queue_offsets, dim3(1), dim3(1024), 0, st, (const int *)seg_count, nseg, seg_start, slow_count);
-    hipLaunchKernelGGL(k_queue_compact<T>, dim3(nseg, cdiv(q_cap, 256)), dim3(256), 0, st, (const int *)seg_count, (const int *)seg_start,
-                       q_cap, (const int2 *)seg_list, (const T *)seg_lb, (const int *)seg_ring, slow_list, slow_lb, slow_ring);
+    hipLaunchKernelGGL(k_queue_compact<T>, dim3(P * 8, cdiv(q_cap, 256)), dim3(256), 0, st, (const int *)seg_count, (const int *)seg_start,
+                       q_cap, (const int2 *)seg_list, (const T *)seg_lb, (const int *)seg_ring, slow_list, slow_lb, slow_ring, active);
 }
 
 template <typename T>
