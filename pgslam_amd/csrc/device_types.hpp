@@ -38,6 +38,8 @@ struct MapDev {
     const int *near;                     // per 2x2x2 block of cells: a nearby occupied cell, -1 if none within kNearReach
     GridDesc<T> g;
     int m;
+    int first;                           // slot of this map's first point: the maps of one batched build share `pts`,
+                                         // and all cell tables hold slots into that shared array (no per-map rebasing pass)
     int nsx, nsy, nsz;                   // super-cell grid dims
 };
 

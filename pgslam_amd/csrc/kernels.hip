@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_cell_count_b(const BuildDesc<T> *__rest
     // the cell table of a range scan is 99 % zeros, which the scan then neither sums nor re-reads
     // (one copy of the sums per XCD -- blocks b and b+8 share one: neighbouring chunks share cache lines, and
     // atomics from eight L2s on one line were the whole kernel)
-    wave_bucket_count(chunk_sums + (long long)(blockIdx.x & (kChunkCopies - 1)) * n_chunks, c / kScanChunk, live);
+    wave_bucket_count(chunk_sums + (long long)((blockIdx.x + gridDim.x * blockIdx.y) & (kChunkCopies - 1)) * n_chunks, c / kScanChunk, live);
     if (!live) return;
     arrival[d.pbase + i] = pos;
     if (pos == 0) {
@@ -415,18 +415,11 @@ __global__ __launch_bounds__(256) void k_rank_place_b(const BuildDesc<T> *__rest
     pts[pos] = make_v4(x, y, z, Bits<T>::pack_idx(li));
     if (d.nrm) nrm_out[pos] = make_v4(d.nrm[(long long)li * d.nstride], d.nrm[(long long)li * d.nstride + 1],
                                       d.nrm[(long long)li * d.nstride + 2], (T)0);
-    slot_of[i] = (int)(pos - d.pbase);
+    slot_of[i] = (int)pos;                                   // a slot of the batch's shared point array (MapDev::first)
 }
 
-// the fine table of this cloud becomes local (offsets into ITS points); the table of the search cells is
-// every kx-th entry of it
-template <typename T>
-__global__ __launch_bounds__(256) void k_localise_b(const BuildDesc<T> *__restrict__ descs, int *__restrict__ cell_start_f)
-{
-    const BuildDesc<T> &d = descs[blockIdx.y];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= d.ncells_f) cell_start_f[d.fbase + c] -= (int)d.pbase;
-}
+// the table of the search cells is every kx-th entry of the fine table (both hold slots of the batch's shared
+// point array: no per-cloud rebasing pass -- it was 3 % of a loop-closure batch)
 template <typename T>
 __global__ __launch_bounds__(256) void k_coarse_table_b(const BuildDesc<T> *__restrict__ descs, const int *__restrict__ cell_start_f,
                                                          int *__restrict__ cell_start)
@@ -1778,7 +1771,7 @@ __global__ __launch_bounds__(128) void k_surface_normals(const MapDev<T> *__rest
     const GridDesc<T> g = M.g;
     const int s0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (s0 >= M.m) return;
-    const auto me = load_rec<T>(M.pts, s0);
+    const auto me = load_rec<T>(M.pts, M.first + s0);
     const T qx = me.x, qy = me.y, qz = me.z;
     const int self = Bits<T>::unpack_idx(me.w);
     const T md2 = max_dist * max_dist;
@@ -1899,14 +1892,14 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_brute(const ProblemDev *__res
     best.d2 = ch.max_dist2; best.idx = 0x7FFFFFFF; best.slot = -1;
     for (int base = 0; base < M.m; base += kBruteTile) {
         const int cnt = min(kBruteTile, M.m - base);
-        for (int k = threadIdx.x; k < cnt; k += kKnnBlock) tile[k] = M.pts[base + k];
+        for (int k = threadIdx.x; k < cnt; k += kKnnBlock) tile[k] = M.pts[M.first + base + k];
         __syncthreads();
         for (int k = 0; k < cnt; ++k) {
             const V4 v = tile[k];
             const T dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
             const T d = (dx * dx + dy * dy) + dz * dz;
             const int idx = Bits<T>::unpack_idx(v.w);
-            if (d < best.d2 || (d == best.d2 && idx < best.idx)) { best.d2 = d; best.idx = idx; best.slot = base + k; }
+            if (d < best.d2 || (d == best.d2 && idx < best.idx)) { best.d2 = d; best.idx = idx; best.slot = M.first + base + k; }
         }
         __syncthreads();
     }
@@ -2636,8 +2629,6 @@ void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, l
                        (const int *)cell_start_f, (const int *)slot_of, order_tmp);
     hipLaunchKernelGGL(k_rank_place_b<T>, dim3(cdiv(max_m, 256), n), dim3(256), 0, st, descs, (const int *)cell_of,
                        (const int *)cell_start_f, (const int *)order_tmp, pts, nrm_out, slot_of);
-    if (n > 1)       // a single cloud's offsets are local already
-        hipLaunchKernelGGL(k_localise_b<T>, dim3(cdiv(max_cells_f + 1, 256), n), dim3(256), 0, st, descs, cell_start_f);
     if (cell_start != cell_start_f)
         hipLaunchKernelGGL(k_coarse_table_b<T>, dim3(cdiv(max_cells + 1, 256), n), dim3(256), 0, st, descs, (const int *)cell_start_f,
                            cell_start);

@@ -59,6 +59,7 @@ struct MapHost {
     int *near = nullptr;
     int *sc_dist = nullptr;
     int *sc_wit = nullptr;
+    int first = 0;                  // MapDev::first
     // the one device allocation holding all of the above -- shared by the maps of one batched build and
     // returned to the pool (or freed) by whoever drops the last reference
     std::shared_ptr<SharedBlock> block;
@@ -257,6 +258,7 @@ int sync_maps_table(pgicp_ctx *c)
         h[i].near = m.near;
         h[i].sc_dist = m.sc_dist;
         h[i].sc_wit = m.sc_wit;
+        h[i].first = m.first;
         h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
     }
     HIPC(c, hipMemcpyAsync(S.d_maps.p, h.data(), sizeof(MapDev<T>) * n, hipMemcpyHostToDevice, c->stream));
@@ -449,8 +451,9 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         MapHost<T> &M = Ms[k];
         const BuildDesc<T> &d = descs[k];
         M.block = blk;
-        M.pts = g_pts + d.pbase;
-        M.nrm = M.has_nrm ? g_nrm + d.pbase : nullptr;
+        M.pts = g_pts;                               // shared by the batch; this map's points start at slot `first`
+        M.nrm = M.has_nrm ? g_nrm : nullptr;
+        M.first = (int)d.pbase;
         M.cell_start = g_cs + d.cbase;
         M.cell_start_f = g_csf + d.fbase;
         M.slot_of = g_slot + d.pbase;
