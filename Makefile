@@ -10,7 +10,7 @@ OBJS = $(CSRC)/kernels.o $(CSRC)/pgicp_api.o
 
 all: $(LIB) oracle
 
-$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.hpp $(CSRC)/device_types.hpp $(CSRC)/icp_math.hpp
+$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/k_*.inc) $(CSRC)/kernels.hpp $(CSRC)/device_types.hpp $(CSRC)/icp_math.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/pgicp_api.o: $(CSRC)/pgicp_api.cpp $(CSRC)/kernels.hpp $(CSRC)/device_types.hpp $(CSRC)/icp_math.hpp include/pgicp.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
