@@ -211,3 +211,27 @@ def test_outlier_selection_f64(ctx, oracle64):
         np.testing.assert_allclose(st["trim_limit"], o["trim_limit"], rtol=1e-11)   # device vs host libm in the transforms
     ctx.set_params(**CHAIN)
     ctx.destroy_map(m)
+
+
+def test_many_small_problems_in_one_batch(ctx, oracle32):
+    """More than 128 problems: the matcher's queue has more than 1024 (problem, XCD) segments, so their offsets are
+    scanned in several rounds.  Every problem must come out as it does alone."""
+    t = synth.make_two_scans(3000, rings=16)
+    m = ctx.set_map(t["ref_xyz"], t["ref_nrm"])
+    P = 300
+    rng = np.random.default_rng(11)
+    readings, T0 = [], []
+    for p in range(P):
+        n = int(rng.integers(200, 900))
+        start = int(rng.integers(0, 3000 - n))
+        readings.append(np.ascontiguousarray(t["reading_xyz"][start:start + n]))
+        T0.append(t["T_init"] @ synth.perturbation(p))
+    Ts, st = ctx.align_batch([m] * P, readings, T0, raise_on_error=False)
+    for p in list(range(0, P, 37)) + [P - 1]:
+        o = oracle32.icp(readings[p], t["ref_xyz"], t["ref_nrm"], T0[p], **CHAIN)
+        assert st[p]["status"] == o["status"], p
+        if o["status"] == 0:
+            dt, dr = pose_error(o["T"], Ts[p])
+            assert dt < 1e-5 and dr < 1e-5, (p, dt, dr)
+            assert st[p]["iterations"] == o["iterations"] and st[p]["n_finite"] == o["n_finite"] and st[p]["n_kept"] == o["n_kept"], p
+    ctx.destroy_map(m)
