@@ -1229,10 +1229,19 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     if (const char *e = std::getenv("PGICP_POLL_US")) c->poll_us = std::atoi(e);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_flag, 64 * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         delete c;
         return PGICP_ERR_HIP;
+    }
+    // the polled iteration flag wants fine-grained (coherent) pinned memory; plain pinned memory also works with the
+    // stream wait the poll falls back to, so a runtime that refuses the flags is not fatal
+    if (hipHostMalloc((void **)&c->h_flag, 64 * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        c->poll_us = 0;
+        if (hipHostMalloc((void **)&c->h_flag, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            delete c;
+            return PGICP_ERR_HIP;
+        }
     }
     c->h_flag[0] = 0; c->h_flag[1] = 0;
     *out = c;
