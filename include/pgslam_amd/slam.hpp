@@ -694,6 +694,17 @@ private:
         out.assign(comp.begin(), comp.end());
         return true;
     }
+public:
+    //! The overlap half of IsBetterComposition (Localizer.hpp:363-372): a candidate composition is taken only
+    //! when its overlap is itself sufficient (IsOverlapEnough, :355-361) AND larger than the current one --
+    //! in the low-overlap branch a neighbour that is better but still insufficient must not stop the new
+    //! keyframe (:228-247).  (The "same composition" half cannot occur here: FindNeighborComposition always
+    //! brings a vertex from outside the composition.)
+    static bool IsBetterOverlap(T current_overlap, T candidate_overlap, T threshold)
+    {
+        return candidate_overlap >= threshold && candidate_overlap > current_overlap;
+    }
+private:
     void UpdateAfterIcp()                                                   // Localizer.hpp:178-268
     {
         auto &g = map_manager_->GetGraph();
@@ -701,7 +712,7 @@ private:
         std::vector<size_t> next = comp_, neigh;
         const bool enough = overlap >= overlap_threshold_;
         bool took_neighbor = false;
-        if (FindNeighborComposition(neigh) && OverlapWith(neigh) > overlap) { next = neigh; took_neighbor = true; }   // IsBetterComposition :363-372
+        if (FindNeighborComposition(neigh) && IsBetterOverlap(overlap, OverlapWith(neigh), overlap_threshold_)) { next = neigh; took_neighbor = true; }
         if (!took_neighbor) {
             if (enough) {
                 size_t best = 0;

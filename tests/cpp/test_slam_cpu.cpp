@@ -36,6 +36,14 @@ int main()
         for (int a = 0; a < 9; a++) CHECK(std::fabs(I.R[a] - (a % 4 == 0 ? 1.0 : 0.0)) < 1e-12);
     }
 
+    // ---- IsBetterComposition (Localizer.hpp:363-372): a neighbour composition whose overlap beats the current one
+    // but stays under the threshold is NOT taken -- in the low-overlap branch the new keyframe must still be created
+    CHECK(!GraphLocalizer<float>::IsBetterOverlap(0.5f, 0.55f, 0.8f));
+    CHECK(GraphLocalizer<float>::IsBetterOverlap(0.5f, 0.85f, 0.8f));
+    CHECK(!GraphLocalizer<float>::IsBetterOverlap(0.9f, 0.85f, 0.8f));
+    CHECK(!GraphLocalizer<double>::IsBetterOverlap(0.85, 0.85, 0.8));
+    CHECK(GraphLocalizer<double>::IsBetterOverlap(0.79, 0.8, 0.8));
+
     // ---- graph: a chain 0-1-2-3-4 with unit steps plus a long edge 0-4; Dijkstra settles by distance
     PoseGraph<double> G;
     for (int i = 0; i < 5; i++) G.AddVertex(kf_at(i, i, 0, 0));
