@@ -100,42 +100,57 @@ def build_workload(n_scan, n_map, n_queries, cache_dir="/tmp"):
     return synth.ScanToMap(map_xyz, map_nrm, scans, [None] * n_queries, truth, init)
 
 
-def cpu_baseline(w, sample_scans, max_threads):
-    """Time the oracle (kd-tree port of the reference chain) on host cores: one
-    independent ICP per thread (pgslam gives each ICP object one thread,
-    LocalizerMT.hpp:43-48).  The kd-tree build is timed separately (setMap)."""
+def cpu_baseline(w, sample_scans, n_threads, reps=3):
+    """Time the oracle (kd-tree port of the reference chain) on ALL host cores: one independent ICP
+    per thread (pgslam gives each ICP object one thread, LocalizerMT.hpp:43-48), scans handed out from
+    a shared counter, `reps` repetitions, median.  The kd-tree build is timed
+    separately (setMap).  The single-core figure is the median of `reps` runs of one scan."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle
+    import itertools
+    import statistics
     o = Oracle(np.float32)
     t0 = time.perf_counter()
     m = o.map_create(w.map_xyz, w.map_nrm, center=True, use_kdtree=True)
     t_build = time.perf_counter() - t0
-    n_thr = max(1, min(max_threads, sample_scans))
-    results = [None] * sample_scans
+    n_thr = max(1, n_threads)
+    n_scans = max(sample_scans, n_thr)                 # every core gets at least one scan
 
-    def work(tid):
-        for b in range(tid, sample_scans, n_thr):
-            q = b % len(w.scans_xyz)
-            results[b] = o.icp_map(m, w.scans_xyz[q], w.T_init[q], **CHAIN)
+    t_one, r0 = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r0 = o.icp_map(m, w.scans_xyz[0], w.T_init[0], **CHAIN)
+        t_one.append(time.perf_counter() - t0)
 
-    # single-core figure on one scan
-    t0 = time.perf_counter()
-    r0 = o.icp_map(m, w.scans_xyz[0], w.T_init[0], **CHAIN)
-    t_one = time.perf_counter() - t0
-    th = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
+    rates, results = [], None
+    for _ in range(reps):
+        results = [None] * n_scans
+        ticket = itertools.count()                     # next() on it is atomic under the GIL
+
+        def work():
+            while True:
+                b = next(ticket)
+                if b >= n_scans:
+                    return
+                q = b % len(w.scans_xyz)
+                results[b] = o.icp_map(m, w.scans_xyz[q], w.T_init[q], **CHAIN)   # ctypes call: the GIL is released
+
+        th = [threading.Thread(target=work) for _ in range(n_thr)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        rates.append(sum(1 for r in results if r["status"] == 0 and r["converged"]) / dt)
     o.map_free(m)
-    conv = sum(1 for r in results if r["status"] == 0 and r["converged"])
     iters = float(np.mean([r["iterations"] for r in results]))
-    return dict(value=conv / dt, unit="scans/s", cores=n_thr, kind="port",
-                sample=f"{sample_scans} of the benchmark's 100k-pt scans vs the 1M-pt map, kd-tree oracle, "
-                       f"one ICP per thread, {n_thr} threads; index build excluded",
-                single_core_scans_per_s=(1.0 / t_one if r0["status"] == 0 else 0.0),
+    return dict(value=statistics.median(rates), unit="scans/s", cores=n_thr, kind="port",
+                sample=f"{n_scans} of the benchmark's 100k-pt scans vs the 1M-pt map, kd-tree oracle (CPU restatement of the "
+                       f"reference chain, not libpointmatcher), one ICP per thread on all {n_thr} host cores "
+                       f"(os.cpu_count() = {os.cpu_count()}), median of {reps} repetitions; index build excluded",
+                host_cores=os.cpu_count(), repetitions=reps, all_core_rates=rates,
+                single_core_scans_per_s=(1.0 / statistics.median(t_one) if r0["status"] == 0 else 0.0),
                 mean_iterations=iters, index_build_s=t_build)
 
 
@@ -452,14 +467,16 @@ def main():
     ap.add_argument("--n-scan", type=int, default=100_000)
     ap.add_argument("--n-map", type=int, default=1_000_000)
     ap.add_argument("--fixed-iters", action="store_true", help="disable the Differential checker: exactly 30 iterations")
-    ap.add_argument("--with-fixed30", action="store_true",
-                    help="after the timed run, also time one step with the Differential checker disabled and report it as "
-                         "`fixed_30_iterations` (off by default so that a kernel trace of the default command holds only the metric's launches)")
+    ap.add_argument("--no-fixed30", action="store_true",
+                    help="skip the companion figure: by default, after the timed run, one step is also timed with the Differential "
+                         "checker disabled (exactly 30 iterations per scan, SURVEY.md section 8(d)) and reported as `fixed_30_iterations`; "
+                         "pass this for a kernel trace that should hold only the metric's launches")
+    ap.add_argument("--with-fixed30", action="store_true", help="(the default now; kept so that older command lines still parse)")
     ap.add_argument("--matcher", choices=["grid", "brute"], default="grid")
     ap.add_argument("--grid-cell", type=float, default=0.0)
     ap.add_argument("--check-every", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--cpu-sample", type=int, default=64, help="scans of the CPU baseline's batch (at least one per host core)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams, one host thread each) the batch is split over; each keeps its own "
@@ -590,34 +607,46 @@ def main():
     err_t = [float(np.linalg.norm((np.linalg.inv(w.T_truth[b % len(d_scans)]) @ T[b])[:3, 3])) for b in range(B)
              if st[b]["status"] == 0]
 
-    # ---- roofline: kNN kernel timed with HIP events on the context's stream ----
+    # ---- roofline: kNN kernel timed with HIP events on the context's stream, over a replay of the timed
+    #      region (the same `--steps` steps once more with an event pair around every launch) ----
     roofline = None
     kern = {}
     if not args.no_profile:
         ctx.set_params(check_every=1)
         ctx.profile_reset()
         ctx.profile_enable(True)
-        step()
+        for _ in range(args.steps):
+            step()
         ctx.profile_enable(False)
         prof = ctx.profile()
         kname = "knn_grid" if args.matcher == "grid" else "knn_brute"
         k = prof[kname]
         if k["launches"]:
+            # algorithmic bytes: 20 N + 12 M per ACTIVE problem of a launch
             alg_bytes = 20.0 * k["units"] + 12.0 * args.n_map * k["problems"]      # sum over launches
+            # physically compulsory bytes: the problems of a launch share ONE resident map, read once
+            shared_bytes = 20.0 * k["units"] + 12.0 * args.n_map * k["launches"]
             avg_s = k["total_ms"] * 1e-3 / k["launches"]
             achieved = alg_bytes / k["launches"] / avg_s / 1e9
-            traffic = None
+            achieved_shared = shared_bytes / k["launches"] / avg_s / 1e9
+            traffic = traffic_raw = traffic_src = None
             tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("n_scan") == args.n_scan and tj.get("n_map") == args.n_map and tj.get("batch") == B:
                         traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_raw = tj.get("hbm_bytes_per_launch_uncorrected")
+                        traffic_src = ("NOT measured in this run: profiles/knn_traffic.json, separate rocprofv3 --pmc FETCH_SIZE / "
+                                       "WRITE_SIZE passes of this command (tools/measure_round.sh); " + str(tj.get("note", "")))
                 except (OSError, ValueError):
                     pass
             roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                            avg_launch_us=avg_s * 1e6, launches=k["launches"],
+                            frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_uncorrected=traffic_raw,
+                            traffic_source=traffic_src,
+                            achieved_shared_map=achieved_shared, frac_shared_map=achieved_shared / HBM_PEAK_GBS,
+                            compulsory_bytes_per_launch_shared_map=shared_bytes / k["launches"],
+                            avg_launch_us=avg_s * 1e6, launches=k["launches"], profiled_steps=args.steps,
                             algorithmic_bytes_per_launch=alg_bytes / k["launches"],
                             active_problems_per_launch=k["problems"] / k["launches"])
         for name, v in prof.items():
@@ -628,7 +657,7 @@ def main():
     # ---- workload-stable companion figure: the same step with the Differential
     #      checker disabled, i.e. exactly 30 iterations per scan; reported next to the metric, never as `value`
     fixed30 = None
-    if args.with_fixed30 and not args.fixed_iters:
+    if not args.no_fixed30 and not args.fixed_iters:
         for c in ctxs:
             c.set_params(min_diff_rot=0.0, min_diff_trans=0.0, check_every=args.check_every)
         step()
@@ -645,6 +674,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, args.cpu_sample, os.cpu_count() or 1)
+        cpu["gpu_over_single_core"] = ((converged_all / elapsed_max) / cpu["single_core_scans_per_s"]
+                                       if cpu["single_core_scans_per_s"] else None)
 
     if rank == 0:
         value = converged_all / elapsed_max

@@ -9,6 +9,9 @@
 //
 // wave = 64 lanes everywhere; no warp-size-32 idiom is used.
 #include "kernels.hpp"
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
 #ifndef PGICP_FAST_BLOCK
 #define PGICP_FAST_BLOCK 64
 #endif
@@ -78,6 +81,8 @@ __device__ __forceinline__ void apply_T(const double *Tc, T x, T y, T z, T &ox, 
 #include "k_build.inc"
 #include "k_sort.inc"
 #include "k_match.inc"
+#include "k_match_quad.inc"
+#include "k_match_pool.inc"
 #include "k_normals.inc"
 #include "k_select.inc"
 #include "k_minimise.inc"

@@ -23,7 +23,7 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf);
+                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf, int fast_kernel);
 size_t knn_queue_bytes(int n_problems, int max_n, size_t elem);
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
@@ -38,6 +38,7 @@ void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const Ch
                         const int *active, int *tables, void *keys);
 size_t trim_select_table_bytes(int P);
 int knn_stats_read(unsigned long long out[56], int reset);
+int knn_phase_read(unsigned long long out[32], int reset);   // diagnostics build only: wave cycles per phase of the fast kernel
 int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
 void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp,
                            int *queue_counters);

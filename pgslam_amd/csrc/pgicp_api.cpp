@@ -104,6 +104,8 @@ struct pgicp_ctx {
     std::multimap<size_t, char *> block_pool;
     size_t pooled_bytes = 0;
     int fast_rings_seeded = 1, fast_rings_unseeded = 3;
+    int fast_kernel = 0;            // fast matcher: 0 one query per lane (k_knn_grid); 1, 2 quads walk the candidates (k_knn_quad);
+                                    // 3, 4 wave-wide candidate pool (k_knn_pool, float only); odd: seeded passes look all rows up in one round
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
@@ -633,7 +635,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
                       c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active, S.none_r.template as<T>(),
-                      L.P, c->queue.p);
+                      L.P, c->queue.p, c->fast_kernel);
         c->counters_clean = 0;
     }
     {
@@ -826,7 +828,7 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p);
+                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p, c->fast_kernel);
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
@@ -1224,6 +1226,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     pgicp_default_params(&c->prm);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_SEEDED")) c->fast_rings_seeded = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_KX")) c->grid_kx = std::atoi(e);
+    if (const char *e = std::getenv("PGICP_FAST_KERNEL")) c->fast_kernel = std::min(4, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("PGICP_NEAR_FRAC")) c->near_frac = std::atof(e);
     if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_POLL_US")) c->poll_us = std::atoi(e);
@@ -1474,9 +1477,19 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
 {
     if (!c || !out) return PGICP_ERR_ARG;
     HIPC(c, hipMemcpy(out, c->small.as<int>() + (c->counters_clean ? 24 : 16), 4 * sizeof(int), hipMemcpyDeviceToHost));
-    if (std::getenv("PGICP_KNN_STATS_DUMP")) {          // diagnostics build only
+    if (std::getenv("PGICP_KNN_STATS_DUMP")) {          // diagnostics builds only
         unsigned long long s[56];
         (void)hipDeviceSynchronize();
+        {
+            unsigned long long ph[32];
+            if (knn_phase_read(ph, 1) == 0)
+                for (int u = 0; u < 2; u++) {
+                    const double nw = (double)std::max<unsigned long long>(1ULL, ph[16 * u + 15]);
+                    std::fprintf(stderr, "  fast kernel, %s: waves=%llu; cycles per wave by phase [set-up, near, own row, row tables, flat walk, rings, finish]:", u ? "seeded passes" : "unseeded pass", ph[16 * u + 15]);
+                    for (int k = 0; k < 7; k++) std::fprintf(stderr, " %.0f", (double)ph[16 * u + k] / nw);
+                    std::fprintf(stderr, "\n");
+                }
+        }
         if (knn_stats_read(s, 1) == 0) {
             std::fprintf(stderr, "knn_stats waves=%llu a1_max=%llu a1_sum=%llu flat_iters_max=%llu a2_sum=%llu b_cand=%llu unresolved=%llu b_lanes=%llu b_max=%llu tot_max=%llu\n",
                          s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9]);

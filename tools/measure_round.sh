@@ -7,7 +7,7 @@ mkdir -p $OUT
 python3 bench.py --prepare-only > /dev/null 2>&1
 python3 bench.py --workload stream --prepare-only > /dev/null 2>&1
 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench_n1.json
-python3 bench.py --with-fixed30 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_n1_with_fixed30.json
+python3 bench.py --fixed-iters --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_n1_fixed30.json
 python3 bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_loopclosure.json
 python3 bench.py --workload stream --streams 1 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_1.json
 python3 bench.py --workload stream --streams 4 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_4.json
@@ -16,9 +16,9 @@ python3 bench.py --workload stream --streams 64 --fleet --steps 1 --warmup 1 2>/
 python3 tools/bench_normals.py 2>/dev/null | grep -v amdgpu > $OUT/bench_normals.json
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace -o t -- python3 $REPO/bench.py > $REPO/$OUT/trace.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $REPO/$OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $REPO/$OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace -o t -- python3 $REPO/bench.py --no-fixed30 --no-cpu-baseline > $REPO/$OUT/trace.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 > $REPO/$OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 > $REPO/$OUT/pmc_write.log 2>&1
 cd $REPO
 python3 tools/trace_summary.py $OUT/trace > $OUT/trace_summary.txt 2>&1
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/knn_traffic.json 100000 1000000 128 > $OUT/pmc.log 2>&1
