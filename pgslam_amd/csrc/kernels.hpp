@@ -23,7 +23,7 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf, int fast_kernel);
+                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf);
 size_t knn_queue_bytes(int n_problems, int max_n, size_t elem);
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,

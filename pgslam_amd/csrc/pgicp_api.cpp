@@ -104,8 +104,6 @@ struct pgicp_ctx {
     std::multimap<size_t, char *> block_pool;
     size_t pooled_bytes = 0;
     int fast_rings_seeded = 1, fast_rings_unseeded = 3;
-    int fast_kernel = 0;            // fast matcher: 0 one query per lane (k_knn_grid); 1, 2 quads walk the candidates (k_knn_quad);
-                                    // 3, 4 wave-wide candidate pool (k_knn_pool, float only); odd: seeded passes look all rows up in one round
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
@@ -635,7 +633,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
                       c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active, S.none_r.template as<T>(),
-                      L.P, c->queue.p, c->fast_kernel);
+                      L.P, c->queue.p);
         c->counters_clean = 0;
     }
     {
@@ -828,7 +826,7 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p, c->fast_kernel);
+                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p);
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
@@ -1226,7 +1224,6 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     pgicp_default_params(&c->prm);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_SEEDED")) c->fast_rings_seeded = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_KX")) c->grid_kx = std::atoi(e);
-    if (const char *e = std::getenv("PGICP_FAST_KERNEL")) c->fast_kernel = std::min(4, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("PGICP_NEAR_FRAC")) c->near_frac = std::atof(e);
     if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_POLL_US")) c->poll_us = std::atoi(e);
