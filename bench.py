@@ -290,6 +290,163 @@ def build_drive(n_scans, n_pts, step, cache_dir="/tmp"):
     return poses, odom, xyz, nrm
 
 
+def _gen_city_scan(args):
+    from pgslam_amd import synth
+    block, s, n_pts, pose = args
+    global _CITY
+    try:
+        city = _CITY[block]
+    except (NameError, KeyError):
+        _CITY = {block: synth.make_city(block)}
+        city = _CITY[block]
+    return synth.make_city_scan(city, pose, n_pts, s)
+
+
+def build_sequence(n_scans, n_pts, step, cache_dir="/tmp"):
+    """BASELINE configs[3]: the KITTI-00-shaped drive of synth.city_route as a sequence file for tools/slam_run
+    (format in its header).  Ray casting spread over host cores, written scan by scan, cached."""
+    from pgslam_amd import synth
+    path = os.path.join(cache_dir, f"pgslam_amd_seq_{n_scans}_{n_pts}_{step}.bin")
+    if os.path.exists(path) and os.path.getsize(path) == 12 + n_scans * (256 + 24 * n_pts):
+        return path
+    import multiprocessing as mp
+    block, poses = synth.city_route(n_scans, step)
+    odom = synth.city_odometry(poses)
+    nproc = max(1, min(os.cpu_count() or 1, 32))
+    with open(path + ".tmp", "wb") as f, mp.get_context("fork").Pool(nproc) as pool:
+        f.write(np.array([0x51534750, n_scans, n_pts], dtype=np.int32).tobytes())
+        jobs = ((block, s, n_pts, poses[s]) for s in range(n_scans))
+        for s, (xyz, nrm) in enumerate(pool.imap(_gen_city_scan, jobs, chunksize=8)):
+            f.write(np.ascontiguousarray(poses[s], dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(odom[s], dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(xyz, dtype=np.float32).tobytes())
+            f.write(np.ascontiguousarray(nrm, dtype=np.float32).tobytes())
+    os.replace(path + ".tmp", path)
+    return path
+
+
+def build_slam_run():
+    """g++ build of the C++ driver against include/ and the in-tree libpgicp.so (always rebuilt: seconds)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "slam_run")
+    lib = os.path.join(ROOT, "pgslam_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unused-local-typedefs", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "slam_run.cpp"), "-o", exe, "-L" + lib, "-lpgicp",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def read_replay(path):
+    """Records written by slam_run --record: list of dicts (kind, scan, reading, ref_xyz, ref_nrm, T_init, T_out, ...)."""
+    out = []
+    with open(path, "rb") as f:
+        head = np.frombuffer(f.read(16), dtype=np.int32)
+        assert head[0] == 0x50524750 and head[1] == 1, "not a slam_run record file"
+        for _ in range(int(head[2])):
+            h = np.frombuffer(f.read(32), dtype=np.int32)
+            t = np.frombuffer(f.read(256), dtype=np.float64)
+            ov = float(np.frombuffer(f.read(8), dtype=np.float64)[0])
+            n, m = int(h[2]), int(h[3])
+            rd = np.frombuffer(f.read(12 * n), dtype=np.float32).reshape(n, 3)
+            rx = np.frombuffer(f.read(12 * m), dtype=np.float32).reshape(m, 3)
+            rn = np.frombuffer(f.read(12 * m), dtype=np.float32).reshape(m, 3)
+            out.append(dict(kind=int(h[0]), scan=int(h[1]), iterations=int(h[4]), converged=int(h[5]), status=int(h[6]),
+                            max_iter_reached=int(h[7]), overlap=ov, T_init=t[:16].reshape(4, 4), T_out=t[16:].reshape(4, 4),
+                            reading=rd, ref_xyz=rx, ref_nrm=rn))
+    return out
+
+
+def main_slam(args):
+    """BASELINE configs[3]: full pose-graph SLAM on the synthetic KITTI-00-shaped sequence through the C++ facade
+    (host clouds in, as a pgslam user feeds them); pose-graph solve on the host.  One step = the whole sequence.
+    N > 1: independent replicas (one sequence per rank, each process pinned to its GPU)."""
+    import subprocess
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")          # only a barrier and a max over ranks: host side
+    if rank == 0:
+        seq = build_sequence(args.slam_scans, args.slam_points, args.slam_step)
+        exe = build_slam_run()
+    if distributed:
+        dist.barrier()
+    if rank != 0:
+        seq = build_sequence(args.slam_scans, args.slam_points, args.slam_step)
+        exe = os.path.join(ROOT, "tools", "slam_run")
+    if args.prepare_only:
+        return
+    env = dict(os.environ)
+    if distributed:
+        env["HIP_VISIBLE_DEVICES"] = str(local_rank)
+    rec = f"/tmp/pgslam_amd_replay_{rank}.bin"
+
+    def run(record):
+        cmd = [exe, seq] + (["--record", str(args.slam_record), rec] if record else [])
+        t0 = time.perf_counter()
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, check=True)
+        return json.loads(out.stdout.strip().splitlines()[-1]), time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        run(False)
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    res = None
+    slam_s = 0.0
+    for _ in range(args.steps):
+        res, _ = run(False)
+        slam_s += res["slam_s"]
+    if distributed:
+        dist.barrier()
+        t = torch.tensor([slam_s], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        slam_s = float(t.item())
+    # one more pass that records ICP calls, replayed through the CPU oracle: parity evidence + the CPU figure
+    cpu = None
+    replay = None
+    if rank == 0 and not args.no_cpu_baseline:
+        run(True)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle import Oracle
+        o = Oracle(np.float32)
+        recs = read_replay(rec)
+        worst_t = worst_r = 0.0
+        same_iters = 0
+        t_cpu = 0.0
+        for r in recs:
+            t1 = time.perf_counter()
+            ref = o.icp(r["reading"], r["ref_xyz"], r["ref_nrm"], r["T_init"], **CHAIN)
+            t_cpu += time.perf_counter() - t1
+            d = np.linalg.inv(ref["T"]) @ r["T_out"]
+            worst_t = max(worst_t, float(np.linalg.norm(d[:3, 3])))
+            # (rotation angle from the skew part: arccos(trace) turns the 6e-8 rounding of the facade's float matrices into 3e-4 rad)
+            worst_r = max(worst_r, float(np.linalg.norm([d[2, 1] - d[1, 2], d[0, 2] - d[2, 0], d[1, 0] - d[0, 1]]) / 2.0))
+            same_iters += int(ref["iterations"] == r["iterations"])
+        replay = dict(calls=len(recs), loop_closure_calls=sum(1 for r in recs if r["kind"] == 1), worst_translation_m=worst_t,
+                      worst_rotation_rad=worst_r, same_iteration_count=same_iters)
+        cpu = dict(value=len(recs) / t_cpu if t_cpu > 0 else 0.0, unit="ICP calls/s", cores=1, kind="port",
+                   sample=f"the {len(recs)} ICP calls recorded from the run (scan-to-local-map and loop closure, index build included), "
+                          f"replayed one after the other through the CPU oracle on one core; host has {os.cpu_count()} cores")
+    if rank == 0:
+        n = res["scans"] - 1
+        print(json.dumps({
+            "metric": "scans/sec through full pose-graph SLAM (synthetic KITTI-00-shaped sequence, loop closures, host pose-graph solve)",
+            "value": args.steps * n * world / slam_s, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": slam_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"full pose-graph SLAM, {res['scans']} scans of {res['points_per_scan']} pts, {args.slam_step} m apart "
+                                   f"(BASELINE.json configs[3]), host clouds through pgslam::PoseGraphSlam<float> (C++ facade)",
+                       "parallelism": f"{world} independent replica(s), one process per GPU"},
+            "slam": res, "replay_vs_oracle": replay, "cpu_baseline": cpu, "roofline": None}))
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main_stream(args):
     """BASELINE configs[2]: a scan feed through the streaming local mapper -- ICP against a sliding,
     device-resident map of `--capacity` keyframes (20 x 100k = 2M points), new keyframe when the overlap
@@ -487,7 +644,11 @@ def main():
     ap.add_argument("--prime-stride", type=int, default=3, help="stream: earlier scans between the keyframes that pre-fill the window")
     ap.add_argument("--sync-rebuild", action="store_true", help="stream: rebuild the map in line, as the reference does")
     ap.add_argument("--fleet", action="store_true", help="stream: step all vehicles together, one device batch per time step")
-    ap.add_argument("--workload", choices=["scan2map", "loopclosure", "stream"], default="scan2map",
+    ap.add_argument("--slam-scans", type=int, default=4500, help="slam: scans of the sequence (KITTI-00 has 4541)")
+    ap.add_argument("--slam-points", type=int, default=10_000, help="slam: points per scan (16 rings)")
+    ap.add_argument("--slam-step", type=float, default=0.8, help="slam: metres between scans (10 Hz at 8 m/s)")
+    ap.add_argument("--slam-record", type=int, default=32, help="slam: ICP calls recorded for the replay through the CPU oracle")
+    ap.add_argument("--workload", choices=["scan2map", "loopclosure", "stream", "slam"], default="scan2map",
                     help="scan2map = BASELINE configs[1] (the headline metric); loopclosure = configs[4]: --pairs candidate "
                          "scan pairs (100k vs 100k) sharded over the ranks, all-gather of the SE(3) edges")
     ap.add_argument("--pairs", type=int, default=512)
@@ -499,6 +660,8 @@ def main():
 
     if args.workload == "stream":
         return main_stream(args)
+    if args.workload == "slam":
+        return main_slam(args)
     if args.prepare_only:
         build_workload(args.n_scan, args.n_map, args.queries)
         return

@@ -122,6 +122,7 @@ public:
     void SetIcpConfigFromString(const std::string &yaml)
     {
         icp_config_buffer_ = yaml;
+        temp_icp_.reset();
         std::istringstream iss(icp_config_buffer_);
         icp_sequence_.loadFromYaml(iss);
     }
@@ -159,9 +160,15 @@ public:
     //! the same partial chain for an explicit (reading in robot frame, robot pose, map in world frame) triple
     T ComputeOverlapOf(const DP &reading_in, const Matrix &T_world_robot, const DP &candidate_map_in_world_frame)
     {
-        typename PM::ICP temp_icp;
-        std::istringstream iss(icp_config_buffer_);
-        temp_icp.loadFromYaml(iss);
+        // The reference builds a fresh ICP object from the YAML for every call (Localizer.hpp:309-311); here an ICP object
+        // owns a device context (stream, pinned buffers, scratch), so the one temporary is kept and re-made only when the
+        // configuration changes -- same chain, same result, without a context creation per scan.
+        if (!temp_icp_) {
+            temp_icp_.reset(new typename PM::ICP());
+            std::istringstream iss(icp_config_buffer_);
+            temp_icp_->loadFromYaml(iss);
+        }
+        typename PM::ICP &temp_icp = *temp_icp_;
         DP reference(candidate_map_in_world_frame);
         temp_icp.referenceDataPointsFilters.init();
         temp_icp.referenceDataPointsFilters.apply(reference);
@@ -187,6 +194,7 @@ private:
     DataPointsFilters input_filters_;
     ICPSequence icp_sequence_;
     std::string icp_config_buffer_;
+    std::unique_ptr<typename PM::ICP> temp_icp_;    // ComputeOverlapOf's temporary (kept: see there)
     Matrix T_refkf_robot_, T_world_robot_, last_input_T_world_robot_, T_world_refkf_;
     T overlap_threshold_, minimal_overlap_;
     bool has_map_;
@@ -327,6 +335,7 @@ public:
     void SetIcpConfigFromString(const std::string &yaml)
     {
         icp_config_buffer_ = yaml;
+        temp_icp_.reset();
         std::istringstream iss(icp_config_buffer_);
         icp_.loadFromYaml(iss);
     }
@@ -354,9 +363,12 @@ public:
     //! findClosests, outlier weights, getResidualError -- one device pass
     T ComputeResidualError(const DP &input_cloud, const DP &candidate_cloud, const Matrix &T_refkf_kf) const
     {
-        typename PM::ICP temp_icp;
-        std::istringstream iss(icp_config_buffer_);
-        temp_icp.loadFromYaml(iss);
+        if (!temp_icp_) {                               // LoopCloser.hpp:346-348 builds it from the YAML every time
+            temp_icp_.reset(new typename PM::ICP());
+            std::istringstream iss(icp_config_buffer_);
+            temp_icp_->loadFromYaml(iss);
+        }
+        typename PM::ICP &temp_icp = *temp_icp_;
         temp_icp.matcher->init(candidate_cloud);
         double Tm[16], ratio = 0, residual = 0;
         pgslam_amd::to_row_major16(T_refkf_kf, Tm);
@@ -370,6 +382,7 @@ public:
 private:
     ICP icp_;
     std::string icp_config_buffer_;
+    mutable std::unique_ptr<typename PM::ICP> temp_icp_;   // ComputeResidualError's temporary (kept: an ICP object owns a device context)
     T overlap_threshold_, residual_error_threshold_;
 };
 

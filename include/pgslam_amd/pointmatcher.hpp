@@ -17,6 +17,7 @@
 #include <cstring>
 #include <istream>
 #include <limits>
+#include <functional>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -575,6 +576,12 @@ struct PointMatcher {
         TransformationCheckers transformationCheckers;
         pgicp_ctx *ctx = nullptr;
         pgicp_stats lastStats;
+        //! Observer of every completed alignment (not part of libpointmatcher; its `inspector` slot sees iterations, not
+        //! calls): the filtered reading, the filtered reference the index was built on, the initial guess, the result and
+        //! the device statistics.  Used to record ICP calls of a SLAM run for replay through the CPU oracle.
+        std::function<void(const DataPoints &, const DataPoints &, const TransformationParameters &, const TransformationParameters &,
+                           const pgicp_stats &)> onAlign;
+        const DataPoints *currentReference = nullptr;
 
         explicit ICPChainBase(int device = 0)
         {
@@ -720,7 +727,9 @@ struct PointMatcher {
             const int rc = A::align(ctx, matcher->mapId, reading.xyzPtr(), reading.xyzStride(), (int)reading.getNbPoints(), Ti, To, &st);
             storeStats(st);
             check(ctx, rc);
-            return pgslam_amd::from_row_major16<T>(To);
+            const TransformationParameters T_out = pgslam_amd::from_row_major16<T>(To);
+            if (onAlign && currentReference) onAlign(reading, *currentReference, T_init, T_out, st);
+            return T_out;
         }
     };
 
@@ -740,6 +749,8 @@ struct PointMatcher {
             this->prefilteredReferencePtsCount = reference.getNbPoints();
             if (!reference.descriptorExists("normals")) throw std::runtime_error("PointToPlaneErrorMinimizer: the reference has no 'normals' descriptor");
             this->matcher->initImpl(reference, 1);
+            this->currentReference = &reference;
+            struct Reset { const DataPoints *&p; ~Reset() { p = nullptr; } } reset{this->currentReference};
             return this->alignOnMap(readingIn, T_init);
         }
     };
@@ -756,9 +767,10 @@ struct PointMatcher {
             this->prefilteredReferencePtsCount = mapPointCloud.getNbPoints();
             if (!mapPointCloud.descriptorExists("normals")) throw std::runtime_error("PointToPlaneErrorMinimizer: the map has no 'normals' descriptor");
             this->matcher->initImpl(mapPointCloud, 1);
+            this->currentReference = &mapPointCloud;
             return true;
         }
-        void clearMap() { mapPointCloud = DataPoints(); this->matcher->release(); }
+        void clearMap() { mapPointCloud = DataPoints(); this->currentReference = nullptr; this->matcher->release(); }
         const DataPoints &getPrefilteredMap() const { return mapPointCloud; }
         TransformationParameters operator()(const DataPoints &cloudIn) { return (*this)(cloudIn, Matrix::Identity(4, 4)); }
         //! Localizer.hpp:126.  Without a map the first cloud becomes the map and identity is returned

@@ -482,6 +482,9 @@ public:
     int last_iterations() const { return last_iterations_; }
     double last_initial_error() const { return e0_; }
     double last_final_error() const { return e1_; }
+    int runs() const { return runs_; }                                  // solves so far and the host seconds they took
+    double total_seconds() const { return seconds_; }
+    int total_iterations() const { return iterations_; }
 
 private:
     //! [x y z rx ry rz] -> [rx ry rz x y z] (Optimizer.hpp:32-42), row-major double
@@ -507,7 +510,10 @@ private:
         for (auto &d : data_buffer_) AddFactor(ls, std::get<0>(d), std::get<1>(d), std::get<2>(d), std::get<3>(d));
         for (size_t v = 0; v < g.NumVertices(); v++) ls.X.push_back(se3::from_matrix(g[v].optimized_T_world_kf));
         ls.fixed = map_manager_->GetFixedVertex();                         // prior with sigma 1e-6 (Optimizer.hpp:122-130)
+        const auto t0 = std::chrono::steady_clock::now();
         ls.Optimize();
+        seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        runs_++; iterations_ += ls.iterations;
         last_iterations_ = ls.iterations; e0_ = ls.initial_error; e1_ = ls.final_error;
         const auto now = std::chrono::high_resolution_clock::now();
         for (size_t v = 0; v < g.NumVertices(); v++) map_manager_->UpdateKeyframeTransform(v, se3::to_matrix<Matrix>(ls.X[v]), now);
@@ -516,8 +522,8 @@ private:
     }
     typename MapManager<T>::Ptr map_manager_;
     std::vector<InputData> data_buffer_;
-    int last_iterations_ = 0;
-    double e0_ = 0, e1_ = 0;
+    int last_iterations_ = 0, runs_ = 0, iterations_ = 0;
+    double e0_ = 0, e1_ = 0, seconds_ = 0;
 };
 
 // ------------------------------------------------------------------ loop closer with its candidate search
@@ -535,6 +541,7 @@ public:
     void AddNewVertex(size_t v) { ProcessVertex(v); }
     int loops_closed() const { return loops_closed_; }
     int candidates_tried() const { return candidates_tried_; }
+    typename PM::ICP &icp() { return closer().icp(); }
 
     //! LoopCloser.hpp:193-305: vertices geometrically close (<= geom threshold) and topologically far (> topo
     //! threshold) from input_v, nearest first; around the first one that admits it, the `capacity` vertices a
@@ -608,11 +615,12 @@ public:
         : map_manager_(mm), capacity_(capacity), rigid_(PM::get().REG(Transformation).create("RigidTransformation")),
           T_refkf_robot_(Matrix::Identity(4, 4)), T_world_robot_(Matrix::Identity(4, 4)), last_input_(Matrix::Identity(4, 4)) {}
     void SetOverlapThreshold(T v) { overlap_threshold_ = v; }
-    void SetIcpConfigFromString(const std::string &yaml) { icp_yaml_ = yaml; std::istringstream iss(yaml); icp_sequence_.loadFromYaml(iss); }
+    void SetIcpConfigFromString(const std::string &yaml) { icp_yaml_ = yaml; probe_.reset(); std::istringstream iss(yaml); icp_sequence_.loadFromYaml(iss); }
     void SetInputFiltersConfigFromString(const std::string &yaml) { std::istringstream iss(yaml); input_filters_ = DataPointsFilters(iss); }
     const Matrix &T_world_robot() const { return T_world_robot_; }
     const std::vector<size_t> &composition() const { return comp_; }
     int rebuilds() const { return rebuilds_; }
+    ICPSequence &icp() { return icp_sequence_; }
 
     void AddNewData(unsigned long long, const std::string &, const Matrix &T_world_robot, const Matrix &T_robot_sensor, DPPtr cloud)
     {
@@ -663,10 +671,12 @@ private:
         LocalMap<T> lm(capacity_);
         for (size_t v : comp) lm.PushKeyframe(g[v]);
         lm.BuildCloudFromData();
-        Localizer<T> probe;
-        probe.SetIcpConfigFromString(icp_yaml_);
+        if (!probe_) {                                  // kept between calls: its ICP objects own device contexts
+            probe_.reset(new Localizer<T>());
+            probe_->SetIcpConfigFromString(icp_yaml_);
+        }
         const DP world_map = rigid_->compute(lm.Cloud(), g[comp.back()].optimized_T_world_kf);
-        return probe.ComputeOverlapOf(*input_cloud_, T_world_robot_, world_map);
+        return probe_->ComputeOverlapOf(*input_cloud_, T_world_robot_, world_map);
     }
     //! Localizer.hpp:393-483
     bool FindNeighborComposition(std::vector<size_t> &out)
@@ -741,6 +751,7 @@ private:
     DataPointsFilters input_filters_;
     ICPSequence icp_sequence_;
     std::string icp_yaml_;
+    std::unique_ptr<Localizer<T>> probe_;            // runs ComputeOverlapWith for candidate compositions
     DPPtr input_cloud_;
     std::vector<size_t> comp_;                       // local map composition, reference keyframe last
     Matrix T_refkf_robot_, T_world_robot_, last_input_;

@@ -368,3 +368,132 @@ def make_drive(n_scans: int, n_pts: int = 100_000, step: float = 0.35, rings: in
         odom.append(T_o.copy())
     scans = [make_scan(world, poses[s], n_pts, 7000 + s, rings=rings) for s in range(n_scans)]
     return Drive(poses, odom, [c[0] for c in scans], [c[1] for c in scans])
+
+
+# ----------------------------------------------------------------------------
+# BASELINE.json configs[3]: a KITTI-00-shaped sequence -- a long drive through a street grid that comes back
+# along streets it has already driven, so that a pose-graph SLAM front end finds loop closures
+# ----------------------------------------------------------------------------
+
+CITY_SEED = 0x5EED0005
+
+# The route on the street grid, block by block: an outer loop, the first street again (first loop closures), then a
+# second loop through the middle that re-drives parts of the first in both directions (14 block edges, 4 of them twice).
+CITY_ROUTE = [(0, 0), (1, 0), (2, 0), (2, 1), (1, 1), (0, 1), (0, 0), (1, 0), (1, 1), (1, 2), (2, 2), (2, 1), (1, 1), (1, 0), (2, 0)]
+
+
+@dataclass
+class City:
+    block: float         # street spacing, metres
+    box_lo: np.ndarray   # buildings (B,3)
+    box_hi: np.ndarray
+    cyl_c: np.ndarray    # trees / poles (C,2)
+    cyl_r: np.ndarray
+    cyl_h: np.ndarray
+
+    def near(self, x: float, y: float, reach: float = 95.0) -> World:
+        """The part of the city a sensor at (x, y) can see, as a World (no street-canyon walls)."""
+        bc = 0.5 * (self.box_lo[:, :2] + self.box_hi[:, :2])
+        half = 0.5 * np.linalg.norm(self.box_hi[:, :2] - self.box_lo[:, :2], axis=1)
+        mb = np.hypot(bc[:, 0] - x, bc[:, 1] - y) - half < reach
+        mc = np.hypot(self.cyl_c[:, 0] - x, self.cyl_c[:, 1] - y) < reach
+        return World(self.box_lo[mb], self.box_hi[mb], self.cyl_c[mc], self.cyl_r[mc], self.cyl_h[mc], wall_y=1e9)
+
+
+def make_city(block: float, seed: int = CITY_SEED) -> City:
+    """Buildings line both sides of every street of a 2 x 2-block grid (3 x 3 streets); trees and poles stand
+    between them and the roadway.  Deterministic; sizes drawn from the SplitMix64 stream."""
+    streets = []                                   # (x0, y0, x1, y1) centre lines
+    for k in range(3):
+        streets.append((0.0, k * block, 2 * block, k * block))
+        streets.append((k * block, 0.0, k * block, 2 * block))
+    lo, hi, cc, cr, chh = [], [], [], [], []
+    u = uniform01(seed, 400000)
+    p = 0
+    for (x0, y0, x1, y1) in streets:
+        horizontal = y0 == y1
+        length = (x1 - x0) if horizontal else (y1 - y0)
+        for side in (-1.0, 1.0):
+            s = -40.0                              # buildings continue a little beyond the grid's ends
+            while s < length + 40.0:
+                blen = 8.0 + 17.0 * u[p]; gap = 2.0 + 6.0 * u[p + 1]; depth = 8.0 + 6.0 * u[p + 2]
+                height = 4.0 + 8.0 * u[p + 3]; setback = 7.0 + 2.5 * u[p + 4]
+                p += 5
+                a, b = s, s + blen
+                s = b + gap
+                # leave the crossings open
+                mid = 0.5 * (a + b)
+                if any(abs(mid - k * block) < 0.5 * blen + 10.0 for k in range(3)):
+                    continue
+                n0, n1 = side * setback, side * (setback + depth)
+                if horizontal:
+                    lo.append([x0 + a, y0 + min(n0, n1), 0.0]); hi.append([x0 + b, y0 + max(n0, n1), height])
+                else:
+                    lo.append([x0 + min(n0, n1), y0 + a, 0.0]); hi.append([x0 + max(n0, n1), y0 + b, height])
+            s = 5.0
+            while s < length - 5.0:                # trees and poles, 4.5-6 m from the centre line
+                spacing = 9.0 + 14.0 * u[p]; off = side * (4.5 + 1.5 * u[p + 1]); r = 0.12 + 0.25 * u[p + 2]; h = 3.0 + 5.0 * u[p + 3]
+                p += 4
+                if not any(abs(s - k * block) < 9.0 for k in range(3)):
+                    cc.append([x0 + s, y0 + off] if horizontal else [x0 + off, y0 + s]); cr.append(r); chh.append(h)
+                s += spacing
+    return City(block, np.array(lo), np.array(hi), np.array(cc), np.array(cr), np.array(chh))
+
+
+def city_route(n_scans: int, step: float, lane_jitter: float = 0.6, corner_radius: float = 7.0):
+    """`n_scans` poses along CITY_ROUTE, `step` metres apart (arc length), with rounded corners; a street that is
+    driven twice is driven `lane_jitter` metres to the side the second time.  Returns (block, [T_world_robot])."""
+    edges = len(CITY_ROUTE) - 1
+    block = max(40.0, ((n_scans - 1) * step + 6.0 * edges + 10.0) / edges)      # (corner rounding shortens the path: ~4 m per turn)
+    pts = []
+    seen = {}
+    for k, (ix, iy) in enumerate(CITY_ROUTE):
+        pts.append(np.array([ix * block, iy * block], dtype=np.float64))
+    # lateral offset per edge: second traversal of the same street segment shifts sideways
+    offs = []
+    for k in range(edges):
+        key = tuple(sorted([CITY_ROUTE[k], CITY_ROUTE[k + 1]]))
+        offs.append(lane_jitter * seen.get(key, 0))
+        seen[key] = seen.get(key, 0) + 1
+    # polyline with offsets applied perpendicular to each edge; corners become arcs by sampling a smoothed path
+    fine = []
+    for k in range(edges):
+        a, b = pts[k], pts[k + 1]
+        d = (b - a) / np.linalg.norm(b - a)
+        nrm = np.array([-d[1], d[0]])
+        a2, b2 = a + offs[k] * nrm, b + offs[k] * nrm
+        m = max(2, int(np.linalg.norm(b2 - a2) / 0.25))
+        t = np.linspace(0.0, 1.0, m, endpoint=False)
+        fine.append(a2[None, :] + t[:, None] * (b2 - a2)[None, :])
+    fine.append((pts[-1] + offs[-1] * np.array([0.0, 0.0]))[None, :])
+    path = np.concatenate(fine)
+    # corner rounding: moving average over 2*corner_radius of arc length
+    w = max(1, int(2 * corner_radius / 0.25))
+    pad = np.concatenate([np.repeat(path[:1], w, 0), path, np.repeat(path[-1:], w, 0)])
+    ker = np.ones(2 * w + 1) / (2 * w + 1)
+    sm = np.stack([np.convolve(pad[:, 0], ker, mode="same"), np.convolve(pad[:, 1], ker, mode="same")], 1)[w:-w]
+    seg = np.linalg.norm(np.diff(sm, axis=0), axis=1)
+    arc = np.concatenate([[0.0], np.cumsum(seg)])
+    want = np.minimum(np.arange(n_scans) * step, arc[-1] - 1e-6)
+    xs = np.interp(want, arc, sm[:, 0]); ys = np.interp(want, arc, sm[:, 1])
+    ahead = np.minimum(want + 1.0, arc[-1])
+    hx = np.interp(ahead, arc, sm[:, 0]) - xs; hy = np.interp(ahead, arc, sm[:, 1]) - ys
+    yaw = np.arctan2(hy, hx)
+    yaw[-1] = yaw[-2] if n_scans > 1 else 0.0
+    return block, [se3(x=float(xs[s]), y=float(ys[s]), yaw=float(yaw[s])) for s in range(n_scans)]
+
+
+def city_odometry(poses, sigma_t: float = 0.02, sigma_yaw_deg: float = 0.1, seed: int = CITY_SEED + 1):
+    """Odometry poses: every true increment with a small uniform error, accumulated (drifts)."""
+    u = uniform01(seed, 3 * len(poses))
+    odom = [poses[0].copy()]
+    for s in range(1, len(poses)):
+        d_true = se3_inv(poses[s - 1]) @ poses[s]
+        err = se3(x=sigma_t * (2 * u[3 * s] - 1), y=sigma_t * (2 * u[3 * s + 1] - 1),
+                  yaw=math.radians(sigma_yaw_deg) * (2 * u[3 * s + 2] - 1))
+        odom.append(odom[-1] @ d_true @ err)
+    return odom
+
+
+def make_city_scan(city: City, T_world_robot: np.ndarray, n_pts: int, scan_idx: int, rings: int = 16):
+    return make_scan(city.near(float(T_world_robot[0, 3]), float(T_world_robot[1, 3])), T_world_robot, n_pts, 9000 + scan_idx, rings=rings)

@@ -1,0 +1,176 @@
+// slam_run -- BASELINE.json configs[3]: a synthetic KITTI-00-shaped sequence through the pgslam facade
+// (pgslam::PoseGraphSlam<float>: scan-to-local-map ICP on the GPU, keyframe graph, loop closing, pose-graph solve on
+// the host), as a C++ pgslam user would run it: host clouds in, poses out.  Driver of `bench.py --workload slam` and of
+// tests/test_slam_replay.py; not part of the library.
+//
+//   slam_run SEQUENCE [--record N FILE] [--limit S]
+//
+// SEQUENCE (written by bench.py / the test from pgslam_amd/synth.py): int32 magic 'PGSQ', n_scans, n_pts; per scan
+// 16 doubles T_world_robot (truth, row-major), 16 doubles odometry pose, n_pts*3 floats xyz (robot frame), n_pts*3
+// floats normals.  --record: every ICP call whose ordinal is a multiple of (calls so far / N) -- in practice an even
+// sample of N scan-to-map calls plus every loop-closure ICP up to N -- is written to FILE for replay through the CPU
+// oracle: reading, reference, initial guess, result, iterations.  Prints one JSON object on stdout.
+#include <pgslam_amd/slam.hpp>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using T = float;
+IMPORT_PGSLAM_TYPES(T)
+
+static const char *kIcpYaml =
+    "matcher:\n  KDTreeMatcher:\n    knn: 1\n    epsilon: 0\n    maxDist: 2.0\n"
+    "outlierFilters:\n  - TrimmedDistOutlierFilter:\n      ratio: 0.85\n"
+    "errorMinimizer:\n  PointToPlaneWithCovErrorMinimizer:\n    sensorStdDev: 0.01\n"
+    "transformationCheckers:\n  - CounterTransformationChecker:\n      maxIterationCount: 30\n"
+    "  - DifferentialTransformationChecker:\n      minDiffRotErr: 0.001\n      minDiffTransErr: 0.01\n      smoothLength: 3\n"
+    "inspector:\n  NullInspector\nlogger:\n  NullLogger\n";
+
+static Matrix from_rows(const double *r)
+{
+    Matrix m(4, 4);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m(i, j) = (T)r[4 * i + j];
+    return m;
+}
+
+struct Recorder {
+    FILE *f = nullptr;
+    int want = 0, written = 0, written_kind[2] = {0, 0}, scan = 0, every = 1;
+    long long calls = 0;
+    void open(const char *path, int n, int expected_calls)
+    {
+        f = std::fopen(path, "wb");
+        want = n;
+        every = std::max(1, expected_calls / std::max(1, n));
+        const int head[4] = {0x50524750 /* 'PGRP' */, 1, 0, 0};
+        if (f) std::fwrite(head, sizeof head, 1, f);
+    }
+    // kind 0: scan-to-local-map ICP (every `every`-th call, at most `want`); kind 1: loop-closure ICP (the first `want`)
+    void operator()(int k, const DP &reading, const DP &reference, const Matrix &Ti, const Matrix &To, const pgicp_stats &st)
+    {
+        if (!f || written_kind[k] >= want) return;
+        if (k == 0 && (calls++ % every) != 0) return;
+        const int n = (int)reading.getNbPoints(), m = (int)reference.getNbPoints();
+        const int head[8] = {k, scan, n, m, st.iterations, st.converged, st.status, st.max_iter_reached};
+        std::fwrite(head, sizeof head, 1, f);
+        double t[32];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { t[4 * i + j] = (double)Ti(i, j); t[16 + 4 * i + j] = (double)To(i, j); }
+        std::fwrite(t, sizeof t, 1, f);
+        const double ov = st.overlap;
+        std::fwrite(&ov, sizeof ov, 1, f);
+        std::vector<float> buf;
+        auto dump = [&](const T *p, int stride, int cnt) {
+            buf.resize((size_t)cnt * 3);
+            for (int i = 0; i < cnt; i++) for (int a = 0; a < 3; a++) buf[(size_t)3 * i + a] = (float)p[(size_t)i * stride + a];
+            std::fwrite(buf.data(), sizeof(float), buf.size(), f);
+        };
+        dump(reading.xyzPtr(), reading.xyzStride(), n);
+        dump(reference.xyzPtr(), reference.xyzStride(), m);
+        dump(reference.normalsPtr(), reference.normalsStride(), m);
+        written++;
+        written_kind[k]++;
+    }
+    void close()
+    {
+        if (!f) return;
+        std::fseek(f, 8, SEEK_SET);
+        std::fwrite(&written, sizeof written, 1, f);
+        std::fclose(f);
+    }
+};
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: slam_run SEQUENCE [--record N FILE] [--limit S]\n"); return 2; }
+    const char *rec_path = nullptr;
+    int rec_n = 0, limit = 1 << 30;
+    for (int a = 2; a < argc; a++) {
+        if (!std::strcmp(argv[a], "--record") && a + 2 < argc) { rec_n = std::atoi(argv[a + 1]); rec_path = argv[a + 2]; a += 2; }
+        else if (!std::strcmp(argv[a], "--limit") && a + 1 < argc) { limit = std::atoi(argv[a + 1]); a += 1; }
+    }
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
+    int head[3];
+    if (std::fread(head, sizeof head, 1, f) != 1 || head[0] != 0x51534750 /* 'PGSQ' */) { std::fprintf(stderr, "bad sequence file\n"); return 2; }
+    const int S = std::min(head[1], limit), N = head[2];
+
+    pgslam::PoseGraphSlam<T> slam;
+    slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+    Recorder rec;
+    if (rec_path) {
+        rec.open(rec_path, rec_n, S);
+        slam.localizer().icp().onAlign = [&](const DP &r, const DP &m, const Matrix &a, const Matrix &b, const pgicp_stats &s) { rec(0, r, m, a, b, s); };
+        slam.loop_closer().icp().onAlign = [&](const DP &r, const DP &m, const Matrix &a, const Matrix &b, const pgicp_stats &s) { rec(1, r, m, a, b, s); };
+    }
+    std::vector<double> Tt(16), To(16);
+    std::vector<float> xyz((size_t)N * 3), nrm((size_t)N * 3);
+    std::vector<Matrix> truth;
+    std::vector<size_t> kf_scan;                    // scan every keyframe (graph vertex) was made from
+    Matrix last_odom = Matrix::Identity(4, 4);
+    std::vector<double> err_track;
+    double t_icp_loop = 0.0, t_io = 0.0;
+    long long icp_iterations = 0;
+    int not_converged = 0;
+    const Matrix I4 = Matrix::Identity(4, 4);
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (int s = 0; s < S; s++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (std::fread(Tt.data(), sizeof(double), 16, f) != 16 || std::fread(To.data(), sizeof(double), 16, f) != 16 ||
+            std::fread(xyz.data(), sizeof(float), xyz.size(), f) != xyz.size() || std::fread(nrm.data(), sizeof(float), nrm.size(), f) != nrm.size()) {
+            std::fprintf(stderr, "sequence file truncated at scan %d\n", s);
+            return 2;
+        }
+        auto cloud = std::make_shared<DP>(DP::fromXYZ(xyz.data(), N, nrm.data()));
+        const auto t1 = std::chrono::steady_clock::now();
+        t_io += std::chrono::duration<double>(t1 - t0).count();
+        rec.scan = s;
+        slam.AddData((unsigned long long)s, "world", from_rows(To.data()), I4, cloud);
+        t_icp_loop += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        truth.push_back(from_rows(Tt.data()));
+        last_odom = from_rows(To.data());
+        while (kf_scan.size() < slam.map_manager().GetGraph().NumVertices()) kf_scan.push_back((size_t)s);
+        if (s > 0) {
+            const auto &st = slam.localizer().icp().lastStats;
+            icp_iterations += st.iterations;
+            not_converged += st.converged ? 0 : 1;
+        }
+        // tracking error: the live pose against the truth, in the frame of the first pose (odometry starts at the truth)
+        const Matrix d = truth[s].inverse() * slam.localizer().T_world_robot();
+        err_track.push_back(std::sqrt((double)(d(0, 3) * d(0, 3) + d(1, 3) * d(1, 3) + d(2, 3) * d(2, 3))));
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    std::fclose(f);
+    rec.close();
+    auto &g = slam.map_manager().GetGraph();
+    int loops = 0;
+    for (size_t e = 0; e < g.NumEdges(); e++) loops += g.Edge(e).c.type == Constraint::kLoopConstraint;
+    // keyframe poses after the last optimisation against the truth of the scans they were made from
+    double kf_max = 0, kf_sum2 = 0;
+    for (size_t v = 0; v < g.NumVertices() && v < kf_scan.size(); v++) {
+        const Matrix d = truth[kf_scan[v]].inverse() * g[v].optimized_T_world_kf;
+        const double e = std::sqrt((double)(d(0, 3) * d(0, 3) + d(1, 3) * d(1, 3) + d(2, 3) * d(2, 3)));
+        kf_max = std::max(kf_max, e);
+        kf_sum2 += e * e;
+    }
+    double e_max = 0, e_sum2 = 0, e_last = err_track.empty() ? 0 : err_track.back();
+    for (double e : err_track) { e_max = std::max(e_max, e); e_sum2 += e * e; }
+    // odometry alone, for comparison: where the last odometry pose ends up against the truth
+    const Matrix d_odo = truth.back().inverse() * last_odom;
+    const double odo_last = std::sqrt((double)(d_odo(0, 3) * d_odo(0, 3) + d_odo(1, 3) * d_odo(1, 3) + d_odo(2, 3) * d_odo(2, 3)));
+    std::printf("{\"scans\": %d, \"points_per_scan\": %d, \"wall_s\": %.6f, \"slam_s\": %.6f, \"io_s\": %.6f, \"scans_per_s\": %.3f, "
+                "\"keyframes\": %zu, \"loop_edges\": %d, \"loop_candidates_tried\": %d, \"loops_closed\": %d, "
+                "\"optimizer_runs\": %d, \"optimizer_iterations\": %d, \"optimizer_host_s\": %.6f, \"map_rebuilds\": %d, "
+                "\"mean_icp_iterations\": %.3f, \"scans_not_converged\": %d, \"tracking_error_rms_m\": %.5f, "
+                "\"tracking_error_max_m\": %.5f, \"tracking_error_last_m\": %.5f, \"odometry_error_last_m\": %.5f, "
+                "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d}\n",
+                S, N, wall, t_icp_loop, t_io, (S - 1) / t_icp_loop, g.NumVertices(), loops, slam.loop_closer().candidates_tried(),
+                slam.loop_closer().loops_closed(), slam.optimizer().runs(), slam.optimizer().total_iterations(), slam.optimizer().total_seconds(),
+                slam.localizer().rebuilds(), S > 1 ? (double)icp_iterations / (S - 1) : 0.0, not_converged,
+                std::sqrt(e_sum2 / std::max<size_t>(1, err_track.size())), e_max, e_last, odo_last,
+                std::sqrt(kf_sum2 / std::max<size_t>(1, kf_scan.size())), kf_max, rec.written, rec.written_kind[1]);
+    return 0;
+}
