@@ -635,6 +635,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=64, help="scans of the CPU baseline's batch (at least one per host core)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-host-input", action="store_true",
+                    help="skip the PCIe-inclusive companion figure: by default the timed steps are repeated with the scans in HOST "
+                         "memory (pinned, and pageable), uploaded one step ahead on the context's copy stream (pgicp_upload_f32) while "
+                         "the current step aligns; reported as `host_input`, never as `value`")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams, one host thread each) the batch is split over; each keeps its own "
                          "resident copy of the map.  >1 overlaps one sub-batch's convergence tail with another's head")
@@ -834,6 +838,49 @@ def main():
         for c in ctxs:
             c.set_params(min_diff_rot=chain["min_diff_rot"], min_diff_trans=chain["min_diff_trans"])
 
+    # ---- PCIe-inclusive companion figure: the caller owns HOST clouds (Localizer.hpp:103-126); step k+1's scans travel on
+    #      the copy stream while step k aligns (pgicp_upload_f32), the compute stream waits for them on the device
+    host_input = None
+    if not args.no_host_input and S == 1:
+        for c in ctxs:
+            c.set_params(check_every=args.check_every)
+
+        def host_loop(srcs, pinned):
+            cyc = [srcs[b % len(srcs)] for b in range(B)]
+            cur = ctx.upload(cyc, pinned=pinned)
+            ctx.align_batch(map_id, cur, T_inits, raise_on_error=False)          # warm-up (allocations of the upload sets)
+            cur = ctx.upload(cyc, pinned=pinned)
+            nxt = ctx.upload(cyc, pinned=pinned)
+            ctx.align_batch(map_id, cur, T_inits, raise_on_error=False)
+            cur = nxt
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ok = 0
+            for k in range(args.steps):
+                nxt = ctx.upload(cyc, pinned=pinned) if k + 1 < args.steps else None
+                _, st_h = ctx.align_batch(map_id, cur, T_inits, raise_on_error=False)
+                ok += sum(1 for s_ in st_h if s_["status"] == 0 and (s_["converged"] or args.fixed_iters))
+                cur = nxt
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            return ok / dt, dt * 1e3 / args.steps
+
+        pinned_scans = []
+        for s_ in w.scans_xyz:
+            a = ctx.host_alloc(s_.shape, np.float32)
+            a[...] = s_
+            pinned_scans.append(a)
+        r_pin, ms_pin = host_loop(pinned_scans, True)
+        r_page, ms_page = host_loop([np.ascontiguousarray(s_) for s_ in w.scans_xyz], False)
+        for a in pinned_scans:
+            ctx.host_free(a)
+        dev_rate = converged / elapsed
+        host_input = dict(pinned_scans_per_s=r_pin, pinned_ms_per_step=ms_pin, pinned_over_device_resident=r_pin / dev_rate,
+                          pageable_scans_per_s=r_page, pageable_ms_per_step=ms_page, pageable_over_device_resident=r_page / dev_rate,
+                          bytes_per_step=int(B * args.n_scan * 12),
+                          how="scans in host memory; step k+1 uploaded on the context's copy stream (pgicp_upload_f32) while step k "
+                              "aligns; pageable sources pass through the context's pinned staging buffer (one host memcpy)")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, args.cpu_sample, os.cpu_count() or 1)
@@ -864,6 +911,7 @@ def main():
             "scans_total": scans_all,
             "scans_converged": converged_all,
             "fixed_30_iterations": fixed30,
+            "host_input": host_input,
             "mean_iterations": iters_all / max(1, scans_all),
             "set_map_ms": t_setmap * 1e3,
             "median_translation_error_m": float(np.median(err_t)) if err_t else None,

@@ -47,6 +47,7 @@ extern "C" {
 
 #define PGICP_HOST 0
 #define PGICP_DEVICE 1
+#define PGICP_HOST_PINNED 2     /* host memory the caller pinned (pgicp_host_alloc / hipHostMalloc): only for pgicp_upload_* */
 
 #define PGICP_MATCHER_GRID 0    /* grid-hashed exact kNN (performance path) */
 #define PGICP_MATCHER_BRUTE 1   /* LDS-tiled brute force (parity path) */
@@ -126,6 +127,29 @@ const char *pgicp_last_error(const pgicp_ctx *ctx);
 /* The HIP stream (hipStream_t) every kernel of this context is launched on. */
 void *pgicp_ctx_stream(pgicp_ctx *ctx);
 int pgicp_ctx_synchronize(pgicp_ctx *ctx);
+
+/* Readable text of a status code (never NULL). */
+const char *pgicp_status_string(int status);
+
+/* ---- host-input pipeline ---------------------------------------------------
+ * pgslam hands the localizer caller-owned HOST clouds (Localizer.hpp:103-126), and in the MT flavour the
+ * next scan is already queued while the current one is being aligned (LocalizerMT.hpp:27-40).
+ * pgicp_upload_* starts the transfer of n host readings to the device on the context's COPY stream and
+ * returns at once; dev_ptrs[k] receives the device address of reading k (same stride as the source).  Any
+ * later call on this context that is given such a pointer (mem = PGICP_DEVICE: pgicp_align*, pgicp_match,
+ * pgicp_partial_chain*, pgicp_map_create*) first makes its own stream wait, ON THE DEVICE, for the
+ * transfer -- the host never blocks on it -- so the upload of scan k+1 overlaps the ICP of scan k.
+ * Two uploads are kept: upload u+2 reuses the buffers of upload u (it waits, on the device, until the
+ * calls that read upload u have consumed it).  `mem` says what the host pointers are: PGICP_HOST
+ * (pageable: copied through a pinned staging buffer of the context first) or PGICP_HOST_PINNED (DMA
+ * straight from the caller's buffer, which must stay untouched until a call that uses it has returned).
+ * pgicp_host_alloc / pgicp_host_free: pinned host memory for such clouds. */
+int pgicp_upload_f32(pgicp_ctx *ctx, int n_readings, const float *const *host, const int *stride, const int *n, int mem,
+                     const float **dev_ptrs);
+int pgicp_upload_f64(pgicp_ctx *ctx, int n_readings, const double *const *host, const int *stride, const int *n, int mem,
+                     const double **dev_ptrs);
+int pgicp_host_alloc(pgicp_ctx *ctx, size_t bytes, void **out);
+int pgicp_host_free(pgicp_ctx *ctx, void *p);
 
 void pgicp_default_params(pgicp_params *p);
 /* replaces ICP::loadFromYaml / setDefault for the supported chain */

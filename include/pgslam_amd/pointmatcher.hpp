@@ -368,7 +368,7 @@ struct PointMatcher {
         SurfaceNormalDataPointsFilter(int k, T md, bool kn, bool ke) : knn(k), maxDist(md), keepNormals(kn), keepEigenValues(ke)
         {
             const int st = pgicp_ctx_create(0, &ctx);
-            if (st != PGICP_OK) throw std::runtime_error(std::string("SurfaceNormalDataPointsFilter: ") + pgicp_last_error(nullptr));
+            if (st != PGICP_OK) throw std::runtime_error(std::string("SurfaceNormalDataPointsFilter: cannot create a device context: ") + pgicp_status_string(st));
         }
         ~SurfaceNormalDataPointsFilter() override { if (ctx) pgicp_ctx_destroy(ctx); }
         SurfaceNormalDataPointsFilter(const SurfaceNormalDataPointsFilter &) = delete;
@@ -586,7 +586,7 @@ struct PointMatcher {
         explicit ICPChainBase(int device = 0)
         {
             const int st = pgicp_ctx_create(device, &ctx);
-            if (st != PGICP_OK) throw std::runtime_error("PointMatcher::ICP: no usable MI355X device (code " + std::to_string(st) + "); there is no CPU fallback");
+            if (st != PGICP_OK) throw std::runtime_error(std::string("PointMatcher::ICP: cannot create a device context: ") + pgicp_status_string(st));
             std::memset(&lastStats, 0, sizeof lastStats);
             setDefault();
         }

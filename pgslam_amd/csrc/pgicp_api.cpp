@@ -92,6 +92,18 @@ struct pgicp_ctx {
     State<double> f64;
     DevBuf probs, src, partials, sums, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
     DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active, sel_tables, queue;
+    // host-input pipeline (pgicp_upload_*): a copy stream and two upload sets used alternately
+    struct UploadSet {
+        DevBuf dev;                     // device copies of the readings of one upload
+        void *pin = nullptr;            // pinned staging for pageable sources
+        size_t pin_cap = 0;
+        size_t bytes = 0;               // bytes of `dev` in use
+        hipEvent_t uploaded = nullptr;  // recorded on the copy stream after the last transfer of the upload
+        hipEvent_t consumed = nullptr;  // recorded on the compute stream after the last kernel that reads the set
+        bool pending = false, has_consumer = false;
+    } up[2];
+    hipStream_t copy_stream = nullptr;
+    int up_next = 0;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     int *h_flag = nullptr;          // coherent pinned pair {problems done, stamp} the last kernel of an iteration writes
     int flag_stamp = 0;
@@ -219,6 +231,29 @@ double key_to_double(unsigned long long k)
     return d;
 }
 
+// A device pointer handed out by pgicp_upload_*: the context stream waits (on the device) for that upload.
+// Returns the bit mask of upload sets the pointer belongs to.
+int upload_wait(pgicp_ctx *c, const void *p)
+{
+    int mask = 0;
+    for (int s = 0; s < 2; s++) {
+        pgicp_ctx::UploadSet &U = c->up[s];
+        if (!U.pending || !U.dev.p) continue;
+        const char *q = (const char *)p;
+        if (q >= (const char *)U.dev.p && q < (const char *)U.dev.p + U.bytes) {
+            (void)hipStreamWaitEvent(c->stream, U.uploaded, 0);
+            mask |= 1 << s;
+        }
+    }
+    return mask;
+}
+// ... and after the last kernel that reads them has been queued, the sets may be overwritten once it has run
+void upload_consumed(pgicp_ctx *c, int mask)
+{
+    for (int s = 0; s < 2; s++)
+        if (mask & (1 << s)) { (void)hipEventRecord(c->up[s].consumed, c->stream); c->up[s].has_consumer = true; }
+}
+
 // Bring a strided point buffer onto the device if it is host memory.
 // Returns the device pointer to use (either the caller's or the staging copy).
 template <typename T>
@@ -327,6 +362,10 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     }
     size_t soff = 0;
     for (int k = 0; k < n; k++) {
+        if (mem == PGICP_DEVICE && (c->up[0].pending || c->up[1].pending)) {       // clouds handed out by pgicp_upload_*
+            (void)upload_wait(c, src[k].xyz);                                       // (this call ends with a stream synchronisation:
+            if (src[k].nrm) (void)upload_wait(c, src[k].nrm);                       //  nothing of it reads them afterwards)
+        }
         int st = to_device<T>(c, src[k].xyz, src[k].xyz_stride, src[k].m, mem, S.staging, soff, &d_xyz[k]);
         if (st) return st;
         if (mem == PGICP_HOST) soff += staged_bytes(sizeof(T), src[k].xyz_stride, src[k].m);
@@ -573,8 +612,10 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     hs.assign(P, SrcDesc());
     size_t soff = 0;
     long long off = 0;
+    int up_mask = 0;
     for (int p = 0; p < P; p++) {
         const T *d_rd = nullptr;
+        if (pr[p].mem == PGICP_DEVICE && (c->up[0].pending || c->up[1].pending)) up_mask |= upload_wait(c, pr[p].reading);
         int st = to_device<T>(c, (const T *)pr[p].reading, pr[p].stride, pr[p].n, pr[p].mem, S.staging, soff, &d_rd);
         if (st) return st;
         if (pr[p].mem == PGICP_HOST) soff += staged_bytes(sizeof(T), pr[p].stride, pr[p].n);
@@ -600,6 +641,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     {
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
         launch_pretransform<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.rd_pre.template as<T>(), P, L.max_n);
+        upload_consumed(c, up_mask);                 // the pre-transform is the only kernel that reads the readings where they lie
         // order each reading by (map row, x) once: waves stay spatially coherent for every iteration
         launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(),
                              S.rd_pre.template as<T>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<unsigned long long>(),
@@ -1183,6 +1225,54 @@ int map_transfer_impl(pgicp_ctx *from, int id, pgicp_ctx *to, int *new_id)
     return sync_maps_table<T>(to);
 }
 
+namespace {
+template <typename T>
+int upload(pgicp_ctx *c, int n, const T *const *host, const int *stride, const int *npts, int mem, const T **dev_ptrs)
+{
+    if (!c || n <= 0 || !host || !stride || !npts || !dev_ptrs || (mem != PGICP_HOST && mem != PGICP_HOST_PINNED))
+        return fail(c, PGICP_ERR_ARG, "pgicp_upload: bad argument");
+    size_t total = 0;
+    for (int k = 0; k < n; k++) {
+        if (!host[k] || npts[k] <= 0 || stride[k] < 3) return fail(c, PGICP_ERR_ARG, "pgicp_upload: bad reading " + std::to_string(k));
+        total += staged_bytes(sizeof(T), stride[k], npts[k]);
+    }
+    HIPC(c, hipSetDevice(c->device));
+    pgicp_ctx::UploadSet &U = c->up[c->up_next];
+    c->up_next ^= 1;
+    // the set is overwritten: the calls that read its last contents must have consumed them (device-side wait), and a
+    // transfer out of its pinned staging must have left it (host-side wait: two uploads ago, over long since)
+    if (U.has_consumer) HIPC(c, hipStreamWaitEvent(c->copy_stream, U.consumed, 0));
+    if (U.pending) HIPC(c, hipEventSynchronize(U.uploaded));
+    if (total > U.dev.cap) {
+        // growing means freeing (hipFree waits for the device): nothing may still read the old block
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipStreamSynchronize(c->copy_stream));
+        HIPC(c, U.dev.ensure(total));
+    }
+    if (mem == PGICP_HOST && total > U.pin_cap) {
+        if (U.pin) HIPC(c, hipHostFree(U.pin));
+        U.pin = nullptr; U.pin_cap = 0;
+        HIPC(c, hipHostMalloc(&U.pin, total + total / 4, hipHostMallocDefault));
+        U.pin_cap = total + total / 4;
+    }
+    size_t off = 0;
+    for (int k = 0; k < n; k++) {
+        const size_t bytes = sizeof(T) * ((size_t)(npts[k] - 1) * stride[k] + 3);
+        if (mem == PGICP_HOST) std::memcpy((char *)U.pin + off, host[k], bytes);
+        else HIPC(c, hipMemcpyAsync((char *)U.dev.p + off, host[k], bytes, hipMemcpyHostToDevice, c->copy_stream));
+        dev_ptrs[k] = (const T *)((char *)U.dev.p + off);
+        off += staged_bytes(sizeof(T), stride[k], npts[k]);
+    }
+    if (mem == PGICP_HOST) HIPC(c, hipMemcpyAsync(U.dev.p, U.pin, total, hipMemcpyHostToDevice, c->copy_stream));
+    HIPC(c, hipEventRecord(U.uploaded, c->copy_stream));
+    U.bytes = total;
+    U.pending = true;
+    U.has_consumer = false;
+    return PGICP_OK;
+}
+}  // namespace
+
+
 extern "C" {
 
 int pgicp_abi_version(void) { return PGICP_ABI_VERSION; }
@@ -1228,9 +1318,14 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_POLL_US")) c->poll_us = std::atoi(e);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
-        delete c;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+    for (int s = 0; ok && s < 2; s++)
+        ok = hipEventCreateWithFlags(&c->up[s].uploaded, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->up[s].consumed, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        pgicp_ctx_destroy(c);
         return PGICP_ERR_HIP;
     }
     // the polled iteration flag wants fine-grained (coherent) pinned memory; plain pinned memory also works with the
@@ -1252,8 +1347,16 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     prof_collect(c);
+    for (int s = 0; s < 2; s++) {
+        c->up[s].dev.release();
+        if (c->up[s].pin) (void)hipHostFree(c->up[s].pin);
+        if (c->up[s].uploaded) (void)hipEventDestroy(c->up[s].uploaded);
+        if (c->up[s].consumed) (void)hipEventDestroy(c->up[s].consumed);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto &m : c->f32.maps) free_map<float>(nullptr, m);
     for (auto &m : c->f64.maps) free_map<double>(nullptr, m);
     for (auto &kv : c->block_pool) (void)hipFree(kv.second);
@@ -1268,6 +1371,42 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int pgicp_upload_f32(pgicp_ctx *c, int n, const float *const *host, const int *stride, const int *npts, int mem, const float **dev_ptrs)
+{
+    return upload<float>(c, n, host, stride, npts, mem, dev_ptrs);
+}
+int pgicp_upload_f64(pgicp_ctx *c, int n, const double *const *host, const int *stride, const int *npts, int mem, const double **dev_ptrs)
+{
+    return upload<double>(c, n, host, stride, npts, mem, dev_ptrs);
+}
+int pgicp_host_alloc(pgicp_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || bytes == 0) return fail(c, PGICP_ERR_ARG, "pgicp_host_alloc: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return PGICP_OK;
+}
+int pgicp_host_free(pgicp_ctx *c, void *p)
+{
+    if (!c) return PGICP_ERR_ARG;
+    if (p) HIPC(c, hipHostFree(p));
+    return PGICP_OK;
+}
+
+const char *pgicp_status_string(int status)
+{
+    switch (status) {
+    case PGICP_OK: return "ok";
+    case PGICP_ERR_NO_MATCH: return "no point to minimize (ConvergenceError)";
+    case PGICP_ERR_NAN: return "NaN in the transformation checkers (ConvergenceError)";
+    case PGICP_ERR_ARG: return "bad argument";
+    case PGICP_ERR_HIP: return "HIP runtime error";
+    case PGICP_ERR_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
+    case PGICP_ERR_NOT_RIGID: return "transformation is not rigid";
+    default: return "unknown status";
+    }
 }
 
 const char *pgicp_last_error(const pgicp_ctx *c) { return c ? c->err.c_str() : "null context"; }

@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGICP_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libpgicp.so")
 
 OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID = range(7)
-HOST, DEVICE = 0, 1
+HOST, DEVICE, HOST_PINNED = 0, 1, 2
 MATCHER_GRID, MATCHER_BRUTE = 0, 1
 PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_update", "pretransform",
               "covariance", "grid_build", "knn_slow", "surface_normals"]
@@ -44,6 +44,7 @@ ABI_SYMBOLS = [
     "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_surface_normals_f32", "pgicp_surface_normals_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
     "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters",
     "pgicp_debug_last_matches_f32", "pgicp_debug_last_matches_f64",
+    "pgicp_status_string", "pgicp_upload_f32", "pgicp_upload_f64", "pgicp_host_alloc", "pgicp_host_free",
 ]
 
 
@@ -103,6 +104,7 @@ def load_library() -> C.CDLL:
                               "pgslam_amd has no CPU fallback")
         _lib = C.CDLL(LIB_PATH)
         _lib.pgicp_last_error.restype = C.c_char_p
+        _lib.pgicp_status_string.restype = C.c_char_p
         _lib.pgicp_ctx_stream.restype = C.c_void_p
     return _lib
 
@@ -111,12 +113,22 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+class DevPtr:
+    """A reading already on the device, as pgicp_upload_* hands it out: raw address, stride, point count."""
+
+    def __init__(self, ptr, stride, n, dtype, keep=None):
+        self.ptr, self.stride, self.n, self.dtype, self.keep = ptr, stride, n, np.dtype(dtype), keep
+
+
 class _Buf:
     """(pointer, stride, n, mem, dtype) view of a numpy array or a torch CUDA tensor.
     Accepts (N,3) packed xyz or (N,4) homogeneous rows (= libpointmatcher's 4xN
     column-major `features`)."""
 
     def __init__(self, x, dtype=None):
+        if isinstance(x, DevPtr):
+            self.keep, self.ptr, self.stride, self.n, self.mem, self.dtype = x, x.ptr, x.stride, x.n, DEVICE, x.dtype
+            return
         if _is_torch(x):
             if not x.is_cuda:
                 x = x.numpy()
@@ -178,6 +190,38 @@ class Context:
         if st in (ERR_NO_MATCH, ERR_NAN):
             raise ConvergenceError(st, msg)
         raise PgicpError(st, msg)
+
+    # ---- host-input pipeline ------------------------------------------------
+    def host_alloc(self, shape, dtype=np.float32):
+        """numpy array in pinned host memory (pgicp_host_alloc); release it with host_free(array)."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self.lib.pgicp_host_alloc(self.h, C.c_size_t(nbytes), C.byref(p)))
+        buf = (C.c_char * nbytes).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a):
+        p = self._pinned.pop(a.ctypes.data)
+        self._check(self.lib.pgicp_host_free(self.h, C.c_void_p(p)))
+
+    def upload(self, readings, pinned=False, dtype=None):
+        """pgicp_upload_*: start the H2D transfer of host readings on the copy stream, return DevPtr handles at once."""
+        bufs = [_Buf(r, dtype) for r in readings]
+        assert all(b.mem == HOST for b in bufs)
+        n = len(bufs)
+        ct = C.c_float if bufs[0].dtype == np.float32 else C.c_double
+        hosts = (C.c_void_p * n)(*[b.ptr for b in bufs])
+        strides = (C.c_int * n)(*[b.stride for b in bufs])
+        counts = (C.c_int * n)(*[b.n for b in bufs])
+        out = (C.c_void_p * n)()
+        fn = getattr(self.lib, "pgicp_upload" + self._sfx(bufs[0].dtype))
+        self._check(fn(self.h, C.c_int(n), hosts, strides, counts, C.c_int(HOST_PINNED if pinned else HOST), out))
+        del ct
+        return [DevPtr(out[k], bufs[k].stride, bufs[k].n, bufs[k].dtype, keep=bufs[k].keep) for k in range(n)]
 
     def set_params(self, **kw):
         for k, v in kw.items():

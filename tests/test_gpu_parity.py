@@ -374,3 +374,38 @@ def test_batch_entry_points_equal_single_calls(ctx):
         np.testing.assert_array_equal(da, d1)
     for m in ids_b + ids_s:
         ctx.destroy_map(m)
+
+
+@pytest.mark.gpu
+def test_upload_pipeline_matches_host_input():
+    """pgicp_upload_*: readings transferred on the copy stream (pinned and pageable sources, sets reused round robin)
+    give the bit-identical result of the same reading passed as a host buffer."""
+    from pgslam_amd import icp, synth
+    w = synth.make_scan_to_map(n_scan=5000, n_map=40000, n_queries=4, n_map_poses=3, rings=16)
+    chain = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01, smooth_length=3,
+                 sensor_std_dev=0.01)
+    ctx = icp.Context(0, **chain)
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=True)
+    ref = [ctx.align(mid, w.scans_xyz[q], w.T_init[q]) for q in range(4)]
+    pinned = []
+    for q in range(4):
+        a = ctx.host_alloc(w.scans_xyz[q].shape, np.float32)
+        a[...] = w.scans_xyz[q]
+        pinned.append(a)
+    # five uploads in a row (two sets, so three reuses), alternating pinned / pageable sources, one step ahead
+    ups = [ctx.upload([pinned[q % 4]] if q % 2 == 0 else [w.scans_xyz[q % 4]], pinned=(q % 2 == 0)) for q in range(2)]
+    for q in range(6):
+        T, st = ctx.align(mid, ups[q % 2][0], w.T_init[q % 4])
+        assert st["status"] == 0 and st["iterations"] == ref[q % 4][1]["iterations"]
+        assert np.array_equal(T, ref[q % 4][0])
+        nq = q + 2
+        ups[q % 2] = ctx.upload([pinned[nq % 4]] if nq % 2 == 0 else [w.scans_xyz[nq % 4]], pinned=(nq % 2 == 0))
+    # a whole batch in one upload, and an uploaded cloud as a reference cloud
+    up = ctx.upload([w.scans_xyz[q] for q in range(4)])
+    Tb, stb = ctx.align_batch(mid, up, [w.T_init[q] for q in range(4)])
+    for q in range(4):
+        assert np.array_equal(Tb[q], ref[q][0])
+    for a in pinned:
+        ctx.host_free(a)
+    ctx.destroy_map(mid)
+    ctx.close()
