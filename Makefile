@@ -6,7 +6,7 @@ ARCH ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -ffp-contract=off -fPIC -std=c++17 -Iinclude -Ipgslam_amd/csrc -Wall -Wno-unused-result
 CSRC = pgslam_amd/csrc
 LIB = pgslam_amd/lib/libpgicp.so
-OBJS = $(CSRC)/kernels.o $(CSRC)/pgicp_api.o
+OBJS = $(CSRC)/kernels.o $(CSRC)/pgicp_api.o $(CSRC)/pgicp_comm.o
 
 all: $(LIB) oracle
 
@@ -14,9 +14,11 @@ $(CSRC)/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/k_*.inc) $(CSRC)/kerne
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/pgicp_api.o: $(CSRC)/pgicp_api.cpp $(CSRC)/kernels.hpp $(CSRC)/device_types.hpp $(CSRC)/icp_math.hpp include/pgicp.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/pgicp_comm.o: $(CSRC)/pgicp_comm.cpp include/pgicp.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIB): $(OBJS)
 	@mkdir -p pgslam_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle

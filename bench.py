@@ -42,6 +42,18 @@ CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, mi
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+def emit(line: dict):
+    """The ONE JSON line, as the last thing on stdout: native libraries (RCCL prints a version banner when a communicator
+    is made) write through C stdio, whose buffer would otherwise be flushed after Python's at exit."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
 def _gen_scan(args):
     from pgslam_amd import synth
     kind, i, n_pts, rings, pose = args
@@ -213,12 +225,18 @@ def main_loopclosure(args):
     ctx = icp.Context(local_rank, **CHAIN, check_every=args.check_every)
     costs = [c.reading.shape[0] + c.ref_xyz.shape[0] for c in cands]
     mine = lc.shard(costs, world, rank)
+    # the collective of the path goes through the C ABI (pgicp_allgather_edges: one ncclAllGather over RCCL / xGMI), at
+    # world size 1 too; torch.distributed only carries the communicator's unique id, the barrier and the timing
+    uid = [icp.comm_unique_id() if rank == 0 else None]
+    if distributed:
+        dist.broadcast_object_list(uid, src=0)
+    comm = icp.Comm(ctx, world, rank, uid[0])
 
     def step():
         parts = [lc.align_local(ctx, [cands[i] for i in mine[k:k + args.pair_chunk]], cfg)
                  for k in range(0, len(mine), args.pair_chunk)]
         local = np.concatenate(parts) if parts else np.zeros(0, dtype=lc.EDGE_DTYPE)
-        return lc.allgather_edges(local, mine, len(cands), device=dev if distributed else None)
+        return lc.allgather_edges_rccl(comm, local, mine, costs)
 
     for _ in range(args.warmup):
         step()
@@ -237,9 +255,48 @@ def main_loopclosure(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- roofline of the dominant kernel (the fast matcher again), per SURVEY.md 8(d) "Config 5 bytes": per pair and
+    #      iteration 20 N + 12 M, with N = M = the clouds' size and every pair holding its own map; measured with HIP
+    #      events over a replay of the timed steps ----
+    roofline = None
+    if not args.no_profile:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(args.steps):
+            step()
+        ctx.profile_enable(False)
+        k = ctx.profile()["knn_grid"]
+        if k["launches"]:
+            alg = 20.0 * k["units"] + 12.0 * args.n_scan * k["problems"]
+            avg_s = k["total_ms"] * 1e-3 / k["launches"]
+            ach = alg / k["launches"] / avg_s / 1e9
+            roofline = dict(bound="hbm", kernel="knn_grid", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                            traffic=None, avg_launch_us=avg_s * 1e6, launches=k["launches"], profiled_steps=args.steps,
+                            algorithmic_bytes_per_launch=alg / k["launches"], active_problems_per_launch=k["problems"] / k["launches"])
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle on a bounded sample of the same pairs: ICP::operator() (index build + loop) + the residual chain
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle import Oracle
+        import statistics
+        o = Oracle(np.float32)
+        sample = list(range(0, len(cands), max(1, len(cands) // 8)))[:8]
+        times = []
+        for p_ in sample:
+            c_ = cands[p_]
+            rd, rx, rn = (c_.reading.cpu().numpy(), c_.ref_xyz.cpu().numpy(), c_.ref_nrm.cpu().numpy())
+            t1 = time.perf_counter()
+            r_ = o.icp(rd, rx, rn, c_.T_init, **CHAIN)
+            if r_["status"] == 0:
+                o.partial_chain(rd, rx, rn, r_["T"], **CHAIN)
+            times.append(time.perf_counter() - t1)
+        cpu = dict(value=1.0 / statistics.median(times), unit="pairs/s", cores=1, kind="port",
+                   sample=f"{len(sample)} of the {len(cands)} pairs through the CPU oracle (k-d tree build + ICP + residual chain per pair) "
+                          f"on one core, median; host has {os.cpu_count()} cores")
     if rank == 0:
         ok = int(np.sum(edges["status"] == 0))
-        print(json.dumps({
+        emit(({
+            "roofline": roofline, "cpu_baseline": cpu,
             "metric": "loop-closure candidate ICPs/sec (100k-pt keyframe vs 100k-pt candidate map)",
             "value": args.steps * len(cands) / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
@@ -247,9 +304,10 @@ def main_loopclosure(args):
             "config": {"workload": f"batched loop-closure ICP, {len(cands)} pairs of {args.n_scan}-pt clouds "
                                    f"(BASELINE.json configs[4]), index build + ICP + residual check per pair, "
                                    f"all-gather of 512-byte edge records", "pair_chunk": args.pair_chunk,
-                       "parallelism": f"pairs sharded over {world} rank(s), one all-gather"},
+                       "parallelism": f"pairs sharded over {world} rank(s), one ncclAllGather (pgicp_allgather_edges, RCCL)"},
             "pairs_ok": ok, "pairs_accepted": int(np.sum(edges["accepted"] == 1)),
             "mean_iterations": float(np.mean(edges["iterations"]))}))
+    comm.close()
     ctx.close()
     if distributed:
         dist.destroy_process_group()
@@ -434,7 +492,7 @@ def main_slam(args):
                           f"replayed one after the other through the CPU oracle on one core; host has {os.cpu_count()} cores")
     if rank == 0:
         n = res["scans"] - 1
-        print(json.dumps({
+        emit(({
             "metric": "scans/sec through full pose-graph SLAM (synthetic KITTI-00-shaped sequence, loop closures, host pose-graph solve)",
             "value": args.steps * n * world / slam_s, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": slam_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -593,7 +651,7 @@ def main_stream(args):
         conv = sum(r[1] for r in res)
         mode = ("one device batch per time step (fleet)" if args.fleet else
                 ("synchronous" if args.sync_rebuild else "background") + " map rebuild, one host thread per vehicle")
-        print(json.dumps({
+        emit(({
             "metric": "streamed scans/sec through the local mapper (100k-pt scans, sliding 2M-pt device-resident map)",
             "value": args.steps * per_step * world / elapsed, "unit": "scans/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
@@ -921,7 +979,7 @@ def main():
         }
         if cpu and cpu["value"] > 0:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-        print(json.dumps(out))
+        emit(out)
     for c_, m_ in zip(ctxs, map_ids):
         c_.destroy_map(m_)
         c_.close()

@@ -126,6 +126,7 @@ void pgicp_ctx_destroy(pgicp_ctx *ctx);
 const char *pgicp_last_error(const pgicp_ctx *ctx);
 /* The HIP stream (hipStream_t) every kernel of this context is launched on. */
 void *pgicp_ctx_stream(pgicp_ctx *ctx);
+int pgicp_ctx_device(const pgicp_ctx *ctx, int *device);
 int pgicp_ctx_synchronize(pgicp_ctx *ctx);
 
 /* Readable text of a status code (never NULL). */
@@ -287,6 +288,29 @@ int pgicp_shard_pairs(int n_pairs, const int64_t *cost, int world_size, int rank
                       int *n_out);
 int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double overlap_threshold,
                            double residual_error_threshold);
+
+/* ---- the collective of the path: all-gather of loop-closure edges over RCCL / xGMI ----------
+ * One process per GPU.  Rank 0 makes a unique id (pgicp_comm_unique_id), the caller passes its bytes to the
+ * other ranks by any channel it has, every rank builds its communicator on its context's device
+ * (pgicp_comm_create = ncclCommInitRank).  RCCL is opened at run time on first use.
+ * pgicp_allgather_edges: every rank contributes the n_local edges it aligned (pair_index[k] = position of
+ * edge k in the job's candidate list) and receives ALL n_total edges in candidate order -- what
+ * OptimizerMT::Main drains into one solve (OptimizerMT.hpp:59-65; payload Optimizer.h:22).  It is ONE
+ * ncclAllGather of fixed-size blocks of slots_per_rank 512-byte records: slots_per_rank is the largest shard,
+ * which every rank computes itself from the deterministic split (pgicp_shard_slots) -- no size exchange.
+ * Empty slots and candidates nobody reported come back with from_id = to_id = status = -1.  The context's
+ * stream carries the collective; the call returns when `out` is complete.  Errors of these entry points:
+ * pgicp_comm_last_error() (per thread). */
+typedef struct pgicp_comm pgicp_comm;
+#define PGICP_UNIQUE_ID_BYTES 128
+int pgicp_comm_unique_id(char id[PGICP_UNIQUE_ID_BYTES]);
+int pgicp_comm_create(pgicp_ctx *ctx, int world_size, int rank, const char id[PGICP_UNIQUE_ID_BYTES], pgicp_comm **out);
+void pgicp_comm_destroy(pgicp_comm *comm);
+int pgicp_comm_info(const pgicp_comm *comm, int *world_size, int *rank);
+const char *pgicp_comm_last_error(void);
+int pgicp_shard_slots(int n_pairs, const int64_t *cost, int world_size, int *slots);
+int pgicp_allgather_edges(pgicp_comm *comm, const pgicp_edge *local, const int *pair_index, int n_local, int slots_per_rank,
+                          int n_total, pgicp_edge *out);
 
 /* ---- measurement -------------------------------------------------------
  * With profiling on, every launch of the named kernels is bracketed by HIP

@@ -419,18 +419,31 @@ public:
         std::vector<pgicp_problem> pr(P);
         std::vector<int> maps(P, -1), xs(P), ns(P), ms(P);
         std::vector<const T *> xyz(P), nrm(P);
+        // the chain's data-point filters act on copies, as ICP::operator() applies them (LoopCloser.hpp:98 -> reference
+        // filters, then reading filters); a chain without filters reads the candidates' clouds where they lie
+        std::vector<DP> ref_f, rd_f;
+        const bool filt_ref = !chain_.referenceDataPointsFilters.empty(), filt_rd = !chain_.readingDataPointsFilters.empty();
+        if (filt_ref) { ref_f.reserve(P); chain_.referenceDataPointsFilters.init(); }
+        if (filt_rd) { rd_f.reserve(P); chain_.readingDataPointsFilters.init(); }
+        auto reference_of = [&](int k) -> const DP & { return filt_ref ? ref_f[k] : *queue_[mine[k]].reference; };
+        auto reading_of = [&](int k) -> const DP & { return filt_rd ? rd_f[k] : *queue_[mine[k]].reading; };
         for (int k = 0; k < P; k++) {
             const Candidate &c = queue_[mine[k]];
-            xyz[k] = c.reference->xyzPtr(); xs[k] = c.reference->xyzStride();
-            nrm[k] = c.reference->normalsPtr(); ns[k] = c.reference->normalsStride();
-            ms[k] = (int)c.reference->getNbPoints();
+            if (filt_ref) { ref_f.push_back(*c.reference); chain_.referenceDataPointsFilters.apply(ref_f.back()); }
+            if (filt_rd) { rd_f.push_back(*c.reading); chain_.readingDataPointsFilters.apply(rd_f.back()); }
+            const DP &ref = reference_of(k);
+            if (!ref.descriptorExists("normals")) throw std::runtime_error("LoopClosureBatch: a candidate reference has no 'normals' descriptor");
+            xyz[k] = ref.xyzPtr(); xs[k] = ref.xyzStride();
+            nrm[k] = ref.normalsPtr(); ns[k] = ref.normalsStride();
+            ms[k] = (int)ref.getNbPoints();
         }
         // every candidate's reference is indexed in one call (ICP::operator() builds it inside, LoopCloser.hpp:98)
         PM::check(ctx, pgslam_amd::Abi<T>::map_create_batch(ctx, P, xyz.data(), xs.data(), nrm.data(), ns.data(), ms.data(), 1, maps.data()));
         for (int k = 0; k < P; k++) {
             const Candidate &c = queue_[mine[k]];
-            pr[k].map_id = maps[k]; pr[k].reading = c.reading->xyzPtr(); pr[k].stride = c.reading->xyzStride();
-            pr[k].n = (int)c.reading->getNbPoints(); pr[k].mem = PGICP_HOST;
+            const DP &rd = reading_of(k);
+            pr[k].map_id = maps[k]; pr[k].reading = rd.xyzPtr(); pr[k].stride = rd.xyzStride();
+            pr[k].n = (int)rd.getNbPoints(); pr[k].mem = PGICP_HOST;
             pgslam_amd::to_row_major16(c.T_init, pr[k].T_init);
         }
         std::vector<double> Tout((size_t)16 * P);
@@ -468,6 +481,21 @@ public:
             pgicp_map_destroy(ctx, maps[k]);
         }
         return edges;
+    }
+    //! Every rank's edges in queue order (OptimizerMT::Main drains them into one solve, OptimizerMT.hpp:59-65): ONE
+    //! ncclAllGather over RCCL (pgicp_allgather_edges).  `mine` / `local` as given to / returned by Run; the block size
+    //! is derived from the same deterministic split on every rank.  Entries nobody reported have from_id -1.
+    std::vector<pgicp_edge> Gather(pgicp_comm *comm, const std::vector<int> &mine, const std::vector<pgicp_edge> &local) const
+    {
+        int world = 1, rank = 0, slots = 0;
+        if (pgicp_comm_info(comm, &world, &rank) != PGICP_OK) throw std::runtime_error("LoopClosureBatch::Gather: no communicator");
+        std::vector<int64_t> cost(queue_.size());
+        for (size_t i = 0; i < queue_.size(); i++) cost[i] = (int64_t)queue_[i].reading->getNbPoints() + (int64_t)queue_[i].reference->getNbPoints();
+        if (pgicp_shard_slots((int)queue_.size(), cost.data(), world, &slots) != PGICP_OK) throw std::runtime_error("pgicp_shard_slots failed");
+        std::vector<pgicp_edge> all(queue_.size());
+        if (pgicp_allgather_edges(comm, local.data(), mine.data(), (int)local.size(), slots, (int)queue_.size(), all.data()) != PGICP_OK)
+            throw std::runtime_error(std::string("pgicp_allgather_edges: ") + pgicp_comm_last_error());
+        return all;
     }
 
 private:

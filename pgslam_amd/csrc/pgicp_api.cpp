@@ -1411,6 +1411,7 @@ const char *pgicp_status_string(int status)
 
 const char *pgicp_last_error(const pgicp_ctx *c) { return c ? c->err.c_str() : "null context"; }
 void *pgicp_ctx_stream(pgicp_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int pgicp_ctx_device(const pgicp_ctx *c, int *device) { if (!c || !device) return PGICP_ERR_ARG; *device = c->device; return PGICP_OK; }
 
 int pgicp_ctx_synchronize(pgicp_ctx *c)
 {

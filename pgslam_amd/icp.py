@@ -45,6 +45,8 @@ ABI_SYMBOLS = [
     "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters",
     "pgicp_debug_last_matches_f32", "pgicp_debug_last_matches_f64",
     "pgicp_status_string", "pgicp_upload_f32", "pgicp_upload_f64", "pgicp_host_alloc", "pgicp_host_free",
+    "pgicp_ctx_device", "pgicp_comm_unique_id", "pgicp_comm_create", "pgicp_comm_destroy", "pgicp_comm_info",
+    "pgicp_comm_last_error", "pgicp_shard_slots", "pgicp_allgather_edges",
 ]
 
 
@@ -105,6 +107,7 @@ def load_library() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.pgicp_last_error.restype = C.c_char_p
         _lib.pgicp_status_string.restype = C.c_char_p
+        _lib.pgicp_comm_last_error.restype = C.c_char_p
         _lib.pgicp_ctx_stream.restype = C.c_void_p
     return _lib
 
@@ -156,6 +159,68 @@ class _Buf:
 def _T16(T):
     T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4))
     return (C.c_double * 16)(*T.ravel())
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """pgicp_comm_unique_id (rank 0); pass the bytes to the other ranks by any channel."""
+    lib = load_library()
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    st = lib.pgicp_comm_unique_id(buf)
+    if st != OK:
+        raise PgicpError(st, lib.pgicp_comm_last_error().decode())
+    return buf.raw
+
+
+def shard_slots(costs, world_size: int) -> int:
+    """Largest shard of the deterministic split: the block size of the edge all-gather, known to every rank."""
+    lib = load_library()
+    n = len(costs)
+    arr = (C.c_int64 * max(n, 1))(*[int(c) for c in costs])
+    out = C.c_int()
+    st = lib.pgicp_shard_slots(C.c_int(n), arr, C.c_int(world_size), C.byref(out))
+    if st != OK:
+        raise PgicpError(st, "pgicp_shard_slots failed")
+    return out.value
+
+
+class Comm:
+    """RCCL communicator of one rank (pgicp_comm_create) on a context's device."""
+
+    def __init__(self, ctx: "Context", world_size: int, rank: int, unique_id: bytes):
+        self.lib = ctx.lib
+        self.ctx = ctx
+        self.world_size, self.rank = world_size, rank
+        h = C.c_void_p()
+        st = self.lib.pgicp_comm_create(ctx.h, C.c_int(world_size), C.c_int(rank), C.create_string_buffer(unique_id, UNIQUE_ID_BYTES), C.byref(h))
+        if st != OK:
+            raise PgicpError(st, self.lib.pgicp_comm_last_error().decode())
+        self.h = h
+
+    def allgather_edges(self, local_edges: np.ndarray, pair_index, slots_per_rank: int, n_total: int) -> np.ndarray:
+        """pgicp_allgather_edges on numpy records of the 512-byte pgicp_edge layout."""
+        assert local_edges.dtype.itemsize == C.sizeof(Edge)
+        local = np.ascontiguousarray(local_edges)
+        idx = np.ascontiguousarray(np.asarray(pair_index, dtype=np.int32))
+        out = np.zeros(n_total, dtype=local_edges.dtype)
+        st = self.lib.pgicp_allgather_edges(self.h, C.c_void_p(local.ctypes.data), C.c_void_p(idx.ctypes.data), C.c_int(len(local)),
+                                            C.c_int(slots_per_rank), C.c_int(n_total), C.c_void_p(out.ctypes.data))
+        if st != OK:
+            raise PgicpError(st, self.lib.pgicp_comm_last_error().decode())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pgicp_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

@@ -90,6 +90,14 @@ def align_local(ctx: icp.Context, cands, cfg: LoopClosureConfig):
     return edges
 
 
+def allgather_edges_rccl(comm: "icp.Comm", local_edges: np.ndarray, pair_index, costs) -> np.ndarray:
+    """The product's collective: pgicp_allgather_edges (one ncclAllGather of fixed-size blocks over RCCL / xGMI, through
+    the C ABI).  `costs` are the candidates' costs the shard was made from: every rank derives the block size from them
+    (icp.shard_slots), so no size is exchanged.  Pairs nobody reported come back with from_id -1."""
+    slots = icp.shard_slots(costs, comm.world_size)
+    return comm.allgather_edges(local_edges, pair_index, slots, len(costs))
+
+
 def allgather_edges(local_edges: np.ndarray, pair_index: np.ndarray, n_pairs: int, group=None, device=None):
     """Every rank ends with the SAME list of n_pairs edges, ordered by pair index.
 
@@ -128,11 +136,14 @@ def allgather_edges(local_edges: np.ndarray, pair_index: np.ndarray, n_pairs: in
 
 
 def close_loops(ctx, candidates, cfg: LoopClosureConfig, rank=0, world_size=1, group=None, device=None,
-                align_fn=align_local):
-    """Shard -> align -> all-gather.  Returns the full edge list (identical on every rank)."""
+                align_fn=align_local, comm=None):
+    """Shard -> align -> all-gather.  Returns the full edge list (identical on every rank).  With `comm` (icp.Comm)
+    the gather is the C ABI's RCCL collective; without, torch.distributed's (the gloo tests of the host logic)."""
     costs = [int(c.reading.shape[0]) + int(c.ref_xyz.shape[0]) for c in candidates]
     mine = shard(costs, world_size, rank)
     local = align_fn(ctx, [candidates[i] for i in mine], cfg)
+    if comm is not None:
+        return allgather_edges_rccl(comm, local, mine, costs)
     return allgather_edges(local, mine, len(candidates), group=group, device=device)
 
 

@@ -12,31 +12,33 @@
         if (!(cond)) { std::fprintf(stderr, "CHECK failed: %s  (%s:%d)\n", #cond, __FILE__, __LINE__); std::exit(1); } \
     } while (0)
 
+#define PGSLAM_TEST_CHAIN_TAIL \
+    "matcher:\n" \
+    "  KDTreeMatcher:\n" \
+    "    knn: 1\n" \
+    "    epsilon: 0\n" \
+    "    maxDist: 2.0     # metres\n" \
+    "outlierFilters:\n" \
+    "  - TrimmedDistOutlierFilter:\n" \
+    "      ratio: 0.85\n" \
+    "errorMinimizer:\n" \
+    "  PointToPlaneWithCovErrorMinimizer:\n" \
+    "    sensorStdDev: 0.01\n" \
+    "transformationCheckers:\n" \
+    "  - CounterTransformationChecker:\n" \
+    "      maxIterationCount: 30\n" \
+    "  - DifferentialTransformationChecker:\n" \
+    "      minDiffRotErr: 0.001\n" \
+    "      minDiffTransErr: 0.01\n" \
+    "      smoothLength: 3\n" \
+    "inspector:\n" \
+    "  NullInspector\n" \
+    "logger:\n" \
+    "  NullLogger\n"
+static const char *kIcpYamlTail = PGSLAM_TEST_CHAIN_TAIL;
 static const char *kIcpYaml =
     "readingDataPointsFilters:\n"
-    "  - IdentityDataPointsFilter\n"
-    "matcher:\n"
-    "  KDTreeMatcher:\n"
-    "    knn: 1\n"
-    "    epsilon: 0\n"
-    "    maxDist: 2.0     # metres\n"
-    "outlierFilters:\n"
-    "  - TrimmedDistOutlierFilter:\n"
-    "      ratio: 0.85\n"
-    "errorMinimizer:\n"
-    "  PointToPlaneWithCovErrorMinimizer:\n"
-    "    sensorStdDev: 0.01\n"
-    "transformationCheckers:\n"
-    "  - CounterTransformationChecker:\n"
-    "      maxIterationCount: 30\n"
-    "  - DifferentialTransformationChecker:\n"
-    "      minDiffRotErr: 0.001\n"
-    "      minDiffTransErr: 0.01\n"
-    "      smoothLength: 3\n"
-    "inspector:\n"
-    "  NullInspector\n"
-    "logger:\n"
-    "  NullLogger\n";
+    "  - IdentityDataPointsFilter\n" PGSLAM_TEST_CHAIN_TAIL;
 
 // deterministic LCG in [0,1)
 struct Lcg {

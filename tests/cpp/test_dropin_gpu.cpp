@@ -88,6 +88,37 @@ void run(const char *name)
         CHECK(pose_diff(pgslam_amd::from_row_major16<T>(e.T_from_to), T1) == 0.0);
     }
     CHECK(sizeof(pgicp_edge) == 512 && e1.size() == s1.size());
+    {   // the collective of the C ABI on the real RCCL path, one rank: the gathered list is the queue in order
+        char uid[PGICP_UNIQUE_ID_BYTES];
+        CHECK(pgicp_comm_unique_id(uid) == PGICP_OK);
+        pgicp_ctx *cctx = nullptr;
+        CHECK(pgicp_ctx_create(0, &cctx) == PGICP_OK);
+        pgicp_comm *comm = nullptr;
+        CHECK(pgicp_comm_create(cctx, 1, 0, uid, &comm) == PGICP_OK);
+        const auto all = batch.Shard(1, 0);
+        const auto ea = batch.Run(all);
+        const auto g = batch.Gather(comm, all, ea);
+        CHECK(g.size() == 3);
+        for (int k = 0; k < 3; k++) {
+            CHECK(g[k].from_id == 100 + k && g[k].to_id == 200 + k && g[k].accepted == 1);
+            CHECK(std::memcmp(g[k].T_from_to, ea[k].T_from_to, sizeof ea[k].T_from_to) == 0);
+        }
+        pgicp_comm_destroy(comm);
+        pgicp_ctx_destroy(cctx);
+    }
+    {   // a chain WITH data-point filters gives the batch what the one-at-a-time loop closer gives (both apply them)
+        const std::string yaml = std::string("readingDataPointsFilters:\n  - BoundingBoxDataPointsFilter:\n      xMin: -100\n      xMax: 100\n      yMin: -100\n      yMax: 100\n      zMin: -100\n      zMax: 0.9\n      removeInside: 0\n"
+                                             "referenceDataPointsFilters:\n  - BoundingBoxDataPointsFilter:\n      xMin: -100\n      xMax: 100\n      yMin: -100\n      yMax: 100\n      zMin: -100\n      zMax: 0.9\n      removeInside: 0\n") + kIcpYamlTail;
+        pgslam::LoopCloser<T> one;
+        one.SetIcpConfigFromString(yaml);
+        const auto r1 = one.ProcessCandidate(reading, map, guess);
+        pgslam::LoopClosureBatch<T> fb;
+        fb.SetIcpConfigFromString(yaml);
+        fb.Add({1, 2, rp, mp, guess});
+        const auto ef = fb.Run(fb.Shard(1, 0));
+        CHECK(ef.size() == 1 && ef[0].status == 0);
+        CHECK(pose_diff(pgslam_amd::from_row_major16<T>(ef[0].T_from_to), r1.T_refkf_kf) == 0.0);
+    }
 
     // --- LocalMap::BuildCloudFromData  (LocalMap.hpp:209-224)
     std::vector<Keyframe> kfs(2);

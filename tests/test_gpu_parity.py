@@ -409,3 +409,33 @@ def test_upload_pipeline_matches_host_input():
         ctx.host_free(a)
     ctx.destroy_map(mid)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_rccl_allgather_edges_world_size_1():
+    """pgicp_allgather_edges on the real RCCL path (communicator of one rank): the gathered list is the local one in
+    candidate order, empty slots and unreported candidates are marked -1."""
+    from pgslam_amd import icp, loop_closure as lc
+    ctx = icp.Context(0)
+    comm = icp.Comm(ctx, 1, 0, icp.comm_unique_id())
+    rng = np.random.default_rng(5)
+    n_total = 7
+    mine = np.array([5, 0, 3], dtype=np.int32)
+    local = np.zeros(3, dtype=lc.EDGE_DTYPE)
+    local["from_id"] = [10, 11, 12]
+    local["to_id"] = [20, 21, 22]
+    local["T_from_to"] = rng.standard_normal((3, 16))
+    local["cov"] = rng.standard_normal((3, 36))
+    local["accepted"] = [1, 0, 1]
+    out = comm.allgather_edges(local, mine, slots_per_rank=5, n_total=n_total)
+    assert out.shape == (n_total,)
+    for k, p in enumerate(mine):
+        for f in ("from_id", "to_id", "accepted"):
+            assert out[f][p] == local[f][k]
+        assert np.array_equal(out["T_from_to"][p], local["T_from_to"][k]) and np.array_equal(out["cov"][p], local["cov"][k])
+    rest = [i for i in range(n_total) if i not in mine]
+    assert np.all(out["from_id"][rest] == -1) and np.all(out["status"][rest] == -1)
+    # the block size every rank derives by itself
+    assert icp.shard_slots([5, 1, 1, 1, 1, 1], 2) == 5 and icp.shard_slots([1] * 9, 4) == 3
+    comm.close()
+    ctx.close()
