@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PGICP_ABI_VERSION 1
+#define PGICP_ABI_VERSION 2
 
 /* status codes (pgslam sees PM::ConvergenceError for 1..2 through the C++ shim) */
 #define PGICP_OK 0
@@ -70,6 +70,8 @@ typedef struct pgicp_params {
     int matcher;             /* PGICP_MATCHER_GRID | PGICP_MATCHER_BRUTE */
     double grid_cell;        /* grid cell edge in metres; 0 = automatic */
     int check_every;         /* host polls the device-side "all done" flag every this many iterations (>=1) */
+    double outlier_max_dist; /* MaxDistOutlierFilter.maxDist: a second outlier filter whose weights multiply the trimmed
+                              * filter's (pairs farther than this get weight 0); 0 or +inf = not in the chain */
 } pgicp_params;
 
 /* What pgslam reads back after an ICP: errorMinimizer->getOverlap()

@@ -359,6 +359,32 @@ struct PointMatcher {
             }
         }
     };
+    //! [EXT] FixStepSamplingDataPointsFilter{startStep (= endStep, stepMult = 1)}: keeps points 0, step, 2 step, ... -- deterministic
+    struct FixStepSamplingDataPointsFilter : DataPointsFilter {
+        int step;
+        explicit FixStepSamplingDataPointsFilter(int s) : step(s < 1 ? 1 : s) {}
+        void inPlaceFilter(DataPoints &c) override
+        {
+            compactColumns(c, [&](int j) { return j % step == 0; });
+        }
+    };
+    //! [EXT] RandomSamplingDataPointsFilter{prob}: upstream keeps a point when rand() / RAND_MAX < prob -- the C library's
+    //! global generator, so no two runs (or platforms) agree and there is nothing to be bit-exact against.  Here the draw is
+    //! a build-owned counter-based generator (SplitMix64 of seed and point index): the sample is reproducible, has the same
+    //! distribution, and is documented as NOT bit-parity with upstream.  `seed` is an extra, optional parameter.
+    struct RandomSamplingDataPointsFilter : DataPointsFilter {
+        T prob; unsigned long long seed;
+        RandomSamplingDataPointsFilter(T p, unsigned long long s) : prob(p), seed(s) {}
+        static unsigned long long mix(unsigned long long z)
+        {
+            z += 0x9E3779B97F4A7C15ULL; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            return z ^ (z >> 31);
+        }
+        void inPlaceFilter(DataPoints &c) override
+        {
+            compactColumns(c, [&](int j) { return (double)(mix(seed * 0x100000001B3ULL + (unsigned long long)j) >> 11) / 9007199254740992.0 < (double)prob; });
+        }
+    };
     //! [EXT] SurfaceNormalDataPointsFilter{knn, maxDist, epsilon, keepNormals, keepEigenValues}: normals (and,
     //! on request, eigenvalues) of every point from its knn neighbours, computed on the device by
     //! pgicp_surface_normals_*; the descriptors are appended as libpointmatcher appends them.
@@ -426,10 +452,19 @@ struct PointMatcher {
                 } else if (m.name == "OrientNormalsDataPointsFilter") {
                     this->push_back(std::make_shared<OrientNormalsDataPointsFilter>(
                         to_double(m.params.count("towardCenter") ? m.params.at("towardCenter") : std::string("1"), m.name) != 0.0));
+                } else if (m.name == "FixStepSamplingDataPointsFilter") {
+                    auto get = [&](const char *k, const char *def) { return to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
+                    const int start = (int)get("startStep", "10");
+                    if ((m.params.count("endStep") && (int)get("endStep", "10") != start) || get("stepMult", "1") != 1.0)
+                        throw std::runtime_error(m.name + ": only a constant step (endStep = startStep, stepMult = 1) is supported");
+                    this->push_back(std::make_shared<FixStepSamplingDataPointsFilter>(start));
+                } else if (m.name == "RandomSamplingDataPointsFilter") {
+                    auto get = [&](const char *k, const char *def) { return to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
+                    this->push_back(std::make_shared<RandomSamplingDataPointsFilter>((T)get("prob", "0.75"), (unsigned long long)get("seed", "1")));
                 } else
                     throw std::runtime_error("DataPointsFilters: unsupported filter '" + m.name +
                                              "' (supported: Identity, MinDist, MaxDist, BoundingBox, RemoveNaN, SurfaceNormal, "
-                                             "ObservationDirection, OrientNormals; the sampling filters draw from rand() upstream and are not restated)");
+                                             "ObservationDirection, OrientNormals, FixStepSampling, RandomSampling (seeded, not bit-parity))");
             }
         }
         void init() { for (auto &f : *this) f->init(); }
@@ -481,6 +516,18 @@ struct PointMatcher {
             chain->pushParams();
             T lim; int nf;
             check(chain->ctx, A::weights(chain->ctx, input.dists.data(), (int)input.dists.size(), w.data(), &lim, &nf));
+            return w;
+        }
+    };
+    //! [EXT] MaxDistOutlierFilter{maxDist}: weight 1 while the squared match distance is <= maxDist^2, else 0
+    struct MaxDistOutlierFilter : OutlierFilter {
+        T maxDist;
+        explicit MaxDistOutlierFilter(T d) : maxDist(d) {}
+        OutlierWeights compute(const DataPoints &, const DataPoints &, const Matches &input) override
+        {
+            OutlierWeights w(input.dists.rows(), input.dists.cols());
+            const T lim = maxDist * maxDist;
+            for (int j = 0; j < w.cols(); j++) for (int i = 0; i < w.rows(); i++) w(i, j) = input.dists(i, j) <= lim ? T(1) : T(0);
             return w;
         }
     };
@@ -636,13 +683,19 @@ struct PointMatcher {
                     else throw std::runtime_error("KDTreeMatcher: unknown parameter " + kv.first);
                 }
             }
-            if (y.has("outlierFilters"))
+            // the chain multiplies its filters' weights (A.4): one TrimmedDist and / or one MaxDist filter, in any order
+            if (y.has("outlierFilters")) {
+                int n_trim = 0, n_max = 0;
                 for (auto &m : y.sections.at("outlierFilters")) {
-                    if (m.name != "TrimmedDistOutlierFilter") throw std::runtime_error("loadFromYaml: unsupported outlier filter " + m.name);
-                    outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, m.params.count("ratio") ? (T)to_double(m.params.at("ratio"), "ratio") : T(0.85)));
+                    if (m.name == "TrimmedDistOutlierFilter" && n_trim++ == 0)
+                        outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, m.params.count("ratio") ? (T)to_double(m.params.at("ratio"), "ratio") : T(0.85)));
+                    else if (m.name == "MaxDistOutlierFilter" && n_max++ == 0)
+                        outlierFilters.push_back(std::make_shared<MaxDistOutlierFilter>(m.params.count("maxDist") ? (T)to_double(m.params.at("maxDist"), "maxDist") : T(1)));
+                    else
+                        throw std::runtime_error("loadFromYaml: unsupported outlier filter chain at " + m.name +
+                                                 " (supported: one TrimmedDistOutlierFilter and / or one MaxDistOutlierFilter)");
                 }
-            else outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
-            if (outlierFilters.size() > 1) throw std::runtime_error("loadFromYaml: one TrimmedDistOutlierFilter is supported");
+            } else outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
             errorMinimizer = std::make_shared<ErrorMinimizer>(this);
             if (y.has("errorMinimizer") && !y.sections.at("errorMinimizer").empty()) {
                 const auto &m = y.sections.at("errorMinimizer")[0];
@@ -683,8 +736,12 @@ struct PointMatcher {
             pgicp_get_params(ctx, &cur);
             p.matcher = cur.matcher; p.grid_cell = cur.grid_cell; p.check_every = cur.check_every;
             if (matcher) { p.knn = matcher->knn; p.epsilon = (double)matcher->epsilon; p.max_dist = (double)matcher->maxDist; }
-            if (!outlierFilters.empty())
-                if (auto t = std::dynamic_pointer_cast<TrimmedDistOutlierFilter>(outlierFilters[0])) p.trim_ratio = (double)t->ratio;
+            p.trim_ratio = 1.0;                    // no TrimmedDist filter in the chain: every finite pair passes it
+            p.outlier_max_dist = 0.0;
+            for (auto &f : outlierFilters) {
+                if (auto t = std::dynamic_pointer_cast<TrimmedDistOutlierFilter>(f)) p.trim_ratio = (double)t->ratio;
+                if (auto m = std::dynamic_pointer_cast<MaxDistOutlierFilter>(f)) p.outlier_max_dist = (double)m->maxDist;
+            }
             if (errorMinimizer) p.sensor_std_dev = (double)errorMinimizer->sensorStdDev;
             bool hasCounter = false, hasDiff = false;
             for (auto &c : transformationCheckers) {
@@ -719,7 +776,12 @@ struct PointMatcher {
             readingDataPointsFilters.init();
             readingDataPointsFilters.apply(reading);
             prefilteredReadingPtsCount = reading.getNbPoints();
-            if (!readingStepDataPointsFilters.empty()) throw std::runtime_error("ICP: readingStepDataPointsFilters are not supported on the device loop");
+            // [EXT] readingStepDataPointsFilters (Localizer.hpp:325-326) act on the filtered reading in ITS OWN frame at every
+            // iteration, before the iteration's transform is applied; every filter restated here is a pure function of the
+            // cloud, so the step filters give the same cloud in every iteration: they are applied once, here (the seeded
+            // random sampler included -- upstream's draws a new sample per iteration from rand(), see its class comment)
+            readingStepDataPointsFilters.init();
+            readingStepDataPointsFilters.apply(reading);
             double Ti[16], To[16];
             pgslam_amd::to_row_major16(T_init, Ti);
             pgicp_stats st;

@@ -78,7 +78,18 @@ typedef struct {
     double sensor_std_dev;  /* PointToPlaneWithCovErrorMinimizer.sensorStdDev */
     int use_kdtree;         /* 0: brute force (ground truth), 1: kd-tree (same results) */
     int center_reference;   /* 1: subtract centroid as ICP::operator()/setMap do [A.2] */
+    real outlier_max_dist;  /* MaxDistOutlierFilter.maxDist, a second filter of the chain [A.4]; <= 0 or +inf: absent */
 } FN(orc_params);
+
+/* [A.4] the chain multiplies the weights of its outlier filters.  MaxDistOutlierFilter: weight 1 while the SQUARED
+ * distance is <= maxDist * maxDist, 0 beyond; the trimmed filter's threshold is not affected by it (each filter sees
+ * all the matches). */
+static void FN(orc_maxdist_weights)(const real *d2, int n, real max_dist, real *w)
+{
+    if (!(max_dist > (real)0) || isinf(max_dist)) return;
+    const real lim = max_dist * max_dist;
+    for (int i = 0; i < n; i++) if (!(d2[i] <= lim)) w[i] = (real)0;
+}
 
 typedef struct {
     int status;
@@ -809,6 +820,7 @@ int FN(orc_partial_chain)(const FN(orc_params) *prm, const real *reading, int n,
     } else FN(orc_knn_brute)(p, n, ref_xyz, m, prm->max_dist, ids, d2);
     real limit; int nf;
     int st = FN(orc_trim_weights)(d2, n, prm->trim_ratio, w, &limit, &nf);
+    if (st == ORC_OK) FN(orc_maxdist_weights)(d2, n, prm->outlier_max_dist, w);
     if (st == ORC_OK) {
         double sys[30];
         st = FN(orc_p2plane_system)(p, n, ref_xyz, ref_nrm, ids, w, sys);
@@ -893,6 +905,7 @@ int FN(orc_icp_map)(const FN(orc_params) *prm, const void *map, const real *read
         real limit; int nf;
         status = FN(orc_trim_weights)(d2, n, prm->trim_ratio, w, &limit, &nf);
         if (status != ORC_OK) break;
+        FN(orc_maxdist_weights)(d2, n, prm->outlier_max_dist, w);
         status = FN(orc_p2plane_system)(step, n, ref, ref_nrm, ids, w, sys);
         if (status != ORC_OK) break;
         double x[6]; int rank;
@@ -903,6 +916,8 @@ int FN(orc_icp_map)(const FN(orc_params) *prm, const void *map, const real *read
         res->overlap = sys[27] / (double)n;
         res->residual = sys[29];
         res->trim_limit = (double)limit;
+        if (prm->outlier_max_dist > (real)0 && !isinf(prm->outlier_max_dist) && prm->outlier_max_dist * prm->outlier_max_dist < limit)
+            res->trim_limit = (double)(prm->outlier_max_dist * prm->outlier_max_dist);   /* the threshold the pairs were kept with */
         res->n_kept = (int)sys[28];
         res->n_finite = nf;
         if (trace && it < trace_cap) memcpy(trace + 16 * it, T_iter, sizeof T_iter);

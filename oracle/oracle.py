@@ -36,7 +36,7 @@ def _params_type(real):
         _fields_ = [("max_dist", real), ("trim_ratio", real), ("max_iters", C.c_int),
                     ("min_diff_rot", C.c_double), ("min_diff_trans", C.c_double),
                     ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double),
-                    ("use_kdtree", C.c_int), ("center_reference", C.c_int)]
+                    ("use_kdtree", C.c_int), ("center_reference", C.c_int), ("outlier_max_dist", real)]
     return Params
 
 
@@ -76,7 +76,7 @@ class Oracle:
         d.update(kw)
         return self.Params(d["max_dist"], d["trim_ratio"], d["max_iters"], d["min_diff_rot"],
                            d["min_diff_trans"], d["smooth_length"], d["sensor_std_dev"],
-                           int(use_kdtree), int(center_reference))
+                           int(use_kdtree), int(center_reference), d.get("outlier_max_dist", 0.0))
 
     # -- stages -----------------------------------------------------------
     def transform(self, T, pts, rotate_only=False):

@@ -62,6 +62,7 @@ struct ChainDev {
     T max_dist;          // may be +inf
     T max_dist2;         // max_dist * max_dist in T
     T trim_ratio;
+    T outlier_max_d2;    // MaxDistOutlierFilter.maxDist squared in T; +inf when the chain has none
     int max_iters;
     int smooth;
     double min_rot, min_trans;

@@ -215,6 +215,10 @@ ChainDev<T> make_chain(const pgicp_params &p)
     ch.max_dist = (T)p.max_dist;
     ch.max_dist2 = ch.max_dist * ch.max_dist;
     ch.trim_ratio = (T)p.trim_ratio;
+    {
+        const T md = (T)p.outlier_max_dist;
+        ch.outlier_max_d2 = (p.outlier_max_dist > 0.0 && std::isfinite(p.outlier_max_dist)) ? md * md : std::numeric_limits<T>::infinity();
+    }
     ch.max_iters = p.max_iters;
     ch.smooth = p.smooth_length;
     ch.min_rot = p.min_diff_rot;
@@ -1292,6 +1296,7 @@ void pgicp_default_params(pgicp_params *p)
     p->epsilon = 0.0;
     p->max_dist = std::numeric_limits<double>::infinity();
     p->trim_ratio = 0.85;
+    p->outlier_max_dist = 0.0;
     p->max_iters = 40;
     p->min_diff_rot = 0.001;
     p->min_diff_trans = 0.001;
@@ -1427,6 +1432,7 @@ int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
     if (p->epsilon != 0.0) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.epsilon: only 0 (exact search) is supported");
     if (!(p->max_dist > 0.0)) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.maxDist must be > 0");
     if (!(p->trim_ratio > 0.0 && p->trim_ratio <= 1.0)) return fail(c, PGICP_ERR_ARG, "TrimmedDistOutlierFilter.ratio must be in (0,1]");
+    if (p->outlier_max_dist < 0.0 || p->outlier_max_dist != p->outlier_max_dist) return fail(c, PGICP_ERR_ARG, "MaxDistOutlierFilter.maxDist must be >= 0");
     if (p->max_iters < 1) return fail(c, PGICP_ERR_ARG, "CounterTransformationChecker.maxIterationCount must be >= 1");
     if (p->smooth_length < 1 || p->smooth_length > kHist - 1)
         return fail(c, PGICP_ERR_ARG, "DifferentialTransformationChecker.smoothLength must be in [1,15]");

@@ -106,8 +106,31 @@ void yaml_and_matrix()
         try { orient.apply(c2); } catch (const std::runtime_error &) { threw = true; }
         CHECK(threw);                                                          // no normals: refused like upstream
     }
+    {   // the sampling filters: FixStep keeps every step-th point; RandomSampling is seeded (reproducible, a different
+        // sample per seed, about prob of the points) -- upstream draws from rand(): same distribution, no bit parity
+        auto cloud_of = [&](int n) { std::vector<float> xyz(3 * n); for (int i = 0; i < n; i++) { xyz[3 * i] = (float)i; xyz[3 * i + 1] = 1.f; xyz[3 * i + 2] = 2.f; } return PointMatcher<float>::DataPoints::fromXYZ(xyz.data(), n, nullptr); };
+        std::istringstream fs("- FixStepSamplingDataPointsFilter:\n    startStep: 4\n");
+        PointMatcher<float>::DataPointsFilters fix(fs);
+        auto a = cloud_of(10);
+        fix.apply(a);
+        CHECK(a.getNbPoints() == 3 && a.features(0, 1) == 4.f && a.features(0, 2) == 8.f);
+        std::istringstream r1("- RandomSamplingDataPointsFilter:\n    prob: 0.5\n"), r2("- RandomSamplingDataPointsFilter:\n    prob: 0.5\n"),
+            r3("- RandomSamplingDataPointsFilter:\n    prob: 0.5\n    seed: 7\n");
+        PointMatcher<float>::DataPointsFilters f1(r1), f2(r2), f3(r3);
+        auto b1 = cloud_of(4000), b2 = cloud_of(4000), b3 = cloud_of(4000);
+        f1.apply(b1); f2.apply(b2); f3.apply(b3);
+        CHECK(b1.getNbPoints() == b2.getNbPoints() && b1.getNbPoints() > 1800 && b1.getNbPoints() < 2200);
+        for (int j = 0; j < (int)b1.getNbPoints(); j++) CHECK(b1.features(0, j) == b2.features(0, j));
+        bool differs = b3.getNbPoints() != b1.getNbPoints();
+        for (int j = 0; !differs && j < (int)b1.getNbPoints(); j++) differs = b1.features(0, j) != b3.features(0, j);
+        CHECK(differs);
+        std::istringstream vs("- FixStepSamplingDataPointsFilter:\n    startStep: 4\n    endStep: 2\n");
+        threw = false;
+        try { PointMatcher<float>::DataPointsFilters v(vs); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);                                                          // a varying step is not restated
+    }
     // anything outside the supported set is refused at load time, never ignored
-    for (const char *txt : {"- RandomSamplingDataPointsFilter:\n    prob: 0.5\n",
+    for (const char *txt : {"- MaxPointCountDataPointsFilter:\n    maxCount: 100\n",
                             "- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: 3.16\n",
                             "- SurfaceNormalDataPointsFilter:\n    knn: 64\n"}) {
         std::istringstream bad(txt);

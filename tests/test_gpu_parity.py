@@ -439,3 +439,30 @@ def test_rccl_allgather_edges_world_size_1():
     assert icp.shard_slots([5, 1, 1, 1, 1, 1], 2) == 5 and icp.shard_slots([1] * 9, 4) == 3
     comm.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trim_ratio, out_max", [(0.85, 0.12), (1.0, 0.2), (0.85, 5.0)])
+def test_max_dist_outlier_filter_in_the_chain(ctx, oracle32, small, trim_ratio, out_max):
+    """A MaxDistOutlierFilter next to (or instead of) the trimmed filter: its weights multiply in."""
+    w = small
+    chain = dict(CHAIN, trim_ratio=trim_ratio, outlier_max_dist=out_max)
+    ctx.set_params(**dict(chain, matcher=icp.MATCHER_GRID))
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=True)
+    for b in range(2):
+        T, st = ctx.align(mid, w.scans_xyz[b], w.T_init[b])
+        o = oracle32.icp(w.scans_xyz[b], w.map_xyz, w.map_nrm, w.T_init[b], **chain)
+        assert o["status"] == 0 and st["status"] == 0
+        dt, dr = pose_error(o["T"], T)
+        assert dt < TOL_TRANS and dr < TOL_ROT, (dt, dr)
+        assert st["iterations"] == o["iterations"] and st["n_kept"] == o["n_kept"] and st["n_finite"] == o["n_finite"]
+        assert st["overlap"] == pytest.approx(o["overlap"], rel=1e-12)
+        assert np.float32(st["trim_limit"]) == np.float32(o["trim_limit"])
+    # ... and in the partial chain (ComputeOverlapWith / ComputeResidualError): raw index, as pgslam builds it there
+    rid = ctx.set_map(w.map_xyz, w.map_nrm, center=False)
+    ov, res = ctx.partial_chain(rid, w.scans_xyz[0], T=w.T_truth[0])
+    po = oracle32.partial_chain(w.scans_xyz[0], w.map_xyz, w.map_nrm, w.T_truth[0], **chain)
+    assert ov == pytest.approx(po["overlap"], rel=1e-12) and res == pytest.approx(po["residual"], rel=1e-6)
+    ctx.destroy_map(rid)
+    ctx.destroy_map(mid)
+    ctx.set_params(**dict(CHAIN, outlier_max_dist=0.0))

@@ -256,3 +256,26 @@ def test_partial_chain_matches_manual_steps(oracle32):
     st, sys_ = oracle32.p2plane_system(q, z["map_xyz"], z["map_nrm"], ids, w)
     assert r["status"] == 0 and np.array_equal(r["ids"], ids)
     assert r["overlap"] == sys_[27] / q.shape[0] and r["residual"] == sys_[29]
+
+
+def test_max_dist_outlier_filter_multiplies_into_the_trimmed_weights(oracle64):
+    """the chain's weights are the PRODUCT of its outlier filters' weights.  Known answer on a plane:
+    with MaxDistOutlierFilter{0.5} next to TrimmedDist{1.0}, the pairs farther than 0.5 m drop out although the trimmed
+    filter keeps everything; the trimmed threshold itself is computed over all matches."""
+    rng = np.random.default_rng(11)
+    ref = np.zeros((400, 3))
+    ref[:, :2] = rng.uniform(-5, 5, (400, 2))
+    nrm = np.tile([0.0, 0.0, 1.0], (400, 1))
+    rd = ref.copy()
+    rd[:, 2] = np.where(np.arange(400) < 100, 0.8, 0.1)          # 100 points 0.8 m above the plane, 300 points 0.1 m
+    T = np.eye(4)
+    a = oracle64.partial_chain(rd, ref, nrm, T, trim_ratio=1.0, max_dist=2.0)
+    b = oracle64.partial_chain(rd, ref, nrm, T, trim_ratio=1.0, max_dist=2.0, outlier_max_dist=0.5)
+    ov_all, res_all, ov_lim, res_lim = a["overlap"], a["residual"], b["overlap"], b["residual"]
+    assert ov_all == pytest.approx(1.0) and ov_lim == pytest.approx(0.75)
+    assert res_all == pytest.approx(100 * 0.64 + 300 * 0.01) and res_lim == pytest.approx(300 * 0.01)
+    # in the loop: the far quarter no longer pulls; the result puts the 300 near points onto the plane
+    r = oracle64.icp(rd, ref, nrm, T, trim_ratio=1.0, max_dist=2.0, outlier_max_dist=0.5, center_reference=False)
+    assert r["status"] == 0 and r["T"][2, 3] == pytest.approx(-0.1, abs=1e-9)
+    r2 = oracle64.icp(rd, ref, nrm, T, trim_ratio=1.0, max_dist=2.0, center_reference=False)
+    assert r2["T"][2, 3] == pytest.approx(-(100 * 0.8 + 300 * 0.1) / 400, abs=1e-3)       # (stops when the Differential checker is satisfied)
