@@ -388,7 +388,7 @@ def build_slam_run():
     import subprocess
     exe = os.path.join(ROOT, "tools", "slam_run")
     lib = os.path.join(ROOT, "pgslam_amd", "lib")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unused-local-typedefs", "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unused-local-typedefs", "-Wno-unused-variable", "-pthread", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tools", "slam_run.cpp"), "-o", exe, "-L" + lib, "-lpgicp",
                            "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
     return exe

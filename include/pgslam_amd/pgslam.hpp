@@ -395,6 +395,7 @@ public:
     struct Candidate { long long from_id, to_id; DPPtr reading, reference; Matrix T_init; };
     void SetIcpConfigFromString(const std::string &yaml) { std::istringstream iss(yaml); chain_.loadFromYaml(iss); yaml_ = yaml; }
     void Add(const Candidate &c) { queue_.push_back(c); }
+    void Clear() { queue_.clear(); }
     size_t Size() const { return queue_.size(); }
     //! indices of the queue this rank owns (deterministic LPT split, identical on every rank)
     std::vector<int> Shard(int world_size, int rank) const

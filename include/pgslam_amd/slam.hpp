@@ -18,8 +18,12 @@
 #include <cmath>
 #include <fstream>
 #include <functional>
+#include <condition_variable>
+#include <deque>
 #include <limits>
+#include <mutex>
 #include <queue>
+#include <thread>
 #include <set>
 
 #include "pgslam.hpp"
@@ -421,6 +425,9 @@ public:
     IMPORT_PGSLAM_TYPES(T)
     using Ptr = std::shared_ptr<MapManager<T>>;
     PoseGraph<T> &GetGraph() { return graph_; }
+    //! MapManagerMT::GetGraphLock (MapManagerMT.hpp:17-21).  Taken by the single-thread flavour too (uncontended there);
+    //! recursive, because in that flavour the loop closer and the optimiser run nested inside the localizer's update.
+    std::unique_lock<std::recursive_mutex> GetGraphLock() { return std::unique_lock<std::recursive_mutex>(graph_mutex_); }
     size_t GetFixedVertex() const { return fixed_vertex_; }
     void SetLocalizer(std::shared_ptr<GraphLocalizer<T>> p) { localizer_ = p; }
     void SetLoopCloser(std::shared_ptr<GraphLoopCloser<T>> p) { loop_closer_ = p; }
@@ -437,7 +444,9 @@ public:
         c.type = Constraint::kLoopConstraint; c.T_from_to = T_from_to; c.cov_from_to = cov; c.weight = (T)PoseWeight(T_from_to);
         graph_.AddEdge(from, to, c);
     }
-    void UpdateKeyframeTransform(size_t v, const Matrix &updated, typename Types<T>::Time t) { graph_[v].optimized_T_world_kf = updated; graph_[v].update_time = t; }
+    void UpdateKeyframeTransform(size_t v, const Matrix &updated, typename Types<T>::Time t) { graph_[v].optimized_T_world_kf = updated; graph_[v].update_time = t; version_++; }
+    //! bumped whenever an optimisation rewrites keyframe poses: a localizer that has seen this version is up to date
+    unsigned long long Version() const { return version_; }
     void NotifyKeyframeUpdate();
     void WriteGraphviz(const std::string &path)
     {
@@ -457,6 +466,8 @@ private:
         return kf;
     }
     PoseGraph<T> graph_;
+    std::recursive_mutex graph_mutex_;
+    unsigned long long version_ = 0;
     size_t fixed_vertex_ = 0;
     std::weak_ptr<GraphLocalizer<T>> localizer_;
     std::weak_ptr<GraphLoopCloser<T>> loop_closer_;
@@ -470,7 +481,8 @@ public:
     using Ptr = std::shared_ptr<Optimizer<T>>;
     using InputData = std::tuple<size_t, size_t, Matrix, Matrix>;       // from, to, T_from_to, COV_from_to (Optimizer.h:22)
     explicit Optimizer(typename MapManager<T>::Ptr mm) : map_manager_(mm) {}
-    void AddNewData(size_t from, size_t to, const Matrix &T_from_to, const Matrix &cov)
+    virtual ~Optimizer() {}
+    virtual void AddNewData(size_t from, size_t to, const Matrix &T_from_to, const Matrix &cov)
     {
         data_buffer_.clear();
         data_buffer_.push_back(std::make_tuple(from, to, T_from_to, cov));
@@ -486,7 +498,7 @@ public:
     double total_seconds() const { return seconds_; }
     int total_iterations() const { return iterations_; }
 
-private:
+protected:
     //! [x y z rx ry rz] -> [rx ry rz x y z] (Optimizer.hpp:32-42), row-major double
     static void PmCovToRotFirst(const Matrix &m, double out[36])
     {
@@ -502,22 +514,30 @@ private:
         if (!PoseGraphLeastSquares::InformationFactor(c, f.L)) throw std::runtime_error("[Optimizer] constraint covariance is not positive definite");
         ls.factors.push_back(f);
     }
+    //! PrepareForOptimization (graph locked) / the solve (unlocked) / UpdateAfterOptimization (graph locked): OptimizerMT.hpp:70-84
     void ProcessData()
     {
         auto &g = map_manager_->GetGraph();
         PoseGraphLeastSquares ls;
-        for (size_t e = 0; e < g.NumEdges(); e++) AddFactor(ls, g.Edge(e).from, g.Edge(e).to, g.Edge(e).c.T_from_to, g.Edge(e).c.cov_from_to);
-        for (auto &d : data_buffer_) AddFactor(ls, std::get<0>(d), std::get<1>(d), std::get<2>(d), std::get<3>(d));
-        for (size_t v = 0; v < g.NumVertices(); v++) ls.X.push_back(se3::from_matrix(g[v].optimized_T_world_kf));
-        ls.fixed = map_manager_->GetFixedVertex();                         // prior with sigma 1e-6 (Optimizer.hpp:122-130)
+        {
+            auto lock = map_manager_->GetGraphLock();
+            for (size_t e = 0; e < g.NumEdges(); e++) AddFactor(ls, g.Edge(e).from, g.Edge(e).to, g.Edge(e).c.T_from_to, g.Edge(e).c.cov_from_to);
+            for (auto &d : data_buffer_) AddFactor(ls, std::get<0>(d), std::get<1>(d), std::get<2>(d), std::get<3>(d));
+            for (size_t v = 0; v < g.NumVertices(); v++) ls.X.push_back(se3::from_matrix(g[v].optimized_T_world_kf));
+            ls.fixed = map_manager_->GetFixedVertex();                     // prior with sigma 1e-6 (Optimizer.hpp:122-130)
+        }
         const auto t0 = std::chrono::steady_clock::now();
         ls.Optimize();
         seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         runs_++; iterations_ += ls.iterations;
         last_iterations_ = ls.iterations; e0_ = ls.initial_error; e1_ = ls.final_error;
-        const auto now = std::chrono::high_resolution_clock::now();
-        for (size_t v = 0; v < g.NumVertices(); v++) map_manager_->UpdateKeyframeTransform(v, se3::to_matrix<Matrix>(ls.X[v]), now);
-        for (auto &d : data_buffer_) map_manager_->AddLoopClosingConstraint(std::get<0>(d), std::get<1>(d), std::get<2>(d), std::get<3>(d));
+        {
+            auto lock = map_manager_->GetGraphLock();
+            const auto now = std::chrono::high_resolution_clock::now();
+            // (keyframes added while the solve ran keep their poses: they were not variables of it)
+            for (size_t v = 0; v < ls.X.size(); v++) map_manager_->UpdateKeyframeTransform(v, se3::to_matrix<Matrix>(ls.X[v]), now);
+            for (auto &d : data_buffer_) map_manager_->AddLoopClosingConstraint(std::get<0>(d), std::get<1>(d), std::get<2>(d), std::get<3>(d));
+        }
         map_manager_->NotifyKeyframeUpdate();
     }
     typename MapManager<T>::Ptr map_manager_;
@@ -538,7 +558,8 @@ public:
     void SetOverlapThreshold(T v) { overlap_threshold_ = v; if (closer_) closer_->SetOverlapThreshold(v); }
     void SetResidualErrorThreshold(T v) { residual_error_threshold_ = v; if (closer_) closer_->SetResidualErrorThreshold(v); }
     void SetIcpConfigFromString(const std::string &yaml) { closer().SetIcpConfigFromString(yaml); }
-    void AddNewVertex(size_t v) { ProcessVertex(v); }
+    virtual ~GraphLoopCloser() {}
+    virtual void AddNewVertex(size_t v) { ProcessVertex(v); }
     int loops_closed() const { return loops_closed_; }
     int candidates_tried() const { return candidates_tried_; }
     typename PM::ICP &icp() { return closer().icp(); }
@@ -565,27 +586,38 @@ public:
         }
         return false;
     }
-    void ProcessVertex(size_t input_v)
+    //! what ProcessVertex hands to the ICP: LoopCloser.hpp:86-95 (graph locked while it is put together, LoopCloserMT.hpp:72-76)
+    struct PreparedCandidate { size_t ref_v, input_v; DPPtr reading; DPPtr reference; Matrix guess; };
+    bool PrepareCandidate(size_t input_v, PreparedCandidate &out)
     {
+        auto lock = map_manager_->GetGraphLock();
         auto &g = map_manager_->GetGraph();
-        if (g.NumVertices() < 2) return;
+        if (g.NumVertices() < 2) return false;
         std::vector<size_t> comp;
-        if (!FindLocalMapCandidate(input_v, comp)) return;
+        if (!FindLocalMapCandidate(input_v, comp)) return false;
         candidates_tried_++;
         // candidate local map: composition order, reference = back (LocalMap::UpdateToNewComposition)
         LocalMap<T> lm(capacity_);
         for (size_t v : comp) lm.PushKeyframe(g[v]);
         lm.BuildCloudFromData();
-        const size_t ref_v = comp.back();
-        const Matrix guess = g[ref_v].optimized_T_world_kf.inverse() * g[input_v].optimized_T_world_kf;      // LoopCloser.hpp:95
-        auto r = closer().ProcessCandidate(*g[input_v].cloud_ptr, lm.Cloud(), guess);                         // :98 + CheckIcpResult
+        out.ref_v = comp.back(); out.input_v = input_v;
+        out.reading = g[input_v].cloud_ptr;
+        out.reference = std::make_shared<DP>(lm.Cloud());
+        out.guess = g[out.ref_v].optimized_T_world_kf.inverse() * g[input_v].optimized_T_world_kf;           // LoopCloser.hpp:95
+        return true;
+    }
+    void ProcessVertex(size_t input_v)
+    {
+        PreparedCandidate c;
+        if (!PrepareCandidate(input_v, c)) return;
+        auto r = closer().ProcessCandidate(*c.reading, *c.reference, c.guess);                                // :98 + CheckIcpResult
         if (r.accepted) {
             loops_closed_++;
-            optimizer_->AddNewData(ref_v, input_v, r.T_refkf_kf, r.cov);                              // :104-108
+            optimizer_->AddNewData(c.ref_v, input_v, r.T_refkf_kf, r.cov);                            // :104-108
         }
     }
 
-private:
+protected:
     typename MapManager<T>::Ptr map_manager_;
     //! the ICP object (and with it the device context) is created on first use: the graph searches need no GPU
     LoopCloser<T> &closer()
@@ -622,7 +654,8 @@ public:
     int rebuilds() const { return rebuilds_; }
     ICPSequence &icp() { return icp_sequence_; }
 
-    void AddNewData(unsigned long long, const std::string &, const Matrix &T_world_robot, const Matrix &T_robot_sensor, DPPtr cloud)
+    virtual ~GraphLocalizer() {}
+    virtual void AddNewData(unsigned long long, const std::string &, const Matrix &T_world_robot, const Matrix &T_robot_sensor, DPPtr cloud)
     {
         ProcessData(T_world_robot, T_robot_sensor, cloud);
     }
@@ -632,7 +665,8 @@ public:
         input_filters_.apply(*cloud);
         (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
         auto &g = map_manager_->GetGraph();
-        if (comp_.empty()) {                                                 // ProcessFirstCloud
+        if (comp_.empty()) {                                                 // ProcessFirstCloud (graph locked, LocalizerMT.hpp:104-108)
+            auto lock = map_manager_->GetGraphLock();
             comp_.push_back(map_manager_->AddFirstKeyframe(cloud, input_T_world_robot));
             Rebuild();
             T_refkf_robot_ = Matrix::Identity(4, 4);
@@ -641,21 +675,32 @@ public:
             return;
         }
         const Matrix d = last_input_.inverse() * input_T_world_robot;
-        T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);
-        T_world_robot_ = g[comp_.back()].optimized_T_world_kf * T_refkf_robot_;
-        UpdateAfterIcp();
+        T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);         // the ICP runs outside the graph lock (LocalizerMT.hpp:95-96)
+        {
+            auto lock = map_manager_->GetGraphLock();                        // LocalizerMT::UpdateAfterIcp, LocalizerMT.hpp:110-121
+            // the graph may have been optimised while the ICP ran (upstream re-reads it unconditionally; here only when
+            // an optimisation has actually rewritten poses since the last look)
+            if (resync_before_update_ && synced_version_ != map_manager_->Version()) UpdateFromGraphNow();
+            T_world_robot_ = g[comp_.back()].optimized_T_world_kf * T_refkf_robot_;
+            UpdateAfterIcp();
+        }
         last_input_ = input_T_world_robot;
     }
     //! MapManager::NotifyKeyframeUpdate -> Localizer::UpdateFromGraph (Localizer.hpp:155-176): after an
     //! optimisation the local map is rebuilt from the corrected poses and the world pose follows the reference
-    void UpdateFromGraph()
+    virtual void UpdateFromGraph() { UpdateFromGraphNow(); }
+    void UpdateFromGraphNow()
     {
+        auto lock = map_manager_->GetGraphLock();
+        synced_version_ = map_manager_->Version();
         if (comp_.empty()) return;
         Rebuild();
         T_world_robot_ = map_manager_->GetGraph()[comp_.back()].optimized_T_world_kf * T_refkf_robot_;
     }
 
-private:
+protected:
+    bool resync_before_update_ = false;              // the MT flavour re-reads the graph before every update
+    unsigned long long synced_version_ = 0;
     void Rebuild()
     {
         auto &g = map_manager_->GetGraph();
@@ -822,6 +867,222 @@ protected:
     typename Optimizer<T>::Ptr optimizer_ptr_;
     typename GraphLoopCloser<T>::Ptr loop_closer_ptr_;
     typename GraphLocalizer<T>::Ptr localizer_ptr_;
+};
+
+// ------------------------------------------------------------------ multi-thread flavour (PoseGraphSlamMT.hpp:21-26)
+// Three workers with input queues, as in the reference: the localizer (LocalizerMT.hpp:27-99), the loop closer
+// (LoopCloserMT.hpp:26-67) and the optimiser (OptimizerMT.hpp:26-68), sharing the graph under MapManager's lock.  Two ICP
+// objects -- two device contexts, two HIP streams -- run concurrently, outside the lock, as upstream's two ICPs do.
+// What differs, on purpose: the loop closer DRAINS its queue and runs all waiting candidates as ONE device batch
+// (pgslam::LoopClosureBatch; upstream pops one vertex at a time, LoopCloserMT.hpp:49-62), and the optimiser -- as
+// upstream -- drains its queue into one solve.  WaitIdle() is an addition for deterministic hosts (tests, benchmarks).
+template <typename T> class PoseGraphSlamMT;
+
+template <typename T>
+class OptimizerMT : public Optimizer<T> {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    using Base = Optimizer<T>;
+    explicit OptimizerMT(typename MapManager<T>::Ptr mm) : Base(mm) {}
+    ~OptimizerMT() override { Stop(); }
+    void AddNewData(size_t from, size_t to, const Matrix &T_from_to, const Matrix &cov) override
+    {
+        { std::lock_guard<std::mutex> l(m_); queue_.push_back(std::make_tuple(from, to, T_from_to, cov)); }
+        cv_.notify_one();
+    }
+    void Run() { stop_ = false; thread_ = std::thread(&OptimizerMT::Main, this); }
+    void Stop() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (thread_.joinable()) thread_.join(); }
+    bool Idle() { std::lock_guard<std::mutex> l(m_); return queue_.empty() && !busy_; }
+
+private:
+    void Main()
+    {
+        for (;;) {
+            std::vector<typename Base::InputData> batch;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return !queue_.empty() || stop_; });
+                if (stop_) break;
+                batch.assign(queue_.begin(), queue_.end());          // all of it: one solve (OptimizerMT.hpp:59-65)
+                queue_.clear();
+                busy_ = true;
+            }
+            this->AddNewDataBatch(batch);
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<typename Base::InputData> queue_;
+    std::thread thread_;
+    bool stop_ = false, busy_ = false;
+};
+
+template <typename T>
+class LoopCloserMT : public GraphLoopCloser<T> {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    using Base = GraphLoopCloser<T>;
+    LoopCloserMT(typename MapManager<T>::Ptr mm, typename Optimizer<T>::Ptr opt) : Base(mm, opt), optimizer_(opt) {}
+    ~LoopCloserMT() override { Stop(); }
+    //! (the batch dispatcher on the worker thread owns the ICP object; the base class's one-at-a-time closer is not made)
+    void SetIcpConfigFromString(const std::string &yaml) { yaml_ = yaml; }
+    void AddNewVertex(size_t v) override
+    {
+        { std::lock_guard<std::mutex> l(m_); queue_.push_back(v); }
+        cv_.notify_one();
+    }
+    void Run() { stop_ = false; thread_ = std::thread(&LoopCloserMT::Main, this); }
+    void Stop() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (thread_.joinable()) thread_.join(); }
+    bool Idle() { std::lock_guard<std::mutex> l(m_); return queue_.empty() && !busy_; }
+    int batches() const { return batches_; }
+    int largest_batch() const { return largest_batch_; }
+
+private:
+    void Main()
+    {
+        LoopClosureBatch<T> batch;                               // its ICP object (device context) lives on this thread
+        bool configured = false;
+        for (;;) {
+            std::vector<size_t> vs;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return !queue_.empty() || stop_; });
+                if (stop_) break;
+                vs.assign(queue_.begin(), queue_.end());          // every waiting vertex: one device batch
+                queue_.clear();
+                busy_ = true;
+            }
+            if (!configured) { batch.SetIcpConfigFromString(yaml_); configured = true; }
+            std::vector<typename Base::PreparedCandidate> cands;
+            for (size_t v : vs) {
+                typename Base::PreparedCandidate c;
+                if (this->PrepareCandidate(v, c)) cands.push_back(c);
+            }
+            if (!cands.empty()) {
+                batch.Clear();
+                for (auto &c : cands) batch.Add({(long long)c.ref_v, (long long)c.input_v, c.reading, c.reference, c.guess});
+                const auto edges = batch.Run(batch.Shard(1, 0), this->overlap_threshold_, this->residual_error_threshold_);
+                batches_++;
+                largest_batch_ = std::max(largest_batch_, (int)cands.size());
+                for (const pgicp_edge &e : edges)
+                    if (e.accepted) {
+                        this->loops_closed_++;
+                        Matrix cov(6, 6);
+                        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) cov(i, j) = (T)e.cov[6 * i + j];
+                        optimizer_->AddNewData((size_t)e.from_id, (size_t)e.to_id, pgslam_amd::from_row_major16<T>(e.T_from_to), cov);
+                    }
+            }
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; }
+        }
+    }
+    typename Optimizer<T>::Ptr optimizer_;
+    std::string yaml_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<size_t> queue_;
+    std::thread thread_;
+    bool stop_ = false, busy_ = false;
+    int batches_ = 0, largest_batch_ = 0;
+};
+
+template <typename T>
+class LocalizerMT : public GraphLocalizer<T> {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    using Base = GraphLocalizer<T>;
+    explicit LocalizerMT(typename MapManager<T>::Ptr mm, size_t capacity = 3) : Base(mm, capacity) { this->resync_before_update_ = true; }
+    ~LocalizerMT() override { Stop(); }
+    void AddNewData(unsigned long long, const std::string &, const Matrix &T_world_robot, const Matrix &T_robot_sensor, DPPtr cloud) override
+    {
+        { std::lock_guard<std::mutex> l(m_); queue_.push_back(std::make_tuple(T_world_robot, T_robot_sensor, cloud)); }
+        cv_.notify_one();
+    }
+    //! MapManager::NotifyKeyframeUpdate lands here from the optimiser's thread: only the flag is set, the update itself
+    //! happens on the localizer's own thread (LocalizerMT.hpp:123-136)
+    void UpdateFromGraph() override
+    {
+        { std::lock_guard<std::mutex> l(m_); outdated_ = true; }
+        cv_.notify_one();
+    }
+    void Run() { stop_ = false; thread_ = std::thread(&LocalizerMT::Main, this); }
+    void Stop() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (thread_.joinable()) thread_.join(); }
+    bool Idle() { std::lock_guard<std::mutex> l(m_); return queue_.empty() && !busy_ && !outdated_; }
+    size_t processed() { std::lock_guard<std::mutex> l(m_); return processed_; }
+
+private:
+    void Main()
+    {
+        for (;;) {
+            bool outdated = false, have = false;
+            std::tuple<Matrix, Matrix, DPPtr> item;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return !queue_.empty() || stop_ || outdated_; });
+                if (stop_) break;
+                outdated = outdated_;
+                outdated_ = false;
+                if (!queue_.empty()) { item = queue_.front(); queue_.pop_front(); have = true; }
+                busy_ = true;
+            }
+            if (outdated) this->UpdateFromGraphNow();             // (takes the graph lock)
+            if (have) this->ProcessData(std::get<0>(item), std::get<1>(item), std::get<2>(item));
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; if (have) processed_++; }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::tuple<Matrix, Matrix, DPPtr>> queue_;
+    std::thread thread_;
+    bool stop_ = false, busy_ = false, outdated_ = false;
+    size_t processed_ = 0;
+};
+
+template <typename T>
+class PoseGraphSlamMT {
+public:
+    IMPORT_PGSLAM_TYPES(T)
+    PoseGraphSlamMT()
+        : map_manager_ptr_(std::make_shared<MapManager<T>>()), optimizer_ptr_(std::make_shared<OptimizerMT<T>>(map_manager_ptr_)),
+          loop_closer_ptr_(std::make_shared<LoopCloserMT<T>>(map_manager_ptr_, optimizer_ptr_)),
+          localizer_ptr_(std::make_shared<LocalizerMT<T>>(map_manager_ptr_))
+    {
+        map_manager_ptr_->SetLocalizer(localizer_ptr_);
+        map_manager_ptr_->SetLoopCloser(loop_closer_ptr_);
+    }
+    ~PoseGraphSlamMT() { localizer_ptr_->Stop(); loop_closer_ptr_->Stop(); optimizer_ptr_->Stop(); }
+    void SetIcpConfigFromStrings(const std::string &input_filters_yaml, const std::string &localizer_icp_yaml, const std::string &loop_closer_icp_yaml)
+    {
+        localizer_ptr_->SetInputFiltersConfigFromString(input_filters_yaml);
+        localizer_ptr_->SetIcpConfigFromString(localizer_icp_yaml);
+        loop_closer_ptr_->SetIcpConfigFromString(loop_closer_icp_yaml);
+    }
+    //! PoseGraphSlamMT::Run (PoseGraphSlamMT.hpp:21-26)
+    void Run() { localizer_ptr_->Run(); loop_closer_ptr_->Run(); optimizer_ptr_->Run(); }
+    void AddData(unsigned long long timestamp, std::string world_frame_id, Matrix T_world_robot, Matrix T_robot_sensor, DPPtr cloud_ptr)
+    {
+        localizer_ptr_->AddNewData(timestamp, world_frame_id, T_world_robot, T_robot_sensor, cloud_ptr);
+    }
+    //! until every queue is empty and every worker rests (the stages feed one another: checked until stable)
+    void WaitIdle()
+    {
+        for (int calm = 0; calm < 3;) {
+            if (localizer_ptr_->Idle() && loop_closer_ptr_->Idle() && optimizer_ptr_->Idle()) calm++;
+            else calm = 0;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    void WriteGraphviz(const std::string &path) { auto lock = map_manager_ptr_->GetGraphLock(); map_manager_ptr_->WriteGraphviz(path); }
+    MapManager<T> &map_manager() { return *map_manager_ptr_; }
+    LocalizerMT<T> &localizer() { return *localizer_ptr_; }
+    LoopCloserMT<T> &loop_closer() { return *loop_closer_ptr_; }
+    OptimizerMT<T> &optimizer() { return *optimizer_ptr_; }
+
+protected:
+    typename MapManager<T>::Ptr map_manager_ptr_;
+    std::shared_ptr<OptimizerMT<T>> optimizer_ptr_;
+    std::shared_ptr<LoopCloserMT<T>> loop_closer_ptr_;
+    std::shared_ptr<LocalizerMT<T>> localizer_ptr_;
 };
 
 }  // namespace pgslam

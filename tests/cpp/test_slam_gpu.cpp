@@ -46,8 +46,58 @@ void run(const char *name)
                 slam.optimizer().last_iterations(), worst);
 }
 
+// The multi-thread flavour (PoseGraphSlamMT.hpp:21-26) on the same drive.  First in lock step (WaitIdle after every scan:
+// the three workers then do exactly what the single-thread facade does), then free running (all scans queued at once:
+// loop closing and optimisation land while the localizer is already further along).
+template <typename T>
+void run_mt(const char *name)
+{
+    IMPORT_PGSLAM_TYPES(T)
+    TransformationPtr rigid = PM::get().REG(Transformation).create("RigidTransformation");
+    const int S = 15;
+    std::vector<Matrix> truth, odom;
+    for (int s = 0; s < S; s++) {
+        const double a = 2 * M_PI * s / (S - 1);
+        truth.push_back(pose<T>(1.5 + 0.5 * std::cos(a), 1.5 + 0.5 * std::sin(a), 0.0, a * 0.2));
+    }
+    odom.push_back(truth[0]);
+    for (int s = 1; s < S; s++) odom.push_back(odom[s - 1] * (truth[s - 1].inverse() * truth[s]) * pose<T>(0.012, -0.009, 0.0, 0.005));
+    for (int free_running = 0; free_running < 2; free_running++) {
+        pgslam::PoseGraphSlamMT<T> slam;
+        slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+        slam.localizer().SetOverlapThreshold(T(0.9));
+        slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
+        slam.loop_closer().SetGeometricalDistanceThreshold(T(0.3));
+        slam.Run();
+        for (int s = 0; s < S; s++) {
+            auto cloud = std::make_shared<DP>(rigid->compute(make_corner<T>(2000, 70 + s, 0.004), truth[s].inverse()));
+            slam.AddData((unsigned long long)s, "world", odom[s], Matrix::Identity(4, 4), cloud);
+            if (!free_running) {
+                slam.WaitIdle();
+                CHECK(pose_diff(slam.localizer().T_world_robot(), truth[s]) < 3e-2);
+            }
+        }
+        slam.WaitIdle();
+        CHECK(slam.localizer().processed() == (size_t)S);
+        auto lock = slam.map_manager().GetGraphLock();
+        auto &g = slam.map_manager().GetGraph();
+        CHECK(g.NumVertices() == (size_t)S);
+        int loops = 0;
+        for (size_t e = 0; e < g.NumEdges(); e++) loops += g.Edge(e).c.type == Constraint::kLoopConstraint;
+        CHECK(loops >= 1 && loops == slam.loop_closer().loops_closed() && slam.optimizer().runs() >= 1);
+        double worst = 0;
+        for (size_t v = 0; v < g.NumVertices(); v++) worst = std::max(worst, pose_diff(g[v].optimized_T_world_kf, truth[v]));
+        CHECK(worst < (free_running ? 6e-2 : 3e-2));
+        CHECK(pose_diff(slam.localizer().T_world_robot(), truth[S - 1]) < (free_running ? 6e-2 : 3e-2));
+        std::printf("%s, %s: ok  (%zu keyframes, %d loop edges in %d device batch(es), largest %d; %d optimiser run(s); worst keyframe error %.2e)\n",
+                    name, free_running ? "free running" : "lock step", g.NumVertices(), loops, slam.loop_closer().batches(),
+                    slam.loop_closer().largest_batch(), slam.optimizer().runs(), worst);
+    }
+}
+
 int main()
 {
+    run_mt<float>("PoseGraphSlamMT<float>");
     run<float>("PoseGraphSlam<float>");
     run<double>("PoseGraphSlam<double>");
     std::puts("slam gpu tests ok");

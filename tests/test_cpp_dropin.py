@@ -13,7 +13,7 @@ def build(name):
     src = exe + ".cpp"
     # always rebuilt: a snapshot pushed to another box flattens mtimes, and a stale binary must never be what runs
     if True:
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-local-typedefs", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-local-typedefs", "-Wno-unused-variable", "-pthread", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
                                "-L" + os.path.join(ROOT, "pgslam_amd", "lib"), "-lpgicp",
                                "-Wl,-rpath," + os.path.join(ROOT, "pgslam_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
     return exe

@@ -3,7 +3,10 @@
 // the host), as a C++ pgslam user would run it: host clouds in, poses out.  Driver of `bench.py --workload slam` and of
 // tests/test_slam_replay.py; not part of the library.
 //
-//   slam_run SEQUENCE [--record N FILE] [--limit S]
+//   slam_run SEQUENCE [--record N FILE] [--limit S] [--mt]
+//
+// --mt: the multi-thread flavour (pgslam::PoseGraphSlamMT): scans are queued as fast as they are read, the three workers
+// run freely (the loop closer drains its queue into device batches); poses are compared at the end only.
 //
 // SEQUENCE (written by bench.py / the test from pgslam_amd/synth.py): int32 magic 'PGSQ', n_scans, n_pts; per scan
 // 16 doubles T_world_robot (truth, row-major), 16 doubles odometry pose, n_pts*3 floats xyz (robot frame), n_pts*3
@@ -17,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using T = float;
@@ -83,14 +87,57 @@ struct Recorder {
     }
 };
 
+// the multi-thread flavour: queue everything, wait for the workers, compare the keyframes with the truth
+static int run_mt(FILE *f, int S, int N)
+{
+    pgslam::PoseGraphSlamMT<T> slam;
+    slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+    slam.Run();
+    std::vector<double> Tt(16), To(16);
+    std::vector<float> xyz((size_t)N * 3), nrm((size_t)N * 3);
+    std::vector<Matrix> truth;
+    const Matrix I4 = Matrix::Identity(4, 4);
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (int s = 0; s < S; s++) {
+        if (std::fread(Tt.data(), sizeof(double), 16, f) != 16 || std::fread(To.data(), sizeof(double), 16, f) != 16 ||
+            std::fread(xyz.data(), sizeof(float), xyz.size(), f) != xyz.size() || std::fread(nrm.data(), sizeof(float), nrm.size(), f) != nrm.size()) {
+            std::fprintf(stderr, "sequence file truncated at scan %d\n", s);
+            return 2;
+        }
+        truth.push_back(from_rows(Tt.data()));
+        slam.AddData((unsigned long long)s, "world", from_rows(To.data()), I4, std::make_shared<DP>(DP::fromXYZ(xyz.data(), N, nrm.data())));
+        // a bounded input queue, as a sensor driver would keep: at most 8 scans ahead of the localizer
+        while ((size_t)s > slam.localizer().processed() + 8) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    slam.WaitIdle();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    std::fclose(f);
+    auto lock = slam.map_manager().GetGraphLock();
+    auto &g = slam.map_manager().GetGraph();
+    int loops = 0;
+    for (size_t e = 0; e < g.NumEdges(); e++) loops += g.Edge(e).c.type == Constraint::kLoopConstraint;
+    const Matrix d = truth.back().inverse() * slam.localizer().T_world_robot();
+    const double e_last = std::sqrt((double)(d(0, 3) * d(0, 3) + d(1, 3) * d(1, 3) + d(2, 3) * d(2, 3)));
+    std::printf("{\"mode\": \"mt\", \"scans\": %d, \"points_per_scan\": %d, \"wall_s\": %.6f, \"slam_s\": %.6f, \"scans_per_s\": %.3f, "
+                "\"keyframes\": %zu, \"loop_edges\": %d, \"loop_candidates_tried\": %d, \"loops_closed\": %d, \"loop_batches\": %d, "
+                "\"largest_loop_batch\": %d, \"optimizer_runs\": %d, \"optimizer_iterations\": %d, \"optimizer_host_s\": %.6f, "
+                "\"map_rebuilds\": %d, \"tracking_error_last_m\": %.5f}\n",
+                S, N, wall, wall, (S - 1) / wall, g.NumVertices(), loops, slam.loop_closer().candidates_tried(), slam.loop_closer().loops_closed(),
+                slam.loop_closer().batches(), slam.loop_closer().largest_batch(), slam.optimizer().runs(), slam.optimizer().total_iterations(),
+                slam.optimizer().total_seconds(), slam.localizer().rebuilds(), e_last);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { std::fprintf(stderr, "usage: slam_run SEQUENCE [--record N FILE] [--limit S]\n"); return 2; }
     const char *rec_path = nullptr;
     int rec_n = 0, limit = 1 << 30;
+    bool mt = false;
     for (int a = 2; a < argc; a++) {
         if (!std::strcmp(argv[a], "--record") && a + 2 < argc) { rec_n = std::atoi(argv[a + 1]); rec_path = argv[a + 2]; a += 2; }
         else if (!std::strcmp(argv[a], "--limit") && a + 1 < argc) { limit = std::atoi(argv[a + 1]); a += 1; }
+        else if (!std::strcmp(argv[a], "--mt")) mt = true;
     }
     FILE *f = std::fopen(argv[1], "rb");
     if (!f) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
@@ -98,6 +145,7 @@ int main(int argc, char **argv)
     if (std::fread(head, sizeof head, 1, f) != 1 || head[0] != 0x51534750 /* 'PGSQ' */) { std::fprintf(stderr, "bad sequence file\n"); return 2; }
     const int S = std::min(head[1], limit), N = head[2];
 
+    if (mt) return run_mt(f, S, N);
     pgslam::PoseGraphSlam<T> slam;
     slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
     Recorder rec;
