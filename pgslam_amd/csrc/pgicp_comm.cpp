@@ -85,6 +85,8 @@ int pgicp_comm_create(pgicp_ctx *ctx, int world_size, int rank, const char id[PG
     }
     int device = 0;
     if (pgicp_ctx_device(ctx, &device) != PGICP_OK || hipSetDevice(device) != hipSuccess) { t_comm_err = "pgicp_comm_create: cannot select the context's device"; return PGICP_ERR_HIP; }
+    (void)hipGetLastError();                        // RCCL reads the runtime's sticky last-error: a stale one from an earlier,
+                                                    // already reported failure in this process would fail the initialisation
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
     pgicp_comm *c = new pgicp_comm();
