@@ -19,6 +19,7 @@
 #include <string>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 using namespace pgicp;
@@ -41,7 +42,12 @@ struct DevBuf {
     template <typename U> U *as() const { return (U *)p; }
 };
 
-struct SharedBlock { char *p = nullptr; size_t bytes = 0; };
+// the one device allocation of a (batch of) map(s); freed here only when nobody released it properly (an error path)
+struct SharedBlock {
+    char *p = nullptr;
+    size_t bytes = 0;
+    ~SharedBlock() { if (p) (void)hipFree(p); }
+};
 
 template <typename T>
 struct MapHost {
@@ -111,10 +117,6 @@ struct pgicp_ctx {
     std::vector<int> h_ident;
     int counters_clean = 0;         // the matcher's queue counters were zeroed by the last kernel of the previous iteration
     int poll_us = 400;              // how long the host polls h_flag before it blocks on the stream instead
-    // Freed map blocks are kept for reuse: hipFree synchronises the device, and loop closing creates
-    // and destroys one index per candidate pair.
-    std::multimap<size_t, char *> block_pool;
-    size_t pooled_bytes = 0;
     int fast_rings_seeded = 1, fast_rings_unseeded = 3;
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
@@ -305,33 +307,71 @@ int sync_maps_table(pgicp_ctx *c)
     return PGICP_OK;
 }
 
-constexpr size_t kPoolLimitBytes = (size_t)8 << 30;
+// Freed map blocks are kept for reuse (hipFree waits for the whole device, and loop closing / the streaming mapper create
+// and destroy an index per candidate pair / per keyframe).  The pool belongs to the DEVICE, not to a context: in the
+// streaming mapper a builder context allocates every block and the serving context -- which received the map through
+// pgicp_map_transfer -- releases it; with per-context pools the blocks piled up where nobody allocates.  A pooled block
+// carries an event recorded on the releasing context's stream; whoever takes it makes its own stream wait for that event,
+// so work still queued on the old owner's stream is ordered before the new contents.
+constexpr size_t kPoolLimitBytes = (size_t)2 << 30;
+struct PooledBlock { char *p; hipEvent_t released; };
+struct DevicePool {
+    std::mutex m;
+    std::multimap<size_t, PooledBlock> blocks;
+    size_t bytes = 0;
+    int contexts = 0;
+};
+DevicePool g_pools[16];
+DevicePool &pool_of(int device) { return g_pools[device & 15]; }
 
 int block_alloc(pgicp_ctx *c, size_t bytes, char **out, size_t *got)
 {
-    auto it = c->block_pool.lower_bound(bytes);
-    if (it != c->block_pool.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
-        *out = it->second; *got = it->first;
-        c->pooled_bytes -= it->first;
-        c->block_pool.erase(it);
-        return PGICP_OK;
+    DevicePool &dp = pool_of(c->device);
+    {
+        std::lock_guard<std::mutex> lock(dp.m);
+        auto it = dp.blocks.lower_bound(bytes);
+        if (it != dp.blocks.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+            *out = it->second.p; *got = it->first;
+            const hipEvent_t ev = it->second.released;
+            dp.bytes -= it->first;
+            dp.blocks.erase(it);
+            if (ev) {
+                (void)hipStreamWaitEvent(c->stream, ev, 0);
+                (void)hipEventDestroy(ev);             // released once the recorded work has completed
+            }
+            return PGICP_OK;
+        }
     }
     HIPC(c, hipMalloc((void **)out, bytes));
     *got = bytes;
     return PGICP_OK;
 }
 
-// The caller guarantees that no work using the map is still queued on another stream; work on the
-// context stream is ordered before whatever reuses the block.
+void block_release(pgicp_ctx *c, char *p, size_t bytes)
+{
+    if (!p) return;
+    if (c) {
+        DevicePool &dp = pool_of(c->device);
+        std::lock_guard<std::mutex> lock(dp.m);
+        if (dp.bytes + bytes <= kPoolLimitBytes) {
+            PooledBlock b{p, nullptr};
+            if (hipEventCreateWithFlags(&b.released, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(b.released, c->stream);
+            else b.released = nullptr;
+            dp.blocks.emplace(bytes, b);
+            dp.bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+// Work on the context stream that uses the map is ordered before whatever reuses the block (block_release records an
+// event there); work queued on OTHER streams must have been waited for by the caller.
 template <typename T>
 void free_map(pgicp_ctx *c, MapHost<T> &m)
 {
     if (m.block && m.block.use_count() == 1 && m.block->p) {
-        if (c && c->pooled_bytes + m.block->bytes <= kPoolLimitBytes) {
-            c->block_pool.emplace(m.block->bytes, m.block->p);
-            c->pooled_bytes += m.block->bytes;
-        } else
-            (void)hipFree(m.block->p);
+        block_release(c, m.block->p, m.block->bytes);
         m.block->p = nullptr;
     }
     m = MapHost<T>();
@@ -417,6 +457,12 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         any_nrm = any_nrm || M.has_nrm;
         double lo[3], hi[3];
         for (int a = 0; a < 3; a++) {
+            // the centroid is an order-independent fixed-point sum (2^-24 units in an int64): sum |v| 2^24 must stay
+            // below 2^63 -- e.g. a million points at ECEF / UTM-scale coordinates would wrap silently.  Refused, not wrong.
+            const double vmax = std::max(std::fabs((double)key_to_double(st[3 + a])), std::fabs((double)key_to_double(st[6 + a])));
+            if (vmax * (double)m >= 5.0e11)
+                return fail(c, PGICP_ERR_ARG, "pgicp_map_create: |coordinate| x points = " + std::to_string(vmax * (double)m) +
+                                              " overflows the centroid's fixed-point sum (limit 5e11): express the cloud in a local frame first");
             const double mean_d = ((double)(long long)st[a] / 16777216.0) / (double)m;
             M.mean[a] = center ? (T)mean_d : (T)0;
             // rounding is monotone: min/max of fl(x - mean) are fl(min - mean), fl(max - mean)
@@ -582,6 +628,10 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         }
         if (s >= 2 || ((long long)L.max_rows < (1LL << 25) && (long long)L.max_rows * P <= (1LL << 26))) break;
     }
+    // (the bin table is indexed with ints on the device)
+    if ((long long)L.max_rows * P > 0x7FFFFFFFLL)
+        return fail(c, PGICP_ERR_ARG, "pgicp: batch too large for the reading sort (problems x map blocks = " +
+                                      std::to_string((long long)L.max_rows * P) + " > 2^31 - 1): split the batch");
     HIPC(c, S.rd_pre.ensure(sizeof(T) * 3 * (size_t)L.total));
     HIPC(c, S.rd_sorted.ensure(sizeof(T) * 3 * (size_t)L.total));
     {
@@ -1329,6 +1379,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     for (int s = 0; ok && s < 2; s++)
         ok = hipEventCreateWithFlags(&c->up[s].uploaded, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->up[s].consumed, hipEventDisableTiming) == hipSuccess;
+    { std::lock_guard<std::mutex> lock(pool_of(device).m); pool_of(device).contexts++; }
     if (!ok) {
         pgicp_ctx_destroy(c);
         return PGICP_ERR_HIP;
@@ -1364,8 +1415,16 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto &m : c->f32.maps) free_map<float>(nullptr, m);
     for (auto &m : c->f64.maps) free_map<double>(nullptr, m);
-    for (auto &kv : c->block_pool) (void)hipFree(kv.second);
-    c->block_pool.clear();
+    {
+        DevicePool &dp = pool_of(c->device);
+        std::lock_guard<std::mutex> lock(dp.m);
+        if (--dp.contexts <= 0) {                      // the device's last context: give the pooled blocks back
+            for (auto &kv : dp.blocks) { if (kv.second.released) (void)hipEventDestroy(kv.second.released); (void)hipFree(kv.second.p); }
+            dp.blocks.clear();
+            dp.bytes = 0;
+            dp.contexts = 0;
+        }
+    }
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,

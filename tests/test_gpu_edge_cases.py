@@ -235,3 +235,31 @@ def test_many_small_problems_in_one_batch(ctx, oracle32):
             assert dt < 1e-5 and dr < 1e-5, (p, dt, dr)
             assert st[p]["iterations"] == o["iterations"] and st[p]["n_finite"] == o["n_finite"] and st[p]["n_kept"] == o["n_kept"], p
     ctx.destroy_map(m)
+
+
+def test_map_blocks_are_shared_between_contexts_and_huge_coordinates_are_refused():
+    from pgslam_amd import icp
+    """Advisor findings of round 1: (1) a map built by one context and released by another (pgicp_map_transfer, the
+    streaming mapper's background rebuild) must give its block back to a pool the BUILDER draws from -- exercised here by
+    build / transfer / destroy cycles whose results stay exact; (2) a cloud whose |coordinate| x point count overflows the
+    centroid's fixed-point sum is refused, not silently mis-centred."""
+    from pgslam_amd import synth
+    w = synth.make_scan_to_map(n_scan=3000, n_map=20000, n_queries=1, n_map_poses=3, rings=16)
+    chain = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01, smooth_length=3,
+                 sensor_std_dev=0.01)
+    serve, build = icp.Context(0, **chain), icp.Context(0, **chain)
+    mid = serve.set_map(w.map_xyz, w.map_nrm, center=True)
+    T_ref, st_ref = serve.align(mid, w.scans_xyz[0], w.T_init[0])
+    serve.destroy_map(mid)
+    for _ in range(6):
+        b = build.set_map(w.map_xyz, w.map_nrm, center=True)
+        m2 = serve.adopt_map(build, b)
+        T, st = serve.align(m2, w.scans_xyz[0], w.T_init[0])
+        assert np.array_equal(T, T_ref) and st["iterations"] == st_ref["iterations"]
+        serve.destroy_map(m2)
+    far = w.map_xyz.astype(np.float64) + np.array([4.2e7, 1.7e5, 4.8e6])       # 4.2e7 x 20 000 points > 5e11
+    with pytest.raises(icp.PgicpError) as e:
+        serve.set_map(far, w.map_nrm.astype(np.float64), center=True, dtype=np.float64)
+    assert e.value.code == icp.ERR_ARG and "fixed-point" in str(e.value)
+    serve.close()
+    build.close()
