@@ -923,15 +923,14 @@ def main():
             dt = time.perf_counter() - t0
             return ok / dt, dt * 1e3 / args.steps
 
-        pinned_scans = []
-        for s_ in w.scans_xyz:
-            a = ctx.host_alloc(s_.shape, np.float32)
-            a[...] = s_
-            pinned_scans.append(a)
-        r_pin, ms_pin = host_loop(pinned_scans, True)
+        # one pinned block holds the distinct scans back to back (a sensor driver's ring buffer): runs of equally spaced
+        # scans travel as single 2-D transfers
+        block = ctx.host_alloc((len(w.scans_xyz),) + w.scans_xyz[0].shape, np.float32)
+        for q_, s_ in enumerate(w.scans_xyz):
+            block[q_] = s_
+        r_pin, ms_pin = host_loop([block[q_] for q_ in range(len(w.scans_xyz))], True)
         r_page, ms_page = host_loop([np.ascontiguousarray(s_) for s_ in w.scans_xyz], False)
-        for a in pinned_scans:
-            ctx.host_free(a)
+        ctx.host_free(block)
         dev_rate = converged / elapsed
         host_input = dict(pinned_scans_per_s=r_pin, pinned_ms_per_step=ms_pin, pinned_over_device_resident=r_pin / dev_rate,
                           pageable_scans_per_s=r_page, pageable_ms_per_step=ms_page, pageable_over_device_resident=r_page / dev_rate,

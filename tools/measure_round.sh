@@ -1,27 +1,35 @@
 #!/bin/bash
-# The round's measurement record (run on the GPU box through gpurun): default bench line, the kernel
-# trace of the same command, the HBM-traffic counters in their own passes, and the two other workloads.
+# The round's measurement record (run on the GPU box through gpurun): default bench line, the kernel trace of the same
+# workload, the HBM-traffic counters in their own passes, and the other workloads.  Output: gpurun_out/measure/ (the
+# summaries are copied by hand into profiles/, named per round).
 set -u
 OUT=gpurun_out/measure
 mkdir -p $OUT
 python3 bench.py --prepare-only > /dev/null 2>&1
 python3 bench.py --workload stream --prepare-only > /dev/null 2>&1
+python3 bench.py --workload slam --prepare-only > /dev/null 2>&1
 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench_n1.json
-python3 bench.py --fixed-iters --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_n1_fixed30.json
 python3 bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_loopclosure.json
 python3 bench.py --workload stream --streams 1 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_1.json
 python3 bench.py --workload stream --streams 4 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_4.json
 python3 bench.py --workload stream --streams 16 --fleet --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_fleet16.json
-python3 bench.py --workload stream --streams 64 --fleet --steps 1 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_fleet64.json
+python3 bench.py --workload slam --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_slam.json
+./tools/slam_run /tmp/pgslam_amd_seq_4500_10000_0.8.bin --mt > $OUT/slam_mt.json 2>/dev/null
 python3 tools/bench_normals.py 2>/dev/null | grep -v amdgpu > $OUT/bench_normals.json
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace -o t -- python3 $REPO/bench.py --no-fixed30 --no-cpu-baseline > $REPO/$OUT/trace.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 > $REPO/$OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 > $REPO/$OUT/pmc_write.log 2>&1
+# kernel trace of the headline command (without the companion figures, so that it holds only the metric's launches)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace -o t -- python3 $REPO/bench.py --no-fixed30 --no-cpu-baseline --no-host-input > $REPO/$OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace_lc -o t -- python3 $REPO/bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $REPO/$OUT/trace_lc.log 2>&1
+# the copy / compute overlap of the host-input pipeline: kernels and memory copies on one time line
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$OUT/trace_host -o t -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-fixed30 --no-cpu-baseline --no-profile > $REPO/$OUT/trace_host.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 --no-host-input > $REPO/$OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 --no-host-input > $REPO/$OUT/pmc_write.log 2>&1
 cd $REPO
 python3 tools/trace_summary.py $OUT/trace > $OUT/trace_summary.txt 2>&1
+python3 tools/trace_summary.py $OUT/trace_lc > $OUT/trace_lc_summary.txt 2>&1
+python3 tools/overlap_summary.py $OUT/trace_host > $OUT/host_input_overlap.txt 2>&1
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/knn_traffic.json 100000 1000000 128 > $OUT/pmc.log 2>&1
-rm -rf $OUT/pmc_fetch/*/*.db $OUT/trace/*.db 2>/dev/null
-for f in $OUT/bench_*.json; do echo "$f: $(cut -c1-260 $f)"; done
-cat $OUT/pmc.log | tail -2; head -8 $OUT/trace_summary.txt
+rm -rf $OUT/pmc_fetch/*/*.db $OUT/trace/*.db $OUT/trace_lc/*.db $OUT/trace_host/*.db 2>/dev/null
+for f in $OUT/bench_*.json $OUT/slam_mt.json; do echo "$f: $(cut -c1-300 $f)"; done
+cat $OUT/pmc.log | tail -2; head -8 $OUT/trace_summary.txt; cat $OUT/host_input_overlap.txt
