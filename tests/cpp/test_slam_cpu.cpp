@@ -2,6 +2,7 @@
 // loop-closure candidate search.  The least-squares problem and its solution are printed so that the Python
 // side can solve the same cost with scipy and compare (tests/test_slam.py).
 #include "common.hpp"
+#include <chrono>
 #include <pgslam_amd/slam.hpp>
 
 using namespace pgslam;
@@ -133,6 +134,38 @@ int main()
     for (size_t v : comp) CHECK(v <= 4);                      // built from old vertices only (topologically far from 13)
     lc.SetGeometricalDistanceThreshold(0.1);
     CHECK(!lc.FindLocalMapCandidate(13, comp));
+    {   // ---- a graph of configs[3]'s size: 400 keyframes hanging on earlier ones (a tree, as AddNewKeyframe builds it), 12 loop
+        //      edges, consistent measurements: the solve must return to the truth, and in well under a second (the
+        //      spanning-tree preconditioner: conjugate gradients only has the loop edges left to fix)
+        const int N = 400;
+        Lcg h(91);
+        std::vector<pgslam_amd::Mat<double>> truth;
+        for (int i = 0; i < N; i++) { const double a = 0.05 * i; truth.push_back(pose<double>(40 * std::cos(a) + 0.05 * i, 40 * std::sin(a), 0.0, a + M_PI / 2)); }
+        PoseGraphLeastSquares big;
+        auto add = [&](int i, int j, double sigma) {
+            PoseGraphLeastSquares::Between f;
+            f.from = i; f.to = j; f.Z = se3::from_matrix(truth[i].inverse() * truth[j]);
+            double cov[36] = {0};
+            for (int a = 0; a < 6; a++) cov[7 * a] = sigma * sigma;
+            CHECK(PoseGraphLeastSquares::InformationFactor(cov, f.L));
+            big.factors.push_back(f);
+        };
+        for (int j = 1; j < N; j++) add(j % 7 == 0 && j > 10 ? j - 3 : j - 1, j, 0.01);          // mostly a chain, some branches
+        for (int k = 0; k < 12; k++) add(10 + 9 * k, 250 + 11 * k, 0.005);
+        for (int i = 0; i < N; i++) {
+            const double e = i == 0 ? 0.0 : 0.2;
+            big.X.push_back(se3::from_matrix(truth[i] * pose<double>(e * (h.next() - 0.5), e * (h.next() - 0.5), 0.1 * e * (h.next() - 0.5), 0.2 * e * (h.next() - 0.5))));
+        }
+        big.fixed = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        big.Optimize();
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        double worst = 0;
+        for (int i = 0; i < N; i++) worst = std::max(worst, pose_diff(se3::to_matrix<pgslam_amd::Mat<double>>(big.X[i]), truth[i]));
+        std::printf("pose graph of %d keyframes, %zu edges: %d LM iterations, %.3f s, cost %.3g -> %.3g, worst pose error %.2e\n", N,
+                    big.factors.size(), big.iterations, secs, big.initial_error, big.final_error, worst);
+        CHECK(worst < 1e-4 && big.final_error < 1e-6 * big.initial_error && secs < 2.0);
+    }
     std::puts("slam cpu tests ok");
     return 0;
 }
