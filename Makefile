@@ -18,7 +18,7 @@ $(CSRC)/pgicp_comm.o: $(CSRC)/pgicp_comm.cpp include/pgicp.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIB): $(OBJS)
 	@mkdir -p pgslam_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl -pthread
 
 oracle:
 	$(MAKE) -C oracle

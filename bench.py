@@ -904,37 +904,40 @@ def main():
             c.set_params(check_every=args.check_every)
 
         def host_loop(srcs, pinned):
+            # the pipeline in its steady state: W untimed steps of the same pattern, then K timed ones; every step (the
+            # last one too) uploads its successor's scans while it aligns
             cyc = [srcs[b % len(srcs)] for b in range(B)]
             cur = ctx.upload(cyc, pinned=pinned)
-            ctx.align_batch(map_id, cur, T_inits, raise_on_error=False)          # warm-up (allocations of the upload sets)
-            cur = ctx.upload(cyc, pinned=pinned)
-            nxt = ctx.upload(cyc, pinned=pinned)
-            ctx.align_batch(map_id, cur, T_inits, raise_on_error=False)
-            cur = nxt
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
             ok = 0
-            for k in range(args.steps):
-                nxt = ctx.upload(cyc, pinned=pinned) if k + 1 < args.steps else None
+            marks, up_ms = [], []
+            for k in range(args.warmup + args.steps):
+                if k == args.warmup:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ok = 0
+                ta = time.perf_counter()
+                nxt = ctx.upload(cyc, pinned=pinned)
+                up_ms.append(round((time.perf_counter() - ta) * 1e3, 2))
                 _, st_h = ctx.align_batch(map_id, cur, T_inits, raise_on_error=False)
                 ok += sum(1 for s_ in st_h if s_["status"] == 0 and (s_["converged"] or args.fixed_iters))
                 cur = nxt
+                marks.append(round((time.perf_counter() - ta) * 1e3, 2))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            return ok / dt, dt * 1e3 / args.steps
+            return ok / dt, dt * 1e3 / args.steps, dict(step_ms=marks, upload_call_ms=up_ms, untimed_first=args.warmup)
 
         # one pinned block holds the distinct scans back to back (a sensor driver's ring buffer): runs of equally spaced
         # scans travel as single 2-D transfers
         block = ctx.host_alloc((len(w.scans_xyz),) + w.scans_xyz[0].shape, np.float32)
         for q_, s_ in enumerate(w.scans_xyz):
             block[q_] = s_
-        r_pin, ms_pin = host_loop([block[q_] for q_ in range(len(w.scans_xyz))], True)
-        r_page, ms_page = host_loop([np.ascontiguousarray(s_) for s_ in w.scans_xyz], False)
+        r_pin, ms_pin, each_pin = host_loop([block[q_] for q_ in range(len(w.scans_xyz))], True)
+        r_page, ms_page, each_page = host_loop([np.ascontiguousarray(s_) for s_ in w.scans_xyz], False)
         ctx.host_free(block)
         dev_rate = converged / elapsed
         host_input = dict(pinned_scans_per_s=r_pin, pinned_ms_per_step=ms_pin, pinned_over_device_resident=r_pin / dev_rate,
                           pageable_scans_per_s=r_page, pageable_ms_per_step=ms_page, pageable_over_device_resident=r_page / dev_rate,
-                          bytes_per_step=int(B * args.n_scan * 12),
+                          bytes_per_step=int(B * args.n_scan * 12), pinned_ms_each_step=each_pin, pageable_ms_each_step=each_page,
                           how="scans in host memory; step k+1 uploaded on the context's copy stream (pgicp_upload_f32) while step k "
                               "aligns; pageable sources pass through the context's pinned staging buffer (one host memcpy)")
 

@@ -1310,6 +1310,8 @@ int upload(pgicp_ctx *c, int n, const T *const *host, const int *stride, const i
         U.pin_cap = total + total / 4;
     }
     size_t off = 0;
+    struct Piece { char *dst; const char *src; size_t len; };
+    std::vector<Piece> pieces;                     // pageable sources: what goes into the pinned staging buffer
     for (int k = 0; k < n;) {
         const size_t bytes = sizeof(T) * ((size_t)(npts[k] - 1) * stride[k] + 3), slot = staged_bytes(sizeof(T), stride[k], npts[k]);
         // pinned sources of equal size at equal spacing (scans carved out of one pinned block) go as ONE 2-D transfer:
@@ -1327,13 +1329,29 @@ int upload(pgicp_ctx *c, int n, const T *const *host, const int *stride, const i
                 run = 1;
         }
         if (run == 1) {
-            if (mem == PGICP_HOST) std::memcpy((char *)U.pin + off, host[k], bytes);
-            else HIPC(c, hipMemcpyAsync((char *)U.dev.p + off, host[k], bytes, hipMemcpyHostToDevice, c->copy_stream));
+            if (mem == PGICP_HOST) {
+                const size_t piece = (size_t)1 << 20;
+                for (size_t b = 0; b < bytes; b += piece)
+                    pieces.push_back({(char *)U.pin + off + b, (const char *)host[k] + b, std::min(piece, bytes - b)});
+            } else HIPC(c, hipMemcpyAsync((char *)U.dev.p + off, host[k], bytes, hipMemcpyHostToDevice, c->copy_stream));
         }
         for (int j = 0; j < run; j++) { dev_ptrs[k + j] = (const T *)((char *)U.dev.p + off); off += slot; }
         k += run;
     }
-    if (mem == PGICP_HOST) HIPC(c, hipMemcpyAsync(U.dev.p, U.pin, total, hipMemcpyHostToDevice, c->copy_stream));
+    if (mem == PGICP_HOST) {
+        // one core copies 25-30 GB/s, and the caller's thread is the one that drives the ICP iterations: a large batch is
+        // staged by a few threads side by side (the sources are the caller's again when this call returns)
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int workers = total < ((size_t)8 << 20) ? 1 : (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 8u), pieces.size());
+        auto stage = [&pieces, workers](int w) {
+            for (size_t i = (size_t)w; i < pieces.size(); i += (size_t)workers) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].len);
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < workers; w++) pool.emplace_back(stage, w);
+        stage(0);
+        for (auto &t : pool) t.join();
+        HIPC(c, hipMemcpyAsync(U.dev.p, U.pin, total, hipMemcpyHostToDevice, c->copy_stream));
+    }
     HIPC(c, hipEventRecord(U.uploaded, c->copy_stream));
     U.bytes = total;
     U.pending = true;
