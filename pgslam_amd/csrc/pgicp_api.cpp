@@ -1731,6 +1731,7 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
                          s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9]);
             std::fprintf(stderr, "  slow: entries=%llu cycles_sum=%llu cycles_max=%llu (worst: supercells=%llu rows=%llu trips=%llu exist_only=%llu found=%llu) trips_sum=%llu\n",
                          s[10], s[11], s[12], s[13] >> 40, (s[13] >> 20) & 0xFFFFF, s[13] & 0xFFFFF, s[14] >> 32, s[14] & 1, s[15]);
+            std::fprintf(stderr, "  slow kinds: bounded stage=%llu capped=%llu exist_only=%llu; super-cells (or stage trips)=%llu rows with points=%llu\n", s[51], s[52], s[53], s[54], s[55]);
             std::fprintf(stderr, "  med: searched=%llu existence_unknown=%llu resolved=%llu candidates=%llu; wave ticks(100MHz) max=%llu sum=%llu waves=%llu\n", s[44], s[45], s[46], s[47], s[48], s[49], s[50]);
             std::fprintf(stderr, "  own-row hist (0,1,2-3,4-7,...):");
             for (int i = 0; i < 12; i++) std::fprintf(stderr, " %llu", s[16 + i]);
