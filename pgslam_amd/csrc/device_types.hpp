@@ -36,6 +36,8 @@ struct MapDev {
     const int *sc_wit;                   // slot of a point in a nearest occupied super-cell (within kWitReach), else -1
     const int *slot_of;                  // original index -> position in pts / nrm
     const int *near;                     // per 2x2x2 block of cells: a nearby occupied cell, -1 if none within kNearReach
+    const unsigned *occ;                 // one bit per cell (cell id = bit index): occupied.  64x smaller than the tables, so it
+                                         // stays in L2 where they do not: the searches that walk mostly EMPTY rows test it first
     GridDesc<T> g;
     int m;
     int first;                           // slot of this map's first point: the maps of one batched build share `pts`,
@@ -53,6 +55,7 @@ struct BuildDesc {
     T mean[3];
     GridDesc<T> g;
     long long pbase, cbase, sbase, fbase;   // fbase: offset of this cloud's FINE cells (+1 sentinel) in the fine table
+    long long obase;                        // offset (32-bit words) of this cloud's occupancy bits
     int ncells, nsc, kx, ncells_f;
 };
 

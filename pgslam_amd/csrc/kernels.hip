@@ -10,6 +10,7 @@
 // wave = 64 lanes everywhere; no warp-size-32 idiom is used.
 #include "kernels.hpp"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>

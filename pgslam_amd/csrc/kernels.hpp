@@ -10,7 +10,7 @@ template <typename T>
 void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_f, long long tot_s,
                              int max_m, int max_cells, int max_cells_f, int max_nsc, int max_blocks, int *cell_of, int *counts, int *block_sums,
                              int *cell_start, int *cell_start_f, int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
-                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit);
+                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit, unsigned *occ, long long tot_o);
 template <typename T>
 void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
                        int *qrow, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
@@ -38,7 +38,7 @@ void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const Ch
                         const int *active, int *tables, void *keys);
 size_t trim_select_table_bytes(int P);
 int knn_stats_read(unsigned long long out[56], int reset);
-int knn_phase_read(unsigned long long out[32], int reset);   // diagnostics build only: wave cycles per phase of the fast kernel
+int knn_phase_read(unsigned long long out[48], int reset);   // diagnostics build only: wave cycles per phase of the fast kernel
 int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
 void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp,
                            int *queue_counters);

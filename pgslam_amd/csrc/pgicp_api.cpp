@@ -65,6 +65,7 @@ struct MapHost {
     int *near = nullptr;
     int *sc_dist = nullptr;
     int *sc_wit = nullptr;
+    unsigned *occ = nullptr;
     int first = 0;                  // MapDev::first
     // the one device allocation holding all of the above -- shared by the maps of one batched build and
     // returned to the pool (or freed) by whoever drops the last reference
@@ -299,6 +300,7 @@ int sync_maps_table(pgicp_ctx *c)
         h[i].near = m.near;
         h[i].sc_dist = m.sc_dist;
         h[i].sc_wit = m.sc_wit;
+        h[i].occ = m.occ;
         h[i].first = m.first;
         h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
     }
@@ -445,7 +447,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
 
     // ---- phase 2: grids; every cloud gets its slice of ONE allocation and ONE set of build launches ----
     std::vector<MapHost<T>> Ms(n);
-    long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0;
+    long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0, tot_o = 0;
     int max_cells = 0, max_nsc = 0, max_cells_f = 0, max_blocks = 0;
     const int kx = std::max(1, std::min(8, c->grid_kx));
     bool any_nrm = false;
@@ -497,13 +499,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         for (int a = 0; a < 3; a++) d.mean[a] = M.mean[a];
         d.ncells = g.nx * g.ny * g.nz;
         d.nsc = ((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
-        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s; d.fbase = tot_f;
+        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s; d.fbase = tot_f; d.obase = tot_o;
         d.kx = kx; d.ncells_f = d.ncells * kx;
         M.kx = kx;
         // a first candidate farther than a fraction of maxDist prunes little: do not look for one beyond that
         const double reach_len = std::isfinite(c->prm.max_dist) ? c->near_frac * c->prm.max_dist : 1e30;
         d.near_reach = (int)std::min((double)kNearReach, std::max(2.0, std::ceil(reach_len / (double)g.h)));
         tot_m += m; tot_c += (long long)d.ncells + 1; tot_s += d.nsc; tot_f += (long long)d.ncells_f + 1;
+        tot_o += (long long)(d.ncells >> 5) + 2;         // (a range test reads one word past the last cell's)
         max_cells = std::max(max_cells, d.ncells);
         max_cells_f = std::max(max_cells_f, d.ncells_f);
         max_nsc = std::max(max_nsc, d.nsc);
@@ -526,9 +529,9 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
                  b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c),
-                 b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0;
+                 b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0, b_occ = up(sizeof(unsigned) * (size_t)tot_o);
     auto blk = std::make_shared<SharedBlock>();
-    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf, &blk->p, &blk->bytes); if (ast) return ast; }
+    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ, &blk->p, &blk->bytes); if (ast) return ast; }
     char *base = blk->p;
     V4 *g_pts = (V4 *)base, *g_nrm = any_nrm ? (V4 *)(base + b_pts) : nullptr;
     int *g_cs = (int *)(base + b_pts + b_nrm), *g_slot = (int *)(base + b_pts + b_nrm + b_cs),
@@ -536,6 +539,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         *g_scd = (int *)(base + b_pts + b_nrm + b_cs + b_slot + b_sc + b_near),
         *g_wit = (int *)(base + b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near),
         *g_csf = kx > 1 ? (int *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near) : g_cs;
+    unsigned *g_occ = (unsigned *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf);
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
         const BuildDesc<T> &d = descs[k];
@@ -550,13 +554,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         M.near = g_near + d.cbase;
         M.sc_dist = g_scd + d.sbase;
         M.sc_wit = g_wit + d.sbase;
+        M.occ = g_occ + d.obase;
     }
     HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
         launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_f, tot_s, max_m, max_cells, max_cells_f, max_nsc, max_blocks, c->tmp_a.as<int>(),
                                    c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), g_pts, g_nrm,
-                                   g_slot, g_sc, g_near, g_scd, g_wit);
+                                   g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o);
     }
     HIPC(c, hipStreamSynchronize(c->stream));          // `descs` (host) feeds an async copy
     HIPC(c, hipGetLastError());
@@ -748,6 +753,14 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                                S.d2.template as<T>(), ch, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
                                c->slow2.as<int>(), 0, S.none_r.template as<T>());
+            static const bool each_pass = std::getenv("PGICP_PHASE_EACH_PASS") != nullptr;     // diagnostics builds only
+            if (each_pass) {
+                unsigned long long ph[48];
+                (void)hipStreamSynchronize(c->stream);
+                if (knn_phase_read(ph, 1) == 0)
+                    std::fprintf(stderr, "    pass (seeded %d): wave-per-query kernel entries=%llu, longest wave %llu, longest entry %llu cycles; per entry: walk %.0f\n",
+                                 use_seed, ph[46], ph[44], ph[45], (double)ph[36] / (double)std::max<unsigned long long>(1ULL, ph[46]));
+            }
         }
         ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
         launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 1, active, c->sel_tables.as<int>(), c->qtmp.p);
@@ -1717,14 +1730,18 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
         unsigned long long s[56];
         (void)hipDeviceSynchronize();
         {
-            unsigned long long ph[32];
-            if (knn_phase_read(ph, 1) == 0)
+            unsigned long long ph[48];
+            if (knn_phase_read(ph, 1) == 0) {
+                std::fprintf(stderr, "  wave-per-query kernel: waves=%llu entries=%llu; cycles per ENTRY by phase [fetch, seed, look-ups, points, super-cell walk, finish]:", ph[47], ph[46]);
+                for (int k = 0; k < 6; k++) std::fprintf(stderr, " %.0f", (double)ph[32 + k] / (double)std::max<unsigned long long>(1ULL, ph[46]));
+                std::fprintf(stderr, "; longest wave %llu, longest entry %llu cycles\n", ph[44], ph[45]);
                 for (int u = 0; u < 2; u++) {
                     const double nw = (double)std::max<unsigned long long>(1ULL, ph[16 * u + 15]);
                     std::fprintf(stderr, "  fast kernel, %s: waves=%llu; cycles per wave by phase [set-up, near, own row, row tables, flat walk, rings, finish]:", u ? "seeded passes" : "unseeded pass", ph[16 * u + 15]);
                     for (int k = 0; k < 7; k++) std::fprintf(stderr, " %.0f", (double)ph[16 * u + k] / nw);
                     std::fprintf(stderr, "\n");
                 }
+            }
         }
         if (knn_stats_read(s, 1) == 0) {
             std::fprintf(stderr, "knn_stats waves=%llu a1_max=%llu a1_sum=%llu flat_iters_max=%llu a2_sum=%llu b_cand=%llu unresolved=%llu b_lanes=%llu b_max=%llu tot_max=%llu\n",
