@@ -163,6 +163,15 @@ public:
         // The reference builds a fresh ICP object from the YAML for every call (Localizer.hpp:309-311); here an ICP object
         // owns a device context (stream, pinned buffers, scratch), so the one temporary is kept and re-made only when the
         // configuration changes -- same chain, same result, without a context creation per scan.
+        PrepareOverlapReference(candidate_map_in_world_frame);
+        return ComputeOverlapAgainstPrepared(reading_in, T_world_robot);
+    }
+    //! the reference half of ComputeOverlapOf (Localizer.hpp:313-317): reference filters + matcher->init.  A caller that
+    //! asks about the SAME candidate map scan after scan (GraphLocalizer's neighbour composition, unchanged while the
+    //! graph is) prepares it once and calls ComputeOverlapAgainstPrepared per scan: same index, same result, without
+    //! assembling, uploading and indexing the map every time.
+    void PrepareOverlapReference(const DP &candidate_map_in_world_frame)
+    {
         if (!temp_icp_) {
             temp_icp_.reset(new typename PM::ICP());
             std::istringstream iss(icp_config_buffer_);
@@ -173,6 +182,12 @@ public:
         temp_icp.referenceDataPointsFilters.init();
         temp_icp.referenceDataPointsFilters.apply(reference);
         temp_icp.matcher->init(reference);
+    }
+    //! the reading half (Localizer.hpp:319-334) against the reference prepared last
+    T ComputeOverlapAgainstPrepared(const DP &reading_in, const Matrix &T_world_robot)
+    {
+        if (!temp_icp_) throw std::logic_error("ComputeOverlapAgainstPrepared: no reference prepared");
+        typename PM::ICP &temp_icp = *temp_icp_;
         DP reading(reading_in);
         temp_icp.readingDataPointsFilters.init();
         temp_icp.readingDataPointsFilters.apply(reading);

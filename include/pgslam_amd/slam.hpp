@@ -702,7 +702,7 @@ public:
         : map_manager_(mm), capacity_(capacity), rigid_(PM::get().REG(Transformation).create("RigidTransformation")),
           T_refkf_robot_(Matrix::Identity(4, 4)), T_world_robot_(Matrix::Identity(4, 4)), last_input_(Matrix::Identity(4, 4)) {}
     void SetOverlapThreshold(T v) { overlap_threshold_ = v; }
-    void SetIcpConfigFromString(const std::string &yaml) { icp_yaml_ = yaml; probe_.reset(); std::istringstream iss(yaml); icp_sequence_.loadFromYaml(iss); }
+    void SetIcpConfigFromString(const std::string &yaml) { icp_yaml_ = yaml; probe_.reset(); probe_comp_.clear(); std::istringstream iss(yaml); icp_sequence_.loadFromYaml(iss); }
     void SetInputFiltersConfigFromString(const std::string &yaml) { std::istringstream iss(yaml); input_filters_ = DataPointsFilters(iss); }
     const Matrix &T_world_robot() const { return T_world_robot_; }
     const std::vector<size_t> &composition() const { return comp_; }
@@ -768,15 +768,25 @@ protected:
     T OverlapWith(const std::vector<size_t> &comp)                          // ComputeOverlapWith, Localizer.hpp:282-348
     {
         auto &g = map_manager_->GetGraph();
-        LocalMap<T> lm(capacity_);
-        for (size_t v : comp) lm.PushKeyframe(g[v]);
-        lm.BuildCloudFromData();
         if (!probe_) {                                  // kept between calls: its ICP objects own device contexts
             probe_.reset(new Localizer<T>());
             probe_->SetIcpConfigFromString(icp_yaml_);
+            probe_comp_.clear();
         }
-        const DP world_map = rigid_->compute(lm.Cloud(), g[comp.back()].optimized_T_world_kf);
-        return probe_->ComputeOverlapOf(*input_cloud_, T_world_robot_, world_map);
+        // The neighbour composition is the same scan after scan until the vehicle moves on or the graph is optimised: its
+        // world-frame map -- keyframe clouds (immutable) under their optimised poses (unchanged while the graph's version
+        // is) -- is assembled, filtered and indexed once and asked again per scan (upstream rebuilds it, kd-tree included,
+        // every time: Localizer.hpp:288-317; the answer is the same).
+        if (probe_comp_ != comp || probe_version_ != map_manager_->Version()) {
+            LocalMap<T> lm(capacity_);
+            for (size_t v : comp) lm.PushKeyframe(g[v]);
+            lm.BuildCloudFromData();
+            const DP world_map = rigid_->compute(lm.Cloud(), g[comp.back()].optimized_T_world_kf);
+            probe_->PrepareOverlapReference(world_map);
+            probe_comp_ = comp;
+            probe_version_ = map_manager_->Version();
+        }
+        return probe_->ComputeOverlapAgainstPrepared(*input_cloud_, T_world_robot_);
     }
     //! Localizer.hpp:393-483
     bool FindNeighborComposition(std::vector<size_t> &out)
@@ -852,6 +862,8 @@ private:
     ICPSequence icp_sequence_;
     std::string icp_yaml_;
     std::unique_ptr<Localizer<T>> probe_;            // runs ComputeOverlapWith for candidate compositions
+    std::vector<size_t> probe_comp_;                 // the composition whose world-frame map the probe holds indexed ...
+    unsigned long long probe_version_ = 0;           // ... built at this version of the graph
     DPPtr input_cloud_;
     std::vector<size_t> comp_;                       // local map composition, reference keyframe last
     Matrix T_refkf_robot_, T_world_robot_, last_input_;

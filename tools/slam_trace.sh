@@ -1,0 +1,17 @@
+#!/bin/bash
+# kernel trace of the C++ SLAM driver over the first scans of the configs[3] sequence: how busy is the GPU, which kernels
+R=$GRAFT_REPO_ROOT; cd $R
+python3 bench.py --workload slam --prepare-only --slam-scans ${1:-1500} > /dev/null 2>&1
+SEQ=/tmp/pgslam_amd_seq_${1:-1500}_10000_0.8.bin
+ls -la $SEQ
+cd /tmp && export TMPDIR=/tmp; O=$R/gpurun_out/slam_trace; mkdir -p $O
+$R/tools/slam_run $SEQ | tail -1 | cut -c1-400
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $R/tools/slam_run $SEQ > $O/trace.log 2>&1
+cd $R; python3 tools/trace_summary.py $O/trace | head -${2:-30}; rm -f $O/trace/*.db
+python3 - <<PY
+import csv, glob
+rows = list(csv.DictReader(open(glob.glob("$O/trace/**/*kernel_trace.csv", recursive=True)[0])))
+busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+span = max(int(r["End_Timestamp"]) for r in rows) - min(int(r["Start_Timestamp"]) for r in rows)
+print("kernels:", len(rows), "busy %.1f ms of %.1f ms span (%.0f %%)" % (busy / 1e6, span / 1e6, 100.0 * busy / span))
+PY
