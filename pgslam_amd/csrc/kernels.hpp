@@ -40,7 +40,7 @@ size_t trim_select_table_bytes(int P);
 int knn_stats_read(unsigned long long out[56], int reset);
 int knn_phase_read(unsigned long long out[48], int reset);   // diagnostics build only: wave cycles per phase of the fast kernel
 int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
-void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int stamp,
+void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int *stamp_counter,
                            int *queue_counters);
 template <typename T>
 int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m, int knn, T max_dist, T eps_rank, T *out_nrm,
