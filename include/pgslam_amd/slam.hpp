@@ -19,6 +19,7 @@
 #include <fstream>
 #include <functional>
 #include <condition_variable>
+#include <chrono>
 #include <deque>
 #include <limits>
 #include <mutex>
@@ -714,11 +715,18 @@ public:
     {
         ProcessData(T_world_robot, T_robot_sensor, cloud);
     }
+    //! host seconds spent in: [0] input filters + sensor transform, [1] the ICP call, [2] everything after it
+    //! (neighbour composition, overlap probe, keyframe insertion, local-map rebuilds)
+    const double *phase_seconds() const { return phase_s_; }
     void ProcessData(const Matrix &input_T_world_robot, const Matrix &input_T_robot_sensor, DPPtr cloud)
     {
+        using clk = std::chrono::steady_clock;
+        const auto t0 = clk::now();
         input_cloud_ = cloud;
         input_filters_.apply(*cloud);
         (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
+        const auto t1 = clk::now();
+        phase_s_[0] += std::chrono::duration<double>(t1 - t0).count();
         auto &g = map_manager_->GetGraph();
         if (comp_.empty()) {                                                 // ProcessFirstCloud (graph locked, LocalizerMT.hpp:104-108)
             auto lock = map_manager_->GetGraphLock();
@@ -731,6 +739,8 @@ public:
         }
         const Matrix d = last_input_.inverse() * input_T_world_robot;
         T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);         // the ICP runs outside the graph lock (LocalizerMT.hpp:95-96)
+        const auto t2 = clk::now();
+        phase_s_[1] += std::chrono::duration<double>(t2 - t1).count();
         {
             auto lock = map_manager_->GetGraphLock();                        // LocalizerMT::UpdateAfterIcp, LocalizerMT.hpp:110-121
             // the graph may have been optimised while the ICP ran (upstream re-reads it unconditionally; here only when
@@ -740,6 +750,7 @@ public:
             UpdateAfterIcp();
         }
         last_input_ = input_T_world_robot;
+        phase_s_[2] += std::chrono::duration<double>(clk::now() - t2).count();
     }
     //! MapManager::NotifyKeyframeUpdate -> Localizer::UpdateFromGraph (Localizer.hpp:155-176): after an
     //! optimisation the local map is rebuilt from the corrected poses and the world pose follows the reference
@@ -869,6 +880,7 @@ private:
     Matrix T_refkf_robot_, T_world_robot_, last_input_;
     T overlap_threshold_ = T(0.8);
     int rebuilds_ = 0;
+    double phase_s_[3] = {0, 0, 0};
 };
 
 template <typename T>

@@ -214,11 +214,13 @@ int main(int argc, char **argv)
                 "\"optimizer_runs\": %d, \"optimizer_iterations\": %d, \"optimizer_host_s\": %.6f, \"map_rebuilds\": %d, "
                 "\"mean_icp_iterations\": %.3f, \"scans_not_converged\": %d, \"tracking_error_rms_m\": %.5f, "
                 "\"tracking_error_max_m\": %.5f, \"tracking_error_last_m\": %.5f, \"odometry_error_last_m\": %.5f, "
-                "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d}\n",
+                "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d, "
+                "\"localizer_host_s\": {\"filters_and_sensor_transform\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f}}\n",
                 S, N, wall, t_icp_loop, t_io, (S - 1) / t_icp_loop, g.NumVertices(), loops, slam.loop_closer().candidates_tried(),
                 slam.loop_closer().loops_closed(), slam.optimizer().runs(), slam.optimizer().total_iterations(), slam.optimizer().total_seconds(),
                 slam.localizer().rebuilds(), S > 1 ? (double)icp_iterations / (S - 1) : 0.0, not_converged,
                 std::sqrt(e_sum2 / std::max<size_t>(1, err_track.size())), e_max, e_last, odo_last,
-                std::sqrt(kf_sum2 / std::max<size_t>(1, kf_scan.size())), kf_max, rec.written, rec.written_kind[1]);
+                std::sqrt(kf_sum2 / std::max<size_t>(1, kf_scan.size())), kf_max, rec.written, rec.written_kind[1],
+                slam.localizer().phase_seconds()[0], slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2]);
     return 0;
 }
