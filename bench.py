@@ -646,6 +646,58 @@ def main_stream(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- roofline of the dominant kernel (the fast matcher), SURVEY.md 8(d): per problem and launch 20 N + 12 M with M the
+    #      sliding map's points; HIP events on the serving context's stream over a replay of one vehicle's (or the fleet's) drive
+    roofline = None
+    if not args.no_profile:
+        v = vehicles[0]
+        v.reset()
+        v.ctx.profile_reset()
+        v.ctx.profile_enable(True)
+        v.run([])
+        v.ctx.profile_enable(False)
+        k = v.ctx.profile()["knn_grid"]
+        if k["launches"]:
+            m_map = args.capacity * args.n_scan
+            alg = 20.0 * k["units"] + 12.0 * m_map * k["problems"]
+            avg_s = k["total_ms"] * 1e-3 / k["launches"]
+            achieved = alg / k["launches"] / avg_s / 1e9
+            roofline = dict(bound="hbm", kernel="knn_grid", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                            traffic=None, avg_launch_us=avg_s * 1e6, launches=k["launches"],
+                            algorithmic_bytes_per_launch=alg / k["launches"], active_problems_per_launch=k["problems"] / k["launches"],
+                            note="one small launch per vehicle (or one per fleet step): the kernel cannot fill the chip; see DESIGN.md section 5")
+    # ---- CPU baseline: the oracle on the same feed, one thread per vehicle (a vehicle's scans are sequential), bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle import Oracle
+        o = Oracle(np.float32)
+        kf = [first] + [kk * args.prime_stride for kk in range(n_prime)]          # reference keyframe first
+        inv_ref = np.linalg.inv(poses[first])
+        t0 = time.perf_counter()
+        mx, mn = o.build_local_map([xyz[s_] for s_ in kf], [nrm[s_] for s_ in kf], [inv_ref @ odom[s_] for s_ in kf])
+        m_o = o.map_create(mx, mn, center=True, use_kdtree=True)
+        t_build = time.perf_counter() - t0
+        n_thr = max(1, min(args.streams, os.cpu_count() or 1))
+        sample = list(range(first + 1, min(n_total, first + 1 + 6)))
+        done = []
+
+        def work():
+            for s_ in sample:
+                done.append(o.icp_map(m_o, xyz[s_], inv_ref @ odom[s_], **CHAIN))
+
+        th = [threading.Thread(target=work) for _ in range(n_thr)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        o.map_free(m_o)
+        cpu = dict(value=sum(1 for r in done if r["status"] == 0 and r["converged"]) / dt, unit="scans/s", cores=n_thr, kind="port",
+                   sample=f"the first {len(sample)} timed scans per vehicle against the first sliding map ({len(kf)} keyframes, {mx.shape[0]} points), "
+                          f"kd-tree oracle, one thread per vehicle ({n_thr}); the map's index build ({t_build:.1f} s, once per keyframe on the CPU) excluded",
+                   host_cores=os.cpu_count(), index_build_s=t_build, mean_iterations=float(np.mean([r["iterations"] for r in done])))
     if rank == 0:
         its = sum(r[0] for r in res)
         conv = sum(r[1] for r in res)
@@ -662,7 +714,8 @@ def main_stream(args):
                        "parallelism": f"{world} GPU(s) x {args.streams} independent vehicles (replicas)"},
             "ms_per_scan_per_vehicle": elapsed * 1e3 / (args.steps * (n_total - first - 1)),
             "mean_iterations": its / per_step, "converged_fraction": conv / per_step,
-            "new_keyframes_per_vehicle": res[0][2], "map_rebuilds_per_vehicle": res[0][3], "final_position_error_m": res[0][4]}))
+            "new_keyframes_per_vehicle": res[0][2], "map_rebuilds_per_vehicle": res[0][3], "final_position_error_m": res[0][4],
+            "roofline": roofline, "cpu_baseline": cpu}))
     for v in vehicles:
         v.m.close()
         v.ctx.close()
