@@ -857,6 +857,8 @@ struct PointMatcher {
     static PointMatcher &get() { static PointMatcher pm; return pm; }
 };
 
+// libpointmatcher's own spelling (pointmatcher/Registrar.h defines this macro for its users: `PM::get().REG(Transformation)
+// .create("RigidTransformation")`, Localizer.hpp:24, LoopCloser.hpp:27): a drop-in header has to provide it, short as it is.
 #ifndef REG
 #define REG(name) name##Registrar
 #endif
