@@ -104,6 +104,15 @@ def load_library() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
                               "pgslam_amd has no CPU fallback")
+        # PyTorch wheels carry their own libamdhip64.  If libpgicp (linked against /opt/rocm's copy) enters the process
+        # first and torch later, the process holds two HIP runtimes and torch reports "No HIP GPUs are available"; with
+        # torch loaded first the loader resolves libpgicp's dependency to the copy that is already there.
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except Exception:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.pgicp_last_error.restype = C.c_char_p
         _lib.pgicp_status_string.restype = C.c_char_p
