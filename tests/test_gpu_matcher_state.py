@@ -95,3 +95,24 @@ def test_full_size_state(ctx, oracle32):
     from bench import build_workload
     w = build_workload(100_000, 1_000_000, 16)
     check_state(ctx, oracle32, w.scans_xyz[3], w.map_xyz, w.map_nrm, w.T_init[3], (2, 4))
+
+
+def test_scan_ahead_of_its_map(ctx, oracle32):
+    """A scan taken metres ahead of a short-range map: a large part of it has its nearest map point a metre or two away
+    (beyond the trim threshold, within maxDist) or none at all.  The regime of the streaming mapper late in a drive:
+    the wave-per-query path's bounded stage, its capped look and its existence-only exits all run."""
+    world = synth.make_world()
+    poses = [synth.se3(x=-40.0 + 2.0 * k) for k in range(3)]
+    ref_inv = synth.se3_inv(poses[0])
+    parts = []
+    for k, P in enumerate(poses):
+        x, n = synth.make_scan(world, P, 8000, 9100 + k, rings=16, max_range=14.0)
+        parts.append(synth.transform_cloud(ref_inv @ P, x.astype(np.float64), n.astype(np.float64)))
+    ref = np.concatenate([p[0] for p in parts]).astype(np.float32)
+    nrm = np.concatenate([p[1] for p in parts]).astype(np.float32)
+    for ahead, its in ((6.0, (1, 2, 3, 6)), (11.0, (1, 2, 4))):
+        P = synth.se3(x=-36.0 + ahead, y=0.3, yaw=np.deg2rad(2.0))
+        rd, _ = synth.make_scan(world, P, 9000, 9200 + int(ahead), rings=16, max_range=14.0)
+        T0 = ref_inv @ P @ synth.se3(x=0.05, y=-0.04, yaw=np.deg2rad(0.4))
+        check_state(ctx, oracle32, rd, ref, nrm, T0, its)
+        check_state(ctx, oracle32, rd, ref, nrm, T0, (2, 3), chain=dict(CHAIN, trim_ratio=0.97))
