@@ -325,12 +325,18 @@ int sync_maps_table(pgicp_ctx *c)
 // pgicp_map_transfer -- releases it; with per-context pools the blocks piled up where nobody allocates.  A pooled block
 // carries an event recorded on the releasing context's stream; whoever takes it makes its own stream wait for that event,
 // so work still queued on the old owner's stream is ordered before the new contents.
-constexpr size_t kPoolLimitBytes = (size_t)2 << 30;
+// A batch of 128 loop-closure maps is ONE block of 3-4 GB: with a 2 GiB pool it was never recycled, every batch paid a
+// hipMalloc and a (device-synchronising) hipFree of that size -- 1 ms on some hosts, 45 ms on others, which made the
+// loop-closing workload run at 4 700 or at 1 700 pairs/s depending on the box.  The pool may hold an eighth of the
+// device's memory (36 GB of an MI355X's 288), and a block is allocated an eighth larger than asked for, so that the
+// slightly larger batch that follows fits the block of the one before.
+constexpr size_t kPoolLimitFallback = (size_t)8 << 30;
 struct PooledBlock { char *p; hipEvent_t released; };
 struct DevicePool {
     std::mutex m;
     std::multimap<size_t, PooledBlock> blocks;
     size_t bytes = 0;
+    size_t limit = 0;               // set on first use: total device memory / 8
     int contexts = 0;
 };
 DevicePool g_pools[16];
@@ -354,6 +360,9 @@ int block_alloc(pgicp_ctx *c, size_t bytes, char **out, size_t *got)
             return PGICP_OK;
         }
     }
+    const size_t padded = bytes + bytes / 8;
+    if (hipMalloc((void **)out, padded) == hipSuccess) { *got = padded; return PGICP_OK; }
+    (void)hipGetLastError();
     HIPC(c, hipMalloc((void **)out, bytes));
     *got = bytes;
     return PGICP_OK;
@@ -365,7 +374,11 @@ void block_release(pgicp_ctx *c, char *p, size_t bytes)
     if (c) {
         DevicePool &dp = pool_of(c->device);
         std::lock_guard<std::mutex> lock(dp.m);
-        if (dp.bytes + bytes <= kPoolLimitBytes) {
+        if (dp.limit == 0) {
+            size_t free_b = 0, total_b = 0;
+            dp.limit = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b / 8 : kPoolLimitFallback;
+        }
+        if (dp.bytes + bytes <= dp.limit) {
             PooledBlock b{p, nullptr};
             if (hipEventCreateWithFlags(&b.released, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(b.released, c->stream);
             else b.released = nullptr;
