@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""One-screen digest of gpurun_out/measure/ (tools/measure_round.sh): the figures DESIGN.md section 5 quotes."""
+import json, sys
+M = (sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/measure') + '/'
+d = json.load(open(M + 'bench_n1.json'))
+print('headline', round(d['value'], 1), 'scans/s', round(d['ms_per_step'], 2), 'ms/step, iterations', d['mean_iterations'], 'set_map', round(d['set_map_ms'], 2),
+      'ms, fixed-30', round(d['fixed_30_iterations']['scans_per_s'], 1))
+h = d['host_input']
+print('  host input: pinned', round(h['pinned_over_device_resident'], 3), h['pinned_ms_each_step']['step_ms'], 'pageable', round(h['pageable_over_device_resident'], 3),
+      h['pageable_ms_each_step']['step_ms'])
+r = d['roofline']
+print('  roofline: frac', round(r['frac'], 4), 'launch', round(r['avg_launch_us'], 1), 'us, shared-map frac', round(r['frac_shared_map'], 4), 'traffic', r['traffic'],
+      'active problems', round(r['active_problems_per_launch'], 2))
+c = d['cpu_baseline']
+print('  cpu:', round(c['value'], 2), 'scans/s on', c['cores'], 'cores, single core', round(c['single_core_scans_per_s'], 2), '; GPU/CPU', round(d['speedup_vs_cpu_baseline'], 1),
+      round(c['gpu_over_single_core'], 1))
+print('  kernels (us per launch):', {k: v['avg_us'] for k, v in d['kernels'].items()})
+l = json.load(open(M + 'bench_loopclosure.json'))
+print('loop closing', round(l['value'], 1), 'pairs/s', round(l['ms_per_step'], 1), 'ms/step, frac', round(l['roofline']['frac'], 4), 'launch', round(l['roofline']['avg_launch_us'], 1),
+      'us, cpu', round(l['cpu_baseline']['value'], 2), 'pairs/s on', l['cpu_baseline']['cores'])
+for f in ('bench_stream_1', 'bench_stream_4', 'bench_stream_fleet16'):
+    x = json.load(open(M + f + '.json'))
+    print(f, round(x['value'], 1), 'scans/s,', round(x['ms_per_scan_per_vehicle'], 3), 'ms per scan and vehicle, iterations', x['mean_iterations'], 'end error', round(x['final_position_error_m'], 4),
+          'frac', x['roofline'] and round(x['roofline']['frac'], 4), 'launch', x['roofline'] and round(x['roofline']['avg_launch_us'], 1), 'cpu', x['cpu_baseline'] and (round(x['cpu_baseline']['value'], 2), x['cpu_baseline']['cores']))
+s = json.load(open(M + 'bench_slam.json'))
+print('slam', round(s['value'], 1), 'scans/s', {k: s['slam'][k] for k in ('keyframes', 'loops_closed', 'map_rebuilds', 'mean_icp_iterations', 'optimizer_host_s', 'localizer_host_s')})
+print('  replay', s['replay_vs_oracle'], 'cpu', round(s['cpu_baseline']['value'], 1), s['cpu_baseline']['unit'])
+print('slam mt', open(M + 'slam_mt.json').read()[:400])
+n = json.load(open(M + 'bench_normals.json'))
+print('normals', {k: (round(v['kernel_ms'], 2) if isinstance(v, dict) else round(v, 1)) for k, v in n.items()})
+print(open(M + 'pmc.log').read().strip().splitlines()[-1][:300])
+print(open(M + 'trace_summary.txt').read()[:700])
+print(open(M + 'host_input_overlap.txt').read())
