@@ -237,11 +237,12 @@ struct PointMatcher {
             pgslam_amd::to_row_major16(parameters, Tm);
             const int n = (int)input.getNbPoints();
             if (n == 0) return out;
-            check(c, A::transform(c, Tm, input.features.data(), input.features.rows(), out.features.data(), out.features.rows(), n, 0));
+            // `out` is a copy of `input`: transformed in place (the call uploads its data once, not input AND output)
+            check(c, A::transform(c, Tm, out.features.data(), out.features.rows(), out.features.data(), out.features.rows(), n, 0));
             for (const char *name : {"normals", "observationDirections"}) {
                 if (!input.descriptorExists(name) || input.getDescriptorDimension(name) != 3) continue;
                 const int row = input.getDescriptorStartingRow(name);
-                check(c, A::transform(c, Tm, input.descriptors.data() + row, input.descriptors.rows(), out.descriptors.data() + row,
+                check(c, A::transform(c, Tm, out.descriptors.data() + row, out.descriptors.rows(), out.descriptors.data() + row,
                                       out.descriptors.rows(), n, 1));
             }
             return out;

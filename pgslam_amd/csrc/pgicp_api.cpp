@@ -1211,6 +1211,18 @@ int transform(pgicp_ctx *c, const double *T16, const T *in, int in_stride, T *ou
     }
     const size_t bi = staged_bytes(sizeof(T), in_stride, n), bo = staged_bytes(sizeof(T), out_stride, n);
     HIPC(c, S.staging.ensure(bi));
+    if (in == out && in_stride == out_stride) {
+        // in place: the staged copy is input and output (a thread reads and writes its own point), the caller's other
+        // rows travel with it -- one upload instead of two
+        const T *d_io = nullptr;
+        int st0 = to_device<T>(c, in, in_stride, n, mem, S.staging, 0, &d_io);
+        if (st0) return st0;
+        launch_transform<T>(c->stream, d_io, in_stride, const_cast<T *>(d_io), out_stride, n, T16, rotate_only);
+        HIPC(c, hipMemcpyAsync(out, d_io, sizeof(T) * ((size_t)(n - 1) * out_stride + 3), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipGetLastError());
+        return PGICP_OK;
+    }
     HIPC(c, S.stage_aux.ensure(bo));
     const T *d_in = nullptr;
     int st = to_device<T>(c, in, in_stride, n, mem, S.staging, 0, &d_in);
