@@ -16,6 +16,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <fstream>
 #include <functional>
 #include <condition_variable>
@@ -788,7 +789,8 @@ protected:
         // world-frame map -- keyframe clouds (immutable) under their optimised poses (unchanged while the graph's version
         // is) -- is assembled, filtered and indexed once and asked again per scan (upstream rebuilds it, kd-tree included,
         // every time: Localizer.hpp:288-317; the answer is the same).
-        if (probe_comp_ != comp || probe_version_ != map_manager_->Version()) {
+        static const bool always_rebuild = std::getenv("PGSLAM_PROBE_REBUILD") != nullptr;   // tests: the reference's own flow
+        if (always_rebuild || probe_comp_ != comp || probe_version_ != map_manager_->Version()) {
             LocalMap<T> lm(capacity_);
             for (size_t v : comp) lm.PushKeyframe(g[v]);
             lm.BuildCloudFromData();

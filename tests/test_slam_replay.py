@@ -63,3 +63,24 @@ def test_slam_facade_closes_loops_and_replays_through_the_oracle():
         dr = float(np.linalg.norm([d[2, 1] - d[1, 2], d[0, 2] - d[2, 0], d[1, 0] - d[0, 1]]) / 2.0)
         assert dt < 1e-5 and dr < 1e-5, (r["kind"], r["scan"], dt, dr)
         assert ref["iterations"] == r["iterations"] and int(ref["converged"]) == r["converged"]
+
+
+@pytest.mark.gpu
+def test_probe_that_keeps_its_indexed_map_changes_nothing():
+    """GraphLocalizer keeps the neighbour composition's world-frame map indexed between scans (the reference assembles and
+    indexes it for every overlap check, Localizer.hpp:282-348).  With PGSLAM_PROBE_REBUILD set the facade does what the
+    reference does: every figure of the run -- keyframes, loops, rebuilds, tracking errors to the printed digit -- is the same."""
+    import bench
+    import os
+    seq = bench.build_sequence(400, 4000, 1.5)
+    exe = bench.build_slam_run()
+    runs = []
+    for env in ({}, {"PGSLAM_PROBE_REBUILD": "1"}):
+        out = subprocess.run([exe, seq], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    same = ("scans", "keyframes", "loop_edges", "loop_candidates_tried", "loops_closed", "optimizer_runs", "optimizer_iterations",
+            "map_rebuilds", "mean_icp_iterations", "scans_not_converged", "tracking_error_rms_m", "tracking_error_max_m",
+            "tracking_error_last_m", "keyframe_error_rms_m", "keyframe_error_max_m")
+    for k in same:
+        assert runs[0][k] == runs[1][k], (k, runs[0][k], runs[1][k])
