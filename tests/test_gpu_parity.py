@@ -466,3 +466,25 @@ def test_max_dist_outlier_filter_in_the_chain(ctx, oracle32, small, trim_ratio, 
     ctx.destroy_map(rid)
     ctx.destroy_map(mid)
     ctx.set_params(**dict(CHAIN, outlier_max_dist=0.0))
+
+
+@pytest.mark.gpu
+def test_host_may_look_at_the_iteration_flag_less_often(ctx, small):
+    """check_every: the convergence checkers run on the device after every iteration; how often the HOST looks at their flag
+    only decides how many (no-op) iterations it enqueues past the last one.  Transforms and statistics do not change."""
+    w = small
+    B = 5
+    rd = [w.scans_xyz[b % len(w.scans_xyz)] for b in range(B)]
+    T0 = [w.T_init[b % len(w.scans_xyz)] @ synth.se3(x=0.01 * b, yaw=0.002 * b) for b in range(B)]
+    m = ctx.set_map(w.map_xyz, w.map_nrm)
+    ref = None
+    for every in (1, 2, 3, 7):
+        ctx.set_params(**CHAIN, check_every=every)
+        Ts, st = ctx.align_batch(m, rd, T0, raise_on_error=False)
+        key = (np.asarray(Ts).tobytes(), [(s["status"], s["iterations"], s["converged"], s["n_kept"], s["n_finite"], s["trim_limit"], s["overlap"],
+                                           s["residual"]) for s in st])
+        if ref is None:
+            ref = key
+        assert key == ref, every
+    ctx.set_params(**CHAIN, check_every=1)
+    ctx.destroy_map(m)
