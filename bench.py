@@ -742,8 +742,9 @@ def main():
     ap.add_argument("--with-fixed30", action="store_true", help="(the default now; kept so that older command lines still parse)")
     ap.add_argument("--matcher", choices=["grid", "brute"], default="grid")
     ap.add_argument("--grid-cell", type=float, default=0.0)
-    ap.add_argument("--check-every", type=int, default=2,
-                    help="the host looks at the device-side convergence flag every this many iterations (results do not depend on it)")
+    ap.add_argument("--check-every", type=int, default=1,
+                    help="the host looks at the device-side convergence flag every this many iterations (results do not depend on it; "
+                         "2 is +0.7 %% but adds an empty launch per step, which the per-launch roofline accounting would have to explain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=64, help="scans of the CPU baseline's batch (at least one per host core)")
     ap.add_argument("--no-profile", action="store_true")
