@@ -536,13 +536,12 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         max_blocks = std::max(max_blocks, ((g.nx + 1) >> 1) * ((g.ny + 1) >> 1) * ((g.nz + 1) >> 1));
     }
     if (tot_m > 0x7FFFFFF0LL || tot_f > 0x7FFFFFF0LL) {
-        // the concatenated index space must fit an int: build the clouds of an oversized batch one by one
+        // the concatenated index space must fit an int: an oversized batch is built in two halves (each may split again)
         if (n == 1) return fail(c, PGICP_ERR_ARG, "pgicp_map_create: cloud too large");
-        for (int k = 0; k < n; k++) {
-            const int st1 = map_create_batch<T>(c, 1, src + k, mem, center, map_ids + k);
-            if (st1) return st1;
-        }
-        return PGICP_OK;
+        const int half = n / 2;
+        const int st1 = map_create_batch<T>(c, half, src, mem, center, map_ids);
+        if (st1) return st1;
+        return map_create_batch<T>(c, n - half, src + half, mem, center, map_ids + half);
     }
     HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)tot_m));                               // cell_of
     HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)tot_f));                               // counts (fine cells), then sweep scratch
