@@ -240,6 +240,9 @@ def main_loopclosure(args):
 
     for _ in range(args.warmup):
         step()
+    import gc
+    gc.collect()
+    gc.freeze()                     # (see main(): collections inside the timed steps must not walk torch's and numpy's objects)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -851,6 +854,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # the harness itself: every object alive now (torch, numpy, the workload) moves to the collector's permanent generation,
+    # so that a collection triggered by a step's few thousand short-lived result objects does not walk them (at 256-320
+    # problems per step a full collection fell into every step: 10-13 ms of Python per 26 ms of ICP)
+    import gc
+    gc.collect()
+    gc.freeze()
 
     def fence():
         torch.cuda.synchronize()

@@ -112,6 +112,11 @@ struct pgicp_ctx {
     hipStream_t copy_stream = nullptr;
     int up_next = 0;
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
+    // pinned bounce buffers for the problem records of a batch (4.6 KB each: a Checker history rides in them): a megabyte
+    // copied between device and PAGEABLE host memory takes the runtime's slow path -- 10-13 ms per step at 256-320
+    // problems, none at 128 or 384 -- so the records travel through pinned memory in both directions
+    char *h_up = nullptr, *h_down = nullptr;
+    size_t h_up_cap = 0, h_down_cap = 0;
     int *h_flag = nullptr;          // coherent pinned pair {problems done, stamp} the last kernel of an iteration writes
     int flag_stamp = 0;             // iterations enqueued so far == the value the last one's k_compact_active will store
     int *stamp_dev = nullptr;       // the same count on the device (k_compact_active advances it)
@@ -280,6 +285,17 @@ int to_device(pgicp_ctx *c, const T *p, int stride, int n, int mem, DevBuf &stag
     const size_t bytes = sizeof(T) * ((size_t)(n - 1) * stride + 3);
     HIPC(c, hipMemcpyAsync((char *)stage.p + stage_off_bytes, p, bytes, hipMemcpyHostToDevice, c->stream));
     *out = (const T *)((char *)stage.p + stage_off_bytes);
+    return PGICP_OK;
+}
+
+static int pinned_ensure(pgicp_ctx *c, char **buf, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return PGICP_OK;
+    HIPC(c, hipStreamSynchronize(c->stream));                 // a transfer out of / into the old buffer may still be queued
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr; *cap = 0;
+    HIPC(c, hipHostMalloc((void **)buf, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+    *cap = bytes + bytes / 4 + 4096;
     return PGICP_OK;
 }
 
@@ -710,7 +726,9 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         for (int i = 0; i < 12; i++) D.Tcur[i] = D.T_iter[i];
         checker_init(D.chk);
     }
-    HIPC(c, hipMemcpyAsync(c->probs.p, hp.data(), sizeof(ProblemDev) * P, hipMemcpyHostToDevice, c->stream));
+    { const int pst = pinned_ensure(c, &c->h_up, &c->h_up_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
+    std::memcpy(c->h_up, hp.data(), sizeof(ProblemDev) * (size_t)P);
+    HIPC(c, hipMemcpyAsync(c->probs.p, c->h_up, sizeof(ProblemDev) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->src.p, hs.data(), sizeof(SrcDesc) * P, hipMemcpyHostToDevice, c->stream));
     std::vector<int> &ident = c->h_ident;
     ident.resize(P);
@@ -894,6 +912,8 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_align: unknown map id");
         if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp_align: reference has no normals descriptor");
     }
+    static const bool host_timing = std::getenv("PGICP_HOST_TIMING") != nullptr;      // diagnostics
+    const auto ht0 = std::chrono::steady_clock::now();
     int st = batch_begin<T>(c, P, pr, [&](int p, double *Tpre) {
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         double mean[3] = {(double)M->mean[0], (double)M->mean[1], (double)M->mean[2]};
@@ -903,6 +923,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         mat4_mul(Tm_inv, pr[p].T_init, Tpre);
     }, L, hp);
     if (st) return st;
+    const auto ht1 = std::chrono::steady_clock::now();
     const ChainDev<T> ch = make_chain<T>(prm);
     const int every = std::max(1, prm.check_every);
     // active-problem accounting for the profile: exact when check_every == 1 and all
@@ -920,6 +941,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
             if (n_done >= P) break;
         }
     }
+    const auto ht2 = std::chrono::steady_clock::now();
     {
         ProfScope ps(c, PGICP_PROF_COV, L.total, P);
         launch_cov<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(), S.rd_sorted.template as<T>(),
@@ -927,10 +949,17 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
                       L.max_n);
     }
     std::vector<double> cs((size_t)P * kCovTerms);
-    HIPC(c, hipMemcpyAsync(hp.data(), c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
+    { const int pst = pinned_ensure(c, &c->h_down, &c->h_down_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
+    HIPC(c, hipMemcpyAsync(c->h_down, c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipMemcpyAsync(cs.data(), c->sums.p, sizeof(double) * cs.size(), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
+    std::memcpy(hp.data(), c->h_down, sizeof(ProblemDev) * (size_t)P);
+    if (host_timing) {
+        const auto ht3 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "align_batch P=%d: begin %.2f ms, iterations %.2f ms, tail %.2f ms\n", P, ms(ht0, ht1), ms(ht1, ht2), ms(ht2, ht3));
+    }
     int worst = PGICP_OK;
     for (int p = 0; p < P; p++) {
         const ProblemDev &D = hp[p];
@@ -1078,9 +1107,11 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
                         c->sums.as<double>(), P);
     std::vector<double> sys((size_t)P * kSys);
     HIPC(c, hipMemcpyAsync(sys.data(), c->sums.p, sizeof(double) * sys.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(hp.data(), c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
+    { const int pst = pinned_ensure(c, &c->h_down, &c->h_down_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
+    HIPC(c, hipMemcpyAsync(c->h_down, c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
+    std::memcpy(hp.data(), c->h_down, sizeof(ProblemDev) * (size_t)P);
     int worst = PGICP_OK;
     for (int p = 0; p < P; p++) {
         const double *s = sys.data() + (size_t)p * kSys;
@@ -1579,6 +1610,8 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
                       &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->sel_tables, &c->queue, &c->f32.none_r, &c->f64.none_r})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_up) (void)hipHostFree(c->h_up);
+    if (c->h_down) (void)hipHostFree(c->h_down);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (std::getenv("PGICP_GRAPH_DEBUG"))
         std::fprintf(stderr, "pgicp context %p: %lld iteration graphs captured, %lld replayed, %d failures\n", (void *)c, c->graph_captures, c->graph_launches, c->graph_failures);

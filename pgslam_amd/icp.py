@@ -121,6 +121,18 @@ def load_library() -> C.CDLL:
     return _lib
 
 
+_TORCH_DTYPES = {}          # torch dtype -> numpy dtype (the string round trip costs microseconds per reading of a batch)
+
+# numpy views of the two ctypes records a batch call exchanges (same layout: ctypes' natural alignment)
+_PROBLEM_DTYPE = np.dtype({"names": ["map_id", "reading", "stride", "n", "mem", "T_init"],
+                           "formats": ["<i4", "<u8", "<i4", "<i4", "<i4", ("<f8", (16,))],
+                           "offsets": [0, 8, 16, 20, 24, 32], "itemsize": 160})
+_STATS_DTYPE = np.dtype({"names": ["status", "iterations", "converged", "max_iter_reached", "overlap", "residual", "trim_limit",
+                                   "n_kept", "n_finite", "cov"],
+                         "formats": ["<i4", "<i4", "<i4", "<i4", "<f8", "<f8", "<f8", "<i4", "<i4", ("<f8", (36,))],
+                         "offsets": [0, 4, 8, 12, 16, 24, 32, 40, 44, 48], "itemsize": 336})
+
+
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
@@ -151,7 +163,10 @@ class _Buf:
                 self.stride = x.stride(0)
                 self.n = x.shape[0]
                 self.mem = DEVICE
-                self.dtype = np.dtype(str(x.dtype).replace("torch.", ""))
+                dt = _TORCH_DTYPES.get(x.dtype)
+                if dt is None:
+                    dt = _TORCH_DTYPES[x.dtype] = np.dtype(str(x.dtype).replace("torch.", ""))
+                self.dtype = dt
                 return
         x = np.asarray(x)
         if dtype is not None:
@@ -366,23 +381,30 @@ class Context:
         if isinstance(map_ids, int):
             map_ids = [map_ids] * P
         bufs = [_Buf(r, dtype) for r in readings]
-        probs = (Problem * P)()
-        for p in range(P):
-            probs[p].map_id = map_ids[p]
-            probs[p].reading = bufs[p].ptr
-            probs[p].stride = bufs[p].stride
-            probs[p].n = bufs[p].n
-            probs[p].mem = bufs[p].mem
-            probs[p].T_init = _T16(T_inits[p])
-        T_out = (C.c_double * (16 * P))()
-        stats = (Stats * P)()
+        # the records are filled and read back through numpy views, column by column: per-problem attribute access on
+        # ctypes structures cost ~9 us a problem, 1.2 ms of a 15 ms step at 128 problems
+        pa = np.zeros(P, dtype=_PROBLEM_DTYPE)
+        pa["map_id"] = map_ids
+        pa["reading"] = [b.ptr for b in bufs]
+        pa["stride"] = [b.stride for b in bufs]
+        pa["n"] = [b.n for b in bufs]
+        pa["mem"] = [b.mem for b in bufs]
+        pa["T_init"] = np.asarray(T_inits, dtype=np.float64).reshape(P, 16)
+        T_out = np.empty((P, 4, 4), dtype=np.float64)
+        sa = np.zeros(P, dtype=_STATS_DTYPE)
         fn = getattr(self.lib, "pgicp_align_batch" + self._sfx(bufs[0].dtype))
-        rc = fn(self.h, C.c_int(P), probs, T_out, stats)
+        rc = fn(self.h, C.c_int(P), C.c_void_p(pa.ctypes.data), C.c_void_p(T_out.ctypes.data), C.c_void_p(sa.ctypes.data))
         if raise_on_error:
             self._check(rc)
         elif rc not in (OK, ERR_NO_MATCH, ERR_NAN):
             self._check(rc)
-        return np.array(T_out[:]).reshape(P, 4, 4), [s.as_dict() for s in stats]
+        cov = sa["cov"].reshape(P, 6, 6)
+        cols = [sa[k].tolist() for k in ("status", "iterations", "converged", "max_iter_reached", "overlap", "residual", "trim_limit",
+                                          "n_kept", "n_finite")]
+        stats = [dict(status=st, iterations=it, converged=bool(cv), max_iter_reached=bool(mx), overlap=ov, residual=rs, trim_limit=tl,
+                      n_kept=nk, n_finite=nf, cov=cov[p])
+                 for p, (st, it, cv, mx, ov, rs, tl, nk, nf) in enumerate(zip(*cols))]
+        return T_out, stats
 
     def icp_pair(self, reading, ref_xyz, ref_nrm, T_init, dtype=None):
         r = _Buf(reading, dtype)

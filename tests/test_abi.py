@@ -70,3 +70,18 @@ def test_check_icp_result_follows_loop_closer():
     assert not icp.check_icp_result(ok, 5000.1)                                  # LoopCloser.hpp:335
     assert icp.check_icp_result(ok, 5000.0)
     assert not icp.check_icp_result(dict(ok, status=1), 1.0)
+
+
+def test_numpy_views_of_the_batch_records_match_the_ctypes_structures():
+    """Context.align_batch fills pgicp_problem[] and reads pgicp_stats[] through numpy structured views: field for field the
+    layout must be the C structures' (include/pgicp.h, mirrored by the ctypes classes)."""
+    import ctypes as C
+    from pgslam_amd import icp
+    assert icp._PROBLEM_DTYPE.itemsize == C.sizeof(icp.Problem)
+    assert icp._STATS_DTYPE.itemsize == C.sizeof(icp.Stats)
+    for name in icp._PROBLEM_DTYPE.names:
+        assert icp._PROBLEM_DTYPE.fields[name][1] == getattr(icp.Problem, name).offset, name
+    for name in icp._STATS_DTYPE.names:
+        assert icp._STATS_DTYPE.fields[name][1] == getattr(icp.Stats, name).offset, name
+    assert set(icp._PROBLEM_DTYPE.names) == {f[0] for f in icp.Problem._fields_}
+    assert set(icp._STATS_DTYPE.names) == {f[0] for f in icp.Stats._fields_}
