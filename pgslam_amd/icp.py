@@ -472,20 +472,20 @@ class Context:
         """(weightedPointUsedRatio, residual, status) arrays of a batch of (map, reading, T) in one device pass."""
         P = len(readings)
         bufs = [_Buf(r, dtype) for r in readings]
-        probs = (Problem * P)()
-        for p in range(P):
-            probs[p].map_id = map_ids[p]
-            probs[p].reading = bufs[p].ptr
-            probs[p].stride = bufs[p].stride
-            probs[p].n = bufs[p].n
-            probs[p].mem = bufs[p].mem
-            probs[p].T_init = _T16(Ts[p])
-        ratio, resid, status = (C.c_double * P)(), (C.c_double * P)(), (C.c_int * P)()
+        pa = np.zeros(P, dtype=_PROBLEM_DTYPE)              # (numpy views of the records: see align_batch)
+        pa["map_id"] = map_ids
+        pa["reading"] = [b.ptr for b in bufs]
+        pa["stride"] = [b.stride for b in bufs]
+        pa["n"] = [b.n for b in bufs]
+        pa["mem"] = [b.mem for b in bufs]
+        pa["T_init"] = np.asarray(Ts, dtype=np.float64).reshape(P, 16)
+        ratio, resid, status = np.zeros(P, dtype=np.float64), np.zeros(P, dtype=np.float64), np.zeros(P, dtype=np.int32)
         fn = getattr(self.lib, "pgicp_partial_chain_batch" + self._sfx(bufs[0].dtype))
-        rc = fn(self.h, C.c_int(P), probs, ratio, resid, status)
+        rc = fn(self.h, C.c_int(P), C.c_void_p(pa.ctypes.data), C.c_void_p(ratio.ctypes.data), C.c_void_p(resid.ctypes.data),
+                C.c_void_p(status.ctypes.data))
         if raise_on_error or rc not in (OK, ERR_NO_MATCH):
             self._check(rc)
-        return np.array(ratio[:]), np.array(resid[:]), np.array(status[:])
+        return ratio, resid, status
 
     def transform(self, T, pts, rotate_only=False, dtype=None):
         r = _Buf(pts, dtype)

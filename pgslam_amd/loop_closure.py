@@ -82,9 +82,19 @@ def align_local(ctx: icp.Context, cands, cfg: LoopClosureConfig):
         _, res, st = ctx.partial_chain_batch([map_ids[k] for k in ok], [readings[k] for k in ok], [Ts[k] for k in ok],
                                              raise_on_error=False)
         residual[ok] = np.where(st == 0, res, np.inf)
+    # the edge records column by column (512 per-candidate record assignments were a tenth of a step)
     edges = np.zeros(len(cands), dtype=EDGE_DTYPE)
-    for k, c in enumerate(cands):
-        edges[k] = make_edge(c.from_id, c.to_id, Ts[k], stats[k], float(residual[k]), cfg)
+    edges["from_id"] = [c.from_id for c in cands]
+    edges["to_id"] = [c.to_id for c in cands]
+    edges["status"] = [s["status"] for s in stats]
+    edges["iterations"] = [s["iterations"] for s in stats]
+    edges["max_iter_reached"] = [int(s["max_iter_reached"]) for s in stats]
+    edges["overlap"] = [s["overlap"] for s in stats]
+    edges["residual"] = residual
+    edges["T_from_to"] = np.asarray(Ts, dtype=np.float64).reshape(len(cands), 16)
+    edges["cov"] = np.stack([s["cov"] for s in stats]).reshape(len(cands), 36)
+    edges["accepted"] = [int(icp.check_icp_result(stats[k], float(residual[k]), cfg.overlap_threshold, cfg.residual_error_threshold))
+                         for k in range(len(cands))]
     for m in map_ids:
         ctx.destroy_map(m)
     return edges
