@@ -631,6 +631,9 @@ def main_stream(args):
         step()
         for v in vehicles:
             v.reset()
+    import gc
+    gc.collect()
+    gc.freeze()                     # (see main())
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
