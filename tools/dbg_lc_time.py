@@ -16,15 +16,16 @@ for p in range(512):
                               T_init=synth.se3_inv(poses[i]) @ poses[j] @ synth.perturbation(5000 + p)))
 ctx = icp.Context(0, **CHAIN)
 def step(show):
-    for k in range(0, 512, 128):
-        cs = cands[k:k + 128]
+    CH = int(os.environ.get('CHUNK', '128'))
+    for k in range(0, 512, CH):
+        cs = cands[k:k + CH]
         t = [time.perf_counter()]
         ids = ctx.set_maps([c.ref_xyz for c in cs], [c.ref_nrm for c in cs], center=True); torch.cuda.synchronize(); t.append(time.perf_counter())
         Ts, st = ctx.align_batch(ids, [c.reading for c in cs], [c.T_init for c in cs], raise_on_error=False); t.append(time.perf_counter())
         ctx.partial_chain_batch(ids, [c.reading for c in cs], Ts, raise_on_error=False); t.append(time.perf_counter())
         for m in ids: ctx.destroy_map(m)
         t.append(time.perf_counter())
-        if show: print('batch', k // 128, 'set_maps %.1f align %.1f (%.1f iterations) partial %.1f destroy %.1f ms' % (
+        if show: print('batch', k // CH, 'set_maps %.1f align %.1f (%.1f iterations) partial %.1f destroy %.1f ms' % (
             (t[1] - t[0]) * 1e3, (t[2] - t[1]) * 1e3, np.mean([s['iterations'] for s in st]), (t[3] - t[2]) * 1e3, (t[4] - t[3]) * 1e3))
 step(False)
 for r in range(2):
