@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PGICP_ABI_VERSION 2
+#define PGICP_ABI_VERSION 3
 
 /* status codes (pgslam sees PM::ConvergenceError for 1..2 through the C++ shim) */
 #define PGICP_OK 0
@@ -301,12 +301,19 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
  * ncclAllGather of fixed-size blocks of slots_per_rank 512-byte records: slots_per_rank is the largest shard,
  * which every rank computes itself from the deterministic split (pgicp_shard_slots) -- no size exchange.
  * Empty slots and candidates nobody reported come back with from_id = to_id = status = -1.  The context's
- * stream carries the collective; the call returns when `out` is complete.  Errors of these entry points:
- * pgicp_comm_last_error() (per thread). */
+ * stream carries the collective; the call returns when `out` is complete (reserved[] of every record is zero
+ * again: the pair index travels in reserved[0] and is removed).  Errors of these entry points:
+ * pgicp_comm_last_error() (per thread).
+ * pgicp_comm_create_host makes a communicator with the HOST transport instead (ABI 3): the same pack / unpack, the
+ * blocks travel through a shared-memory file `shm_path` (rank 0 creates it, the others wait for it; the path must
+ * not be reused by two live communicators; the last rank to be destroyed removes it) holding at most
+ * max_slots_per_rank records per rank.  No device is needed: it is how the slot / reorder logic is tested at world
+ * sizes > 1 on a CPU box, and a single-node job without RCCL can gather through it. */
 typedef struct pgicp_comm pgicp_comm;
 #define PGICP_UNIQUE_ID_BYTES 128
 int pgicp_comm_unique_id(char id[PGICP_UNIQUE_ID_BYTES]);
 int pgicp_comm_create(pgicp_ctx *ctx, int world_size, int rank, const char id[PGICP_UNIQUE_ID_BYTES], pgicp_comm **out);
+int pgicp_comm_create_host(int world_size, int rank, const char *shm_path, int max_slots_per_rank, pgicp_comm **out);
 void pgicp_comm_destroy(pgicp_comm *comm);
 int pgicp_comm_info(const pgicp_comm *comm, int *world_size, int *rank);
 const char *pgicp_comm_last_error(void);

@@ -39,6 +39,8 @@ void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const Ch
 size_t trim_select_table_bytes(int P);
 int knn_stats_read(unsigned long long out[56], int reset);
 int knn_phase_read(unsigned long long out[48], int reset);   // diagnostics build only: wave cycles per phase of the fast kernel
+int knn_dump_setup(long long total, int passes);              // diagnostics build only: per-query candidate dump
+int knn_dump_read(unsigned *cnt, float *d2, long long n);
 int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
 void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int *stamp_counter,
                            int *queue_counters);

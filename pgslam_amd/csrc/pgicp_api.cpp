@@ -1897,6 +1897,10 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
     return PGICP_OK;
 }
 
+// diagnostics builds only (not part of the ABI): per-query candidate dump of the fast matcher
+int pgicp_debug_dump_setup(long long total, int passes) { return knn_dump_setup(total, passes); }
+int pgicp_debug_dump_read(unsigned *cnt, float *d2, long long n) { return knn_dump_read(cnt, d2, n); }
+
 int pgicp_debug_last_matches_f32(pgicp_ctx *c, int problem, int32_t *ids, float *dist2) { return debug_last_matches<float>(c, problem, ids, dist2); }
 int pgicp_debug_last_matches_f64(pgicp_ctx *c, int problem, int32_t *ids, double *dist2) { return debug_last_matches<double>(c, problem, ids, dist2); }
 

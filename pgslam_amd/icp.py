@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "pgicp_debug_last_matches_f32", "pgicp_debug_last_matches_f64",
     "pgicp_status_string", "pgicp_upload_f32", "pgicp_upload_f64", "pgicp_host_alloc", "pgicp_host_free",
     "pgicp_ctx_device", "pgicp_comm_unique_id", "pgicp_comm_create", "pgicp_comm_destroy", "pgicp_comm_info",
-    "pgicp_comm_last_error", "pgicp_shard_slots", "pgicp_allgather_edges",
+    "pgicp_comm_last_error", "pgicp_shard_slots", "pgicp_allgather_edges", "pgicp_comm_create_host",
 ]
 
 
@@ -222,6 +222,27 @@ class Comm:
         if st != OK:
             raise PgicpError(st, self.lib.pgicp_comm_last_error().decode())
         self.h = h
+
+    @classmethod
+    def host(cls, world_size: int, rank: int, shm_path: str, max_slots_per_rank: int) -> "Comm":
+        """pgicp_comm_create_host: the same collective with the blocks travelling through a shared-memory file
+        (no device; the host 'fake all-gather' of SURVEY.md section 4 T4)."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self.ctx = None
+        self.world_size, self.rank = world_size, rank
+        h = C.c_void_p()
+        st = self.lib.pgicp_comm_create_host(C.c_int(world_size), C.c_int(rank), shm_path.encode(), C.c_int(max_slots_per_rank), C.byref(h))
+        if st != OK:
+            raise PgicpError(st, self.lib.pgicp_comm_last_error().decode())
+        self.h = h
+        return self
+
+    def info(self):
+        """(world_size, rank) as the communicator itself reports them (pgicp_comm_info)."""
+        w, r = C.c_int(), C.c_int()
+        self.lib.pgicp_comm_info(self.h, C.byref(w), C.byref(r))
+        return w.value, r.value
 
     def allgather_edges(self, local_edges: np.ndarray, pair_index, slots_per_rank: int, n_total: int) -> np.ndarray:
         """pgicp_allgather_edges on numpy records of the 512-byte pgicp_edge layout."""

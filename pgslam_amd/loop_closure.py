@@ -121,7 +121,7 @@ def allgather_edges(local_edges: np.ndarray, pair_index: np.ndarray, n_pairs: in
 
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     out = np.zeros(n_pairs, dtype=EDGE_DTYPE)
-    out["from_id"] = -1
+    out["from_id"] = out["to_id"] = out["status"] = -1          # a pair nobody reported: the C ABI's marking
     if world == 1:
         out[pair_index] = local_edges
         return out
