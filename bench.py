@@ -54,6 +54,83 @@ def emit(line: dict):
     print(json.dumps(line), flush=True)
 
 
+_DIST = {"on": False}
+
+
+def ranks():
+    """(world size, rank, local rank) of this process: torch.distributed.run's variables, or the ones launch_ranks set"""
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def dist_begin(backend, local_rank):
+    """One process group per process, made by whichever leg needs it first ("nccl" IS RCCL on ROCm; "gloo" where only host
+    numbers travel).  Returns whether the job is distributed."""
+    world = ranks()[0]
+    if world <= 1:
+        return False
+    if not _DIST["on"]:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        _DIST["on"] = True
+    return True
+
+
+def dist_end():
+    if _DIST["on"]:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        _DIST["on"] = False
+
+
+def require_device(local_rank):
+    """Fail loudly, before any rendezvous, when this rank has no GPU: the product has no CPU path (PGICP_ERR_NO_DEVICE)."""
+    from pgslam_amd import icp
+    icp.Context(local_rank).close()
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` started by hand: the parent (which never touches a GPU) starts N fresh rank processes of this
+    same command line -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them --
+    passes rank 0's output through and exits with the worst exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PGSLAM_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, failed_at = 0, None
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p_ in list(live):
+            c = p_.poll()
+            if c is None:
+                continue
+            live.remove(p_)
+            if c != 0:
+                rc = rc or c
+                failed_at = failed_at or time.time()
+        if failed_at and live and time.time() - failed_at > 20.0:
+            for p_ in live:                      # a rank died: the others would wait at the rendezvous for ever
+                p_.terminate()
+            failed_at = time.time() + 1e9
+    if rc:
+        print(f"bench.py: a rank failed (exit code {rc}); no result line", file=sys.stderr)
+    sys.exit(rc)
+
+
 def _gen_scan(args):
     from pgslam_amd import synth
     kind, i, n_pts, rings, pose = args
@@ -189,21 +266,17 @@ def build_pairs(n_pts, n_keyframes=24, cache_dir="/tmp"):
     return xyz, nrm, poses
 
 
-def main_loopclosure(args):
+def main_loopclosure(args, collect=False):
     """BASELINE configs[4]: `--pairs` candidate pairs sharded over the ranks (strong scaling),
-    every rank aligns its shard in device batches, one all-gather of the 512-byte edge records."""
+    every rank aligns its shard in device batches, one all-gather of the 512-byte edge records.
+    At N > 1 rank 0 then aligns ALL pairs alone in the same run: `speedup_vs_one_gpu` is north_star's ratio."""
     import torch
     import torch.distributed as dist
     from pgslam_amd import icp, synth, loop_closure as lc
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    world, rank, local_rank = ranks()
+    require_device(local_rank)
+    distributed = dist_begin("nccl", local_rank)
     dev = torch.device("cuda", local_rank)
     if rank == 0:
         xyz, nrm, poses = build_pairs(args.n_scan)
@@ -232,10 +305,14 @@ def main_loopclosure(args):
         dist.broadcast_object_list(uid, src=0)
     comm = icp.Comm(ctx, world, rank, uid[0])
 
+    def align_shard(idx):
+        parts = [lc.align_local(ctx, [cands[i] for i in idx[k:k + args.pair_chunk]], cfg)
+                 for k in range(0, len(idx), args.pair_chunk)]
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=lc.EDGE_DTYPE)
+
     def step():
-        parts = [lc.align_local(ctx, [cands[i] for i in mine[k:k + args.pair_chunk]], cfg)
-                 for k in range(0, len(mine), args.pair_chunk)]
-        local = np.concatenate(parts) if parts else np.zeros(0, dtype=lc.EDGE_DTYPE)
+        local = align_shard(mine)
+        local["reserved"][:, 1] = rank + 1          # which rank aligned the pair: the line proves the ranks it saw
         return lc.allgather_edges_rccl(comm, local, mine, costs)
 
     for _ in range(args.warmup):
@@ -276,6 +353,21 @@ def main_loopclosure(args):
             roofline = dict(bound="hbm", kernel="knn_grid", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                             traffic=None, avg_launch_us=avg_s * 1e6, launches=k["launches"], profiled_steps=args.steps,
                             algorithmic_bytes_per_launch=alg / k["launches"], active_problems_per_launch=k["problems"] / k["launches"])
+    # ---- strong-scaling reference, same run: rank 0 aligns ALL pairs alone while the others wait
+    single = None
+    if distributed:
+        every = list(range(len(cands)))
+        if rank == 0:
+            align_shard(every)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                align_shard(every)
+            torch.cuda.synchronize()
+            single = args.steps * len(cands) / (time.perf_counter() - t1)
+        dist.barrier()
+    seen = sorted(set(int(v) - 1 for v in np.asarray(edges["reserved"])[:, 1] if v > 0))
+    comm_world, comm_rank = comm.info()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the oracle on a bounded sample of the same pairs: ICP::operator() (index build + loop) + the residual chain
@@ -296,9 +388,10 @@ def main_loopclosure(args):
         cpu = dict(value=1.0 / statistics.median(times), unit="pairs/s", cores=1, kind="port",
                    sample=f"{len(sample)} of the {len(cands)} pairs through the CPU oracle (k-d tree build + ICP + residual chain per pair) "
                           f"on one core, median; host has {os.cpu_count()} cores")
+    out = None
     if rank == 0:
         ok = int(np.sum(edges["status"] == 0))
-        emit(({
+        out = ({
             "roofline": roofline, "cpu_baseline": cpu,
             "metric": "loop-closure candidate ICPs/sec (100k-pt keyframe vs 100k-pt candidate map)",
             "value": args.steps * len(cands) / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -309,11 +402,17 @@ def main_loopclosure(args):
                                    f"all-gather of 512-byte edge records", "pair_chunk": args.pair_chunk,
                        "parallelism": f"pairs sharded over {world} rank(s), one ncclAllGather (pgicp_allgather_edges, RCCL)"},
             "pairs_ok": ok, "pairs_accepted": int(np.sum(edges["accepted"] == 1)),
-            "mean_iterations": float(np.mean(edges["iterations"]))}))
+            "mean_iterations": float(np.mean(edges["iterations"])),
+            "rccl_ranks_seen": len(seen), "ranks_that_reported_edges": seen, "comm_world_size": comm_world,
+            "pairs_per_s_one_gpu_same_run": single,
+            "speedup_vs_one_gpu": (args.steps * len(cands) / elapsed) / single if single else None})
     comm.close()
     ctx.close()
-    if distributed:
-        dist.destroy_process_group()
+    if collect:
+        return out
+    if out is not None:
+        emit(out)
+    dist_end()
 
 
 def build_drive(n_scans, n_pts, step, cache_dir="/tmp"):
@@ -417,20 +516,32 @@ def read_replay(path):
     return out
 
 
-def main_slam(args):
+def slam_roofline(res):
+    """Fast-matcher roofline of a slam_run pass made with PGICP_PROFILE_ALL=1: 20 N + 12 M per active problem
+    over every context of the facade (pgicp_profile_process), HIP events on the contexts' streams."""
+    k = (res or {}).get("knn_profile")
+    if not k or not k["launches"]:
+        return None
+    alg = 20.0 * k["reading_points"] + 12.0 * k["map_points"]
+    avg_s = k["total_ms"] * 1e-3 / k["launches"]
+    ach = alg / k["launches"] / avg_s / 1e9
+    return dict(bound="hbm", kernel="knn_grid", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                avg_launch_us=avg_s * 1e6, launches=k["launches"], algorithmic_bytes_per_launch=alg / k["launches"],
+                active_problems_per_launch=k["problems"] / k["launches"],
+                note="one 10k-pt scan against a 30k-pt local map per launch: launch-latency-bound, the kernel cannot fill the chip; "
+                     "measured in the recorded pass (every context profiling), not in the timed one")
+
+
+def main_slam(args, collect=False):
     """BASELINE configs[3]: full pose-graph SLAM on the synthetic KITTI-00-shaped sequence through the C++ facade
     (host clouds in, as a pgslam user feeds them); pose-graph solve on the host.  One step = the whole sequence.
     N > 1: independent replicas (one sequence per rank, each process pinned to its GPU)."""
     import subprocess
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    world, rank, local_rank = ranks()
+    distributed = dist_begin("gloo", local_rank)          # only a barrier and a max over ranks: host side
     if distributed:
         import torch
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")          # only a barrier and a max over ranks: host side
     if rank == 0:
         seq = build_sequence(args.slam_scans, args.slam_points, args.slam_step)
         exe = build_slam_run()
@@ -449,7 +560,7 @@ def main_slam(args):
     def run(record):
         cmd = [exe, seq] + (["--record", str(args.slam_record), rec] if record else [])
         t0 = time.perf_counter()
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, check=True)
+        out = subprocess.run(cmd, env=dict(env, PGICP_PROFILE_ALL="1") if record else env, capture_output=True, text=True, check=True)
         return json.loads(out.stdout.strip().splitlines()[-1]), time.perf_counter() - t0
 
     for _ in range(args.warmup):
@@ -470,8 +581,9 @@ def main_slam(args):
     # one more pass that records ICP calls, replayed through the CPU oracle: parity evidence + the CPU figure
     cpu = None
     replay = None
+    res_prof = None
     if rank == 0 and not args.no_cpu_baseline:
-        run(True)
+        res_prof, _ = run(True)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from oracle import Oracle
         o = Oracle(np.float32)
@@ -493,9 +605,10 @@ def main_slam(args):
         cpu = dict(value=len(recs) / t_cpu if t_cpu > 0 else 0.0, unit="ICP calls/s", cores=1, kind="port",
                    sample=f"the {len(recs)} ICP calls recorded from the run (scan-to-local-map and loop closure, index build included), "
                           f"replayed one after the other through the CPU oracle on one core; host has {os.cpu_count()} cores")
+    out = None
     if rank == 0:
         n = res["scans"] - 1
-        emit(({
+        out = ({
             "metric": "scans/sec through full pose-graph SLAM (synthetic KITTI-00-shaped sequence, loop closures, host pose-graph solve)",
             "value": args.steps * n * world / slam_s, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": slam_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -503,12 +616,15 @@ def main_slam(args):
             "config": {"workload": f"full pose-graph SLAM, {res['scans']} scans of {res['points_per_scan']} pts, {args.slam_step} m apart "
                                    f"(BASELINE.json configs[3]), host clouds through pgslam::PoseGraphSlam<float> (C++ facade)",
                        "parallelism": f"{world} independent replica(s), one process per GPU"},
-            "slam": res, "replay_vs_oracle": replay, "cpu_baseline": cpu, "roofline": None}))
-    if distributed:
-        dist.destroy_process_group()
+            "slam": res, "replay_vs_oracle": replay, "cpu_baseline": cpu, "roofline": slam_roofline(res_prof)})
+    if collect:
+        return out
+    if out is not None:
+        emit(out)
+    dist_end()
 
 
-def main_stream(args):
+def main_stream(args, collect=False):
     """BASELINE configs[2]: a scan feed through the streaming local mapper -- ICP against a sliding,
     device-resident map of `--capacity` keyframes (20 x 100k = 2M points), new keyframe when the overlap
     drops below 0.8, the next map assembled and indexed on a background context while scans keep
@@ -520,14 +636,10 @@ def main_stream(args):
     from pgslam_amd import icp
     from pgslam_amd.local_mapper import Keyframe, LocalMapperConfig, StreamingLocalMapper
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    world, rank, local_rank = ranks()
+    if not args.prepare_only:
+        require_device(local_rank)
+    distributed = dist_begin("nccl", local_rank) if not args.prepare_only else False
     dev = torch.device("cuda", local_rank)
     n_prime = args.capacity - 1
     n_total = n_prime * args.prime_stride + args.stream_scans
@@ -704,12 +816,13 @@ def main_stream(args):
                    sample=f"the first {len(sample)} timed scans per vehicle against the first sliding map ({len(kf)} keyframes, {mx.shape[0]} points), "
                           f"kd-tree oracle, one thread per vehicle ({n_thr}); the map's index build ({t_build:.1f} s, once per keyframe on the CPU) excluded",
                    host_cores=os.cpu_count(), index_build_s=t_build, mean_iterations=float(np.mean([r["iterations"] for r in done])))
+    out = None
     if rank == 0:
         its = sum(r[0] for r in res)
         conv = sum(r[1] for r in res)
-        mode = ("one device batch per time step (fleet)" if args.fleet else
+        mode = ("one device batch per time step (fleet; the vehicles are replicas of ONE drive: same scans, odometry and keyframes)" if args.fleet else
                 ("synchronous" if args.sync_rebuild else "background") + " map rebuild, one host thread per vehicle")
-        emit(({
+        out = ({
             "metric": "streamed scans/sec through the local mapper (100k-pt scans, sliding 2M-pt device-resident map)",
             "value": args.steps * per_step * world / elapsed, "unit": "scans/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
@@ -721,14 +834,71 @@ def main_stream(args):
             "ms_per_scan_per_vehicle": elapsed * 1e3 / (args.steps * (n_total - first - 1)),
             "mean_iterations": its / per_step, "converged_fraction": conv / per_step,
             "new_keyframes_per_vehicle": res[0][2], "map_rebuilds_per_vehicle": res[0][3], "final_position_error_m": res[0][4],
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "roofline": roofline, "cpu_baseline": cpu})
     for v in vehicles:
         v.m.close()
         v.ctx.close()
         if v.builder:
             v.builder.close()
-    if distributed:
-        dist.destroy_process_group()
+    if collect:
+        return out
+    if out is not None:
+        emit(out)
+    dist_end()
+
+
+def compact_leg(d, wall_s):
+    """What a leg contributes to the headline's line: the figure, its roofline and its CPU baseline, a few facts."""
+    if d is None:
+        return None
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "cpu_baseline",
+            "mean_iterations", "converged_fraction", "final_position_error_m", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
+            "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size",
+            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "replay_vs_oracle")
+    out = {k: d[k] for k in keep if k in d}
+    if "slam" in d:
+        out["slam"] = {k: d["slam"].get(k) for k in ("scans", "points_per_scan", "keyframes", "loops_closed", "loop_candidates_tried",
+                                                     "map_rebuilds", "mean_icp_iterations", "tracking_error_rms_m", "localizer_host_s")}
+    r = out.get("roofline")
+    if r:
+        out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches",
+                                             "active_problems_per_launch", "algorithmic_bytes_per_launch") if k in r}
+    out["leg_wall_s"] = wall_s
+    return out
+
+
+def workload_legs(args, world, rank):
+    """BASELINE.json configs[2], [3], [4] next to the headline, bounded: the streaming local mapper (one vehicle, 2M-pt
+    sliding map), full SLAM (the 4 500-scan sequence, recorded ICP calls replayed through the oracle) -- both replicas,
+    run at N = 1 only -- and the batched loop-closure ICP (512 pairs, at every N: sharded over the ranks, one
+    pgicp_allgather_edges over RCCL; at N > 1 also aligned by rank 0 alone, for the strong-scaling ratio)."""
+    if args.no_workloads or args.fixed_iters or args.matcher != "grid":
+        return None, None
+    import copy
+    legs = {}
+
+    def run(name, fn, **over):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            d = fn(a, collect=True)
+        except Exception as e:                      # a leg must not take the headline down with it
+            if world > 1:
+                raise                               # (but the ranks of a job must not part ways)
+            legs[name] = dict(error=f"{type(e).__name__}: {e}")
+            return None
+        c = compact_leg(d, time.perf_counter() - t0)
+        if c is not None:
+            legs[name] = c
+        return c
+
+    lc_leg = run("loop_closure", main_loopclosure, steps=2, warmup=1, pairs=512, pair_chunk=512)
+    if world == 1:
+        run("stream", main_stream, steps=1, warmup=1, streams=1, fleet=False)
+        run("slam", main_slam, steps=1, warmup=0)
+    return (legs if rank == 0 else None), lc_leg
 
 
 def main():
@@ -777,10 +947,20 @@ def main():
     ap.add_argument("--pairs", type=int, default=512)
     ap.add_argument("--pair-chunk", type=int, default=512,
                     help="pairs aligned per device batch (measured at 512 pairs on one GPU: 64 -> 4 260, 128 -> 4 820, 256 -> 5 180, 512 -> 5 440 pairs/s)")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="scan2map: skip the `workloads` legs the default line carries next to the headline (stream, loop closure, "
+                         "SLAM -- BASELINE.json configs[2..4], each with its own roofline and cpu_baseline, never `value`)")
     ap.add_argument("--prepare-only", action="store_true",
                     help="generate + cache the synthetic workload and exit (run this before a rocprofv3 --pmc pass: the "
                          "generator forks worker processes, which must not happen under the counter profiler)")
     args = ap.parse_args()
+
+    # `--gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run sets WORLD_SIZE; then we ARE a rank)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.prepare_only:
+        return launch_ranks(args.gpus)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's world size is what runs "
+              f"(n_gpus in the line)", file=sys.stderr)
 
     if args.workload == "stream":
         return main_stream(args)
@@ -796,14 +976,10 @@ def main():
     import torch.distributed as dist
     from pgslam_amd import icp
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    t_cmd0 = time.perf_counter()
+    world, rank, local_rank = ranks()
+    require_device(local_rank)
+    distributed = dist_begin("nccl", local_rank)
     dev = torch.device("cuda", local_rank)
 
     # ---- inputs (rank 0 generates + caches, the others load the cache) ----
@@ -1015,6 +1191,15 @@ def main():
         cpu["gpu_over_single_core"] = ((converged_all / elapsed_max) / cpu["single_core_scans_per_s"]
                                        if cpu["single_core_scans_per_s"] else None)
 
+    for c_, m_ in zip(ctxs, map_ids):
+        c_.destroy_map(m_)
+        c_.close()
+    del d_map_xyz, d_map_nrm, d_scans, readings
+    torch.cuda.empty_cache()
+
+    # ---- the other BASELINE configs under the same clock: compact legs, never `value` ----
+    legs, lc_leg = workload_legs(args, world, rank)
+
     if rank == 0:
         value = converged_all / elapsed_max
         out = {
@@ -1046,15 +1231,17 @@ def main():
             "roofline": roofline,
             "kernels": kern,
             "cpu_baseline": cpu,
+            "workloads": legs,
+            "loop_closure": lc_leg,
+            "rccl_ranks_seen": (lc_leg or {}).get("rccl_ranks_seen"),
+            "launched_by": ("bench.py itself (launch_ranks)" if os.environ.get("PGSLAM_BENCH_SELF_LAUNCHED") else
+                            ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process")),
+            "command_wall_s": time.perf_counter() - t_cmd0,
         }
         if cpu and cpu["value"] > 0:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         emit(out)
-    for c_, m_ in zip(ctxs, map_ids):
-        c_.destroy_map(m_)
-        c_.close()
-    if distributed:
-        dist.destroy_process_group()
+    dist_end()
 
 
 if __name__ == "__main__":

@@ -354,6 +354,13 @@ int pgicp_profile_get(pgicp_ctx *ctx, int kernel_id, long long *launches, double
                       long long *units /* reading points of the ACTIVE problems of those launches */,
                       long long *problems /* ACTIVE (not yet converged) problems of those launches */);
 
+/* Process-wide profile (ABI 3): the same sums over EVERY context of the process, destroyed or alive (alive ones must be
+ * idle), plus the reference points of the active problems of the matcher launches -- what the roofline's algorithmic
+ * bytes need (20 N + 12 M per active problem).  With PGICP_PROFILE_ALL=1 in the environment every context profiles
+ * from its creation: for callers that never see the contexts (the C++ facade's ICP objects own them). */
+int pgicp_profile_process(int kernel_id, long long *launches, double *total_ms, long long *units, long long *problems,
+                          long long *map_points);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,7 @@ struct ProfEvent {
     int kid;
     long long units;
     long long problems;
+    long long map_points;
 };
 
 }  // namespace
@@ -143,6 +144,8 @@ struct pgicp_ctx {
     double prof_ms[PGICP_PROF_COUNT] = {0};
     long long prof_units[PGICP_PROF_COUNT] = {0};
     long long prof_problems[PGICP_PROF_COUNT] = {0};
+    long long prof_map_points[PGICP_PROF_COUNT] = {0};      // reference points of the active problems of those launches
+    long long prof_next_m = 0;                               // what the next matcher launch is charged with
 };
 
 namespace {
@@ -186,6 +189,16 @@ int fail(pgicp_ctx *c, int code, const std::string &msg)
             return fail(ctx, PGICP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
+// process-wide view of the profile (pgicp_profile_process): totals of the contexts already destroyed plus, at the time
+// of the call, of the live ones -- for callers that do not hold the contexts themselves (the C++ facade's ICP objects)
+struct ProcessProfile {
+    std::mutex m;
+    std::vector<pgicp_ctx *> live;
+    long long launches[PGICP_PROF_COUNT] = {0}, units[PGICP_PROF_COUNT] = {0}, problems[PGICP_PROF_COUNT] = {0}, map_points[PGICP_PROF_COUNT] = {0};
+    double ms[PGICP_PROF_COUNT] = {0};
+};
+ProcessProfile &process_profile() { static ProcessProfile *p = new ProcessProfile(); return *p; }
+
 struct ProfScope {
     pgicp_ctx *c;
     int kid;
@@ -197,6 +210,7 @@ struct ProfScope {
         ev.kid = kid;
         ev.units = units;
         ev.problems = problems;
+        ev.map_points = (kid_ == PGICP_PROF_KNN_GRID || kid_ == PGICP_PROF_KNN_BRUTE) ? c_->prof_next_m : 0;
         if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(ev.a, c->stream);
     }
@@ -219,6 +233,7 @@ void prof_collect(pgicp_ctx *c)
             c->prof_ms[e.kid] += ms;
             c->prof_units[e.kid] += e.units;
             c->prof_problems[e.kid] += e.problems;
+            c->prof_map_points[e.kid] += e.map_points;
         }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -923,6 +938,8 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         mat4_mul(Tm_inv, pr[p].T_init, Tpre);
     }, L, hp);
     if (st) return st;
+    long long total_m = 0;                       // (profile only) reference points over the batch's problems
+    if (c->prof_on) for (int p = 0; p < P; p++) total_m += get_map<T>(c, pr[p].map_id)->m;
     const auto ht1 = std::chrono::steady_clock::now();
     const ChainDev<T> ch = make_chain<T>(prm);
     const int every = std::max(1, prm.check_every);
@@ -931,6 +948,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     int n_done = 0;
     for (int it = 0; it < prm.max_iters; it++) {
         const long long act_p = P - n_done;
+        c->prof_next_m = total_m * act_p / P;
         one_iteration<T>(c, L, ch, true, L.total * act_p / P, act_p, it > 0 ? 1 : 0);
         if ((it + 1) % every == 0 || it + 1 == prm.max_iters) {
             // k_compact_active stores {problems done, stamp} straight into pinned host memory: polling it spares
@@ -1573,6 +1591,8 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
         return PGICP_ERR_HIP;
     }
     if (const char *e = std::getenv("PGICP_GRAPH_MAX_P")) c->graph_max_problems = std::atoi(e);
+    if (const char *e = std::getenv("PGICP_PROFILE_ALL")) c->prof_on = std::atoi(e) != 0;      // see pgicp_profile_process
+    { ProcessProfile &pp = process_profile(); std::lock_guard<std::mutex> lock(pp.m); pp.live.push_back(c); }
     *out = c;
     return PGICP_OK;
 }
@@ -1584,6 +1604,15 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     prof_collect(c);
+    {
+        ProcessProfile &pp = process_profile();
+        std::lock_guard<std::mutex> lock(pp.m);
+        for (size_t i = 0; i < pp.live.size(); i++) if (pp.live[i] == c) { pp.live.erase(pp.live.begin() + i); break; }
+        for (int k = 0; k < PGICP_PROF_COUNT; k++) {
+            pp.launches[k] += c->prof_launches[k]; pp.ms[k] += c->prof_ms[k]; pp.units[k] += c->prof_units[k];
+            pp.problems[k] += c->prof_problems[k]; pp.map_points[k] += c->prof_map_points[k];
+        }
+    }
     for (int s = 0; s < 2; s++) {
         c->up[s].dev.release();
         if (c->up[s].pin) (void)hipHostFree(c->up[s].pin);
@@ -1912,11 +1941,31 @@ int pgicp_profile_enable(pgicp_ctx *c, int on)
     return PGICP_OK;
 }
 
+int pgicp_profile_process(int kid, long long *launches, double *total_ms, long long *units, long long *problems, long long *map_points)
+{
+    if (kid < 0 || kid >= PGICP_PROF_COUNT) return PGICP_ERR_ARG;
+    ProcessProfile &pp = process_profile();
+    std::lock_guard<std::mutex> lock(pp.m);
+    long long l = pp.launches[kid], u = pp.units[kid], pr = pp.problems[kid], mp = pp.map_points[kid];
+    double ms = pp.ms[kid];
+    for (pgicp_ctx *c : pp.live) {            // (the caller's contexts are idle: they are thread-compatible, not thread-safe)
+        (void)hipSetDevice(c->device);
+        prof_collect(c);
+        l += c->prof_launches[kid]; ms += c->prof_ms[kid]; u += c->prof_units[kid]; pr += c->prof_problems[kid]; mp += c->prof_map_points[kid];
+    }
+    if (launches) *launches = l;
+    if (total_ms) *total_ms = ms;
+    if (units) *units = u;
+    if (problems) *problems = pr;
+    if (map_points) *map_points = mp;
+    return PGICP_OK;
+}
+
 int pgicp_profile_reset(pgicp_ctx *c)
 {
     if (!c) return PGICP_ERR_ARG;
     prof_collect(c);
-    for (int i = 0; i < PGICP_PROF_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_units[i] = 0; c->prof_problems[i] = 0; }
+    for (int i = 0; i < PGICP_PROF_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_units[i] = 0; c->prof_problems[i] = 0; c->prof_map_points[i] = 0; }
     return PGICP_OK;
 }
 

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "pgicp_debug_last_matches_f32", "pgicp_debug_last_matches_f64",
     "pgicp_status_string", "pgicp_upload_f32", "pgicp_upload_f64", "pgicp_host_alloc", "pgicp_host_free",
     "pgicp_ctx_device", "pgicp_comm_unique_id", "pgicp_comm_create", "pgicp_comm_destroy", "pgicp_comm_info",
-    "pgicp_comm_last_error", "pgicp_shard_slots", "pgicp_allgather_edges", "pgicp_comm_create_host",
+    "pgicp_comm_last_error", "pgicp_shard_slots", "pgicp_allgather_edges", "pgicp_comm_create_host", "pgicp_profile_process",
 ]
 
 
@@ -274,7 +274,7 @@ class Context:
         h = C.c_void_p()
         st = self.lib.pgicp_ctx_create(C.c_int(device), C.byref(h))
         if st != OK:
-            raise PgicpError(st, "pgicp_ctx_create failed (no usable gfx950 device?)")
+            raise PgicpError(st, "pgicp_ctx_create failed" + (": PGICP_ERR_NO_DEVICE (no usable gfx950 device for this rank; the product has no CPU path)" if st == ERR_NO_DEVICE else ""))
         self.h = h
         self.device = device
         self.params = Params()

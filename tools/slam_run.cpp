@@ -209,18 +209,24 @@ int main(int argc, char **argv)
     // odometry alone, for comparison: where the last odometry pose ends up against the truth
     const Matrix d_odo = truth.back().inverse() * last_odom;
     const double odo_last = std::sqrt((double)(d_odo(0, 3) * d_odo(0, 3) + d_odo(1, 3) * d_odo(1, 3) + d_odo(2, 3) * d_odo(2, 3)));
+    // the fast matcher over every context of the process (all zero unless PGICP_PROFILE_ALL=1 made the contexts profile)
+    long long kp_l = 0, kp_u = 0, kp_p = 0, kp_m = 0;
+    double kp_ms = 0;
+    (void)pgicp_profile_process(PGICP_PROF_KNN_GRID, &kp_l, &kp_ms, &kp_u, &kp_p, &kp_m);
     std::printf("{\"scans\": %d, \"points_per_scan\": %d, \"wall_s\": %.6f, \"slam_s\": %.6f, \"io_s\": %.6f, \"scans_per_s\": %.3f, "
                 "\"keyframes\": %zu, \"loop_edges\": %d, \"loop_candidates_tried\": %d, \"loops_closed\": %d, "
                 "\"optimizer_runs\": %d, \"optimizer_iterations\": %d, \"optimizer_host_s\": %.6f, \"map_rebuilds\": %d, "
                 "\"mean_icp_iterations\": %.3f, \"scans_not_converged\": %d, \"tracking_error_rms_m\": %.5f, "
                 "\"tracking_error_max_m\": %.5f, \"tracking_error_last_m\": %.5f, \"odometry_error_last_m\": %.5f, "
                 "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d, "
-                "\"localizer_host_s\": {\"filters_and_sensor_transform\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f}}\n",
+                "\"localizer_host_s\": {\"filters_and_sensor_transform\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f}, "
+                "\"knn_profile\": {\"launches\": %lld, \"total_ms\": %.4f, \"reading_points\": %lld, \"problems\": %lld, \"map_points\": %lld}}\n",
                 S, N, wall, t_icp_loop, t_io, (S - 1) / t_icp_loop, g.NumVertices(), loops, slam.loop_closer().candidates_tried(),
                 slam.loop_closer().loops_closed(), slam.optimizer().runs(), slam.optimizer().total_iterations(), slam.optimizer().total_seconds(),
                 slam.localizer().rebuilds(), S > 1 ? (double)icp_iterations / (S - 1) : 0.0, not_converged,
                 std::sqrt(e_sum2 / std::max<size_t>(1, err_track.size())), e_max, e_last, odo_last,
                 std::sqrt(kf_sum2 / std::max<size_t>(1, kf_scan.size())), kf_max, rec.written, rec.written_kind[1],
-                slam.localizer().phase_seconds()[0], slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2]);
+                slam.localizer().phase_seconds()[0], slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2],
+                kp_l, kp_ms, kp_u, kp_p, kp_m);
     return 0;
 }

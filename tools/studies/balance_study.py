@@ -43,6 +43,8 @@ d2 = np.zeros(PASSES * total, dtype=np.float32)
 assert lib.pgicp_debug_dump_read(cnt.ctypes.data, d2.ctypes.data, PASSES * total) == 0
 cnt = cnt.reshape(PASSES, B, N)
 d2 = d2.reshape(PASSES, B, N)
+os.makedirs("gpurun_out/r3", exist_ok=True)
+np.savez_compressed("gpurun_out/r3/balance_dump.npz", cnt=cnt[:, :6], d2=d2[:, :6].astype(np.float16))      # for offline what-ifs
 own, flat, ring = (cnt & 1023).astype(np.int64), ((cnt >> 10) & 1023).astype(np.int64), (cnt >> 20).astype(np.int64)
 
 
