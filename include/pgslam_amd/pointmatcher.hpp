@@ -47,6 +47,28 @@ inline pgicp_ctx *default_context(int device = 0)
     return h.c;
 }
 
+//! A device context made at FIRST USE: an ICP chain (and therefore a default-constructed pgslam facade, as the
+//! reference's tests/instantiation.cpp constructs them) touches no GPU until it is asked to compute something.
+struct LazyContext {
+    int device = 0;
+    mutable pgicp_ctx *p = nullptr;
+    explicit LazyContext(int d = 0) : device(d) {}
+    LazyContext(const LazyContext &) = delete;
+    LazyContext &operator=(const LazyContext &) = delete;
+    ~LazyContext() { destroy(); }
+    bool made() const { return p != nullptr; }
+    pgicp_ctx *get() const
+    {
+        if (!p) {
+            const int st = pgicp_ctx_create(device, &p);
+            if (st != PGICP_OK) { p = nullptr; throw std::runtime_error(std::string("pgslam_amd: cannot create a device context: ") + pgicp_status_string(st)); }
+        }
+        return p;
+    }
+    operator pgicp_ctx *() const { return get(); }
+    void destroy() { if (p) { pgicp_ctx_destroy(p); p = nullptr; } }
+};
+
 template <typename T> struct Abi;
 template <> struct Abi<float> {
     static int map_create(pgicp_ctx *c, const float *x, int xs, const float *n, int ns, int m, int center, int *id) { return pgicp_map_create_f32(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
@@ -215,8 +237,8 @@ struct PointMatcher {
         virtual bool checkParameters(const TransformationParameters &parameters) const = 0;
     };
     struct RigidTransformation : Transformation {
-        pgicp_ctx *ctx;
-        explicit RigidTransformation(pgicp_ctx *c = nullptr) : ctx(c) {}
+        const pgslam_amd::LazyContext *ctx;          // the owning chain's context (made at first use), or none
+        explicit RigidTransformation(const pgslam_amd::LazyContext *c = nullptr) : ctx(c) {}
         bool checkParameters(const TransformationParameters &p) const override
         {
             double e = 0;
@@ -231,7 +253,7 @@ struct PointMatcher {
         //! features' = T * features; the normals / observationDirections descriptors are rotated
         DataPoints compute(const DataPoints &input, const TransformationParameters &parameters) const override
         {
-            pgicp_ctx *c = ctx ? ctx : pgslam_amd::default_context();
+            pgicp_ctx *c = ctx ? ctx->get() : pgslam_amd::default_context();
             DataPoints out(input);
             double Tm[16];
             pgslam_amd::to_row_major16(parameters, Tm);
@@ -391,13 +413,8 @@ struct PointMatcher {
     //! pgicp_surface_normals_*; the descriptors are appended as libpointmatcher appends them.
     struct SurfaceNormalDataPointsFilter : DataPointsFilter {
         int knn = 5; T maxDist = std::numeric_limits<T>::infinity(); bool keepNormals = true, keepEigenValues = false;
-        pgicp_ctx *ctx = nullptr;
-        SurfaceNormalDataPointsFilter(int k, T md, bool kn, bool ke) : knn(k), maxDist(md), keepNormals(kn), keepEigenValues(ke)
-        {
-            const int st = pgicp_ctx_create(0, &ctx);
-            if (st != PGICP_OK) throw std::runtime_error(std::string("SurfaceNormalDataPointsFilter: cannot create a device context: ") + pgicp_status_string(st));
-        }
-        ~SurfaceNormalDataPointsFilter() override { if (ctx) pgicp_ctx_destroy(ctx); }
+        pgslam_amd::LazyContext ctx;                 // made when the filter first runs, not when a YAML file is read
+        SurfaceNormalDataPointsFilter(int k, T md, bool kn, bool ke) : knn(k), maxDist(md), keepNormals(kn), keepEigenValues(ke) {}
         SurfaceNormalDataPointsFilter(const SurfaceNormalDataPointsFilter &) = delete;
         SurfaceNormalDataPointsFilter &operator=(const SurfaceNormalDataPointsFilter &) = delete;
         void inPlaceFilter(DataPoints &c) override
@@ -481,7 +498,7 @@ struct PointMatcher {
         int mapId = -1; int mapSize = 0;
         explicit Matcher(ICPChainBase *c) : chain(c) {}
         virtual ~Matcher() { release(); }
-        void release() { if (mapId >= 0 && chain && chain->ctx) { pgicp_map_destroy(chain->ctx, mapId); mapId = -1; } }
+        void release() { if (mapId >= 0 && chain && chain->ctx.made()) { pgicp_map_destroy(chain->ctx, mapId); mapId = -1; } }
         //! Localizer.hpp:317, LoopCloser.hpp:356 -- index over the cloud AS GIVEN (not centred)
         virtual void init(const DataPoints &filteredReference) { initImpl(filteredReference, 0); }
         void initImpl(const DataPoints &ref, int center)
@@ -622,7 +639,7 @@ struct PointMatcher {
         OutlierFilters outlierFilters;
         std::shared_ptr<ErrorMinimizer> errorMinimizer;
         TransformationCheckers transformationCheckers;
-        pgicp_ctx *ctx = nullptr;
+        pgslam_amd::LazyContext ctx;                 // the chain's device context and stream, made at first use
         pgicp_stats lastStats;
         //! Observer of every completed alignment (not part of libpointmatcher; its `inspector` slot sees iterations, not
         //! calls): the filtered reading, the filtered reference the index was built on, the initial guess, the result and
@@ -631,10 +648,8 @@ struct PointMatcher {
                            const pgicp_stats &)> onAlign;
         const DataPoints *currentReference = nullptr;
 
-        explicit ICPChainBase(int device = 0)
+        explicit ICPChainBase(int device = 0) : ctx(device)
         {
-            const int st = pgicp_ctx_create(device, &ctx);
-            if (st != PGICP_OK) throw std::runtime_error(std::string("PointMatcher::ICP: cannot create a device context: ") + pgicp_status_string(st));
             std::memset(&lastStats, 0, sizeof lastStats);
             setDefault();
         }
@@ -643,7 +658,7 @@ struct PointMatcher {
         virtual ~ICPChainBase()
         {
             matcher.reset();
-            if (ctx) pgicp_ctx_destroy(ctx);
+            ctx.destroy();
         }
         void cleanup()
         {
@@ -655,7 +670,7 @@ struct PointMatcher {
         virtual void setDefault()
         {
             cleanup();
-            transformations.push_back(std::make_shared<RigidTransformation>(ctx));
+            transformations.push_back(std::make_shared<RigidTransformation>(&ctx));
             matcher = std::make_shared<Matcher>(this);
             outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
             errorMinimizer = std::make_shared<ErrorMinimizer>(this);
@@ -668,9 +683,18 @@ struct PointMatcher {
             using pgslam_amd::yaml_lite::to_double;
             const auto y = pgslam_amd::yaml_lite::parse(in);
             cleanup();
-            transformations.push_back(std::make_shared<RigidTransformation>(ctx));
+            transformations.push_back(std::make_shared<RigidTransformation>(&ctx));
             if (y.has("readingDataPointsFilters")) readingDataPointsFilters.load(y.sections.at("readingDataPointsFilters"));
-            if (y.has("readingStepDataPointsFilters")) readingStepDataPointsFilters.load(y.sections.at("readingStepDataPointsFilters"));
+            if (y.has("readingStepDataPointsFilters")) {
+                // step filters are applied ONCE here (they are pure functions of the cloud); upstream's random sampler draws
+                // a fresh sample in every iteration, which one fixed subsample does not reproduce (overlap and covariance
+                // would be those of the subsample): refused in this slot, never silently approximated
+                for (auto &m : y.sections.at("readingStepDataPointsFilters"))
+                    if (m.name == "RandomSamplingDataPointsFilter")
+                        throw std::runtime_error("loadFromYaml: RandomSamplingDataPointsFilter is not supported in readingStepDataPointsFilters "
+                                                 "(per-iteration resampling); use it in readingDataPointsFilters");
+                readingStepDataPointsFilters.load(y.sections.at("readingStepDataPointsFilters"));
+            }
             if (y.has("referenceDataPointsFilters")) referenceDataPointsFilters.load(y.sections.at("referenceDataPointsFilters"));
             matcher = std::make_shared<Matcher>(this);
             if (y.has("matcher") && !y.sections.at("matcher").empty()) {
@@ -779,8 +803,8 @@ struct PointMatcher {
             prefilteredReadingPtsCount = reading.getNbPoints();
             // [EXT] readingStepDataPointsFilters (Localizer.hpp:325-326) act on the filtered reading in ITS OWN frame at every
             // iteration, before the iteration's transform is applied; every filter restated here is a pure function of the
-            // cloud, so the step filters give the same cloud in every iteration: they are applied once, here (the seeded
-            // random sampler included -- upstream's draws a new sample per iteration from rand(), see its class comment)
+            // cloud, so the step filters give the same cloud in every iteration: they are applied once, here (the random
+            // sampler, whose upstream version draws a new sample per iteration, is refused in this slot by loadFromYaml)
             readingStepDataPointsFilters.init();
             readingStepDataPointsFilters.apply(reading);
             double Ti[16], To[16];

@@ -903,6 +903,15 @@ void MapManager<T>::NotifyKeyframeUpdate()
 }
 
 // ------------------------------------------------------------------ facade (PoseGraphSlam.h:17-68, single-thread flavour)
+inline std::string slurp_config_file(const std::string &p)
+{
+    std::ifstream ifs(p);
+    if (!ifs) throw std::runtime_error("[PoseGraphSlam] cannot open " + p);
+    std::stringstream ss;
+    ss << ifs.rdbuf();
+    return ss.str();
+}
+
 template <typename T>
 class PoseGraphSlam {
 public:
@@ -915,6 +924,13 @@ public:
         map_manager_ptr_->SetLocalizer(localizer_ptr_);
         map_manager_ptr_->SetLoopCloser(loop_closer_ptr_);
     }
+    //! PoseGraphSlam.hpp:29-36: construct and configure from the three YAML files
+    PoseGraphSlam(const std::string &localizer_input_filters_config, const std::string &localizer_icp_config,
+                  const std::string &loop_closer_icp_config)
+        : PoseGraphSlam()
+    {
+        SetIcpConfig(localizer_input_filters_config, localizer_icp_config, loop_closer_icp_config);
+    }
     //! the reference takes three file paths (PoseGraphSlam.hpp:38-48); the YAML texts are accepted as well
     void SetIcpConfigFromStrings(const std::string &input_filters_yaml, const std::string &localizer_icp_yaml, const std::string &loop_closer_icp_yaml)
     {
@@ -924,14 +940,7 @@ public:
     }
     void SetIcpConfig(const std::string &input_filters_path, const std::string &localizer_icp_path, const std::string &loop_closer_icp_path)
     {
-        auto slurp = [](const std::string &p) {
-            std::ifstream ifs(p);
-            if (!ifs) throw std::runtime_error("[PoseGraphSlam] cannot open " + p);
-            std::stringstream ss;
-            ss << ifs.rdbuf();
-            return ss.str();
-        };
-        SetIcpConfigFromStrings(slurp(input_filters_path), slurp(localizer_icp_path), slurp(loop_closer_icp_path));
+        SetIcpConfigFromStrings(slurp_config_file(input_filters_path), slurp_config_file(localizer_icp_path), slurp_config_file(loop_closer_icp_path));
     }
     void AddData(unsigned long long timestamp, std::string world_frame_id, Matrix T_world_robot, Matrix T_robot_sensor, DPPtr cloud_ptr)
     {
@@ -988,8 +997,9 @@ private:
                 queue_.clear();
                 busy_ = true;
             }
-            this->AddNewDataBatch(batch);
-            { std::lock_guard<std::mutex> l(m_); busy_ = false; }
+            std::exception_ptr err;
+            try { this->AddNewDataBatch(batch); } catch (...) { err = std::current_exception(); }
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; if (err && !error_) error_ = err; }
         }
     }
     std::mutex m_;
@@ -997,6 +1007,9 @@ private:
     std::deque<typename Base::InputData> queue_;
     std::thread thread_;
     bool stop_ = false, busy_ = false;
+    std::exception_ptr error_;
+public:
+    std::exception_ptr TakeError() { std::lock_guard<std::mutex> l(m_); std::exception_ptr e = error_; error_ = nullptr; return e; }
 };
 
 template <typename T>
@@ -1034,6 +1047,8 @@ private:
                 queue_.clear();
                 busy_ = true;
             }
+            std::exception_ptr err;
+            try {
             if (!configured) { batch.SetIcpConfigFromString(yaml_); configured = true; }
             std::vector<typename Base::PreparedCandidate> cands;
             for (size_t v : vs) {
@@ -1054,7 +1069,8 @@ private:
                         optimizer_->AddNewData((size_t)e.from_id, (size_t)e.to_id, pgslam_amd::from_row_major16<T>(e.T_from_to), cov);
                     }
             }
-            { std::lock_guard<std::mutex> l(m_); busy_ = false; }
+            } catch (...) { err = std::current_exception(); }
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; if (err && !error_) error_ = err; }
         }
     }
     typename Optimizer<T>::Ptr optimizer_;
@@ -1065,6 +1081,9 @@ private:
     std::thread thread_;
     bool stop_ = false, busy_ = false;
     int batches_ = 0, largest_batch_ = 0;
+    std::exception_ptr error_;
+public:
+    std::exception_ptr TakeError() { std::lock_guard<std::mutex> l(m_); std::exception_ptr e = error_; error_ = nullptr; return e; }
 };
 
 template <typename T>
@@ -1106,9 +1125,12 @@ private:
                 if (!queue_.empty()) { item = queue_.front(); queue_.pop_front(); have = true; }
                 busy_ = true;
             }
-            if (outdated) this->UpdateFromGraphNow();             // (takes the graph lock)
-            if (have) this->ProcessData(std::get<0>(item), std::get<1>(item), std::get<2>(item));
-            { std::lock_guard<std::mutex> l(m_); busy_ = false; if (have) processed_++; }
+            std::exception_ptr err;
+            try {
+                if (outdated) this->UpdateFromGraphNow();             // (takes the graph lock)
+                if (have) this->ProcessData(std::get<0>(item), std::get<1>(item), std::get<2>(item));
+            } catch (...) { err = std::current_exception(); }
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; if (have) processed_++; if (err && !error_) error_ = err; }
         }
     }
     std::mutex m_;
@@ -1117,6 +1139,9 @@ private:
     std::thread thread_;
     bool stop_ = false, busy_ = false, outdated_ = false;
     size_t processed_ = 0;
+    std::exception_ptr error_;
+public:
+    std::exception_ptr TakeError() { std::lock_guard<std::mutex> l(m_); std::exception_ptr e = error_; error_ = nullptr; return e; }
 };
 
 template <typename T>
@@ -1131,7 +1156,19 @@ public:
         map_manager_ptr_->SetLocalizer(localizer_ptr_);
         map_manager_ptr_->SetLoopCloser(loop_closer_ptr_);
     }
+    //! PoseGraphSlamMT.h:23-27
+    PoseGraphSlamMT(const std::string &localizer_input_filters_config, const std::string &localizer_icp_config,
+                    const std::string &loop_closer_icp_config)
+        : PoseGraphSlamMT()
+    {
+        SetIcpConfig(localizer_input_filters_config, localizer_icp_config, loop_closer_icp_config);
+    }
     ~PoseGraphSlamMT() { localizer_ptr_->Stop(); loop_closer_ptr_->Stop(); optimizer_ptr_->Stop(); }
+    //! PoseGraphSlam.hpp:38-48 (inherited by the MT flavour upstream): three YAML file paths
+    void SetIcpConfig(const std::string &input_filters_path, const std::string &localizer_icp_path, const std::string &loop_closer_icp_path)
+    {
+        SetIcpConfigFromStrings(slurp_config_file(input_filters_path), slurp_config_file(localizer_icp_path), slurp_config_file(loop_closer_icp_path));
+    }
     void SetIcpConfigFromStrings(const std::string &input_filters_yaml, const std::string &localizer_icp_yaml, const std::string &loop_closer_icp_yaml)
     {
         localizer_ptr_->SetInputFiltersConfigFromString(input_filters_yaml);
@@ -1152,6 +1189,14 @@ public:
             else calm = 0;
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
+        RethrowWorkerError();
+    }
+    //! An exception inside a worker (upstream lets it reach std::terminate) is kept; the worker goes on with its next item,
+    //! and the first such exception is thrown here, on the caller's thread.
+    void RethrowWorkerError()
+    {
+        for (std::exception_ptr e : {localizer_ptr_->TakeError(), loop_closer_ptr_->TakeError(), optimizer_ptr_->TakeError()})
+            if (e) std::rethrow_exception(e);
     }
     void WriteGraphviz(const std::string &path) { auto lock = map_manager_ptr_->GetGraphLock(); map_manager_ptr_->WriteGraphviz(path); }
     MapManager<T> &map_manager() { return *map_manager_ptr_; }

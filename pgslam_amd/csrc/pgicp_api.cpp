@@ -112,6 +112,7 @@ struct pgicp_ctx {
     } up[2];
     hipStream_t copy_stream = nullptr;
     int up_next = 0;
+    int up_seen = 0;            // upload sets whose device pointers the running call was handed (see UploadUse)
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
     // pinned bounce buffers for the problem records of a batch (4.6 KB each: a Checker history rides in them): a megabyte
     // copied between device and PAGEABLE host memory takes the runtime's slow path -- 10-13 ms per step at 256-320
@@ -291,12 +292,26 @@ void upload_consumed(pgicp_ctx *c, int mask)
         if (mask & (1 << s)) { (void)hipEventRecord(c->up[s].consumed, c->stream); c->up[s].has_consumer = true; }
 }
 
+// Every entry point that may be handed a device pointer of pgicp_upload_* declares one of these: to_device() makes the
+// compute stream wait for the upload (on the device) and notes the set; when the call returns -- its kernels queued, most
+// calls synchronised -- the set is marked consumed, so that the next upload into it waits for them.
+struct UploadUse {
+    pgicp_ctx *c;
+    explicit UploadUse(pgicp_ctx *c_) : c(c_) { if (c) c->up_seen = 0; }
+    ~UploadUse() { if (c && c->up_seen) { upload_consumed(c, c->up_seen); c->up_seen = 0; } }
+    void touch(const void *p) { if (c && p && (c->up[0].pending || c->up[1].pending)) c->up_seen |= upload_wait(c, p); }
+};
+
 // Bring a strided point buffer onto the device if it is host memory.
 // Returns the device pointer to use (either the caller's or the staging copy).
 template <typename T>
 int to_device(pgicp_ctx *c, const T *p, int stride, int n, int mem, DevBuf &stage, size_t stage_off_bytes, const T **out)
 {
-    if (mem == PGICP_DEVICE) { *out = p; return PGICP_OK; }
+    if (mem == PGICP_DEVICE) {
+        if (c->up[0].pending || c->up[1].pending) c->up_seen |= upload_wait(c, p);
+        *out = p;
+        return PGICP_OK;
+    }
     const size_t bytes = sizeof(T) * ((size_t)(n - 1) * stride + 3);
     HIPC(c, hipMemcpyAsync((char *)stage.p + stage_off_bytes, p, bytes, hipMemcpyHostToDevice, c->stream));
     *out = (const T *)((char *)stage.p + stage_off_bytes);
@@ -370,8 +385,16 @@ struct DevicePool {
     size_t limit = 0;               // set on first use: total device memory / 8
     int contexts = 0;
 };
-DevicePool g_pools[16];
-DevicePool &pool_of(int device) { return g_pools[device & 15]; }
+// one pool per device, made on first use (never destroyed: contexts may outlive static destruction order)
+DevicePool &pool_of(int device)
+{
+    static std::mutex m;
+    static std::vector<DevicePool *> pools;
+    std::lock_guard<std::mutex> lock(m);
+    if ((size_t)device >= pools.size()) pools.resize((size_t)device + 1, nullptr);
+    if (!pools[device]) pools[device] = new DevicePool();
+    return *pools[device];
+}
 
 int block_alloc(pgicp_ctx *c, size_t bytes, char **out, size_t *got)
 {
@@ -451,6 +474,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
             return fail(c, PGICP_ERR_ARG, "pgicp_map_create: bad argument");
     HIPC(c, hipSetDevice(c->device));
     State<T> &S = state<T>(c);
+    UploadUse use(c);
     using V4 = typename Vec4<T>::type;
     // ---- phase 1: inputs on the device, centroid + bbox of every cloud ----
     std::vector<const T *> d_xyz(n), d_nrm(n, nullptr);
@@ -756,6 +780,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
         launch_pretransform<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.rd_pre.template as<T>(), P, L.max_n);
         upload_consumed(c, up_mask);                 // the pre-transform is the only kernel that reads the readings where they lie
+        c->up_seen = 0;
         // order each reading by (map row, x) once: waves stay spatially coherent for every iteration
         launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(),
                              S.rd_pre.template as<T>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<unsigned long long>(),
@@ -908,7 +933,14 @@ static int wait_iteration_flag(pgicp_ctx *c)
         }
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess) { fail(c, PGICP_ERR_HIP, "pgicp: stream synchronisation failed"); return -1; }
-    if (__atomic_load_n(&c->h_flag[1], __ATOMIC_ACQUIRE) != want) { fail(c, PGICP_ERR_HIP, "pgicp: iteration flag not written"); return -1; }
+    if (__atomic_load_n(&c->h_flag[1], __ATOMIC_ACQUIRE) != want) {
+        // a launch failed somewhere: the device's stamp and the host's are out of step.  Take the device's, so that the
+        // context's NEXT call can work again instead of timing out for ever.
+        int dev_stamp = 0;
+        if (hipMemcpy(&dev_stamp, c->stamp_dev, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) c->flag_stamp = dev_stamp;
+        fail(c, PGICP_ERR_HIP, "pgicp: iteration flag not written");
+        return -1;
+    }
     return __atomic_load_n(&c->h_flag[0], __ATOMIC_RELAXED);
 }
 
@@ -1197,6 +1229,8 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     State<T> &S = state<T>(c);
     const T *d_rd = reading, *d_w = w;
     const int *d_ids = ids;
+    UploadUse use(c);
+    if (mem == PGICP_DEVICE) use.touch(reading);
     if (mem == PGICP_HOST) {
         HIPC(c, S.staging.ensure(staged_bytes(sizeof(T), stride, n)));
         int st = to_device<T>(c, reading, stride, n, mem, S.staging, 0, &d_rd);
@@ -1252,7 +1286,9 @@ int transform(pgicp_ctx *c, const double *T16, const T *in, int in_stride, T *ou
     if (n == 0) return PGICP_OK;
     HIPC(c, hipSetDevice(c->device));
     State<T> &S = state<T>(c);
+    UploadUse use(c);
     if (mem == PGICP_DEVICE) {
+        use.touch(in);
         launch_transform<T>(c->stream, in, in_stride, out, out_stride, n, T16, rotate_only);
         HIPC(c, hipStreamSynchronize(c->stream));
         return PGICP_OK;
@@ -1292,6 +1328,7 @@ int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const 
         return fail(c, PGICP_ERR_ARG, "pgicp_build_local_map: bad argument");
     HIPC(c, hipSetDevice(c->device));
     State<T> &S = state<T>(c);
+    UploadUse use(c);
     long long total = 0;
     size_t stage = 0;
     for (int k = 0; k < n_kf; k++) {
@@ -1448,8 +1485,9 @@ int upload(pgicp_ctx *c, int n, const T *const *host, const int *stride, const i
         total += staged_bytes(sizeof(T), stride[k], npts[k]);
     }
     HIPC(c, hipSetDevice(c->device));
-    pgicp_ctx::UploadSet &U = c->up[c->up_next];
-    c->up_next ^= 1;
+    const int set = c->up_next;                    // flipped only when the upload has been queued completely
+    pgicp_ctx::UploadSet &U = c->up[set];
+    std::vector<const T *> ptrs((size_t)n);
     // the set is overwritten: the calls that read its last contents must have consumed them (device-side wait), and a
     // transfer out of its pinned staging must have left it (host-side wait: two uploads ago, over long since)
     if (U.has_consumer) HIPC(c, hipStreamWaitEvent(c->copy_stream, U.consumed, 0));
@@ -1492,7 +1530,7 @@ int upload(pgicp_ctx *c, int n, const T *const *host, const int *stride, const i
                     pieces.push_back({(char *)U.pin + off + b, (const char *)host[k] + b, std::min(piece, bytes - b)});
             } else HIPC(c, hipMemcpyAsync((char *)U.dev.p + off, host[k], bytes, hipMemcpyHostToDevice, c->copy_stream));
         }
-        for (int j = 0; j < run; j++) { dev_ptrs[k + j] = (const T *)((char *)U.dev.p + off); off += slot; }
+        for (int j = 0; j < run; j++) { ptrs[k + j] = (const T *)((char *)U.dev.p + off); off += slot; }
         k += run;
     }
     if (mem == PGICP_HOST) {
@@ -1513,6 +1551,8 @@ int upload(pgicp_ctx *c, int n, const T *const *host, const int *stride, const i
     U.bytes = total;
     U.pending = true;
     U.has_consumer = false;
+    c->up_next = set ^ 1;
+    for (int k = 0; k < n; k++) dev_ptrs[k] = ptrs[k];
     return PGICP_OK;
 }
 }  // namespace
@@ -1581,7 +1621,8 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
         (void)hipGetLastError();
         c->poll_us = 0;
         if (hipHostMalloc((void **)&c->h_flag, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
-            delete c;
+            c->h_flag = nullptr;
+            pgicp_ctx_destroy(c);               // (streams, events, pinned memory and the device pool's context count)
             return PGICP_ERR_HIP;
         }
     }

@@ -148,10 +148,29 @@ int main()
     datapoints_semantics<double>();
     yaml_and_matrix();
     if (pgicp_device_count() == 0) {
+        // construction touches no device (contexts are made at first use: tests/instantiation.cpp of the reference only
+        // constructs); the first COMPUTE call refuses -- there is no CPU fallback
+        PointMatcher<float>::ICP icp;
+        std::vector<float> xyz = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+        auto dp = PointMatcher<float>::DataPoints::fromXYZ(xyz.data(), 3, nullptr);
         bool threw = false;
-        try { PointMatcher<float>::ICP icp; } catch (const std::runtime_error &) { threw = true; }
-        CHECK(threw);            // no CPU fallback
-        std::puts("no GPU: ICP construction refuses, as required");
+        try { icp.matcher->init(dp); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
+        std::puts("no GPU: the first compute call refuses, as required");
+    }
+    {   // a chain whose YAML puts the random sampler into the per-iteration slot is refused (upstream resamples every
+        // iteration: one fixed subsample would change overlap and covariance), the same filter as a reading filter loads
+        PointMatcher<float>::ICP icp;
+        std::istringstream bad("readingStepDataPointsFilters:\n  - RandomSamplingDataPointsFilter:\n      prob: 0.5\n"
+                               "matcher:\n  KDTreeMatcher:\n    knn: 1\n");
+        bool threw = false;
+        try { icp.loadFromYaml(bad); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
+        std::istringstream good("readingDataPointsFilters:\n  - RandomSamplingDataPointsFilter:\n      prob: 0.5\n"
+                                "readingStepDataPointsFilters:\n  - FixStepSamplingDataPointsFilter:\n      startStep: 2\n"
+                                "matcher:\n  KDTreeMatcher:\n    knn: 1\n");
+        icp.loadFromYaml(good);
+        CHECK(icp.readingDataPointsFilters.size() == 1 && icp.readingStepDataPointsFilters.size() == 1);
     }
     std::puts("dropin cpu tests ok");
     return 0;

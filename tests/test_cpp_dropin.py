@@ -25,6 +25,15 @@ def test_dropin_cpu():
     assert "dropin cpu tests ok" in out.stdout
 
 
+def test_four_way_instantiation_without_a_device():
+    """float / double x single / multi thread through the forwarding headers pgslam user code includes
+    (reference tests/instantiation.cpp:4-19), the 3-string constructors and SetIcpConfig(paths) on both flavours."""
+    out = subprocess.run([build("test_instantiation")], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "instantiation tests ok" in out.stdout
+
+
 @pytest.mark.gpu
 def test_dropin_gpu():
     out = subprocess.run([build("test_dropin_gpu")], capture_output=True, text=True, timeout=600)
