@@ -784,6 +784,37 @@ def main_stream(args, collect=False):
                             traffic=None, avg_launch_us=avg_s * 1e6, launches=k["launches"],
                             algorithmic_bytes_per_launch=alg / k["launches"], active_problems_per_launch=k["problems"] / k["launches"],
                             note="one small launch per vehicle (or one per fleet step): the kernel cannot fill the chip; see DESIGN.md section 5")
+    # ---- PCIe-inclusive companion (never `value`): the caller owns HOST scans (Localizer.hpp:103-126); the mapper uploads
+    #      scan k + 1 on the context's copy stream while scan k aligns (LocalizerMT.hpp:27-40 has it queued by then)
+    host_input = None
+    if not args.no_host_input and not args.fleet and args.streams == 1:
+        v = vehicles[0]
+        block = v.ctx.host_alloc((n_total - first,) + xyz[0].shape, np.float32)     # a sensor driver's pinned ring buffer
+        for s_ in range(first, n_total):
+            block[s_ - first] = xyz[s_]
+        rates = {}
+        for label, src, pinned in (("pinned", [block[s_ - first] for s_ in range(first, n_total)], True),
+                                   ("pageable", [np.ascontiguousarray(xyz[s_]) for s_ in range(first, n_total)], False)):
+            best = 0.0
+            for _ in range(1 + max(1, args.steps)):                                 # the first pass is the pipeline's warm-up
+                v.reset()
+                v.m.pinned_sources = pinned
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                v.m.stage(src[1])
+                for s_ in range(first + 1, n_total):
+                    nxt = src[s_ + 1 - first] if s_ + 1 < n_total else None
+                    v.m.process(odom[s_], src[s_ - first], nrm[s_], next_xyz=nxt)
+                torch.cuda.synchronize()
+                best = max(best, (n_total - first - 1) / (time.perf_counter() - t0))
+            rates[label] = best
+        v.ctx.host_free(block)
+        dev_rate = args.steps * per_step / elapsed
+        host_input = dict(pinned_scans_per_s=rates["pinned"], pageable_scans_per_s=rates["pageable"],
+                          pinned_over_device_resident=rates["pinned"] / dev_rate, pageable_over_device_resident=rates["pageable"] / dev_rate,
+                          bytes_per_scan=int(args.n_scan * 12),
+                          how="host scans through StreamingLocalMapper.process(..., next_xyz=): scan k + 1 uploaded on the copy stream "
+                              "(pgicp_upload_f32) while scan k aligns; best of the passes after the pipeline's first")
     # ---- CPU baseline: the oracle on the same feed, one thread per vehicle (a vehicle's scans are sequential), bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -834,7 +865,7 @@ def main_stream(args, collect=False):
             "ms_per_scan_per_vehicle": elapsed * 1e3 / (args.steps * (n_total - first - 1)),
             "mean_iterations": its / per_step, "converged_fraction": conv / per_step,
             "new_keyframes_per_vehicle": res[0][2], "map_rebuilds_per_vehicle": res[0][3], "final_position_error_m": res[0][4],
-            "roofline": roofline, "cpu_baseline": cpu})
+            "host_input": host_input, "roofline": roofline, "cpu_baseline": cpu})
     for v in vehicles:
         v.m.close()
         v.ctx.close()
@@ -852,7 +883,7 @@ def compact_leg(d, wall_s):
     if d is None:
         return None
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "cpu_baseline",
-            "mean_iterations", "converged_fraction", "final_position_error_m", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
+            "mean_iterations", "converged_fraction", "final_position_error_m", "host_input", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
             "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size",
             "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "replay_vs_oracle")
     out = {k: d[k] for k in keep if k in d}
@@ -1194,6 +1225,7 @@ def main():
     for c_, m_ in zip(ctxs, map_ids):
         c_.destroy_map(m_)
         c_.close()
+    n_distinct = len(d_scans)
     del d_map_xyz, d_map_nrm, d_scans, readings
     torch.cuda.empty_cache()
 
@@ -1218,7 +1250,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"scan-to-map ICP, {args.n_scan}-pt Velodyne-shaped scan vs {args.n_map}-pt local map, "
                                    f"<=30 iterations (BASELINE.json configs[1])",
-                       "batch_scans_per_step": B, "distinct_scans": len(d_scans), "matcher": args.matcher, "streams": S,
+                       "batch_scans_per_step": B, "distinct_scans": n_distinct, "matcher": args.matcher, "streams": S,
                        "chain": chain, "fixed_iterations": bool(args.fixed_iters),
                        "parallelism": f"{world} independent replica(s), one process per GPU"},
             "scans_total": scans_all,

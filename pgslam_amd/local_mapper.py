@@ -23,6 +23,12 @@ pgicp_build_local_map and indexed by pgicp_map_create entirely on the device.  W
 while scans keep aligning against the current map; the finished index is handed over with
 pgicp_map_transfer and the pose is re-expressed in the new reference frame.  The synchronous mode
 reproduces the reference's order of operations exactly and is what the parity tests use.
+
+Host clouds (the caller owns the scans, Localizer.hpp:103-126; LocalizerMT.hpp:27-40 has the next scan queued while the
+current one aligns): `process(odom, xyz, nrm, next_xyz=...)` with numpy scans starts the upload of the NEXT scan on the
+context's copy stream (pgicp_upload_*) before it aligns the current one, so the transfer hides behind the ICP; the
+alignment is handed the device pointer of an upload that was started one call earlier.  A scan that becomes a keyframe is
+copied into device memory of its own (the upload sets are recycled two uploads later).
 """
 from __future__ import annotations
 
@@ -97,6 +103,8 @@ class StreamingLocalMapper:
         self.last_stats = None
         self._pending = None                 # (thread, result holder, window snapshot)
         self._job = None                     # scan between prepare() and complete()
+        self._staged = None                  # (host array, device handle) of a scan uploaded one call ahead
+        self.pinned_sources = False          # host scans lie in pinned memory (pgicp_host_alloc): no staging copy
 
     # ---- map (re)building ---------------------------------------------------------------
     def _build(self, ctx, window):
@@ -145,13 +153,40 @@ class StreamingLocalMapper:
         self.T_refkf_robot = _inv(window[-1].T_world_kf) @ self.T_world_robot
 
     # ---- per scan -----------------------------------------------------------------------
-    def process(self, odom_T_world_robot, scan_xyz, scan_nrm):
-        """One scan (already in the robot frame).  Returns T_world_robot."""
+    def process(self, odom_T_world_robot, scan_xyz, scan_nrm, next_xyz=None):
+        """One scan (already in the robot frame).  Returns T_world_robot.  `next_xyz`: the host scan that will be
+        processed next -- its upload starts now and travels while this scan aligns."""
         job = self.prepare(odom_T_world_robot, scan_xyz, scan_nrm)
+        if next_xyz is not None:
+            self.stage(next_xyz)
         if job is not None:
             T, stats = self.be.align(job[0], job[1], job[2])                  # Localizer.hpp:126
             self.complete(T, stats)
         return self.T_world_robot.copy()
+
+    # ---- host scans, one step ahead ------------------------------------------------------
+    def _is_host(self, a):
+        return isinstance(a, np.ndarray) and hasattr(self.be, "upload")
+
+    def stage(self, host_xyz):
+        """Start the transfer of a host scan on the context's copy stream (returns at once)."""
+        if self._is_host(host_xyz):
+            self._staged = (host_xyz, self.be.upload([host_xyz], pinned=self.pinned_sources)[0])
+
+    def _reading(self, scan_xyz):
+        """What the ICP call is handed: the device pointer of the upload started one call ago (or started now)."""
+        if not self._is_host(scan_xyz):
+            return self.to_device(scan_xyz)
+        if self._staged is None or self._staged[0] is not scan_xyz:
+            self.stage(scan_xyz)
+        handle = self._staged[1]
+        self._staged = None
+        return handle
+
+    def _own(self, host_array):
+        """A keyframe's cloud must outlive the upload sets (recycled two uploads later): device memory of its own."""
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(host_array)).to(torch.device("cuda", self.be.device))
 
     def prepare(self, odom_T_world_robot, scan_xyz, scan_nrm):
         """First half of ProcessData: everything up to the ICP call.  Returns (map_id, reading, T_init) for
@@ -160,6 +195,8 @@ class StreamingLocalMapper:
         odom = np.asarray(odom_T_world_robot, dtype=np.float64).reshape(4, 4)
         self.count += 1
         if self.map_id is None and self._pending is None:
+            if self._is_host(scan_xyz):
+                scan_xyz, scan_nrm = self._own(scan_xyz), self._own(scan_nrm)
             kf = Keyframe(self.next_kf_id, self.to_device(scan_xyz), self.to_device(scan_nrm), odom.copy())
             self.next_kf_id += 1
             self.window.append(kf)
@@ -172,20 +209,20 @@ class StreamingLocalMapper:
         self._finish_pending(wait=False)
         d_odom = _inv(self.last_odom) @ odom                                   # Localizer.hpp:119
         T_init = self.T_refkf_robot @ d_odom                                   # :123
-        self._job = (odom, self.to_device(scan_xyz), scan_nrm)
+        self._job = (odom, self._reading(scan_xyz), scan_nrm, scan_xyz)
         return self.map_id, self._job[1], T_init
 
     def complete(self, T, stats):
         """Second half of ProcessData: the ICP result, the world pose, UpdateAfterIcp."""
-        odom, dev_xyz, scan_nrm = self._job
+        odom, dev_xyz, scan_nrm, host_xyz = self._job
         self._job = None
         self.last_stats = stats
         self.T_refkf_robot = np.asarray(T, dtype=np.float64).reshape(4, 4)
         self.T_world_robot = self.map_window[-1].T_world_kf @ self.T_refkf_robot   # :127
-        self._update_after_icp(stats["overlap"], dev_xyz, scan_nrm)
+        self._update_after_icp(stats["overlap"], dev_xyz, scan_nrm, host_xyz)
         self.last_odom = odom.copy()
 
-    def _update_after_icp(self, overlap, dev_xyz, scan_nrm):
+    def _update_after_icp(self, overlap, dev_xyz, scan_nrm, host_xyz=None):
         if self._pending is not None:
             return                      # a rebuild is in flight: decisions resume on the new map
         old_ref = self.window[-1]
@@ -201,6 +238,8 @@ class StreamingLocalMapper:
                 self.window = deque(items, maxlen=self.cfg.capacity)
                 changed = True
         else:
+            if isinstance(dev_xyz, icp.DevPtr):          # a host scan: the keyframe owns device copies of cloud and normals
+                dev_xyz, scan_nrm = self._own(host_xyz), self._own(scan_nrm)
             kf = Keyframe(self.next_kf_id, dev_xyz, self.to_device(scan_nrm), self.T_world_robot.copy())
             self.next_kf_id += 1
             self.window.append(kf)                      # circular buffer: the oldest drops out

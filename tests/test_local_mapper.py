@@ -167,3 +167,40 @@ def test_gpu_fleet_equals_vehicles_stepped_alone(drive):
     for m in solo:
         m.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_host_scans_one_step_ahead_equal_device_resident(drive):
+    """The caller owns HOST scans (Localizer.hpp:103-126): scan k + 1 travels on the copy stream (pgicp_upload_*) while
+    scan k aligns (LocalizerMT.hpp:27-40).  Poses, keyframe decisions and the keyframes' device clouds are those of the
+    run whose scans were resident in HBM beforehand -- pinned or pageable sources alike."""
+    import torch
+    from pgslam_amd import icp
+    dev = torch.device("cuda", 0)
+    S = len(drive.odom)
+    cfg = LocalMapperConfig(capacity=3, overlap_threshold=0.8, chain=CHAIN)
+    ctx = icp.Context(0, **CHAIN)
+    resident = StreamingLocalMapper(ctx, cfg)
+    want = [resident.process(drive.odom[s], torch.from_numpy(np.ascontiguousarray(drive.scans_xyz[s])).to(dev),
+                             torch.from_numpy(np.ascontiguousarray(drive.scans_nrm[s])).to(dev)) for s in range(S)]
+    for pinned in (False, True):
+        if pinned:
+            block = ctx.host_alloc((S,) + drive.scans_xyz[0].shape, np.float32)
+            for s in range(S):
+                block[s] = drive.scans_xyz[s]
+            src = [block[s] for s in range(S)]
+        else:
+            src = [np.ascontiguousarray(x) for x in drive.scans_xyz]
+        m = StreamingLocalMapper(ctx, cfg)
+        m.pinned_sources = pinned
+        got = [m.process(drive.odom[s], src[s], drive.scans_nrm[s], next_xyz=src[s + 1] if s + 1 < S else None) for s in range(S)]
+        for s in range(S):
+            np.testing.assert_array_equal(got[s], want[s])
+        assert m.keyframe_scans == resident.keyframe_scans and m.rebuilds == resident.rebuilds
+        for a, b in zip(m.window, resident.window):
+            assert torch.equal(a.xyz, b.xyz) and torch.equal(a.nrm, b.nrm)
+        m.close()
+        if pinned:
+            ctx.host_free(block)
+    resident.close()
+    ctx.close()
