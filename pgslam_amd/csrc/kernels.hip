@@ -83,7 +83,6 @@ __device__ __forceinline__ void apply_T(const double *Tc, T x, T y, T z, T &ox, 
 #include "k_build.inc"
 #include "k_sort.inc"
 #include "k_match.inc"
-#include "k_match_pool.inc"
 #include "k_normals.inc"
 #include "k_select.inc"
 #include "k_minimise.inc"

@@ -87,6 +87,23 @@ struct Recorder {
     }
 };
 
+// How many keyframes lie within `thr` metres of a keyframe made at least `gap` keyframes earlier (a revisit the loop
+// closer's geometric test, LoopCloser.hpp:17, can see), by the given positions.
+template <typename P>
+static int count_revisits(size_t n, P pos, double thr, size_t gap)
+{
+    int c = 0;
+    for (size_t v = gap; v < n; v++) {
+        bool hit = false;
+        for (size_t u = 0; u + gap <= v && !hit; u++) {
+            const double dx = pos(v, 0) - pos(u, 0), dy = pos(v, 1) - pos(u, 1), dz = pos(v, 2) - pos(u, 2);
+            hit = dx * dx + dy * dy + dz * dz <= thr * thr;
+        }
+        c += hit ? 1 : 0;
+    }
+    return c;
+}
+
 // the multi-thread flavour: queue everything, wait for the workers, compare the keyframes with the truth
 static int run_mt(FILE *f, int S, int N)
 {
@@ -121,10 +138,11 @@ static int run_mt(FILE *f, int S, int N)
     std::printf("{\"mode\": \"mt\", \"scans\": %d, \"points_per_scan\": %d, \"wall_s\": %.6f, \"slam_s\": %.6f, \"scans_per_s\": %.3f, "
                 "\"keyframes\": %zu, \"loop_edges\": %d, \"loop_candidates_tried\": %d, \"loops_closed\": %d, \"loop_batches\": %d, "
                 "\"largest_loop_batch\": %d, \"optimizer_runs\": %d, \"optimizer_iterations\": %d, \"optimizer_host_s\": %.6f, "
-                "\"map_rebuilds\": %d, \"tracking_error_last_m\": %.5f}\n",
+                "\"map_rebuilds\": %d, \"tracking_error_last_m\": %.5f, \"keyframes_revisiting_within_3m_by_estimate\": %d}\n",
                 S, N, wall, wall, (S - 1) / wall, g.NumVertices(), loops, slam.loop_closer().candidates_tried(), slam.loop_closer().loops_closed(),
                 slam.loop_closer().batches(), slam.loop_closer().largest_batch(), slam.optimizer().runs(), slam.optimizer().total_iterations(),
-                slam.optimizer().total_seconds(), slam.localizer().rebuilds(), e_last);
+                slam.optimizer().total_seconds(), slam.localizer().rebuilds(), e_last,
+                count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4));
     return 0;
 }
 
@@ -220,6 +238,7 @@ int main(int argc, char **argv)
                 "\"tracking_error_max_m\": %.5f, \"tracking_error_last_m\": %.5f, \"odometry_error_last_m\": %.5f, "
                 "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d, "
                 "\"localizer_host_s\": {\"filters_and_sensor_transform\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f}, "
+                "\"keyframes_revisiting_within_3m_by_truth\": %d, \"keyframes_revisiting_within_3m_by_estimate\": %d, "
                 "\"knn_profile\": {\"launches\": %lld, \"total_ms\": %.4f, \"reading_points\": %lld, \"problems\": %lld, \"map_points\": %lld}}\n",
                 S, N, wall, t_icp_loop, t_io, (S - 1) / t_icp_loop, g.NumVertices(), loops, slam.loop_closer().candidates_tried(),
                 slam.loop_closer().loops_closed(), slam.optimizer().runs(), slam.optimizer().total_iterations(), slam.optimizer().total_seconds(),
@@ -227,6 +246,8 @@ int main(int argc, char **argv)
                 std::sqrt(e_sum2 / std::max<size_t>(1, err_track.size())), e_max, e_last, odo_last,
                 std::sqrt(kf_sum2 / std::max<size_t>(1, kf_scan.size())), kf_max, rec.written, rec.written_kind[1],
                 slam.localizer().phase_seconds()[0], slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2],
+                count_revisits(std::min(g.NumVertices(), kf_scan.size()), [&](size_t v, int a) { return (double)truth[kf_scan[v]](a, 3); }, 3.0, 4),
+                count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4),
                 kp_l, kp_ms, kp_u, kp_p, kp_m);
     return 0;
 }
