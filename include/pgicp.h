@@ -143,7 +143,8 @@ const char *pgicp_status_string(int status);
  * pgicp_partial_chain*, pgicp_map_create*) first makes its own stream wait, ON THE DEVICE, for the
  * transfer -- the host never blocks on it -- so the upload of scan k+1 overlaps the ICP of scan k.
  * Two uploads are kept: upload u+2 reuses the buffers of upload u (it waits, on the device, until the
- * calls that read upload u have consumed it).  `mem` says what the host pointers are: PGICP_HOST
+ * calls that read upload u have consumed it) -- the pointers of upload u are dead once upload u+2 has been started, so
+ * readings that one call will use together travel in ONE upload.  `mem` says what the host pointers are: PGICP_HOST
  * (pageable: copied through a pinned staging buffer of the context first) or PGICP_HOST_PINNED (DMA
  * straight from the caller's buffer, which must stay untouched until a call that uses it has returned).
  * pgicp_host_alloc / pgicp_host_free: pinned host memory for such clouds. */

@@ -268,6 +268,13 @@ class StreamingFleet:
         self.mappers = [StreamingLocalMapper(backend, cfg, builder=builder, to_device=to_device) for _ in range(n_vehicles)]
 
     def step(self, odoms, scans_xyz, scans_nrm):
+        # host scans of one time step travel as ONE upload (a context keeps two upload sets: one in use, one in flight;
+        # a third separate upload would overwrite the first before the batch has read it)
+        host = [k for k, (m, x) in enumerate(zip(self.mappers, scans_xyz)) if m._is_host(x) and m.map_id is not None]
+        if host:
+            handles = self.be.upload([scans_xyz[k] for k in host], pinned=self.mappers[0].pinned_sources)
+            for k, h in zip(host, handles):
+                self.mappers[k]._staged = (scans_xyz[k], h)
         jobs = [m.prepare(o, x, n) for m, o, x, n in zip(self.mappers, odoms, scans_xyz, scans_nrm)]
         live = [k for k, j in enumerate(jobs) if j is not None]
         if live:
