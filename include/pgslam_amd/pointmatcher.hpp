@@ -73,6 +73,8 @@ template <typename T> struct Abi;
 template <> struct Abi<float> {
     static int map_create(pgicp_ctx *c, const float *x, int xs, const float *n, int ns, int m, int center, int *id) { return pgicp_map_create_f32(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
     static int align(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f32(c, id, r, s, n, PGICP_HOST, Ti, To, st); }
+    static int align_dev(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f32(c, id, r, s, n, PGICP_DEVICE, Ti, To, st); }
+    static int upload(pgicp_ctx *c, const float *host, int stride, int n, const float **dev) { return pgicp_upload_f32(c, 1, &host, &stride, &n, PGICP_HOST, dev); }
     static int match(pgicp_ctx *c, int id, const float *r, int s, int n, int32_t *ids, float *d2) { return pgicp_match_f32(c, id, r, s, n, PGICP_HOST, nullptr, ids, d2); }
     static int weights(pgicp_ctx *c, const float *d2, int n, float *w, float *lim, int *nf) { return pgicp_outlier_weights_f32(c, d2, n, PGICP_HOST, w, lim, nf); }
     static int stats(pgicp_ctx *c, int id, const float *r, int s, int n, const int32_t *ids, const float *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f32(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
@@ -85,6 +87,8 @@ template <> struct Abi<float> {
 template <> struct Abi<double> {
     static int map_create(pgicp_ctx *c, const double *x, int xs, const double *n, int ns, int m, int center, int *id) { return pgicp_map_create_f64(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
     static int align(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f64(c, id, r, s, n, PGICP_HOST, Ti, To, st); }
+    static int align_dev(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f64(c, id, r, s, n, PGICP_DEVICE, Ti, To, st); }
+    static int upload(pgicp_ctx *c, const double *host, int stride, int n, const double **dev) { return pgicp_upload_f64(c, 1, &host, &stride, &n, PGICP_HOST, dev); }
     static int match(pgicp_ctx *c, int id, const double *r, int s, int n, int32_t *ids, double *d2) { return pgicp_match_f64(c, id, r, s, n, PGICP_HOST, nullptr, ids, d2); }
     static int weights(pgicp_ctx *c, const double *d2, int n, double *w, double *lim, int *nf) { return pgicp_outlier_weights_f64(c, d2, n, PGICP_HOST, w, lim, nf); }
     static int stats(pgicp_ctx *c, int id, const double *r, int s, int n, const int32_t *ids, const double *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f64(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
@@ -795,6 +799,43 @@ struct PointMatcher {
             for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) cov(i, j) = (T)s.cov[i * 6 + j];
             errorMinimizer->lastCov = cov;
         }
+    public:
+        //! A reading whose filtered copy is on its way to (or already in) device memory: pgicp_upload_* started the
+        //! transfer on the context's COPY stream and returned at once.  Not part of libpointmatcher; it is how a caller
+        //! that already holds the next scan (LocalizerMT.hpp:27-40: it is queued while the current one aligns) lets the
+        //! transfer overlap the running ICP.  Valid until the second-next uploadReading() on the same chain.
+        struct DeviceReading {
+            const T *dev = nullptr;
+            std::shared_ptr<DataPoints> filtered;         // the host copy after the chain's reading filters (what was uploaded)
+            explicit operator bool() const { return dev != nullptr; }
+        };
+        DeviceReading uploadReading(const DataPoints &readingIn)
+        {
+            DeviceReading r;
+            r.filtered = std::make_shared<DataPoints>(readingIn);
+            readingDataPointsFilters.init();
+            readingDataPointsFilters.apply(*r.filtered);
+            readingStepDataPointsFilters.init();
+            readingStepDataPointsFilters.apply(*r.filtered);          // (applied once: see alignOnMap)
+            check(ctx, A::upload(ctx, r.filtered->xyzPtr(), r.filtered->xyzStride(), (int)r.filtered->getNbPoints(), &r.dev));
+            return r;
+        }
+    protected:
+        TransformationParameters alignOnMap(const DeviceReading &r, const TransformationParameters &T_init)
+        {
+            prefilteredReadingPtsCount = r.filtered->getNbPoints();
+            double Ti[16], To[16];
+            pgslam_amd::to_row_major16(T_init, Ti);
+            pgicp_stats st;
+            pushParams();
+            // (the call makes its stream wait, on the device, for the upload; the host does not)
+            const int rc = A::align_dev(ctx, matcher->mapId, r.dev, r.filtered->xyzStride(), (int)r.filtered->getNbPoints(), Ti, To, &st);
+            storeStats(st);
+            check(ctx, rc);
+            const TransformationParameters T_out = pgslam_amd::from_row_major16<T>(To);
+            if (onAlign && currentReference) onAlign(*r.filtered, *currentReference, T_init, T_out, st);
+            return T_out;
+        }
         TransformationParameters alignOnMap(const DataPoints &readingIn, const TransformationParameters &T_init)
         {
             DataPoints reading(readingIn);
@@ -865,6 +906,12 @@ struct PointMatcher {
         {
             if (!hasMap()) { setMap(cloudIn); return Matrix::Identity(4, 4); }
             return this->alignOnMap(cloudIn, initialTransformationParameters);
+        }
+        //! the same against a reading whose upload was started earlier (ICPChainBase::uploadReading): needs a map
+        TransformationParameters operator()(const typename ICPChainBase::DeviceReading &reading, const TransformationParameters &initialTransformationParameters)
+        {
+            if (!hasMap()) throw std::runtime_error("ICPSequence: a device reading needs a map (setMap)");
+            return this->alignOnMap(reading, initialTransformationParameters);
         }
     private:
         DataPoints mapPointCloud;

@@ -724,8 +724,7 @@ public:
         using clk = std::chrono::steady_clock;
         const auto t0 = clk::now();
         input_cloud_ = cloud;
-        input_filters_.apply(*cloud);
-        (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
+        PreProcess(input_T_robot_sensor, cloud);
         const auto t1 = clk::now();
         phase_s_[0] += std::chrono::duration<double>(t1 - t0).count();
         auto &g = map_manager_->GetGraph();
@@ -739,7 +738,12 @@ public:
             return;
         }
         const Matrix d = last_input_.inverse() * input_T_world_robot;
-        T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);         // the ICP runs outside the graph lock (LocalizerMT.hpp:95-96)
+        // the ICP runs outside the graph lock (LocalizerMT.hpp:95-96); on the device copy of the cloud if its upload was
+        // started while the previous scan aligned (Prefetch), from the host cloud otherwise
+        if (prefetched_cloud_ == cloud.get() && prefetched_) T_refkf_robot_ = icp_sequence_(prefetched_, T_refkf_robot_ * d);
+        else T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);
+        prefetched_ = typename PM::ICPChainBase::DeviceReading();
+        prefetched_cloud_ = nullptr;
         const auto t2 = clk::now();
         phase_s_[1] += std::chrono::duration<double>(t2 - t1).count();
         {
@@ -753,6 +757,27 @@ public:
         last_input_ = input_T_world_robot;
         phase_s_[2] += std::chrono::duration<double>(clk::now() - t2).count();
     }
+    //! Localizer.hpp:103-106: the input filters in place, then sensor frame -> robot frame.  Once per cloud (a cloud whose
+    //! upload was prefetched has been through it already).
+    void PreProcess(const Matrix &input_T_robot_sensor, DPPtr cloud)
+    {
+        if (preprocessed_cloud_ == cloud.get()) return;
+        input_filters_.apply(*cloud);
+        (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
+        preprocessed_cloud_ = cloud.get();
+    }
+    //! The NEXT scan, already queued (LocalizerMT.hpp:27-40): pre-process it and start its transfer to the device on the ICP
+    //! context's copy stream (pgicp_upload_*), so that it travels while the current scan aligns.  Needs a map (the chain
+    //! aligns device readings only against one) -- before the first keyframe nothing is prefetched.
+    void Prefetch(const Matrix &input_T_robot_sensor, DPPtr cloud)
+    {
+        if (comp_.empty() || !icp_sequence_.hasMap() || prefetched_cloud_ == cloud.get()) return;
+        PreProcess(input_T_robot_sensor, cloud);
+        prefetched_ = icp_sequence_.uploadReading(*cloud);
+        prefetched_cloud_ = cloud.get();
+        prefetches_++;
+    }
+    size_t prefetches() const { return prefetches_; }
     //! MapManager::NotifyKeyframeUpdate -> Localizer::UpdateFromGraph (Localizer.hpp:155-176): after an
     //! optimisation the local map is rebuilt from the corrected poses and the world pose follows the reference
     virtual void UpdateFromGraph() { UpdateFromGraphNow(); }
@@ -766,6 +791,9 @@ public:
     }
 
 protected:
+    typename PM::ICPChainBase::DeviceReading prefetched_;
+    const DP *prefetched_cloud_ = nullptr, *preprocessed_cloud_ = nullptr;
+    size_t prefetches_ = 0;
     bool resync_before_update_ = false;              // the MT flavour re-reads the graph before every update
     unsigned long long synced_version_ = 0;
     void Rebuild()
@@ -1114,8 +1142,8 @@ private:
     void Main()
     {
         for (;;) {
-            bool outdated = false, have = false;
-            std::tuple<Matrix, Matrix, DPPtr> item;
+            bool outdated = false, have = false, have_next = false;
+            std::tuple<Matrix, Matrix, DPPtr> item, next;
             {
                 std::unique_lock<std::mutex> l(m_);
                 cv_.wait(l, [this] { return !queue_.empty() || stop_ || outdated_; });
@@ -1123,11 +1151,14 @@ private:
                 outdated = outdated_;
                 outdated_ = false;
                 if (!queue_.empty()) { item = queue_.front(); queue_.pop_front(); have = true; }
+                if (have && !queue_.empty()) { next = queue_.front(); have_next = true; }     // (stays queued)
                 busy_ = true;
             }
             std::exception_ptr err;
             try {
                 if (outdated) this->UpdateFromGraphNow();             // (takes the graph lock)
+                // the scan after this one is already here: its transfer starts now and overlaps this scan's ICP
+                if (have_next) this->Prefetch(std::get<1>(next), std::get<2>(next));
                 if (have) this->ProcessData(std::get<0>(item), std::get<1>(item), std::get<2>(item));
             } catch (...) { err = std::current_exception(); }
             { std::lock_guard<std::mutex> l(m_); busy_ = false; if (have) processed_++; if (err && !error_) error_ = err; }

@@ -79,6 +79,10 @@ void run_mt(const char *name)
         }
         slam.WaitIdle();
         CHECK(slam.localizer().processed() == (size_t)S);
+        // free running, the next scan is queued while the current one aligns: its cloud was uploaded ahead (pgicp_upload_*,
+        // LocalizerMT.hpp:27-40) and the ICP ran on the device copy; in lock step there is never a next scan to prefetch
+        if (free_running) CHECK(slam.localizer().prefetches() > (size_t)S / 2);
+        else CHECK(slam.localizer().prefetches() == 0);
         auto lock = slam.map_manager().GetGraphLock();
         auto &g = slam.map_manager().GetGraph();
         CHECK(g.NumVertices() == (size_t)S);

@@ -138,11 +138,13 @@ static int run_mt(FILE *f, int S, int N)
     std::printf("{\"mode\": \"mt\", \"scans\": %d, \"points_per_scan\": %d, \"wall_s\": %.6f, \"slam_s\": %.6f, \"scans_per_s\": %.3f, "
                 "\"keyframes\": %zu, \"loop_edges\": %d, \"loop_candidates_tried\": %d, \"loops_closed\": %d, \"loop_batches\": %d, "
                 "\"largest_loop_batch\": %d, \"optimizer_runs\": %d, \"optimizer_iterations\": %d, \"optimizer_host_s\": %.6f, "
-                "\"map_rebuilds\": %d, \"tracking_error_last_m\": %.5f, \"keyframes_revisiting_within_3m_by_estimate\": %d}\n",
+                "\"map_rebuilds\": %d, \"tracking_error_last_m\": %.5f, \"keyframes_revisiting_within_3m_by_estimate\": %d, "
+                "\"clouds_uploaded_one_scan_ahead\": %zu}\n",
                 S, N, wall, wall, (S - 1) / wall, g.NumVertices(), loops, slam.loop_closer().candidates_tried(), slam.loop_closer().loops_closed(),
                 slam.loop_closer().batches(), slam.loop_closer().largest_batch(), slam.optimizer().runs(), slam.optimizer().total_iterations(),
                 slam.optimizer().total_seconds(), slam.localizer().rebuilds(), e_last,
-                count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4));
+                count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4),
+                slam.localizer().prefetches());
     return 0;
 }
 
