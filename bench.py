@@ -234,7 +234,20 @@ def cpu_baseline(w, sample_scans, n_threads, reps=3):
         rates.append(sum(1 for r in results if r["status"] == 0 and r["converged"]) / dt)
     o.map_free(m)
     iters = float(np.mean([r["iterations"] for r in results]))
-    return dict(value=statistics.median(rates), unit="scans/s", cores=n_thr, kind="port",
+    # an installed libpointmatcher would be timed here instead (kind "reference") -- probed, never stubbed
+    import ref_probe
+    pr = ref_probe.probe()
+    ref_line = None
+    if pr["exe"]:
+        try:
+            rr = ref_probe.run(pr["exe"], w.scans_xyz[0], w.map_xyz, w.map_nrm, w.T_init[0], repetitions=2)
+            dT = np.linalg.inv(rr["T"]) @ r0["T"]
+            ref_line = dict(single_core_scans_per_s=1.0 / rr["seconds"], translation_vs_port_m=float(np.linalg.norm(dT[:3, 3])),
+                            note="ICP::operator() of the installed libpointmatcher (index build included in every call)")
+        except Exception as e:                  # a reference that does not run is reported, not hidden
+            ref_line = dict(error=f"{type(e).__name__}: {e}")
+    probe_line = dict(libpointmatcher_found=pr["found"], missing=pr["missing"][:4], build_error=pr["build_error"], reference=ref_line)
+    return dict(value=statistics.median(rates), unit="scans/s", cores=n_thr, kind="port", reference_probe=probe_line,
                 sample=f"{n_scans} of the benchmark's 100k-pt scans vs the 1M-pt map, kd-tree oracle (CPU restatement of the "
                        f"reference chain, not libpointmatcher), one ICP per thread on all {n_thr} host cores "
                        f"(os.cpu_count() = {os.cpu_count()}), median of {reps} repetitions; index build excluded",

@@ -279,3 +279,22 @@ def test_max_dist_outlier_filter_multiplies_into_the_trimmed_weights(oracle64):
     assert r["status"] == 0 and r["T"][2, 3] == pytest.approx(-0.1, abs=1e-9)
     r2 = oracle64.icp(rd, ref, nrm, T, trim_ratio=1.0, max_dist=2.0, center_reference=False)
     assert r2["T"][2, 3] == pytest.approx(-(100 * 0.8 + 300 * 0.1) / 400, abs=1e-3)       # (stops when the Differential checker is satisfied)
+
+
+# ------------------------------------------------------------------ the only possible reference-anchored pin
+def test_golden_fixtures_through_installed_libpointmatcher(oracle32):
+    """BASELINE.md section 2's probe: where a REAL libpointmatcher is installed (not in this image, not on this pool's GPU
+    boxes), the golden fixtures AND the oracle are checked against it -- the one way the oracle could ever be pinned by
+    the reference's own arithmetic (north_star's 1e-5 m / 1e-5 rad).  Skipped, loudly, where the library is absent."""
+    import ref_probe
+    pr = ref_probe.probe()
+    if not pr["found"]:
+        pytest.skip("libpointmatcher is not installed (missing: " + ", ".join(pr["missing"][:3]) + " ...): parity stays unpinned")
+    assert pr["exe"], "libpointmatcher found but oracle/pm_ref_harness.cpp did not build:\n" + str(pr["build_error"])
+    z = np.load(os.path.join(GOLD, "scan_to_map_small.npz"))
+    for b in (0, 1):
+        ref = ref_probe.run(pr["exe"], z[f"reading{b}"], z["map_xyz"], z["map_nrm"], z[f"T_init{b}"])
+        o = oracle32.icp(z[f"reading{b}"], z["map_xyz"], z["map_nrm"], z[f"T_init{b}"], **CHAIN)
+        d = np.linalg.inv(ref["T"]) @ o["T"]
+        assert np.linalg.norm(d[:3, 3]) < 1e-5 and np.linalg.norm([d[2, 1] - d[1, 2], d[0, 2] - d[2, 0], d[1, 0] - d[0, 1]]) / 2 < 1e-5
+        assert ref["overlap"] == pytest.approx(o["overlap"], rel=1e-6)
