@@ -19,8 +19,13 @@
 #endif
 // The fast matcher kernel keeps ~100 scalars live; capping its SGPR allocation at 80 (the rest spill into
 // lanes of one VGPR) admits 7 waves per SIMD instead of 6 (800 SGPRs per SIMD: MI355X_MICROARCH.md).
+// ... and asking for 6 waves per SIMD keeps it within 80 VGPRs without a spill (left alone the allocator takes 91: 5 waves).
+#ifndef PGICP_FAST_WAVES
+#define PGICP_FAST_WAVES 6
+#endif
 #ifndef PGICP_FAST_ATTR
-#define PGICP_FAST_ATTR __attribute__((amdgpu_num_sgpr(80)))
+// (the double instantiation needs ~105 registers: 4 waves)
+#define PGICP_FAST_ATTR __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(sizeof(T) == 4 ? PGICP_FAST_WAVES : 4, sizeof(T) == 4 ? PGICP_FAST_WAVES : 4)))
 #endif
 
 namespace pgicp {
