@@ -8,7 +8,7 @@ mkdir -p $OUT
 python3 bench.py --prepare-only > /dev/null 2>&1
 python3 bench.py --workload stream --prepare-only > /dev/null 2>&1
 python3 bench.py --workload slam --prepare-only > /dev/null 2>&1
-python3 bench.py 2>/dev/null | tail -1 > $OUT/bench_n1.json
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_n1.json     # (the driver's command line)
 python3 bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_loopclosure.json
 python3 bench.py --workload stream --streams 1 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_1.json
 python3 bench.py --workload stream --streams 4 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_4.json
@@ -19,12 +19,12 @@ python3 tools/bench_normals.py 2>/dev/null | grep -v amdgpu > $OUT/bench_normals
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 # kernel trace of the headline command (without the companion figures, so that it holds only the metric's launches)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace -o t -- python3 $REPO/bench.py --no-fixed30 --no-cpu-baseline --no-host-input > $REPO/$OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace -o t -- python3 $REPO/bench.py --no-fixed30 --no-cpu-baseline --no-host-input --no-workloads > $REPO/$OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace_lc -o t -- python3 $REPO/bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $REPO/$OUT/trace_lc.log 2>&1
 # the copy / compute overlap of the host-input pipeline: kernels and memory copies on one time line
-timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$OUT/trace_host -o t -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-fixed30 --no-cpu-baseline --no-profile > $REPO/$OUT/trace_host.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 --no-host-input > $REPO/$OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 --no-host-input > $REPO/$OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$OUT/trace_host -o t -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-fixed30 --no-cpu-baseline --no-profile --no-workloads > $REPO/$OUT/trace_host.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 --no-host-input --no-workloads > $REPO/$OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 --no-host-input --no-workloads > $REPO/$OUT/pmc_write.log 2>&1
 cd $REPO
 python3 tools/trace_summary.py $OUT/trace > $OUT/trace_summary.txt 2>&1
 python3 tools/trace_summary.py $OUT/trace_lc > $OUT/trace_lc_summary.txt 2>&1
