@@ -263,3 +263,27 @@ def test_map_blocks_are_shared_between_contexts_and_huge_coordinates_are_refused
     assert e.value.code == icp.ERR_ARG and "fixed-point" in str(e.value)
     serve.close()
     build.close()
+
+
+def test_crowded_cells_overflow_the_item_pool(ctx, oracle32):
+    """The fast matcher pools the neighbour rows' point ranges as items of 8 records (512 per wave); a wave whose ranges
+    would overflow the pool takes larger items.  Here a map's bounding box is stretched by a few far points, so that the
+    grid's cells are coarse and a dense cluster piles thousands of points into the rows around the queries: items of
+    hundreds of records, several rounds.  Matches and the ICP must still be the oracle's, bit for bit / within 1e-5."""
+    rng = np.random.default_rng(7)
+    cluster = (rng.random((60_000, 3)) * np.array([1.2, 1.2, 0.4]) + np.array([10.0, -3.0, 0.5])).astype(np.float32)
+    far = np.array([[-80, -80, -5], [80, 80, 5], [80, -80, 5], [-80, 80, -5]], dtype=np.float32)
+    ref = np.concatenate([cluster, far])
+    nrm = np.tile(np.array([[0.0, 0.0, 1.0]], dtype=np.float32), (ref.shape[0], 1))
+    q = (rng.random((5_000, 3)) * np.array([1.6, 1.6, 0.8]) + np.array([9.8, -3.2, 0.3])).astype(np.float32)
+    m = ctx.set_map(ref, nrm, center=False)
+    for T in (np.eye(4), synth.se3(x=0.07, y=-0.05, z=0.03, yaw=np.deg2rad(1.0))):
+        ids, d2 = ctx.match(m, q, T=T)
+        oid, od2 = oracle32.knn_kdtree(oracle32.transform(T, q), ref, 2.0)
+        assert np.array_equal(ids, oid)
+        assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+    ctx.destroy_map(m)
+    # and through the ICP loop (seeded passes, trimmed filter) on the centred map
+    from test_gpu_matcher_state import check_state
+    T0 = synth.se3(x=0.05, y=0.04, z=-0.02, yaw=np.deg2rad(0.8))
+    check_state(ctx, oracle32, q, ref, nrm, T0, (1, 2, 4))
