@@ -72,6 +72,9 @@ typedef struct pgicp_params {
     int check_every;         /* host polls the device-side "all done" flag every this many iterations (>=1) */
     double outlier_max_dist; /* MaxDistOutlierFilter.maxDist: a second outlier filter whose weights multiply the trimmed
                               * filter's (pairs farther than this get weight 0); 0 or +inf = not in the chain */
+    double quantile_scale;   /* (ABI 3) MedianDistOutlierFilter.factor: the chain's quantile filter keeps pairs with
+                              * dist <= quantile_scale * getDistsQuantile(trim_ratio) (squared distances).  TrimmedDist is
+                              * (trim_ratio, 1); MedianDist is (0.5, factor).  Default 1 */
 } pgicp_params;
 
 /* What pgslam reads back after an ICP: errorMinimizer->getOverlap()

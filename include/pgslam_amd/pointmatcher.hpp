@@ -541,6 +541,21 @@ struct PointMatcher {
             return w;
         }
     };
+    //! [EXT] MedianDistOutlierFilter{factor}: limit = factor * getDistsQuantile(0.5) on the SQUARED match distances, weight 1
+    //! while dist <= limit (OutlierFiltersImpl.cpp as restated in oracle/icp_oracle.c: orc_median_weights).  On the device
+    //! it is the trimmed filter's exact order statistic at ratio 0.5, scaled (pgicp_params.quantile_scale).
+    struct MedianDistOutlierFilter : OutlierFilter {
+        ICPChainBase *chain; T factor;
+        MedianDistOutlierFilter(ICPChainBase *c, T f) : chain(c), factor(f) {}
+        OutlierWeights compute(const DataPoints &, const DataPoints &, const Matches &input) override
+        {
+            OutlierWeights w(input.dists.rows(), input.dists.cols());
+            chain->pushParams();
+            T lim; int nf;
+            check(chain->ctx, A::weights(chain->ctx, input.dists.data(), (int)input.dists.size(), w.data(), &lim, &nf));
+            return w;
+        }
+    };
     //! [EXT] MaxDistOutlierFilter{maxDist}: weight 1 while the squared match distance is <= maxDist^2, else 0
     struct MaxDistOutlierFilter : OutlierFilter {
         T maxDist;
@@ -712,17 +727,22 @@ struct PointMatcher {
                     else throw std::runtime_error("KDTreeMatcher: unknown parameter " + kv.first);
                 }
             }
-            // the chain multiplies its filters' weights (A.4): one TrimmedDist and / or one MaxDist filter, in any order
+            // the chain multiplies its filters' weights (A.4): one QUANTILE filter (TrimmedDist or MedianDist) and / or one
+            // MaxDist filter, in any order
             if (y.has("outlierFilters")) {
                 int n_trim = 0, n_max = 0;
                 for (auto &m : y.sections.at("outlierFilters")) {
                     if (m.name == "TrimmedDistOutlierFilter" && n_trim++ == 0)
                         outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, m.params.count("ratio") ? (T)to_double(m.params.at("ratio"), "ratio") : T(0.85)));
-                    else if (m.name == "MaxDistOutlierFilter" && n_max++ == 0)
+                    else if (m.name == "MedianDistOutlierFilter" && n_trim++ == 0) {
+                        const T f = m.params.count("factor") ? (T)to_double(m.params.at("factor"), "factor") : T(3);
+                        if (!(f > T(0))) throw std::runtime_error("MedianDistOutlierFilter: factor must be positive");
+                        outlierFilters.push_back(std::make_shared<MedianDistOutlierFilter>(this, f));
+                    } else if (m.name == "MaxDistOutlierFilter" && n_max++ == 0)
                         outlierFilters.push_back(std::make_shared<MaxDistOutlierFilter>(m.params.count("maxDist") ? (T)to_double(m.params.at("maxDist"), "maxDist") : T(1)));
                     else
                         throw std::runtime_error("loadFromYaml: unsupported outlier filter chain at " + m.name +
-                                                 " (supported: one TrimmedDistOutlierFilter and / or one MaxDistOutlierFilter)");
+                                                 " (supported: one TrimmedDistOutlierFilter or MedianDistOutlierFilter, and / or one MaxDistOutlierFilter)");
                 }
             } else outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
             errorMinimizer = std::make_shared<ErrorMinimizer>(this);
@@ -768,7 +788,8 @@ struct PointMatcher {
             p.trim_ratio = 1.0;                    // no TrimmedDist filter in the chain: every finite pair passes it
             p.outlier_max_dist = 0.0;
             for (auto &f : outlierFilters) {
-                if (auto t = std::dynamic_pointer_cast<TrimmedDistOutlierFilter>(f)) p.trim_ratio = (double)t->ratio;
+                if (auto t = std::dynamic_pointer_cast<TrimmedDistOutlierFilter>(f)) { p.trim_ratio = (double)t->ratio; p.quantile_scale = 1.0; }
+                if (auto md = std::dynamic_pointer_cast<MedianDistOutlierFilter>(f)) { p.trim_ratio = 0.5; p.quantile_scale = (double)md->factor; }
                 if (auto m = std::dynamic_pointer_cast<MaxDistOutlierFilter>(f)) p.outlier_max_dist = (double)m->maxDist;
             }
             if (errorMinimizer) p.sensor_std_dev = (double)errorMinimizer->sensorStdDev;

@@ -79,6 +79,9 @@ typedef struct {
     int use_kdtree;         /* 0: brute force (ground truth), 1: kd-tree (same results) */
     int center_reference;   /* 1: subtract centroid as ICP::operator()/setMap do [A.2] */
     real outlier_max_dist;  /* MaxDistOutlierFilter.maxDist, a second filter of the chain [A.4]; <= 0 or +inf: absent */
+    real quantile_scale;    /* [A.4] MedianDistOutlierFilter.factor: with trim_ratio = 0.5 the chain's quantile filter is the
+                             * median filter -- limit = factor * getDistsQuantile(0.5), weight = (dist <= limit), all on
+                             * SQUARED distances, as [EXT] OutlierFiltersImpl.cpp writes it; 1 (or <= 0) = TrimmedDist */
 } FN(orc_params);
 
 /* [A.4] the chain multiplies the weights of its outlier filters.  MaxDistOutlierFilter: weight 1 while the SQUARED
@@ -458,7 +461,17 @@ static int cmp_real(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
+static int FN(orc_quantile_weights)(const real *d2, int n, real ratio, real scale, real *w, real *limit_out, int *n_finite_out);
 int FN(orc_trim_weights)(const real *d2, int n, real ratio, real *w, real *limit_out, int *n_finite_out)
+{
+    return FN(orc_quantile_weights)(d2, n, ratio, (real)1, w, limit_out, n_finite_out);
+}
+/* TrimmedDist (scale 1) and MedianDist (ratio 0.5, scale = factor): limit = scale * getDistsQuantile(ratio) in T */
+int FN(orc_median_weights)(const real *d2, int n, real factor, real *w, real *limit_out, int *n_finite_out)
+{
+    return FN(orc_quantile_weights)(d2, n, (real)0.5, factor, w, limit_out, n_finite_out);
+}
+static int FN(orc_quantile_weights)(const real *d2, int n, real ratio, real scale, real *w, real *limit_out, int *n_finite_out)
 {
     real *vals = (real *)malloc(sizeof(real) * (n > 0 ? n : 1));
     int nf = 0;
@@ -477,6 +490,7 @@ int FN(orc_trim_weights)(const real *d2, int n, real ratio, real *w, real *limit
         limit = vals[k];
     }
     free(vals);
+    if (scale > (real)0 && scale != (real)1) limit = scale * limit;
     for (int i = 0; i < n; i++) w[i] = (d2[i] <= limit) ? (real)1 : (real)0;
     if (limit_out) *limit_out = limit;
     return ORC_OK;
@@ -819,7 +833,7 @@ int FN(orc_partial_chain)(const FN(orc_params) *prm, const real *reading, int n,
         FN(orc_kdtree_free)(t);
     } else FN(orc_knn_brute)(p, n, ref_xyz, m, prm->max_dist, ids, d2);
     real limit; int nf;
-    int st = FN(orc_trim_weights)(d2, n, prm->trim_ratio, w, &limit, &nf);
+    int st = FN(orc_quantile_weights)(d2, n, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
     if (st == ORC_OK) FN(orc_maxdist_weights)(d2, n, prm->outlier_max_dist, w);
     if (st == ORC_OK) {
         double sys[30];
@@ -903,7 +917,7 @@ int FN(orc_icp_map)(const FN(orc_params) *prm, const void *map, const real *read
         if (tree) FN(orc_kdtree_knn)(tree, step, n, prm->max_dist, ids, d2);
         else FN(orc_knn_brute)(step, n, ref, m, prm->max_dist, ids, d2);
         real limit; int nf;
-        status = FN(orc_trim_weights)(d2, n, prm->trim_ratio, w, &limit, &nf);
+        status = FN(orc_quantile_weights)(d2, n, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
         if (status != ORC_OK) break;
         FN(orc_maxdist_weights)(d2, n, prm->outlier_max_dist, w);
         status = FN(orc_p2plane_system)(step, n, ref, ref_nrm, ids, w, sys);

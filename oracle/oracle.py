@@ -36,7 +36,8 @@ def _params_type(real):
         _fields_ = [("max_dist", real), ("trim_ratio", real), ("max_iters", C.c_int),
                     ("min_diff_rot", C.c_double), ("min_diff_trans", C.c_double),
                     ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double),
-                    ("use_kdtree", C.c_int), ("center_reference", C.c_int), ("outlier_max_dist", real)]
+                    ("use_kdtree", C.c_int), ("center_reference", C.c_int), ("outlier_max_dist", real),
+                    ("quantile_scale", real)]
     return Params
 
 
@@ -76,7 +77,7 @@ class Oracle:
         d.update(kw)
         return self.Params(d["max_dist"], d["trim_ratio"], d["max_iters"], d["min_diff_rot"],
                            d["min_diff_trans"], d["smooth_length"], d["sensor_std_dev"],
-                           int(use_kdtree), int(center_reference), d.get("outlier_max_dist", 0.0))
+                           int(use_kdtree), int(center_reference), d.get("outlier_max_dist", 0.0), d.get("quantile_scale", 1.0))
 
     # -- stages -----------------------------------------------------------
     def transform(self, T, pts, rotate_only=False):
@@ -119,6 +120,16 @@ class Oracle:
         st = self._f("orc_trim_weights")(self._p(d2), C.c_int(d2.shape[0]), self.real(ratio), self._p(w),
                                          C.byref(limit), C.byref(nf))
         return st, w, limit.value, nf.value
+
+    def median_weights(self, d2, factor):
+        """[EXT] MedianDistOutlierFilter{factor} -> (weights, limit, n_finite)"""
+        d2 = np.ascontiguousarray(d2, dtype=self.dtype)
+        w = np.empty_like(d2)
+        limit = self.real(0)
+        nf = C.c_int(0)
+        st = self._f("orc_median_weights")(self._p(d2), C.c_int(d2.shape[0]), self.real(factor), self._p(w), C.byref(limit), C.byref(nf))
+        assert st == 0
+        return w, np.dtype(self.dtype).type(limit.value), nf.value
 
     def p2plane_system(self, p, ref_xyz, ref_nrm, ids, w):
         p, ref_xyz, ref_nrm = self._a(p), self._a(ref_xyz), self._a(ref_nrm)

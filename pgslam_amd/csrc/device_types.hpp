@@ -65,6 +65,7 @@ struct ChainDev {
     T max_dist;          // may be +inf
     T max_dist2;         // max_dist * max_dist in T
     T trim_ratio;
+    T trim_scale;        // the quantile filter's limit = trim_scale * order statistic (1: TrimmedDist; MedianDist: its factor)
     T outlier_max_d2;    // MaxDistOutlierFilter.maxDist squared in T; +inf when the chain has none
     int max_iters;
     int smooth;
@@ -87,8 +88,10 @@ struct ProblemDev {
     int done, status, iters, converged, max_iter_reached;
     int n_finite, n_kept, rank;
     int n_refined;           // queued queries the slow path resolved since the last threshold selection
-    double limit;            // last trim threshold (squared distance)
-    double prev_limit;       // the threshold the last fast matcher pass derived its search cap from
+    double limit;            // last threshold the pairs are KEPT with: min(scale * quantile, MaxDist filter) (squared distance)
+    double rlimit;           // what the matcher must be exact up to for that: max(quantile, limit) -- equal to `limit` for the
+                             // TrimmedDist filter; larger with a MedianDist factor below 1 or a MaxDist filter below the quantile
+    double prev_limit;       // the `rlimit` the last fast matcher pass derived its search cap from
     double sys[kSys];        // final sums of the last iteration
     Checker chk;
 };

@@ -60,7 +60,7 @@ void launch_cov(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, 
 void launch_sum_partials(hipStream_t st, const double *partials, int max_blocks, int nt, const ProblemDev *probs,
                          int nb_uniform, double *out, int P);
 template <typename T>
-void launch_trim_raw(hipStream_t st, const T *d2, int n, T ratio, T *limit_nf, T *w);
+void launch_trim_raw(hipStream_t st, const T *d2, int n, T ratio, T scale, T *limit_nf, T *w);
 template <typename T>
 void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const int *slot_of, const T *rd, int stride,
                         const int *ids, const T *w, int n, const T mean[3], double *partials, double *out);

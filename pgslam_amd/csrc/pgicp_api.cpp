@@ -249,6 +249,7 @@ ChainDev<T> make_chain(const pgicp_params &p)
     ch.max_dist = (T)p.max_dist;
     ch.max_dist2 = ch.max_dist * ch.max_dist;
     ch.trim_ratio = (T)p.trim_ratio;
+    ch.trim_scale = (T)p.quantile_scale;
     {
         const T md = (T)p.outlier_max_dist;
         ch.outlier_max_d2 = (p.outlier_max_dist > 0.0 && std::isfinite(p.outlier_max_dist)) ? md * md : std::numeric_limits<T>::infinity();
@@ -1204,7 +1205,7 @@ int outlier_weights(pgicp_ctx *c, const T *dist2, int n, int mem, T *weights, T 
     HIPC(c, c->small.ensure(256));
     {
         ProfScope ps(c, PGICP_PROF_TRIM, n);
-        launch_trim_raw<T>(c->stream, d_d2, n, (T)c->prm.trim_ratio, c->small.as<T>(), d_w);
+        launch_trim_raw<T>(c->stream, d_d2, n, (T)c->prm.trim_ratio, (T)c->prm.quantile_scale, c->small.as<T>(), d_w);
     }
     T h[2];
     HIPC(c, hipMemcpyAsync(h, c->small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -1577,6 +1578,7 @@ void pgicp_default_params(pgicp_params *p)
     p->epsilon = 0.0;
     p->max_dist = std::numeric_limits<double>::infinity();
     p->trim_ratio = 0.85;
+    p->quantile_scale = 1.0;
     p->outlier_max_dist = 0.0;
     p->max_iters = 40;
     p->min_diff_rot = 0.001;
@@ -1745,6 +1747,7 @@ int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
     if (p->epsilon != 0.0) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.epsilon: only 0 (exact search) is supported");
     if (!(p->max_dist > 0.0)) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.maxDist must be > 0");
     if (!(p->trim_ratio > 0.0 && p->trim_ratio <= 1.0)) return fail(c, PGICP_ERR_ARG, "TrimmedDistOutlierFilter.ratio must be in (0,1]");
+    if (!(p->quantile_scale > 0.0) || !std::isfinite(p->quantile_scale)) return fail(c, PGICP_ERR_ARG, "MedianDistOutlierFilter.factor (quantile_scale) must be positive and finite");
     if (p->outlier_max_dist < 0.0 || p->outlier_max_dist != p->outlier_max_dist) return fail(c, PGICP_ERR_ARG, "MaxDistOutlierFilter.maxDist must be >= 0");
     if (p->max_iters < 1) return fail(c, PGICP_ERR_ARG, "CounterTransformationChecker.maxIterationCount must be >= 1");
     if (p->smooth_length < 1 || p->smooth_length > kHist - 1)

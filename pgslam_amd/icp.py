@@ -54,7 +54,8 @@ class Params(C.Structure):
     _fields_ = [("knn", C.c_int), ("epsilon", C.c_double), ("max_dist", C.c_double), ("trim_ratio", C.c_double),
                 ("max_iters", C.c_int), ("min_diff_rot", C.c_double), ("min_diff_trans", C.c_double),
                 ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double), ("matcher", C.c_int),
-                ("grid_cell", C.c_double), ("check_every", C.c_int), ("outlier_max_dist", C.c_double)]
+                ("grid_cell", C.c_double), ("check_every", C.c_int), ("outlier_max_dist", C.c_double),
+                ("quantile_scale", C.c_double)]
 
 
 class Stats(C.Structure):

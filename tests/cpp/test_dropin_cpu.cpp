@@ -171,6 +171,15 @@ int main()
                                 "matcher:\n  KDTreeMatcher:\n    knn: 1\n");
         icp.loadFromYaml(good);
         CHECK(icp.readingDataPointsFilters.size() == 1 && icp.readingStepDataPointsFilters.size() == 1);
+        // the quantile filter of the chain may be the median filter; two quantile filters are refused
+        std::istringstream med("matcher:\n  KDTreeMatcher:\n    knn: 1\noutlierFilters:\n  - MedianDistOutlierFilter:\n      factor: 2.5\n  - MaxDistOutlierFilter:\n      maxDist: 1.0\n");
+        icp.loadFromYaml(med);
+        CHECK(icp.outlierFilters.size() == 2);
+        CHECK(std::dynamic_pointer_cast<PointMatcher<float>::MedianDistOutlierFilter>(icp.outlierFilters[0])->factor == 2.5f);
+        std::istringstream two("matcher:\n  KDTreeMatcher:\n    knn: 1\noutlierFilters:\n  - MedianDistOutlierFilter:\n      factor: 2.5\n  - TrimmedDistOutlierFilter:\n      ratio: 0.8\n");
+        threw = false;
+        try { icp.loadFromYaml(two); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
     }
     std::puts("dropin cpu tests ok");
     return 0;

@@ -116,3 +116,17 @@ def test_scan_ahead_of_its_map(ctx, oracle32):
         T0 = ref_inv @ P @ synth.se3(x=0.05, y=-0.04, yaw=np.deg2rad(0.4))
         check_state(ctx, oracle32, rd, ref, nrm, T0, its)
         check_state(ctx, oracle32, rd, ref, nrm, T0, (2, 3), chain=dict(CHAIN, trim_ratio=0.97))
+
+
+def test_median_dist_outlier_filter_state(ctx, oracle32):
+    """The chain's quantile filter as MedianDistOutlierFilter{factor}: limit = factor x the exact median of the finite squared
+    distances (pgicp_params.trim_ratio = 0.5, quantile_scale = factor).  The lazily exact matcher resolves everything up to
+    that larger threshold: per-point state after every iteration against the oracle, bit for bit."""
+    w = synth.make_scan_to_map(n_scan=6000, n_map=50_000, n_queries=1, n_map_poses=4, rings=16)
+    for factor in (3.0, 1.0, 0.4):
+        check_state(ctx, oracle32, w.scans_xyz[0], w.map_xyz, w.map_nrm, w.T_init[0], (1, 2, 4, 30),
+                    chain=dict(CHAIN, trim_ratio=0.5, quantile_scale=factor))
+    t = synth.make_two_scans(8000, rings=16)
+    T0 = t["T_truth"] @ synth.se3(x=0.8, y=-0.5, z=0.2, yaw=np.deg2rad(6.0))
+    check_state(ctx, oracle32, t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], T0, (1, 2, 3, 8), chain=dict(CHAIN, max_dist=0.5, trim_ratio=0.5, quantile_scale=3.0))
+    ctx.set_params(quantile_scale=1.0)

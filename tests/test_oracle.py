@@ -298,3 +298,27 @@ def test_golden_fixtures_through_installed_libpointmatcher(oracle32):
         d = np.linalg.inv(ref["T"]) @ o["T"]
         assert np.linalg.norm(d[:3, 3]) < 1e-5 and np.linalg.norm([d[2, 1] - d[1, 2], d[0, 2] - d[2, 0], d[1, 0] - d[0, 1]]) / 2 < 1e-5
         assert ref["overlap"] == pytest.approx(o["overlap"], rel=1e-6)
+
+
+def test_median_dist_outlier_filter_restatement(oracle32, oracle64):
+    """[EXT] MedianDistOutlierFilter{factor}: limit = factor * getDistsQuantile(0.5) on the squared distances (finite ones
+    only, index (size_t)(n * 0.5) of the sorted values), weight = (dist <= limit).  Known answers + numpy."""
+    for o, dt in ((oracle32, np.float32), (oracle64, np.float64)):
+        d2 = np.array([4.0, 1.0, np.inf, 9.0, 0.25, 16.0, 2.25], dtype=dt)          # finite sorted: .25 1 2.25 4 9 16 -> index 3 -> 4
+        w, limit, nf = o.median_weights(d2, 1.5)
+        assert nf == 6 and limit == dt(6.0)
+        np.testing.assert_array_equal(w, (d2 <= 6.0).astype(dt))
+        rng = np.random.default_rng(5)
+        d2 = (rng.random(5001) ** 2).astype(dt)
+        d2[::7] = np.inf
+        for factor in (0.5, 1.0, 3.0):
+            w, limit, nf = o.median_weights(d2, factor)
+            fin = np.sort(d2[np.isfinite(d2)])
+            want = dt(factor) * fin[int(dt(fin.size) * dt(0.5))]
+            assert nf == fin.size and limit == want
+            np.testing.assert_array_equal(w, (d2 <= want).astype(dt))
+    # inside the ICP loop: the chain with the median filter is the chain with ratio 0.5 and the limit scaled
+    t = __import__("pgslam_amd.synth", fromlist=["x"]).make_two_scans(3000, rings=16)
+    a = oracle32.icp(t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], t["T_init"], **dict(CHAIN, trim_ratio=0.5, quantile_scale=3.0))
+    b = oracle32.icp(t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], t["T_init"], **dict(CHAIN, trim_ratio=0.5))
+    assert a["status"] == 0 and a["n_kept"] > b["n_kept"] and a["trim_limit"] > b["trim_limit"]
