@@ -85,6 +85,8 @@ struct ProblemDev {
     double dT[16];           // last increment
     double Tcur[12];         // T_iter as 3x4 for the kernels (cast to T when applied)
     double Tcur_prev[12];    // the Tcur the previous matcher pass ran with (how far each query moved since)
+    float Tcur_f[12], Tcur_prev_f[12];   // the same two rounded to float once (by whoever writes Tcur): the float kernels read these
+                             // instead of converting twelve uniform doubles per wave and pass
     int done, status, iters, converged, max_iter_reached;
     int n_finite, n_kept, rank;
     int n_refined;           // queued queries the slow path resolved since the last threshold selection

@@ -73,8 +73,8 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-template <typename T>
-__device__ __forceinline__ void apply_T(const double *Tc, T x, T y, T z, T &ox, T &oy, T &oz)
+template <typename T, typename S>
+__device__ __forceinline__ void apply_T(const S *Tc, T x, T y, T z, T &ox, T &oy, T &oz)
 {
     const T r00 = (T)Tc[0], r01 = (T)Tc[1], r02 = (T)Tc[2], tx = (T)Tc[3];
     const T r10 = (T)Tc[4], r11 = (T)Tc[5], r12 = (T)Tc[6], ty = (T)Tc[7];
@@ -82,6 +82,16 @@ __device__ __forceinline__ void apply_T(const double *Tc, T x, T y, T z, T &ox, 
     ox = ((r00 * x + r01 * y) + r02 * z) + tx;
     oy = ((r10 * x + r11 * y) + r12 * z) + ty;
     oz = ((r20 * x + r21 * y) + r22 * z) + tz;
+}
+
+// The current / previous iteration transform of a problem in the kernel's arithmetic type (ProblemDev keeps a float copy)
+template <typename T> __device__ __forceinline__ auto tcur_of(const ProblemDev &P)
+{
+    if constexpr (sizeof(T) == 4) return (const float *)P.Tcur_f; else return (const double *)P.Tcur;
+}
+template <typename T> __device__ __forceinline__ auto tcur_prev_of(const ProblemDev &P)
+{
+    if constexpr (sizeof(T) == 4) return (const float *)P.Tcur_prev_f; else return (const double *)P.Tcur_prev;
 }
 
 // The kernels, by stage (all part of this translation unit):

@@ -763,7 +763,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         off += pr[p].n;
         Tpre_of(p, D.Tpre);
         mat4_identity(D.T_iter); mat4_identity(D.T_prev); mat4_identity(D.dT);
-        for (int i = 0; i < 12; i++) D.Tcur[i] = D.T_iter[i];
+        for (int i = 0; i < 12; i++) { D.Tcur[i] = D.T_iter[i]; D.Tcur_f[i] = (float)D.T_iter[i]; }
         checker_init(D.chk);
     }
     { const int pst = pinned_ensure(c, &c->h_up, &c->h_up_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
