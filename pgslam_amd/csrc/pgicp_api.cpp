@@ -136,6 +136,7 @@ struct pgicp_ctx {
     int counters_clean = 0;         // the matcher's queue counters were zeroed by the last kernel of the previous iteration
     int poll_us = 400;              // how long the host polls h_flag before it blocks on the stream instead
     int fast_rings_seeded = 1, fast_rings_unseeded = 3;
+    double cell_scale = 1.0;     // experiment knob PGICP_CELL_SCALE: the automatic grid cell times this
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
@@ -561,6 +562,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
             const double area = ex * ey + ey * ez + ex * ez;
             h = std::sqrt(2.0 * std::max(area, 1e-12) / (double)m);
             const double diag = std::sqrt(ex * ex + ey * ey + ez * ez);
+            h *= c->cell_scale;
             if (!(h > diag * 1e-4)) h = std::max(diag * 1e-4, 1e-6);
         }
         for (;;) {   // bound the dense cell table
@@ -1602,6 +1604,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     pgicp_default_params(&c->prm);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_SEEDED")) c->fast_rings_seeded = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_KX")) c->grid_kx = std::atoi(e);
+    if (const char *e = std::getenv("PGICP_CELL_SCALE")) { const double v = std::atof(e); if (v > 0.05 && v < 20.0) c->cell_scale = v; }
     if (const char *e = std::getenv("PGICP_NEAR_FRAC")) c->near_frac = std::atof(e);
     if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_POLL_US")) c->poll_us = std::atoi(e);
