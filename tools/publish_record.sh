@@ -1,0 +1,19 @@
+#!/bin/bash
+# copies the files of a tools/measure_round.sh run (gpurun_out/measure/) into profiles/ under this round's names:
+# tools/publish_record.sh r03
+R=${1:?round prefix, e.g. r03}; M=gpurun_out/measure; P=profiles
+cp $M/bench_n1.json $P/${R}_bench_n1.json
+cp $M/bench_loopclosure.json $P/${R}_bench_loopclosure.json
+cp $M/bench_normals.json $P/${R}_bench_normals.json
+cp $M/bench_slam.json $P/${R}_bench_slam.json
+cp $M/bench_stream_1.json $P/${R}_bench_stream_1vehicle.json
+cp $M/bench_stream_4.json $P/${R}_bench_stream_4vehicles.json
+cp $M/bench_stream_fleet16.json $P/${R}_bench_stream_fleet16.json
+cp $M/host_input_overlap.txt $P/${R}_host_input_overlap.txt
+cp $M/trace_lc/t_kernel_stats.csv $P/${R}_loopclosure_kernel_stats.csv
+cp $M/trace_lc_summary.txt $P/${R}_loopclosure_trace_summary.txt
+cp $M/trace/t_kernel_stats.csv $P/${R}_rocprofv3_kernel_stats.csv
+cp $M/trace_summary.txt $P/${R}_trace_summary.txt
+cp $M/slam_mt.json $P/${R}_slam_run_mt.json
+cp $M/knn_traffic.json $P/knn_traffic.json
+python3 tools/measure_digest.py $M > $P/${R}_digest.txt 2>&1
