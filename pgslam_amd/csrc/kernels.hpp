@@ -10,7 +10,7 @@ template <typename T>
 void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_f, long long tot_s,
                              int max_m, int max_cells, int max_cells_f, int max_nsc, int max_blocks, int *cell_of, int *counts, int *block_sums,
                              int *cell_start, int *cell_start_f, int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
-                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit, unsigned *occ, long long tot_o);
+                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit, unsigned *occ, long long tot_o, float *sc_ext);
 template <typename T>
 void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
                        int *qrow, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,

@@ -65,6 +65,7 @@ struct MapHost {
     int *near = nullptr;
     int *sc_dist = nullptr;
     int *sc_wit = nullptr;
+    float *sc_ext = nullptr;
     unsigned *occ = nullptr;
     int first = 0;                  // MapDev::first
     // the one device allocation holding all of the above -- shared by the maps of one batched build and
@@ -358,6 +359,7 @@ int sync_maps_table(pgicp_ctx *c)
         h[i].near = m.near;
         h[i].sc_dist = m.sc_dist;
         h[i].sc_wit = m.sc_wit;
+        h[i].sc_ext = m.sc_ext;
         h[i].occ = m.occ;
         h[i].first = m.first;
         h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
@@ -609,9 +611,10 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
                  b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c),
-                 b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0, b_occ = up(sizeof(unsigned) * (size_t)tot_o);
+                 b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0, b_occ = up(sizeof(unsigned) * (size_t)tot_o),
+                 b_ext = up(sizeof(float) * 6 * (size_t)tot_s);
     auto blk = std::make_shared<SharedBlock>();
-    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ, &blk->p, &blk->bytes); if (ast) return ast; }
+    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext, &blk->p, &blk->bytes); if (ast) return ast; }
     char *base = blk->p;
     V4 *g_pts = (V4 *)base, *g_nrm = any_nrm ? (V4 *)(base + b_pts) : nullptr;
     int *g_cs = (int *)(base + b_pts + b_nrm), *g_slot = (int *)(base + b_pts + b_nrm + b_cs),
@@ -620,6 +623,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         *g_wit = (int *)(base + b_pts + b_nrm + b_cs + b_slot + 2 * b_sc + b_near),
         *g_csf = kx > 1 ? (int *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near) : g_cs;
     unsigned *g_occ = (unsigned *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf);
+    float *g_ext = (float *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ);
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
         const BuildDesc<T> &d = descs[k];
@@ -634,6 +638,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         M.near = g_near + d.cbase;
         M.sc_dist = g_scd + d.sbase;
         M.sc_wit = g_wit + d.sbase;
+        M.sc_ext = g_ext + 6 * d.sbase;
         M.occ = g_occ + d.obase;
     }
     HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
@@ -641,7 +646,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
         launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_f, tot_s, max_m, max_cells, max_cells_f, max_nsc, max_blocks, c->tmp_a.as<int>(),
                                    c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), g_pts, g_nrm,
-                                   g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o);
+                                   g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o, g_ext);
     }
     HIPC(c, hipStreamSynchronize(c->stream));          // `descs` (host) feeds an async copy
     HIPC(c, hipGetLastError());
