@@ -23,7 +23,7 @@ void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc 
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf);
+                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf, int clear_queue_counters);
 size_t knn_queue_bytes(int n_problems, int max_n, size_t elem);
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
@@ -35,7 +35,7 @@ void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, c
                      const int *slow2_idx, int exact_all, T *none_r);
 template <typename T>
 void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int max_n, int second,
-                        const int *active, int *tables, void *keys);
+                        const int *active, int *tables, void *keys, int *seg_count);
 size_t trim_select_table_bytes(int P);
 int knn_stats_read(unsigned long long out[56], int reset);
 int knn_phase_read(unsigned long long out[48], int reset);   // diagnostics build only: wave cycles per phase of the fast kernel

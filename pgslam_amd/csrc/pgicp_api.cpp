@@ -135,6 +135,7 @@ struct pgicp_ctx {
     std::vector<SrcDesc> h_src;     // host copies of per-batch descriptors (uploaded asynchronously)
     std::vector<int> h_ident;
     int counters_clean = 0;         // the matcher's queue counters were zeroed by the last kernel of the previous iteration
+    int seg_clean = 0;              // the matcher's SEGMENTED queue counters were zeroed by the previous iteration's first selection
     int poll_us = 400;              // how long the host polls h_flag before it blocks on the stream instead
     int fast_rings_seeded = 1, fast_rings_unseeded = 3;
     double cell_scale = 1.0;     // experiment knob PGICP_CELL_SCALE: the automatic grid cell times this
@@ -783,6 +784,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     HIPC(c, hipMemcpyAsync(c->active.p, ident.data(), sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
     c->counters_clean = 1;
+    c->seg_clean = 0;               // a new batch: its first matcher launch clears the segmented counters itself
     HIPC(c, hipMemsetAsync(c->sel_tables.p, 0, trim_select_table_bytes(P), c->stream));
     {
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
@@ -822,12 +824,16 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
                       c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active, S.none_r.template as<T>(),
-                      L.P, c->queue.p);
+                      L.P, c->queue.p, c->seg_clean ? 0 : 1);
         c->counters_clean = 0;
     }
     {
         ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 0, active, c->sel_tables.as<int>(), c->qtmp.p);
+        // (with the grid matcher this selection also clears the matcher's segmented queue counters for the next iteration)
+        const bool grid = c->prm.matcher == PGICP_MATCHER_GRID;
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 0, active, c->sel_tables.as<int>(), c->qtmp.p,
+                              grid ? (int *)c->queue.p : nullptr);
+        c->seg_clean = grid ? 1 : 0;
     }
     if (c->prm.matcher == PGICP_MATCHER_GRID) {
         // lazy resolution: only queued queries whose lower bound is within the threshold just
@@ -851,7 +857,7 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
             }
         }
         ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 1, active, c->sel_tables.as<int>(), c->qtmp.p);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 1, active, c->sel_tables.as<int>(), c->qtmp.p, nullptr);
     }
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
@@ -883,8 +889,8 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         // FNV-1a over the argument values: shapes, switches, chain parameters, and every buffer the launches name
         unsigned long long key = 1469598103934665603ULL;
         auto mix = [&key](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ULL; } };
-        const int shape[10] = {(int)sizeof(T), L.P, (int)act_probs, L.max_n, use_seed, with_solve ? 1 : 0, c->med_rings, c->fast_rings_seeded,
-                               c->fast_rings_unseeded, c->prm.matcher};
+        const int shape[11] = {(int)sizeof(T), L.P, (int)act_probs, L.max_n, use_seed, with_solve ? 1 : 0, c->med_rings, c->fast_rings_seeded,
+                               c->fast_rings_unseeded, c->prm.matcher, c->seg_clean};
         mix(shape, sizeof shape);
         mix(&ch, sizeof ch);
         const void *bufs[] = {c->probs.p, S.d_maps.p, S.rd_sorted.p, S.slot.p, S.d2.p, S.none_r.p, c->small.p, c->slow_list.p, c->slow_lb.p,
@@ -924,6 +930,7 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
     }
     if (!done) enqueue_iteration<T>(c, L, ch, with_solve, act_units, act_probs, use_seed);
     c->counters_clean = with_solve ? 1 : 0;      // k_compact_active clears the matcher's queue counters
+    c->seg_clean = c->prm.matcher == PGICP_MATCHER_GRID ? 1 : 0;     // (a replayed graph did not pass through enqueue_iteration)
     if (with_solve) ++c->flag_stamp;
 }
 
@@ -1105,7 +1112,8 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p);
+                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p, 1);
+        c->seg_clean = 0;
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
             launch_knn_slow<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
