@@ -92,6 +92,8 @@ struct ProblemDev {
     int done, status, iters, converged, max_iter_reached;
     int n_finite, n_kept, rank;
     int n_refined;           // queued queries the slow path resolved since the last threshold selection
+    int far_mode;            // the last matcher pass queued more than an eighth of the queries (a scan that has left its map behind):
+                             // the fast kernel then looks at every far query's proven empty radius before it searches (k_sel_final sets it)
     double limit;            // last threshold the pairs are KEPT with: min(scale * quantile, MaxDist filter) (squared distance)
     double rlimit;           // what the matcher must be exact up to for that: max(quantile, limit) -- equal to `limit` for the
                              // TrimmedDist filter; larger with a MedianDist factor below 1 or a MaxDist filter below the quantile
