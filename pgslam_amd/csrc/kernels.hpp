@@ -53,7 +53,7 @@ void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *map
                    const T *d2, double *partials, int P, int max_n, const int *active);
 template <typename T>
 void launch_solve(hipStream_t st, ProblemDev *probs, const double *partials, const ChainDev<T> &ch, int *n_done, int P,
-                  int max_n, const int *active);
+                  int max_n, const int *active, int *single_host_flag, int *single_stamp, int *single_queue_counters);
 template <typename T>
 void launch_cov(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
                 const T *d2, double *partials, double *out, int P, int max_n);

@@ -866,8 +866,14 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
     }
     if (with_solve) {
         ProfScope ps(c, PGICP_PROF_SOLVE, act_units, act_probs);
-        launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), nA, L.max_n, active);
-        launch_compact_active(c->stream, probs, L.P, c->active.as<int>(), c->h_flag, c->stamp_dev, c->small.as<int>() + 16);
+        if (L.P == 1) {
+            // one problem: the solve kernel also does the bookkeeping of k_compact_active (one launch less per iteration)
+            launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), nA, L.max_n, active, c->h_flag, c->stamp_dev,
+                            c->small.as<int>() + 16);
+        } else {
+            launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), nA, L.max_n, active, nullptr, nullptr, nullptr);
+            launch_compact_active(c->stream, probs, L.P, c->active.as<int>(), c->h_flag, c->stamp_dev, c->small.as<int>() + 16);
+        }
     }
 }
 
