@@ -34,8 +34,8 @@ struct MapDev {
     const int *sc_count;                 // occupancy flag per 8x8x8 super-cell
     const int *sc_dist;                  // Chebyshev distance (in super-cells, capped at kScReach + 1) to the nearest occupied one
     const int *sc_wit;                   // slot of a point in a nearest occupied super-cell (within kWitReach), else -1
-    const float *sc_ext;                 // per super-cell: the box of its POINTS, (min x, y, z, max x, y, z) in the map's (centred)
-                                         // frame, float, min > max when empty -- the slices of a street scene fill little of a 0.7 m cube
+    const float *sc_ext;                 // per super-cell: the box of its POINTS, (min x, y, z, max x, y, z) as offsets from the grid
+                                         // origin, float, min > max when empty -- the slices of a street scene fill little of a 0.7 m cube
     const int *slot_of;                  // original index -> position in pts / nrm
     const int *near;                     // per 2x2x2 block of cells: a nearby occupied cell, -1 if none within kNearReach
     const unsigned *occ;                 // one bit per cell (cell id = bit index): occupied.  64x smaller than the tables, so it
