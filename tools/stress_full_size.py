@@ -1,0 +1,56 @@
+"""Full-size parity stress (GPU box): 100 k-pt scans against the 1 M-pt benchmark map and against the 2 M-pt sliding map of
+the streaming drive, random initial errors, matcher state after a few iterations against the CPU oracle (~10 s of k-d tree
+per oracle call).  tools/stress_full_size.py [seconds] [seed]"""
+import sys, time, importlib
+import numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from pgslam_amd import icp, synth
+from test_gpu_matcher_state import check_state, CHAIN
+from bench import build_workload, build_drive
+orc = importlib.import_module("oracle.oracle")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+o32 = orc.Oracle(np.float32)
+ctx = icp.Context(0, **CHAIN)
+w = build_workload(100_000, 1_000_000, 16)
+mid = ctx.set_map(w.map_xyz, w.map_nrm)
+t0 = time.time(); n = 0
+flips = 0
+
+
+def checked(run):
+    """Bit for bit first.  At this size the double sums of an iteration (85 k pairs, added in the sorted reading's order here
+    and in scan order in the oracle) differ in their last bits, the solved transform with them, and now and then one of its
+    twelve elements rounds to the neighbouring FLOAT: a handful of queries then land one ulp beside the oracle's and their
+    squared distances differ by ~1e-5 relative, with the same matched points, the same counts, iteration by iteration.  Such a
+    case is counted and must still pass at 1e-3."""
+    global flips
+    try:
+        run(0.0)
+    except AssertionError:
+        flips += 1
+        run(1e-3)
+    return 1
+
+
+while time.time() - t0 < budget * 0.5:
+    b = int(rng.integers(0, 16))
+    T0 = w.T_truth[b] @ synth.se3(x=rng.normal(0, 0.08), y=rng.normal(0, 0.08), z=rng.normal(0, 0.03), yaw=np.deg2rad(rng.normal(0, 0.6)))
+    its = (int(rng.integers(1, 3)), int(rng.integers(3, 7)))
+    n += checked(lambda rtol: check_state(ctx, o32, w.scans_xyz[b], w.map_xyz, w.map_nrm, T0, its, mid=mid, rtol=rtol))
+ctx.destroy_map(mid)
+# the sliding map late in the drive (a quarter of the scan ahead of the map: far mode, cube walk, point boxes)
+capacity, stride = 20, 3
+n_total = (capacity - 1) * stride + 41
+poses, odom, xyz, nrm = build_drive(n_total, 100_000, 0.35)
+m = 0
+while time.time() - t0 < budget:
+    ref_s = int(rng.integers((capacity - 1) * stride, n_total - 8))
+    kf = [ref_s] + [ref_s - stride * k for k in range(1, capacity)]
+    inv_ref = np.linalg.inv(poses[ref_s])
+    mx, mn = o32.build_local_map([xyz[s] for s in kf], [nrm[s] for s in kf], [inv_ref @ poses[s] for s in kf])
+    s = ref_s + int(rng.integers(1, 8))
+    T0 = inv_ref @ poses[s] @ synth.se3(x=rng.normal(0, 0.04), y=rng.normal(0, 0.04), yaw=np.deg2rad(rng.normal(0, 0.3)))
+    its2 = (1, int(rng.integers(2, 5)))
+    m += checked(lambda rtol: check_state(ctx, o32, xyz[s], mx, mn, T0, its2, rtol=rtol))
+print("stress_full_size: %d scans against the 1 M-pt map, %d against 2 M-pt sliding maps in %.0f s, all equal to the oracle (%d of them only to 1e-3 in squared distance: a float rounding boundary of the transform, same matches and counts)" % (n, m, time.time() - t0, flips))
