@@ -740,10 +740,11 @@ public:
         const Matrix d = last_input_.inverse() * input_T_world_robot;
         // the ICP runs outside the graph lock (LocalizerMT.hpp:95-96); on the device copy of the cloud if its upload was
         // started while the previous scan aligned (Prefetch), from the host cloud otherwise
-        if (prefetched_cloud_ == cloud.get() && prefetched_) T_refkf_robot_ = icp_sequence_(prefetched_, T_refkf_robot_ * d);
+        // (only THIS cloud's slot is consumed: the slot of the scan after it, whose transfer is under way, stays)
+        typename PM::ICPChainBase::DeviceReading ahead;
+        if (Prefetched *slot = FindPrefetched(cloud.get())) { ahead = slot->reading; *slot = Prefetched(); }   // (freed even if the ICP throws)
+        if (ahead) { T_refkf_robot_ = icp_sequence_(ahead, T_refkf_robot_ * d); device_readings_used_++; }
         else T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);
-        prefetched_ = typename PM::ICPChainBase::DeviceReading();
-        prefetched_cloud_ = nullptr;
         const auto t2 = clk::now();
         phase_s_[1] += std::chrono::duration<double>(t2 - t1).count();
         {
@@ -761,23 +762,32 @@ public:
     //! upload was prefetched has been through it already).
     void PreProcess(const Matrix &input_T_robot_sensor, DPPtr cloud)
     {
-        if (preprocessed_cloud_ == cloud.get()) return;
+        // per-cloud state: while scan k aligns, scan k + 1 has been through here already (Prefetch) -- one "last cloud"
+        // memo would alternate between the two and send every prefetched cloud through the filters and the sensor
+        // transform a second time, in place
+        Prefetched *slot = FindPrefetched(cloud.get());
+        if (slot && slot->preprocessed) return;
         input_filters_.apply(*cloud);
         (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
-        preprocessed_cloud_ = cloud.get();
+        if (slot) slot->preprocessed = true;
     }
     //! The NEXT scan, already queued (LocalizerMT.hpp:27-40): pre-process it and start its transfer to the device on the ICP
     //! context's copy stream (pgicp_upload_*), so that it travels while the current scan aligns.  Needs a map (the chain
     //! aligns device readings only against one) -- before the first keyframe nothing is prefetched.
     void Prefetch(const Matrix &input_T_robot_sensor, DPPtr cloud)
     {
-        if (comp_.empty() || !icp_sequence_.hasMap() || prefetched_cloud_ == cloud.get()) return;
+        if (comp_.empty() || !icp_sequence_.hasMap() || FindPrefetched(cloud.get())) return;
+        // two slots, as the context keeps two upload sets (pgicp_upload_*): the scan being aligned and the one after it
+        Prefetched *slot = FindPrefetched(nullptr);
+        if (!slot) return;
+        slot->cloud = cloud.get();
         PreProcess(input_T_robot_sensor, cloud);
-        prefetched_ = icp_sequence_.uploadReading(*cloud);
-        prefetched_cloud_ = cloud.get();
+        slot->reading = icp_sequence_.uploadReading(*cloud);
         prefetches_++;
     }
     size_t prefetches() const { return prefetches_; }
+    //! scans whose ICP ran on a device copy uploaded ahead of time
+    size_t device_readings_used() const { return device_readings_used_; }
     //! MapManager::NotifyKeyframeUpdate -> Localizer::UpdateFromGraph (Localizer.hpp:155-176): after an
     //! optimisation the local map is rebuilt from the corrected poses and the world pose follows the reference
     virtual void UpdateFromGraph() { UpdateFromGraphNow(); }
@@ -791,9 +801,18 @@ public:
     }
 
 protected:
-    typename PM::ICPChainBase::DeviceReading prefetched_;
-    const DP *prefetched_cloud_ = nullptr, *preprocessed_cloud_ = nullptr;
-    size_t prefetches_ = 0;
+    struct Prefetched {
+        const DP *cloud = nullptr;                              // null: the slot is free
+        bool preprocessed = false;
+        typename PM::ICPChainBase::DeviceReading reading;
+    };
+    Prefetched prefetched_[2];
+    Prefetched *FindPrefetched(const DP *cloud)
+    {
+        for (auto &p : prefetched_) if (p.cloud == cloud) return &p;
+        return nullptr;
+    }
+    size_t prefetches_ = 0, device_readings_used_ = 0;
     bool resync_before_update_ = false;              // the MT flavour re-reads the graph before every update
     unsigned long long synced_version_ = 0;
     void Rebuild()

@@ -143,6 +143,7 @@ struct pgicp_ctx {
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
+    std::mutex prof_m;              // prof_events and the sums below: pgicp_profile_process collects from another thread
     std::vector<ProfEvent> prof_events;
     long long prof_launches[PGICP_PROF_COUNT] = {0};
     double prof_ms[PGICP_PROF_COUNT] = {0};
@@ -218,15 +219,11 @@ struct ProfScope {
         if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(ev.a, c->stream);
     }
-    ~ProfScope()
-    {
-        if (!on) return;
-        (void)hipEventRecord(ev.b, c->stream);
-        c->prof_events.push_back(ev);
-    }
+    ~ProfScope();
 };
 
-void prof_collect(pgicp_ctx *c)
+// (with c->prof_m held) waits for the stream and folds the finished event pairs into the sums
+void prof_collect_locked(pgicp_ctx *c)
 {
     if (c->prof_events.empty()) return;
     (void)hipStreamSynchronize(c->stream);
@@ -243,6 +240,21 @@ void prof_collect(pgicp_ctx *c)
         (void)hipEventDestroy(e.b);
     }
     c->prof_events.clear();
+}
+void prof_collect(pgicp_ctx *c)
+{
+    std::lock_guard<std::mutex> lock(c->prof_m);
+    prof_collect_locked(c);
+}
+ProfScope::~ProfScope()
+{
+    if (!on) return;
+    (void)hipEventRecord(ev.b, c->stream);
+    std::lock_guard<std::mutex> lock(c->prof_m);
+    c->prof_events.push_back(ev);
+    // a context that profiles from its creation (PGICP_PROFILE_ALL: the facade's ICP objects) is never asked for its
+    // numbers between calls: fold the events in now and then, or a long run holds hundreds of thousands of live events
+    if (c->prof_events.size() >= 4096) prof_collect_locked(c);
 }
 
 template <typename T>
@@ -2014,9 +2026,10 @@ int pgicp_profile_process(int kid, long long *launches, double *total_ms, long l
     std::lock_guard<std::mutex> lock(pp.m);
     long long l = pp.launches[kid], u = pp.units[kid], pr = pp.problems[kid], mp = pp.map_points[kid];
     double ms = pp.ms[kid];
-    for (pgicp_ctx *c : pp.live) {            // (the caller's contexts are idle: they are thread-compatible, not thread-safe)
-        (void)hipSetDevice(c->device);
-        prof_collect(c);
+    for (pgicp_ctx *c : pp.live) {            // (a context that is mid-call on another thread: its events so far are collected
+        (void)hipSetDevice(c->device);        //  under its profile lock -- a wait on its stream, no access to its other state)
+        std::lock_guard<std::mutex> plock(c->prof_m);
+        prof_collect_locked(c);
         l += c->prof_launches[kid]; ms += c->prof_ms[kid]; u += c->prof_units[kid]; pr += c->prof_problems[kid]; mp += c->prof_map_points[kid];
     }
     if (launches) *launches = l;

@@ -22,6 +22,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -83,10 +84,13 @@ thread_local std::string t_comm_err;
 // block, publishes arrived[rank] = g, waits until every rank has, reads all blocks, publishes left[rank] = g; nobody
 // writes generation g + 1 before every rank has left g.  The counters are lock-free 64-bit atomics in the mapping.
 struct ShmHeader {
-    std::atomic<uint64_t> magic;           // set last by rank 0: the others wait for it
+    std::atomic<uint64_t> magic;           // set last by rank 0, before the file gets its name
     uint64_t world, max_slots;
-    std::atomic<uint64_t> attached;        // ranks that have mapped the file (the creator unlinks nothing before that)
-    struct alignas(64) Line { std::atomic<uint64_t> arrived, left; } rank[1];     // `world` of them
+    std::atomic<uint64_t> attached;        // ranks attached to THIS file (the last one to detach removes it)
+    // hello / ack: rank r writes a token of its own, the LIVE rank 0 answers with the same token.  A file left behind by a
+    // crashed run has the magic and even counters, but nobody who answers: a rank that opened it never takes part in a
+    // collective on it (see pgicp_comm_create_host).
+    struct alignas(64) Line { std::atomic<uint64_t> arrived, left, hello, ack; } rank[1];     // `world` of them
 };
 constexpr uint64_t kShmMagic = 0x5047494350434F4DULL;      // "PGICPCOM"
 constexpr double kShmTimeoutS = 120.0;
@@ -259,40 +263,97 @@ int pgicp_comm_create_host(int world_size, int rank, const char *shm_path, int m
     }
     *out = nullptr;
     const size_t bytes = shm_header_bytes(world_size) + sizeof(pgicp_edge) * (size_t)world_size * (size_t)std::max(1, max_slots_per_rank);
-    int fd = -1;
+    // Rendezvous (collective: returns on every rank once all ranks are attached, like ncclCommInitRank).
+    // Rank 0 makes a FRESH inode -- a stale file of that name (a crashed or timed-out run never removes its own) is
+    // unlinked, the new one is written under a temporary name, its header completed, and only then renamed into place: a
+    // file that carries the name is never truncated or half initialised under someone's mapping.  The other ranks say
+    // hello with a token of their own and take part only once the live rank 0 has answered it; a rank that mapped a
+    // stale inode gets no answer, notices that the name now belongs to another inode, and starts over with that one.
+    const int slots_cap = std::max(1, max_slots_per_rank);
+    auto map_fd = [&](int fd) -> void * {
+        void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        return q == MAP_FAILED ? nullptr : q;
+    };
+    void *p = nullptr;
     if (rank == 0) {
-        fd = open(shm_path, O_RDWR | O_CREAT | O_TRUNC, 0600);
-        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { t_comm_err = std::string("pgicp_comm_create_host: cannot create ") + shm_path; if (fd >= 0) close(fd); return PGICP_ERR_ARG; }
+        (void)unlink(shm_path);
+        const std::string tmp = std::string(shm_path) + ".init." + std::to_string((long long)getpid());
+        (void)unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { t_comm_err = std::string("pgicp_comm_create_host: cannot create ") + tmp; if (fd >= 0) { close(fd); (void)unlink(tmp.c_str()); } return PGICP_ERR_ARG; }
+        p = map_fd(fd);
+        close(fd);
+        if (!p) { t_comm_err = "pgicp_comm_create_host: mmap failed"; (void)unlink(tmp.c_str()); return PGICP_ERR_ARG; }
+        ShmHeader *H = (ShmHeader *)p;             // (a fresh file is zero-filled: all counters start at 0)
+        H->world = (uint64_t)world_size; H->max_slots = (uint64_t)slots_cap;
+        H->attached.store(1, std::memory_order_relaxed);
+        H->magic.store(kShmMagic, std::memory_order_release);
+        if (rename(tmp.c_str(), shm_path) != 0) { t_comm_err = std::string("pgicp_comm_create_host: cannot name ") + shm_path; munmap(p, bytes); (void)unlink(tmp.c_str()); return PGICP_ERR_ARG; }
+        // answer every rank's hello
+        for (int r = 1; r < world_size; r++) {
+            uint64_t tok = 0;
+            if (!spin_until([&] { tok = H->rank[r].hello.load(std::memory_order_acquire); return tok != 0; })) {
+                t_comm_err = "pgicp_comm_create_host: rank " + std::to_string(r) + " never attached";
+                munmap(p, bytes); (void)unlink(shm_path);
+                return PGICP_ERR_ARG;
+            }
+            H->rank[r].ack.store(tok, std::memory_order_release);
+        }
+        if (!spin_until([&] { return H->attached.load(std::memory_order_acquire) >= (uint64_t)world_size; })) {
+            t_comm_err = "pgicp_comm_create_host: not every rank attached";
+            munmap(p, bytes); (void)unlink(shm_path);
+            return PGICP_ERR_ARG;
+        }
     } else {
-        // rank 0 creates the file: wait until it exists at its full size
-        const bool ok = spin_until([&] {
-            fd = open(shm_path, O_RDWR);
-            if (fd < 0) return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        const uint64_t token = (((uint64_t)getpid() << 32) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)rank << 56)) | 1u;
+        bool shape_error = false;
+        for (;;) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kShmTimeoutS) break;
+            const int fd = open(shm_path, O_RDWR);
             struct stat sb;
-            if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) return true;
-            close(fd); fd = -1;
-            return false;
-        });
-        if (!ok) { t_comm_err = std::string("pgicp_comm_create_host: rank 0 never created ") + shm_path; return PGICP_ERR_ARG; }
+            if (fd < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) {       // not there yet (or a stale file of another shape)
+                if (fd >= 0) close(fd);
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+                continue;
+            }
+            void *q = map_fd(fd);
+            close(fd);
+            if (!q) { t_comm_err = "pgicp_comm_create_host: mmap failed"; return PGICP_ERR_ARG; }
+            ShmHeader *H = (ShmHeader *)q;
+            bool answered = false, replaced = false;
+            if (H->magic.load(std::memory_order_acquire) == kShmMagic) {
+                if (H->world != (uint64_t)world_size || H->max_slots != (uint64_t)slots_cap) shape_error = true;
+                else {
+                    shape_error = false;
+                    H->rank[rank].hello.store(token, std::memory_order_release);
+                    // wait for the answer; meanwhile watch whether the NAME still refers to this inode
+                    for (int k = 0; !answered && !replaced; ++k) {
+                        answered = H->rank[rank].ack.load(std::memory_order_acquire) == token;
+                        if (answered) break;
+                        if (k < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        if ((k & 255) == 255) {
+                            struct stat now;
+                            replaced = stat(shm_path, &now) != 0 || now.st_ino != sb.st_ino || now.st_dev != sb.st_dev;
+                            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kShmTimeoutS) break;
+                        }
+                    }
+                }
+            }
+            if (answered) { p = q; break; }
+            munmap(q, bytes);
+            if (!replaced) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        if (!p) {
+            t_comm_err = shape_error ? "pgicp_comm_create_host: the shared file belongs to a communicator of another shape"
+                                     : std::string("pgicp_comm_create_host: no live rank 0 answered on ") + shm_path;
+            return PGICP_ERR_ARG;
+        }
+        ((ShmHeader *)p)->attached.fetch_add(1, std::memory_order_acq_rel);
     }
-    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) { t_comm_err = "pgicp_comm_create_host: mmap failed"; return PGICP_ERR_ARG; }
     pgicp_comm *c = new pgicp_comm();
     c->host = true; c->world = world_size; c->rank = rank; c->shm = (char *)p; c->shm_bytes = bytes;
-    c->max_slots = std::max(1, max_slots_per_rank); c->shm_path = shm_path;
-    ShmHeader *H = (ShmHeader *)p;
-    if (rank == 0) {
-        // (a fresh file is zero-filled: all counters start at 0)
-        H->world = (uint64_t)world_size; H->max_slots = (uint64_t)c->max_slots;
-        H->magic.store(kShmMagic, std::memory_order_release);
-    } else if (!spin_until([&] { return H->magic.load(std::memory_order_acquire) == kShmMagic; }) ||
-               H->world != (uint64_t)world_size || H->max_slots != (uint64_t)c->max_slots) {
-        t_comm_err = "pgicp_comm_create_host: the shared file belongs to a communicator of another shape";
-        munmap(p, bytes); delete c;
-        return PGICP_ERR_ARG;
-    }
-    H->attached.fetch_add(1, std::memory_order_acq_rel);
+    c->max_slots = slots_cap; c->shm_path = shm_path;
     *out = c;
     return PGICP_OK;
 }

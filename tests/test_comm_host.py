@@ -88,6 +88,47 @@ def test_host_allgather_gives_every_rank_the_single_process_list(tmp_path, world
     assert not os.path.exists(path)          # the last rank to leave removes the file
 
 
+def stale_file(path, world, slots):
+    """what a crashed run leaves behind: a file of the right size with the magic set, counters mid-collective and garbage
+    records -- byte layout of ShmHeader in pgicp_comm.cpp (magic, world, max_slots, attached, then a 64-byte line per rank)"""
+    header = (32 + 64 * world + 64 + 4095) // 4096 * 4096
+    buf = np.zeros(header + 512 * world * max(1, slots), dtype=np.uint8)
+    buf[header:] = 0xAB
+    h = buf[:header].view(np.uint64)
+    h[0], h[1], h[2], h[3] = 0x5047494350434F4D, world, max(1, slots), world
+    for r in range(world):
+        h[8 + 8 * r] = 7          # arrived
+        h[8 + 8 * r + 1] = 7      # left
+    buf.tofile(path)
+
+
+@pytest.mark.parametrize("late_rank0", [False, True])
+def test_host_comm_ignores_a_stale_file_of_a_crashed_run(tmp_path, late_rank0):
+    """a rank must never complete a collective against the counters of a file nobody is alive behind.
+    Rank 0 makes a fresh inode and answers every rank's hello; with rank 0 started LATE the others have already mapped the
+    stale file and must move over to the new one."""
+    import time
+    world, n_pairs, rounds = 3, 20, 2
+    path = str(tmp_path / "comm.shm")
+    slots = icp.shard_slots(costs_of(n_pairs), world)
+    stale_file(path, world, slots)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=rank_main, args=(world, r, path, n_pairs, (), rounds, str(tmp_path))) for r in range(world)]
+    order = [1, 2, 0] if late_rank0 else [0, 1, 2]
+    for k, r in enumerate(order):
+        if late_rank0 and r == 0:
+            time.sleep(1.0)
+        procs[r].start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    want = expected(n_pairs, (), rounds)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"edges_{r}.npy"))
+        assert got.tobytes() == want.tobytes(), f"rank {r}"
+    assert not os.path.exists(path)
+
+
 def test_host_comm_refuses_what_does_not_fit(tmp_path):
     comm = icp.Comm.host(1, 0, str(tmp_path / "c.shm"), 2)
     local = np.zeros(3, dtype=lc.EDGE_DTYPE)

@@ -469,11 +469,12 @@ def test_max_dist_outlier_filter_in_the_chain(ctx, oracle32, small, trim_ratio, 
 
 
 @pytest.mark.gpu
-def test_host_may_look_at_the_iteration_flag_less_often(ctx, small):
+@pytest.mark.parametrize("B", [5, 1])
+def test_host_may_look_at_the_iteration_flag_less_often(ctx, small, B):
     """check_every: the convergence checkers run on the device after every iteration; how often the HOST looks at their flag
-    only decides how many (no-op) iterations it enqueues past the last one.  Transforms and statistics do not change."""
+    only decides how many (no-op) iterations it enqueues past the last one.  Transforms and statistics do not change.
+    (B = 1: the solve kernel keeps the iteration stamp itself -- also in the no-op iterations past the converged one.)"""
     w = small
-    B = 5
     rd = [w.scans_xyz[b % len(w.scans_xyz)] for b in range(B)]
     T0 = [w.T_init[b % len(w.scans_xyz)] @ synth.se3(x=0.01 * b, yaw=0.002 * b) for b in range(B)]
     m = ctx.set_map(w.map_xyz, w.map_nrm)
