@@ -1104,6 +1104,7 @@ def main():
         last = (T, st)
     fence()
     elapsed = time.perf_counter() - t0
+    sel_fallbacks = ctx.debug_counters()[3]          # (since the context's creation: warm-up included)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -1271,6 +1272,7 @@ def main():
             "fixed_30_iterations": fixed30,
             "host_input": host_input,
             "mean_iterations": iters_all / max(1, scans_all),
+            "selection_guess_misses_per_step": sel_fallbacks / max(1, args.steps + args.warmup),
             "set_map_ms": t_setmap * 1e3,
             "median_translation_error_m": float(np.median(err_t)) if err_t else None,
             "roofline": roofline,

@@ -34,9 +34,9 @@
 extern "C" {
 #endif
 
-#define PGICP_ABI_VERSION 3
+#define PGICP_ABI_VERSION 4
 
-/* status codes (pgslam sees PM::ConvergenceError for 1..2 through the C++ shim) */
+/* status codes (pgslam sees PM::ConvergenceError for 1, 2 and 7 through the C++ shim) */
 #define PGICP_OK 0
 #define PGICP_ERR_NO_MATCH 1    /* "no outlier to filter" / "no point to minimize" */
 #define PGICP_ERR_NAN 2         /* NaN in the transformation checkers */
@@ -44,6 +44,7 @@ extern "C" {
 #define PGICP_ERR_HIP 4
 #define PGICP_ERR_NO_DEVICE 5
 #define PGICP_ERR_NOT_RIGID 6   /* RigidTransformation::checkParameters failed */
+#define PGICP_ERR_BOUND 7       /* BoundTransformationChecker: limit exceeded (ConvergenceError) */
 
 #define PGICP_HOST 0
 #define PGICP_DEVICE 1
@@ -52,13 +53,19 @@ extern "C" {
 #define PGICP_MATCHER_GRID 0    /* grid-hashed exact kNN (performance path) */
 #define PGICP_MATCHER_BRUTE 1   /* LDS-tiled brute force (parity path) */
 
+#define PGICP_MINIMIZER_POINT_TO_PLANE 0   /* PointToPlane(WithCov)ErrorMinimizer */
+#define PGICP_MINIMIZER_POINT_TO_POINT 1   /* PointToPointErrorMinimizer (no covariance: the base class's zeros) */
+#define PGICP_MAX_KNN 16
+
 typedef struct pgicp_ctx pgicp_ctx;
 
 /* The ICP chain configuration: what pgslam loads from YAML through
  * icp_sequence_.loadFromYaml (Localizer.hpp:70) / icp_.loadFromYaml
  * (LoopCloser.hpp:73).  Field <- libpointmatcher module.parameter. */
 typedef struct pgicp_params {
-    int knn;                 /* KDTreeMatcher.knn; only 1 is supported */
+    int knn;                 /* KDTreeMatcher.knn, 1 .. PGICP_MAX_KNN.  With knn > 1 the matches are knn x N ([point][neighbour], in
+                              * (distance, index) order), the quantile filter runs over all knn * N distances, every pair is a
+                              * constraint of the minimiser and the ratios are over knn * N */
     double epsilon;          /* KDTreeMatcher.epsilon; only 0 (exact) is supported */
     double max_dist;         /* KDTreeMatcher.maxDist, metres; +inf allowed */
     double trim_ratio;       /* TrimmedDistOutlierFilter.ratio */
@@ -75,6 +82,12 @@ typedef struct pgicp_params {
     double quantile_scale;   /* (ABI 3) MedianDistOutlierFilter.factor: the chain's quantile filter keeps pairs with
                               * dist <= quantile_scale * getDistsQuantile(trim_ratio) (squared distances).  TrimmedDist is
                               * (trim_ratio, 1); MedianDist is (0.5, factor).  Default 1 */
+    /* (ABI 4) the other modules the chain's slots may hold */
+    int error_minimizer;     /* PGICP_MINIMIZER_POINT_TO_PLANE | PGICP_MINIMIZER_POINT_TO_POINT */
+    double bound_max_rot;    /* BoundTransformationChecker.maxRotationNorm (rad): 0 or +inf = not in the chain.  The ICP fails with */
+    double bound_max_trans;  /* PGICP_ERR_BOUND when the accumulated correction exceeds either (.maxTranslationNorm) */
+    double normal_max_angle; /* SurfaceNormalOutlierFilter.maxAngle (rad): a pair whose reading and reference normals differ by more
+                              * gets weight 0 (the weights multiply in); needs pgicp_problem.normals; 0 = not in the chain */
 } pgicp_params;
 
 /* What pgslam reads back after an ICP: errorMinimizer->getOverlap()
@@ -102,6 +115,8 @@ typedef struct pgicp_problem {
     int n;
     int mem;
     double T_init[16];
+    const void *normals;     /* (ABI 4) the reading's `normals` descriptor (same type and `mem` as `reading`), or NULL: only a */
+    int nstride;             /* SurfaceNormalOutlierFilter in the chain looks at it */
 } pgicp_problem;
 
 /* Loop-closure edge record exchanged between GPUs: the payload of
@@ -216,7 +231,8 @@ int pgicp_icp_pair_f64(pgicp_ctx *ctx, const double *reading, int rd_stride, int
  * pgicp_match = matcher->findClosests (Localizer.hpp:328, LoopCloser.hpp:358):
  * the reading is first moved by T (NULL = identity), then matched.  ids are
  * indices into the cloud given to pgicp_map_create (-1 = no neighbour within
- * maxDist), dist2 are SQUARED distances (+inf when id == -1).
+ * maxDist), dist2 are SQUARED distances (+inf when id == -1); both hold knn entries
+ * per reading point ([point][neighbour]: a knn x N column-major Matches matrix).
  * pgicp_outlier_weights = outlierFilters.compute (Localizer.hpp:330,
  * LoopCloser.hpp:360) for TrimmedDistOutlierFilter.
  * pgicp_error_stats = ErrorElements(...) + weightedPointUsedRatio
@@ -344,7 +360,8 @@ int pgicp_allgather_edges(pgicp_comm *comm, const pgicp_edge *local, const int *
 #define PGICP_PROF_COUNT 10
 /* diagnostics of the last kNN launch: [0] queries queued by the fast path, [1] queued queries
  * resolved because their existence was unknown, [2] resolved because their lower bound was
- * within the trim threshold, [3] reserved. */
+ * within the trim threshold, [3] outlier-filter selections since the last call (all contexts of the device) whose
+ * guess -- the last selection's result -- was off, so that one block selected over all of a problem's distances. */
 int pgicp_debug_counters(pgicp_ctx *ctx, int out[4]);
 /* Diagnostics: the correspondences the LAST iteration of problem `problem` of the last align call
  * ended with, in reading order (host buffers of n entries).  ids: reference index, -1 = no neighbour

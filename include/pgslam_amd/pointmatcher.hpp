@@ -74,6 +74,14 @@ template <> struct Abi<float> {
     static int map_create(pgicp_ctx *c, const float *x, int xs, const float *n, int ns, int m, int center, int *id) { return pgicp_map_create_f32(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
     static int align(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f32(c, id, r, s, n, PGICP_HOST, Ti, To, st); }
     static int align_dev(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f32(c, id, r, s, n, PGICP_DEVICE, Ti, To, st); }
+    static int align_nrm(pgicp_ctx *c, int id, const float *r, int s, int n, const float *nr, int ns, const double *Ti, double *To, pgicp_stats *st)
+    {
+        pgicp_problem p;
+        std::memset(&p, 0, sizeof p);
+        p.map_id = id; p.reading = r; p.stride = s; p.n = n; p.mem = PGICP_HOST; p.normals = nr; p.nstride = ns;
+        std::memcpy(p.T_init, Ti, sizeof p.T_init);
+        return pgicp_align_batch_f32(c, 1, &p, To, st);
+    }
     static int upload(pgicp_ctx *c, const float *host, int stride, int n, const float **dev) { return pgicp_upload_f32(c, 1, &host, &stride, &n, PGICP_HOST, dev); }
     static int match(pgicp_ctx *c, int id, const float *r, int s, int n, int32_t *ids, float *d2) { return pgicp_match_f32(c, id, r, s, n, PGICP_HOST, nullptr, ids, d2); }
     static int weights(pgicp_ctx *c, const float *d2, int n, float *w, float *lim, int *nf) { return pgicp_outlier_weights_f32(c, d2, n, PGICP_HOST, w, lim, nf); }
@@ -88,6 +96,14 @@ template <> struct Abi<double> {
     static int map_create(pgicp_ctx *c, const double *x, int xs, const double *n, int ns, int m, int center, int *id) { return pgicp_map_create_f64(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
     static int align(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f64(c, id, r, s, n, PGICP_HOST, Ti, To, st); }
     static int align_dev(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Ti, double *To, pgicp_stats *st) { return pgicp_align_f64(c, id, r, s, n, PGICP_DEVICE, Ti, To, st); }
+    static int align_nrm(pgicp_ctx *c, int id, const double *r, int s, int n, const double *nr, int ns, const double *Ti, double *To, pgicp_stats *st)
+    {
+        pgicp_problem p;
+        std::memset(&p, 0, sizeof p);
+        p.map_id = id; p.reading = r; p.stride = s; p.n = n; p.mem = PGICP_HOST; p.normals = nr; p.nstride = ns;
+        std::memcpy(p.T_init, Ti, sizeof p.T_init);
+        return pgicp_align_batch_f64(c, 1, &p, To, st);
+    }
     static int upload(pgicp_ctx *c, const double *host, int stride, int n, const double **dev) { return pgicp_upload_f64(c, 1, &host, &stride, &n, PGICP_HOST, dev); }
     static int match(pgicp_ctx *c, int id, const double *r, int s, int n, int32_t *ids, double *d2) { return pgicp_match_f64(c, id, r, s, n, PGICP_HOST, nullptr, ids, d2); }
     static int weights(pgicp_ctx *c, const double *d2, int n, double *w, double *lim, int *nf) { return pgicp_outlier_weights_f64(c, d2, n, PGICP_HOST, w, lim, nf); }
@@ -118,7 +134,7 @@ struct PointMatcher {
     {
         if (st == PGICP_OK) return;
         const std::string msg = c ? pgicp_last_error(c) : "pgicp error";
-        if (st == PGICP_ERR_NO_MATCH || st == PGICP_ERR_NAN) throw ConvergenceError(msg);
+        if (st == PGICP_ERR_NO_MATCH || st == PGICP_ERR_NAN || st == PGICP_ERR_BOUND) throw ConvergenceError(msg);
         if (st == PGICP_ERR_NOT_RIGID) throw std::runtime_error("RigidTransformation: " + msg);
         throw std::runtime_error("pgicp (" + std::to_string(st) + "): " + msg);
     }
@@ -517,7 +533,7 @@ struct PointMatcher {
         {
             if (mapId < 0) throw std::runtime_error("Matcher::findClosests: init() was not called");
             const int n = (int)filteredReading.getNbPoints();
-            Matches m(1, n);
+            Matches m(knn < 1 ? 1 : knn, n);                  // knn x N, column-major: [point][neighbour], as the ABI writes them
             chain->pushParams();
             check(chain->ctx, A::match(chain->ctx, mapId, filteredReading.xyzPtr(), filteredReading.xyzStride(), n, m.ids.data(), m.dists.data()));
             return m;
@@ -565,6 +581,34 @@ struct PointMatcher {
             OutlierWeights w(input.dists.rows(), input.dists.cols());
             const T lim = maxDist * maxDist;
             for (int j = 0; j < w.cols(); j++) for (int i = 0; i < w.rows(); i++) w(i, j) = input.dists(i, j) <= lim ? T(1) : T(0);
+            return w;
+        }
+    };
+    //! [EXT] SurfaceNormalOutlierFilter{maxAngle}: weight 0 when the angle between the (normalised) normals of a reading
+    //! point and of its matched reference point exceeds maxAngle, or the match is invalid; ones when either cloud has no
+    //! `normals` descriptor.  Inside an ICP run the device applies it (pgicp_params.normal_max_angle); this
+    //! host version serves the stage-level call of the partial chains (Localizer.hpp:330, LoopCloser.hpp:360).
+    struct SurfaceNormalOutlierFilter : OutlierFilter {
+        T maxAngle;
+        explicit SurfaceNormalOutlierFilter(T a) : maxAngle(a) {}
+        OutlierWeights compute(const DataPoints &reading, const DataPoints &reference, const Matches &input) override
+        {
+            OutlierWeights w = OutlierWeights::Constant(input.ids.rows(), input.ids.cols(), T(1));
+            if (!reading.descriptorExists("normals") || !reference.descriptorExists("normals")) return w;
+            const int rr = reading.getDescriptorStartingRow("normals"), rf = reference.getDescriptorStartingRow("normals");
+            const T eps = std::cos(maxAngle);
+            auto normalized = [](T &x, T &y, T &z) { const T zz = (x * x + y * y) + z * z; if (zz > T(0)) { const T s = std::sqrt(zz); x = x / s; y = y / s; z = z / s; } };
+            for (int j = 0; j < w.cols(); j++) {
+                T ax = reading.descriptors(rr, j), ay = reading.descriptors(rr + 1, j), az = reading.descriptors(rr + 2, j);
+                normalized(ax, ay, az);
+                for (int i = 0; i < w.rows(); i++) {
+                    const int id = input.ids(i, j);
+                    if (id < 0) { w(i, j) = T(0); continue; }
+                    T bx = reference.descriptors(rf, id), by = reference.descriptors(rf + 1, id), bz = reference.descriptors(rf + 2, id);
+                    normalized(bx, by, bz);
+                    if (((ax * bx + ay * by) + az * bz) < eps) w(i, j) = T(0);
+                }
+            }
             return w;
         }
     };
@@ -623,6 +667,7 @@ struct PointMatcher {
         ICPChainBase *chain;
         T sensorStdDev = T(0.01);
         bool withCov = false;
+        bool pointToPoint = false;       //!< PointToPointErrorMinimizer (Kabsch); else PointToPlane(WithCov)
         // state of the last ICP run / compute()
         T lastOverlap = 0; T lastResidual = 0; Matrix lastCov = Matrix::Zero(6, 6);
         explicit ErrorMinimizer(ICPChainBase *c) : chain(c) {}
@@ -648,6 +693,9 @@ struct PointMatcher {
     struct TransformationChecker { virtual ~TransformationChecker() {} std::string name; };
     struct CounterTransformationChecker : TransformationChecker { int maxIterationCount = 40; };
     struct DifferentialTransformationChecker : TransformationChecker { T minDiffRotErr = T(0.001), minDiffTransErr = T(0.001); int smoothLength = 3; };
+    //! [EXT] BoundTransformationChecker{maxRotationNorm, maxTranslationNorm}: ConvergenceError when the accumulated correction
+    //! leaves the bound
+    struct BoundTransformationChecker : TransformationChecker { T maxRotationNorm = T(1), maxTranslationNorm = T(1); };
     struct TransformationCheckers : std::vector<std::shared_ptr<TransformationChecker>> {};
 
     // ------------------------------------------------------------------ ICP chain
@@ -730,8 +778,12 @@ struct PointMatcher {
             // the chain multiplies its filters' weights (A.4): one QUANTILE filter (TrimmedDist or MedianDist) and / or one
             // MaxDist filter, in any order
             if (y.has("outlierFilters")) {
-                int n_trim = 0, n_max = 0;
+                int n_trim = 0, n_max = 0, n_nrm = 0;
                 for (auto &m : y.sections.at("outlierFilters")) {
+                    if (m.name == "SurfaceNormalOutlierFilter" && n_nrm++ == 0) {
+                        outlierFilters.push_back(std::make_shared<SurfaceNormalOutlierFilter>(m.params.count("maxAngle") ? (T)to_double(m.params.at("maxAngle"), "maxAngle") : T(1.57)));
+                        continue;
+                    }
                     if (m.name == "TrimmedDistOutlierFilter" && n_trim++ == 0)
                         outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, m.params.count("ratio") ? (T)to_double(m.params.at("ratio"), "ratio") : T(0.85)));
                     else if (m.name == "MedianDistOutlierFilter" && n_trim++ == 0) {
@@ -742,13 +794,15 @@ struct PointMatcher {
                         outlierFilters.push_back(std::make_shared<MaxDistOutlierFilter>(m.params.count("maxDist") ? (T)to_double(m.params.at("maxDist"), "maxDist") : T(1)));
                     else
                         throw std::runtime_error("loadFromYaml: unsupported outlier filter chain at " + m.name +
-                                                 " (supported: one TrimmedDistOutlierFilter or MedianDistOutlierFilter, and / or one MaxDistOutlierFilter)");
+                                                 " (supported: one TrimmedDistOutlierFilter or MedianDistOutlierFilter, and / or one MaxDistOutlierFilter, "
+                                                 "and / or one SurfaceNormalOutlierFilter)");
                 }
             } else outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
             errorMinimizer = std::make_shared<ErrorMinimizer>(this);
             if (y.has("errorMinimizer") && !y.sections.at("errorMinimizer").empty()) {
                 const auto &m = y.sections.at("errorMinimizer")[0];
                 if (m.name == "PointToPlaneWithCovErrorMinimizer") errorMinimizer->withCov = true;
+                else if (m.name == "PointToPointErrorMinimizer") errorMinimizer->pointToPoint = true;
                 else if (m.name != "PointToPlaneErrorMinimizer") throw std::runtime_error("loadFromYaml: unsupported error minimizer " + m.name);
                 for (auto &kv : m.params) {
                     if (kv.first == "sensorStdDev") errorMinimizer->sensorStdDev = (T)to_double(kv.second, "sensorStdDev");
@@ -768,6 +822,11 @@ struct PointMatcher {
                         if (m.params.count("minDiffTransErr")) c->minDiffTransErr = (T)to_double(m.params.at("minDiffTransErr"), "minDiffTransErr");
                         if (m.params.count("smoothLength")) c->smoothLength = (int)to_double(m.params.at("smoothLength"), "smoothLength");
                         transformationCheckers.push_back(c);
+                    } else if (m.name == "BoundTransformationChecker") {
+                        auto c = std::make_shared<BoundTransformationChecker>();
+                        if (m.params.count("maxRotationNorm")) c->maxRotationNorm = (T)to_double(m.params.at("maxRotationNorm"), "maxRotationNorm");
+                        if (m.params.count("maxTranslationNorm")) c->maxTranslationNorm = (T)to_double(m.params.at("maxTranslationNorm"), "maxTranslationNorm");
+                        transformationCheckers.push_back(c);
                     } else
                         throw std::runtime_error("loadFromYaml: unsupported transformation checker " + m.name);
                 }
@@ -776,8 +835,9 @@ struct PointMatcher {
                 transformationCheckers.push_back(std::make_shared<DifferentialTransformationChecker>());
             }
         }
-        //! chain objects -> pgicp_params
-        void pushParams()
+        //! chain objects -> pgicp_params.  `readingHasNormals`: a SurfaceNormalOutlierFilter only acts when both clouds carry
+        //! the `normals` descriptor (else its weights are all ones: it is left out of the device chain for that call)
+        void pushParams(bool readingHasNormals = false)
         {
             pgicp_params p;
             pgicp_default_params(&p);
@@ -792,9 +852,18 @@ struct PointMatcher {
                 if (auto md = std::dynamic_pointer_cast<MedianDistOutlierFilter>(f)) { p.trim_ratio = 0.5; p.quantile_scale = (double)md->factor; }
                 if (auto m = std::dynamic_pointer_cast<MaxDistOutlierFilter>(f)) p.outlier_max_dist = (double)m->maxDist;
             }
-            if (errorMinimizer) p.sensor_std_dev = (double)errorMinimizer->sensorStdDev;
+            if (errorMinimizer) {
+                p.sensor_std_dev = (double)errorMinimizer->sensorStdDev;
+                p.error_minimizer = errorMinimizer->pointToPoint ? PGICP_MINIMIZER_POINT_TO_POINT : PGICP_MINIMIZER_POINT_TO_PLANE;
+            }
+            for (auto &f : outlierFilters)
+                if (auto sn = std::dynamic_pointer_cast<SurfaceNormalOutlierFilter>(f))
+                    p.normal_max_angle = readingHasNormals ? (double)sn->maxAngle : 0.0;
             bool hasCounter = false, hasDiff = false;
             for (auto &c : transformationCheckers) {
+                if (auto bc = std::dynamic_pointer_cast<BoundTransformationChecker>(c)) {
+                    p.bound_max_rot = (double)bc->maxRotationNorm; p.bound_max_trans = (double)bc->maxTranslationNorm;
+                }
                 if (auto cc = std::dynamic_pointer_cast<CounterTransformationChecker>(c)) { p.max_iters = cc->maxIterationCount; hasCounter = true; }
                 if (auto dc = std::dynamic_pointer_cast<DifferentialTransformationChecker>(c)) {
                     p.min_diff_rot = (double)dc->minDiffRotErr; p.min_diff_trans = (double)dc->minDiffTransErr; p.smooth_length = dc->smoothLength; hasDiff = true;
@@ -872,8 +941,14 @@ struct PointMatcher {
             double Ti[16], To[16];
             pgslam_amd::to_row_major16(T_init, Ti);
             pgicp_stats st;
-            pushParams();
-            const int rc = A::align(ctx, matcher->mapId, reading.xyzPtr(), reading.xyzStride(), (int)reading.getNbPoints(), Ti, To, &st);
+            std::memset(&st, 0, sizeof st);
+            bool normalFilter = false;
+            for (auto &f : outlierFilters) normalFilter = normalFilter || std::dynamic_pointer_cast<SurfaceNormalOutlierFilter>(f) != nullptr;
+            const bool withNormals = normalFilter && reading.normalsPtr() != nullptr;
+            pushParams(withNormals);
+            const int rc = withNormals ? A::align_nrm(ctx, matcher->mapId, reading.xyzPtr(), reading.xyzStride(), (int)reading.getNbPoints(),
+                                                      reading.normalsPtr(), reading.normalsStride(), Ti, To, &st)
+                                       : A::align(ctx, matcher->mapId, reading.xyzPtr(), reading.xyzStride(), (int)reading.getNbPoints(), Ti, To, &st);
             storeStats(st);
             check(ctx, rc);
             const TransformationParameters T_out = pgslam_amd::from_row_major16<T>(To);
@@ -896,7 +971,8 @@ struct PointMatcher {
             this->referenceDataPointsFilters.init();
             this->referenceDataPointsFilters.apply(reference);
             this->prefilteredReferencePtsCount = reference.getNbPoints();
-            if (!reference.descriptorExists("normals")) throw std::runtime_error("PointToPlaneErrorMinimizer: the reference has no 'normals' descriptor");
+            if (!reference.descriptorExists("normals") && !(this->errorMinimizer && this->errorMinimizer->pointToPoint))
+                throw std::runtime_error("PointToPlaneErrorMinimizer: the reference has no 'normals' descriptor");
             this->matcher->initImpl(reference, 1);
             this->currentReference = &reference;
             struct Reset { const DataPoints *&p; ~Reset() { p = nullptr; } } reset{this->currentReference};
@@ -914,7 +990,8 @@ struct PointMatcher {
             this->referenceDataPointsFilters.init();
             this->referenceDataPointsFilters.apply(mapPointCloud);
             this->prefilteredReferencePtsCount = mapPointCloud.getNbPoints();
-            if (!mapPointCloud.descriptorExists("normals")) throw std::runtime_error("PointToPlaneErrorMinimizer: the map has no 'normals' descriptor");
+            if (!mapPointCloud.descriptorExists("normals") && !(this->errorMinimizer && this->errorMinimizer->pointToPoint))
+                throw std::runtime_error("PointToPlaneErrorMinimizer: the map has no 'normals' descriptor");
             this->matcher->initImpl(mapPointCloud, 1);
             this->currentReference = &mapPointCloud;
             return true;

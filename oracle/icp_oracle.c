@@ -32,6 +32,10 @@
  *   orc_covariance       getCovariance          Localizer.hpp:238,
  *                        LoopCloser.hpp:108                             [A.8]
  *   checkers             getMaxNumIterationsReached LoopCloser.hpp:317  [A.9]
+ *                        (Counter, Differential, Bound)
+ *   orc_p2point_system / orc_solve_p2point, orc_normal_weights, knn > 1
+ *                        the other modules the same chain slots may name: the chain is whatever the user's YAML says
+ *                        (loadFromYaml at Localizer.hpp:70, LoopCloser.hpp:73)  [A.3, A.4, A.6]
  *   orc_transform        rigid_transformation_->compute Localizer.hpp:106,323
  *                        LocalMap.hpp:97,222  LoopCloser.hpp:352        [a9]
  *   orc_build_local_map  LocalMap::BuildCloudFromData LocalMap.hpp:209-224 [a12]
@@ -67,6 +71,7 @@ typedef float real;
 #define ORC_ERR_NO_MATCH 1      /* "no outlier to filter" / "no point to minimize" (ConvergenceError) */
 #define ORC_ERR_NAN 2
 #define ORC_ERR_ARG 3
+#define ORC_ERR_BOUND 7         /* BoundTransformationChecker: limit exceeded (ConvergenceError) */
 
 typedef struct {
     real max_dist;          /* KDTreeMatcher.maxDist (may be +inf) */
@@ -82,6 +87,13 @@ typedef struct {
     real quantile_scale;    /* [A.4] MedianDistOutlierFilter.factor: with trim_ratio = 0.5 the chain's quantile filter is the
                              * median filter -- limit = factor * getDistsQuantile(0.5), weight = (dist <= limit), all on
                              * SQUARED distances, as [EXT] OutlierFiltersImpl.cpp writes it; 1 (or <= 0) = TrimmedDist */
+    /* ---- round 4: the rest of the chain slots a pgslam user's YAML may fill (Localizer.hpp:70, LoopCloser.hpp:73) ---- */
+    int knn;                /* [A.3] KDTreeMatcher.knn: neighbours per reading point (<= 1: one).  Matches are knn x N; every
+                             * later stage sees knn * N pairs */
+    int minimizer;          /* 0: PointToPlane(WithCov)ErrorMinimizer [A.6]; 1: PointToPointErrorMinimizer (Kabsch / SVD) */
+    double bound_max_rot;   /* [A.9] BoundTransformationChecker.maxRotationNorm (rad); <= 0 or inf: not in the chain */
+    double bound_max_trans; /* [A.9] BoundTransformationChecker.maxTranslationNorm; <= 0 or inf: not in the chain */
+    real normal_max_angle;  /* [A.4] SurfaceNormalOutlierFilter.maxAngle (rad); <= 0: not in the chain */
 } FN(orc_params);
 
 /* [A.4] the chain multiplies the weights of its outlier filters.  MaxDistOutlierFilter: weight 1 while the SQUARED
@@ -367,6 +379,19 @@ void FN(orc_kdtree_knn_k)(const void *h, const real *q, int nq, int k, real max_
     }
 }
 
+/* brute force with knn > 1: the ground truth of [A.3] for the k-d tree version above (same order, same sentinels) */
+void FN(orc_knn_brute_k)(const real *q, int nq, const real *m, int nm, int k, real max_dist, int *ids, real *d2)
+{
+    const real md2 = max_dist * max_dist;
+    for (int i = 0; i < nq; i++) {
+        kbest b = { d2 + (size_t)i * k, ids + (size_t)i * k, k };
+        for (int j = 0; j < k; j++) { b.d[j] = md2; b.i[j] = INT32_MAX; }
+        for (int j = 0; j < nm; j++) kbest_push(&b, dist2(q + 3 * i, m + 3 * j), j);
+        for (int j = 0; j < k; j++)
+            if (b.i[j] == INT32_MAX || !(b.d[j] <= md2)) { b.i[j] = -1; b.d[j] = INFINITY; }
+    }
+}
+
 /* cyclic Jacobi eigen-decomposition of a symmetric 3x3 (double): a -> diag(ev), columns of v */
 static void jacobi3(double a[3][3], double v[3][3], double ev[3])
 {
@@ -502,14 +527,18 @@ static int FN(orc_quantile_weights)(const real *d2, int n, real ratio, real scal
  *   sys[21..26] b
  *   sys[27] sum w, sys[28] kept count, sys[29] residual sum w e^2
  * ------------------------------------------------------------------------ */
-int FN(orc_p2plane_system)(const real *p, int n, const real *ref_xyz, const real *ref_nrm,
-                           const int *ids, const real *w, double *sys)
+/* knn = K neighbours per reading point: pair e = i * K + k is (reading point i, its k-th neighbour); the pairs are taken
+ * k-major (all first neighbours, then all second ones), the order ErrorElements compacts them in [A.5] */
+static int FN(p2plane_system_k)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm,
+                                const int *ids, const real *w, double *sys)
 {
     for (int i = 0; i < 30; i++) sys[i] = 0.0;
+    for (int k = 0; k < K; k++)
     for (int i = 0; i < n; i++) {
-        if (w[i] == (real)0 || ids[i] < 0) continue;
-        const int j = ids[i];
-        const double wi = (double)w[i];
+        const size_t pe = (size_t)i * K + k;
+        if (w[pe] == (real)0 || ids[pe] < 0) continue;
+        const int j = ids[pe];
+        const double wi = (double)w[pe];
         const double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
         const double nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
         const double dx = px - (double)ref_xyz[3 * j], dy = py - (double)ref_xyz[3 * j + 1],
@@ -527,6 +556,79 @@ int FN(orc_p2plane_system)(const real *p, int n, const real *ref_xyz, const real
         sys[27] += wi;
         sys[28] += 1.0;
         sys[29] += wi * (e * e);
+    }
+    return sys[28] > 0 ? ORC_OK : ORC_ERR_NO_MATCH;
+}
+int FN(orc_p2plane_system)(const real *p, int n, const real *ref_xyz, const real *ref_nrm,
+                           const int *ids, const real *w, double *sys)
+{
+    return FN(p2plane_system_k)(p, n, 1, ref_xyz, ref_nrm, ids, w, sys);
+}
+
+/* --------------------------------------------------------------------------
+ * [A.4] SurfaceNormalOutlierFilter{maxAngle}: weight 0 when the angle between the reading point's normal (rotated with the
+ * reading) and the matched reference point's normal exceeds maxAngle -- [EXT] OutlierFiltersImpl.cpp: both normals
+ * .normalized() (v / sqrt(v.v), left alone when v.v == 0), value = dot, weight = value < cos(maxAngle) ? 0 : 1; an invalid
+ * match gets 0.  Without normals on the reading the filter leaves every weight at 1.  Like every filter of the chain it
+ * sees all matches and its weights multiply in.
+ * ------------------------------------------------------------------------ */
+static inline void FN(normalized3)(const real *v, real *o)
+{
+    const real z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    if (z > (real)0) {
+#ifdef ORC_DOUBLE
+        const real s = sqrt(z);
+#else
+        const real s = sqrtf(z);
+#endif
+        o[0] = v[0] / s; o[1] = v[1] / s; o[2] = v[2] / s;
+    } else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
+}
+void FN(orc_normal_weights)(const real *rd_nrm, const real *ref_nrm, const int *ids, int n, int K, real max_angle, real *w)
+{
+    if (!(max_angle > (real)0) || !rd_nrm) return;
+#ifdef ORC_DOUBLE
+    const real eps = cos(max_angle);
+#else
+    const real eps = cosf(max_angle);
+#endif
+    for (int i = 0; i < n; i++) {
+        real a[3];
+        FN(normalized3)(rd_nrm + 3 * i, a);
+        for (int k = 0; k < K; k++) {
+            const size_t e = (size_t)i * K + k;
+            if (ids[e] < 0) { w[e] = (real)0; continue; }
+            real b[3];
+            FN(normalized3)(ref_nrm + 3 * (size_t)ids[e], b);
+            const real v = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+            if (v < eps) w[e] = (real)0;
+        }
+    }
+}
+
+/* --------------------------------------------------------------------------
+ * PointToPointErrorMinimizer ([EXT] ErrorMinimizersImpl.cpp / PointToPoint.cpp): weighted means of the kept reading and
+ * reference points, M = sum w (q - mq)(p - mp)^T, SVD M = U S V^T, R = U V^T -- with the last row of V^T negated when that is
+ * a reflection --, t = mq - R mp.  getResidualError = sum over the kept pairs of |p - q| (the norm, unweighted: "return sum
+ * of the norm of each delta").  getCovariance is the base class's: zeros.
+ *   sys[0..2] sum w p   sys[3..5] sum w q   sys[6..14] sum w q_a p_b (row major)   sys[27] sum w  sys[28] kept  sys[29] residual
+ * ------------------------------------------------------------------------ */
+int FN(orc_p2point_system)(const real *p, int n, int K, const real *ref_xyz, const int *ids, const real *w, double *sys)
+{
+    for (int i = 0; i < 30; i++) sys[i] = 0.0;
+    for (int k = 0; k < K; k++)
+    for (int i = 0; i < n; i++) {
+        const size_t e = (size_t)i * K + k;
+        if (w[e] == (real)0 || ids[e] < 0) continue;
+        const real *pp = p + 3 * i, *qq = ref_xyz + 3 * (size_t)ids[e];
+        const double wi = (double)w[e];
+        for (int a = 0; a < 3; a++) { sys[a] += wi * (double)pp[a]; sys[3 + a] += wi * (double)qq[a]; }
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) sys[6 + 3 * a + b] += wi * ((double)qq[a] * (double)pp[b]);
+        const double dx = (double)(real)(pp[0] - qq[0]), dy = (double)(real)(pp[1] - qq[1]), dz = (double)(real)(pp[2] - qq[2]);
+        sys[27] += wi;
+        sys[28] += 1.0;
+        sys[29] += sqrt((dx * dx + dy * dy) + dz * dz);
     }
     return sys[28] > 0 ? ORC_OK : ORC_ERR_NO_MATCH;
 }
@@ -652,6 +754,75 @@ void FN(orc_delta_T)(const double *x, double *T)
     T[3] = x[3]; T[7] = x[4]; T[11] = x[5];
 }
 
+/* SVD of a 3x3 through the eigen-decomposition of M^T M (cyclic Jacobi, double): singular values descending, V's columns
+ * the right singular vectors, U's columns M v / s -- completed to an orthonormal frame where M is rank deficient. */
+static void svd3(const double M[3][3], double U[3][3], double S[3], double V[3][3])
+{
+    double B[3][3], W[3][3], ev[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) B[i][j] = (M[0][i] * M[0][j] + M[1][i] * M[1][j]) + M[2][i] * M[2][j];
+    jacobi3(B, W, ev);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; a++)
+        for (int b = a + 1; b < 3; b++)
+            if (ev[ord[b]] > ev[ord[a]]) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    for (int c = 0; c < 3; c++) {
+        S[c] = ev[ord[c]] > 0.0 ? sqrt(ev[ord[c]]) : 0.0;
+        for (int r = 0; r < 3; r++) V[r][c] = W[r][ord[c]];
+    }
+    const double tol = 1e-12 * S[0];
+    int have[3] = {0, 0, 0};
+    for (int c = 0; c < 3; c++) {
+        if (!(S[c] > tol)) continue;
+        double u[3], nn = 0.0;
+        for (int r = 0; r < 3; r++) { u[r] = ((M[r][0] * V[0][c] + M[r][1] * V[1][c]) + M[r][2] * V[2][c]) / S[c]; }
+        /* Gram-Schmidt against the columns before it (they are orthogonal up to rounding already) */
+        for (int b = 0; b < c; b++)
+            if (have[b]) {
+                const double d = (u[0] * U[0][b] + u[1] * U[1][b]) + u[2] * U[2][b];
+                for (int r = 0; r < 3; r++) u[r] -= d * U[r][b];
+            }
+        nn = sqrt((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2]);
+        if (!(nn > 0.0)) continue;
+        for (int r = 0; r < 3; r++) U[r][c] = u[r] / nn;
+        have[c] = 1;
+    }
+    if (have[0] && have[1] && !have[2]) {                       /* rank 2: the third direction is the cross product */
+        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+        have[2] = 1;
+    }
+    if (!(have[0] && have[1] && have[2]))                       /* rank < 2: no rotation is determined; leave it out */
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { U[r][c] = r == c ? 1.0 : 0.0; V[r][c] = r == c ? 1.0 : 0.0; }
+}
+
+/* PointToPoint: sums -> increment (4x4).  Returns the rank of M (3, 2, or less: identity rotation). */
+int FN(orc_solve_p2point)(const double *sys, double *T)
+{
+    mat4_identity(T);
+    const double sw = sys[27];
+    if (!(sw > 0.0)) return 0;
+    double mp[3], mq[3], M[3][3], U[3][3], S[3], V[3][3];
+    for (int a = 0; a < 3; a++) { mp[a] = sys[a] / sw; mq[a] = sys[3 + a] / sw; }
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) M[a][b] = sys[6 + 3 * a + b] - sw * (mq[a] * mp[b]);
+    svd3(M, U, S, V);
+    double R[3][3];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) R[a][b] = (U[a][0] * V[b][0] + U[a][1] * V[b][1]) + U[a][2] * V[b][2];
+    const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                       R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+    if (det < 0.0)                                              /* a reflection: the second best solution, a rotation */
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) R[a][b] = (U[a][0] * V[b][0] + U[a][1] * V[b][1]) - U[a][2] * V[b][2];
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) T[4 * a + b] = R[a][b];
+        T[4 * a + 3] = mq[a] - ((R[a][0] * mp[0] + R[a][1] * mp[1]) + R[a][2] * mp[2]);
+    }
+    return S[0] > 0.0 ? (S[2] > 1e-12 * S[0] ? 3 : (S[1] > 1e-12 * S[0] ? 2 : 1)) : 0;
+}
+
 /* rotation block -> unit quaternion (w,x,y,z), Shepperd's method */
 __attribute__((unused)) static void rot_to_quat(const double *T, double *q)
 {
@@ -694,9 +865,11 @@ typedef struct {
     int n_hist;
     double quat[ORC_HIST][4];
     double trans[ORC_HIST][3];
+    double bound_rot, bound_trans;    /* BoundTransformationChecker limits; <= 0: not in the chain */
 } orc_checker;
 
 void orc_checker_init(orc_checker *c, int max_iters, double min_rot, double min_trans, int smooth);
+void orc_checker_set_bound(orc_checker *c, double max_rot, double max_trans);
 int orc_checker_check(orc_checker *c, const double *T);
 #ifndef ORC_DOUBLE   /* type-independent: defined once, in the f32 object */
 void orc_checker_init(orc_checker *c, int max_iters, double min_rot, double min_trans, int smooth)
@@ -708,7 +881,17 @@ void orc_checker_init(orc_checker *c, int max_iters, double min_rot, double min_
     c->quat[0][0] = 1.0; c->n_hist = 1;
 }
 
-/* returns: bit0 = keep iterating, bit1 = differential stop, bit2 = counter stop, bit3 = NaN */
+/* [A.9] BoundTransformationChecker{maxRotationNorm, maxTranslationNorm}: the checkers are initialised with T_iter = I
+ * (A.2), so the bound is on the accumulated correction itself: angular distance of its rotation from the identity and norm
+ * of its translation; exceeding either raises ConvergenceError.  The checkers run in the order Counter, Differential,
+ * Bound: the Counter's max-iterations condition leaves the check before the Bound is looked at. */
+void orc_checker_set_bound(orc_checker *c, double max_rot, double max_trans)
+{
+    c->bound_rot = (max_rot > 0.0 && isfinite(max_rot)) ? max_rot : 0.0;
+    c->bound_trans = (max_trans > 0.0 && isfinite(max_trans)) ? max_trans : 0.0;
+}
+
+/* returns: bit0 = keep iterating, bit1 = differential stop, bit2 = counter stop, bit3 = NaN, bit4 = bound exceeded */
 int orc_checker_check(orc_checker *c, const double *T)
 {
     int iterate = 1, flags = 0;
@@ -736,14 +919,27 @@ int orc_checker_check(orc_checker *c, const double *T)
         if (isnan(rsum) || isnan(tsum)) return 8;
         if (rsum < c->min_rot && tsum < c->min_trans) { iterate = 0; flags |= 2; }
     }
+    if (!(flags & 4) && (c->bound_rot > 0.0 || c->bound_trans > 0.0)) {
+        const double ident[4] = {1.0, 0.0, 0.0, 0.0};
+        const double *q = c->quat[c->n_hist - 1], *t = c->trans[c->n_hist - 1];
+        const double rot = quat_angdist(q, ident), tr = sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+        if ((c->bound_rot > 0.0 && rot > c->bound_rot) || (c->bound_trans > 0.0 && tr > c->bound_trans)) return 16;
+    }
     return flags | iterate;
 }
 #endif
 
 /* [A.8] PointToPlaneWithCov: Censi closed form on the kept pairs of the last
  * iteration (p = reading moved by the previous T_iter), dT = last increment. */
+static void FN(covariance_k)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm, const int *ids,
+                             const real *w, const double *dT, double sensor_std_dev, double *cov);
 void FN(orc_covariance)(const real *p, int n, const real *ref_xyz, const real *ref_nrm, const int *ids,
                         const real *w, const double *dT, double sensor_std_dev, double *cov)
+{
+    FN(covariance_k)(p, n, 1, ref_xyz, ref_nrm, ids, w, dT, sensor_std_dev, cov);
+}
+static void FN(covariance_k)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm, const int *ids,
+                             const real *w, const double *dT, double sensor_std_dev, double *cov)
 {
     double H[36], G[36];
     memset(H, 0, sizeof H); memset(G, 0, sizeof G);
@@ -751,9 +947,11 @@ void FN(orc_covariance)(const real *p, int n, const real *ref_xyz, const real *r
     const double alpha = atan2(dT[9], dT[10]);
     const double gamma = atan2(dT[4] / cos(beta), dT[0] / cos(beta));
     const double t_x = dT[3], t_y = dT[7], t_z = dT[11];
+    for (int k = 0; k < K; k++)
     for (int i = 0; i < n; i++) {
-        if (w[i] == (real)0 || ids[i] < 0) continue;
-        const int j = ids[i];
+        const size_t pe = (size_t)i * K + k;
+        if (w[pe] == (real)0 || ids[pe] < 0) continue;
+        const int j = ids[pe];
         const double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
         const double qx = ref_xyz[3 * j], qy = ref_xyz[3 * j + 1], qz = ref_xyz[3 * j + 2];
         const double nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
@@ -814,6 +1012,18 @@ void FN(orc_covariance)(const real *p, int n, const real *ref_xyz, const real *r
         }
 }
 
+/* one matcher call of the chain: K neighbours per point of `q`, ids / d2 laid out [point][neighbour] */
+static void FN(match_k)(const FN(orc_params) *prm, void *tree, const real *q, int n, const real *ref, int m, int K, int *ids, real *d2)
+{
+    if (K <= 1) {
+        if (tree) FN(orc_kdtree_knn)(tree, q, n, prm->max_dist, ids, d2);
+        else FN(orc_knn_brute)(q, n, ref, m, prm->max_dist, ids, d2);
+    } else {
+        if (tree) FN(orc_kdtree_knn_k)(tree, q, n, K, prm->max_dist, ids, d2);
+        else FN(orc_knn_brute_k)(q, n, ref, m, K, prm->max_dist, ids, d2);
+    }
+}
+
 /* partial chain used by Localizer::ComputeOverlapWith (Localizer.hpp:309-347)
  * and LoopCloser::ComputeResidualError (LoopCloser.hpp:346-364): reading is
  * moved by T, matched against the RAW (un-centred) reference, weighted, and
@@ -822,23 +1032,26 @@ int FN(orc_partial_chain)(const FN(orc_params) *prm, const real *reading, int n,
                           const real *ref_nrm, int m, const double *T, double *overlap, double *residual,
                           int *ids_out, real *d2_out)
 {
+    const int K = prm->knn > 1 ? prm->knn : 1;
+    const size_t np = (size_t)(n > 0 ? n : 1) * K;              /* ids_out / d2_out hold knn entries per point */
     real *p = (real *)malloc(sizeof(real) * 3 * (n > 0 ? n : 1));
-    int *ids = ids_out ? ids_out : (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
-    real *d2 = d2_out ? d2_out : (real *)malloc(sizeof(real) * (n > 0 ? n : 1));
-    real *w = (real *)malloc(sizeof(real) * (n > 0 ? n : 1));
+    int *ids = ids_out ? ids_out : (int *)malloc(sizeof(int) * np);
+    real *d2 = d2_out ? d2_out : (real *)malloc(sizeof(real) * np);
+    real *w = (real *)malloc(sizeof(real) * np);
     FN(orc_transform)(T, reading, p, n, 0);
-    if (prm->use_kdtree) {
-        void *t = FN(orc_kdtree_build)(ref_xyz, m);
-        FN(orc_kdtree_knn)(t, p, n, prm->max_dist, ids, d2);
-        FN(orc_kdtree_free)(t);
-    } else FN(orc_knn_brute)(p, n, ref_xyz, m, prm->max_dist, ids, d2);
+    {
+        void *t = prm->use_kdtree ? FN(orc_kdtree_build)(ref_xyz, m) : NULL;
+        FN(match_k)(prm, t, p, n, ref_xyz, m, K, ids, d2);
+        if (t) FN(orc_kdtree_free)(t);
+    }
     real limit; int nf;
-    int st = FN(orc_quantile_weights)(d2, n, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
-    if (st == ORC_OK) FN(orc_maxdist_weights)(d2, n, prm->outlier_max_dist, w);
+    int st = FN(orc_quantile_weights)(d2, n * K, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
+    if (st == ORC_OK) FN(orc_maxdist_weights)(d2, n * K, prm->outlier_max_dist, w);
     if (st == ORC_OK) {
         double sys[30];
-        st = FN(orc_p2plane_system)(p, n, ref_xyz, ref_nrm, ids, w, sys);
-        if (overlap) *overlap = sys[27] / (double)n;
+        st = prm->minimizer == 1 ? FN(orc_p2point_system)(p, n, K, ref_xyz, ids, w, sys)
+                                 : FN(p2plane_system_k)(p, n, K, ref_xyz, ref_nrm, ids, w, sys);
+        if (overlap) *overlap = sys[27] / ((double)n * K);
         if (residual) *residual = sys[29];
     }
     free(p); free(w);
@@ -884,8 +1097,17 @@ void FN(orc_map_free)(void *h)
     free(M->ref); free(M);
 }
 
+int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *reading, const real *reading_nrm, int n,
+                       const double *T_init, double *T_out, orc_result *res, double *trace, int trace_cap, int *last_ids, real *last_d2);
 int FN(orc_icp_map)(const FN(orc_params) *prm, const void *map, const real *reading, int n, const double *T_init,
                     double *T_out, orc_result *res, double *trace, int trace_cap, int *last_ids, real *last_d2)
+{
+    return FN(orc_icp_map_ex)(prm, map, reading, NULL, n, T_init, T_out, res, trace, trace_cap, last_ids, last_d2);
+}
+/* `reading_nrm` (optional): the reading's `normals` descriptor, which RigidTransformation rotates with the points (a9) and the
+ * SurfaceNormalOutlierFilter compares with the reference's; last_ids / last_d2 hold knn entries per point */
+int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *reading, const real *reading_nrm, int n,
+                       const double *T_init, double *T_out, orc_result *res, double *trace, int trace_cap, int *last_ids, real *last_d2)
 {
     const FN(orc_map) *M = (const FN(orc_map) *)map;
     memset(res, 0, sizeof *res);
@@ -898,36 +1120,49 @@ int FN(orc_icp_map)(const FN(orc_params) *prm, const void *map, const real *read
     mat4_rigid_inverse(T_ref_mean, T_ref_mean_inv);
     mat4_mul(T_ref_mean_inv, T_init, T_pre);
 
+    const int K = prm->knn > 1 ? prm->knn : 1;
+    const size_t np = (size_t)n * K;
     real *rd = (real *)malloc(sizeof(real) * 3 * n);       /* reading in centred-map frame */
     real *step = (real *)malloc(sizeof(real) * 3 * n);
-    int *ids = (int *)malloc(sizeof(int) * n);
-    real *d2 = (real *)malloc(sizeof(real) * n);
-    real *w = (real *)malloc(sizeof(real) * n);
+    int *ids = (int *)malloc(sizeof(int) * np);
+    real *d2 = (real *)malloc(sizeof(real) * np);
+    real *w = (real *)malloc(sizeof(real) * np);
     FN(orc_transform)(T_pre, reading, rd, n, 0);
+    const int use_nrm = reading_nrm && prm->normal_max_angle > (real)0;
+    real *rd_n = use_nrm ? (real *)malloc(sizeof(real) * 3 * n) : NULL, *step_n = use_nrm ? (real *)malloc(sizeof(real) * 3 * n) : NULL;
+    if (use_nrm) FN(orc_transform)(T_pre, reading_nrm, rd_n, n, 1);
 
     void *tree = M->tree;
     double T_iter[16], dT[16], T_prev[16];
     mat4_identity(T_iter); mat4_identity(dT); mat4_identity(T_prev);
     orc_checker chk;
     orc_checker_init(&chk, prm->max_iters, prm->min_diff_rot, prm->min_diff_trans, prm->smooth_length);
+    orc_checker_set_bound(&chk, prm->bound_max_rot, prm->bound_max_trans);
     int status = ORC_OK, iterate = 1, it = 0;
     double sys[30];
     while (iterate) {
         FN(orc_transform)(T_iter, rd, step, n, 0);
-        if (tree) FN(orc_kdtree_knn)(tree, step, n, prm->max_dist, ids, d2);
-        else FN(orc_knn_brute)(step, n, ref, m, prm->max_dist, ids, d2);
+        if (use_nrm) FN(orc_transform)(T_iter, rd_n, step_n, n, 1);
+        FN(match_k)(prm, tree, step, n, ref, m, K, ids, d2);
         real limit; int nf;
-        status = FN(orc_quantile_weights)(d2, n, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
+        status = FN(orc_quantile_weights)(d2, n * K, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
         if (status != ORC_OK) break;
-        FN(orc_maxdist_weights)(d2, n, prm->outlier_max_dist, w);
-        status = FN(orc_p2plane_system)(step, n, ref, ref_nrm, ids, w, sys);
-        if (status != ORC_OK) break;
-        double x[6]; int rank;
-        FN(orc_solve6)(sys, x, &rank);
-        FN(orc_delta_T)(x, dT);
+        FN(orc_maxdist_weights)(d2, n * K, prm->outlier_max_dist, w);
+        if (use_nrm) FN(orc_normal_weights)(step_n, ref_nrm, ids, n, K, prm->normal_max_angle, w);
+        if (prm->minimizer == 1) {
+            status = FN(orc_p2point_system)(step, n, K, ref, ids, w, sys);
+            if (status != ORC_OK) break;
+            FN(orc_solve_p2point)(sys, dT);
+        } else {
+            status = FN(p2plane_system_k)(step, n, K, ref, ref_nrm, ids, w, sys);
+            if (status != ORC_OK) break;
+            double x[6]; int rank;
+            FN(orc_solve6)(sys, x, &rank);
+            FN(orc_delta_T)(x, dT);
+        }
         memcpy(T_prev, T_iter, sizeof T_iter);
         mat4_mul(dT, T_iter, T_iter);
-        res->overlap = sys[27] / (double)n;
+        res->overlap = sys[27] / ((double)n * K);
         res->residual = sys[29];
         res->trim_limit = (double)limit;
         if (prm->outlier_max_dist > (real)0 && !isinf(prm->outlier_max_dist) && prm->outlier_max_dist * prm->outlier_max_dist < limit)
@@ -938,6 +1173,7 @@ int FN(orc_icp_map)(const FN(orc_params) *prm, const void *map, const real *read
         it++;
         const int f = orc_checker_check(&chk, T_iter);
         if (f & 8) { status = ORC_ERR_NAN; break; }
+        if (f & 16) { status = ORC_ERR_BOUND; break; }
         iterate = f & 1;
         if (f & 2) res->converged = 1;
         if (f & 4) res->max_iter_reached = 1;
@@ -945,25 +1181,33 @@ int FN(orc_icp_map)(const FN(orc_params) *prm, const void *map, const real *read
     res->iterations = it;
     res->status = status;
     if (status == ORC_OK) {
-        /* covariance on the last iteration's error elements (step = T_prev*rd) */
-        FN(orc_covariance)(step, n, ref, ref_nrm, ids, w, dT, prm->sensor_std_dev, res->cov);
+        /* covariance on the last iteration's error elements (step = T_prev*rd); the point-to-point minimiser has the base
+         * class's getCovariance: zeros */
+        if (prm->minimizer == 1) memset(res->cov, 0, sizeof res->cov);
+        else FN(covariance_k)(step, n, K, ref, ref_nrm, ids, w, dT, prm->sensor_std_dev, res->cov);
         double t1[16];
         mat4_mul(T_iter, T_pre, t1);
         mat4_mul(T_ref_mean, t1, T_out);
     } else mat4_identity(T_out);
-    if (last_ids) memcpy(last_ids, ids, sizeof(int) * n);
-    if (last_d2) memcpy(last_d2, d2, sizeof(real) * n);
-    free(rd); free(step); free(ids); free(d2); free(w);
+    if (last_ids) memcpy(last_ids, ids, sizeof(int) * np);
+    if (last_d2) memcpy(last_d2, d2, sizeof(real) * np);
+    free(rd); free(step); free(ids); free(d2); free(w); free(rd_n); free(step_n);
     return status;
 }
 
+int FN(orc_icp_ex)(const FN(orc_params) *prm, const real *reading, const real *reading_nrm, int n, const real *ref_xyz_in,
+                   const real *ref_nrm, int m, const double *T_init, double *T_out, orc_result *res,
+                   double *trace, int trace_cap, int *last_ids, real *last_d2)
+{
+    if (n <= 0 || m <= 0) { memset(res, 0, sizeof *res); res->status = ORC_ERR_ARG; return ORC_ERR_ARG; }
+    void *M = FN(orc_map_create)(ref_xyz_in, ref_nrm, m, prm->center_reference, prm->use_kdtree);
+    const int st = FN(orc_icp_map_ex)(prm, M, reading, reading_nrm, n, T_init, T_out, res, trace, trace_cap, last_ids, last_d2);
+    FN(orc_map_free)(M);
+    return st;
+}
 int FN(orc_icp)(const FN(orc_params) *prm, const real *reading, int n, const real *ref_xyz_in,
                 const real *ref_nrm, int m, const double *T_init, double *T_out, orc_result *res,
                 double *trace, int trace_cap, int *last_ids, real *last_d2)
 {
-    if (n <= 0 || m <= 0) { memset(res, 0, sizeof *res); res->status = ORC_ERR_ARG; return ORC_ERR_ARG; }
-    void *M = FN(orc_map_create)(ref_xyz_in, ref_nrm, m, prm->center_reference, prm->use_kdtree);
-    const int st = FN(orc_icp_map)(prm, M, reading, n, T_init, T_out, res, trace, trace_cap, last_ids, last_d2);
-    FN(orc_map_free)(M);
-    return st;
+    return FN(orc_icp_ex)(prm, reading, NULL, n, ref_xyz_in, ref_nrm, m, T_init, T_out, res, trace, trace_cap, last_ids, last_d2);
 }

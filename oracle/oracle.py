@@ -37,14 +37,16 @@ def _params_type(real):
                     ("min_diff_rot", C.c_double), ("min_diff_trans", C.c_double),
                     ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double),
                     ("use_kdtree", C.c_int), ("center_reference", C.c_int), ("outlier_max_dist", real),
-                    ("quantile_scale", real)]
+                    ("quantile_scale", real), ("knn", C.c_int), ("minimizer", C.c_int), ("bound_max_rot", C.c_double),
+                    ("bound_max_trans", C.c_double), ("normal_max_angle", real)]
     return Params
 
 
 class Checker(C.Structure):
     _fields_ = [("count", C.c_int), ("max_iters", C.c_int), ("smooth", C.c_int),
                 ("min_rot", C.c_double), ("min_trans", C.c_double), ("n_hist", C.c_int),
-                ("quat", C.c_double * (64 * 4)), ("trans", C.c_double * (64 * 3))]
+                ("quat", C.c_double * (64 * 4)), ("trans", C.c_double * (64 * 3)),
+                ("bound_rot", C.c_double), ("bound_trans", C.c_double)]
 
 
 DEFAULT_CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001,
@@ -77,7 +79,9 @@ class Oracle:
         d.update(kw)
         return self.Params(d["max_dist"], d["trim_ratio"], d["max_iters"], d["min_diff_rot"],
                            d["min_diff_trans"], d["smooth_length"], d["sensor_std_dev"],
-                           int(use_kdtree), int(center_reference), d.get("outlier_max_dist", 0.0), d.get("quantile_scale", 1.0))
+                           int(use_kdtree), int(center_reference), d.get("outlier_max_dist", 0.0), d.get("quantile_scale", 1.0),
+                           int(d.get("knn", 1)), int(d.get("error_minimizer", 0)), float(d.get("bound_max_rot", 0.0)),
+                           float(d.get("bound_max_trans", 0.0)), float(d.get("normal_max_angle", 0.0)))
 
     # -- stages -----------------------------------------------------------
     def transform(self, T, pts, rotate_only=False):
@@ -111,6 +115,41 @@ class Oracle:
                                   self._p(ids), self._p(d2))
         self._f("orc_kdtree_free")(C.c_void_p(t))
         return ids, d2
+
+    def knn_brute_k(self, q, m, k, max_dist=np.inf):
+        """brute-force k nearest neighbours: (ids (n,k), d2 (n,k)) in (d2, index) order, -1 / +inf where fewer lie within maxDist"""
+        q, m = self._a(q), self._a(m)
+        ids = np.empty((q.shape[0], k), dtype=np.int32)
+        d2 = np.empty((q.shape[0], k), dtype=self.dtype)
+        self._f("orc_knn_brute_k")(self._p(q), C.c_int(q.shape[0]), self._p(m), C.c_int(m.shape[0]), C.c_int(k),
+                                   self.real(max_dist), self._p(ids), self._p(d2))
+        return ids, d2
+
+    def normal_weights(self, rd_nrm, ref_nrm, ids, max_angle, w=None):
+        """[EXT] SurfaceNormalOutlierFilter{maxAngle}: multiplies its weights into w (ones by default); ids (n,) or (n,k)"""
+        rd_nrm, ref_nrm = self._a(rd_nrm), self._a(ref_nrm)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        k = 1 if ids.ndim == 1 else ids.shape[1]
+        w = np.ones(ids.shape, dtype=self.dtype) if w is None else np.ascontiguousarray(w, dtype=self.dtype).copy()
+        self._f("orc_normal_weights")(self._p(rd_nrm), self._p(ref_nrm), self._p(ids), C.c_int(rd_nrm.shape[0]), C.c_int(k),
+                                      self.real(max_angle), self._p(w))
+        return w
+
+    def p2point_system(self, p, ref_xyz, ids, w):
+        p, ref_xyz = self._a(p), self._a(ref_xyz)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        w = np.ascontiguousarray(w, dtype=self.dtype)
+        k = 1 if ids.ndim == 1 else ids.shape[1]
+        sys_ = np.zeros(30, dtype=np.float64)
+        st = self._f("orc_p2point_system")(self._p(p), C.c_int(p.shape[0]), C.c_int(k), self._p(ref_xyz), self._p(ids), self._p(w),
+                                           self._p(sys_))
+        return st, sys_
+
+    def solve_p2point(self, sys_):
+        sys_ = np.ascontiguousarray(sys_, dtype=np.float64)
+        T = np.zeros((4, 4))
+        rank = self._f("orc_solve_p2point")(self._p(sys_), self._p(T))
+        return T, rank
 
     def trim_weights(self, d2, ratio):
         d2 = np.ascontiguousarray(d2, dtype=self.dtype)
@@ -207,26 +246,33 @@ class Oracle:
         prm = self.params(**kw)
         T = np.ascontiguousarray(T, dtype=np.float64)
         ov, rs = C.c_double(0), C.c_double(0)
-        ids = np.empty(reading.shape[0], dtype=np.int32)
-        d2 = np.empty(reading.shape[0], dtype=self.dtype)
+        k = max(1, int(prm.knn))
+        shape = (reading.shape[0],) if k == 1 else (reading.shape[0], k)
+        ids = np.empty(shape, dtype=np.int32)
+        d2 = np.empty(shape, dtype=self.dtype)
         st = self._f("orc_partial_chain")(C.byref(prm), self._p(reading), C.c_int(reading.shape[0]), self._p(ref_xyz),
                                           self._p(ref_nrm), C.c_int(ref_xyz.shape[0]), self._p(T), C.byref(ov),
                                           C.byref(rs), self._p(ids), self._p(d2))
         return dict(status=st, overlap=ov.value, residual=rs.value, ids=ids, d2=d2)
 
-    def icp(self, reading, ref_xyz, ref_nrm, T_init, trace=False, **kw):
+    def icp(self, reading, ref_xyz, ref_nrm, T_init, trace=False, reading_nrm=None, **kw):
+        """reading_nrm: the reading's `normals` descriptor (only the SurfaceNormalOutlierFilter looks at it); with knn > 1
+        last_ids / last_d2 are (n, knn)"""
         reading, ref_xyz, ref_nrm = self._a(reading), self._a(ref_xyz), self._a(ref_nrm)
+        rn = self._a(reading_nrm) if reading_nrm is not None else None
         prm = self.params(**kw)
         T_init = np.ascontiguousarray(T_init, dtype=np.float64)
         T_out = np.zeros((4, 4))
         res = Result()
         cap = prm.max_iters if trace else 0
         tr = np.zeros((max(cap, 1), 4, 4))
-        ids = np.empty(reading.shape[0], dtype=np.int32)
-        d2 = np.empty(reading.shape[0], dtype=self.dtype)
-        st = self._f("orc_icp")(C.byref(prm), self._p(reading), C.c_int(reading.shape[0]), self._p(ref_xyz),
-                                self._p(ref_nrm), C.c_int(ref_xyz.shape[0]), self._p(T_init), self._p(T_out),
-                                C.byref(res), self._p(tr) if trace else None, C.c_int(cap), self._p(ids), self._p(d2))
+        k = max(1, int(prm.knn))
+        shape = (reading.shape[0],) if k == 1 else (reading.shape[0], k)
+        ids = np.empty(shape, dtype=np.int32)
+        d2 = np.empty(shape, dtype=self.dtype)
+        st = self._f("orc_icp_ex")(C.byref(prm), self._p(reading), self._p(rn) if rn is not None else None, C.c_int(reading.shape[0]),
+                                   self._p(ref_xyz), self._p(ref_nrm), C.c_int(ref_xyz.shape[0]), self._p(T_init), self._p(T_out),
+                                   C.byref(res), self._p(tr) if trace else None, C.c_int(cap), self._p(ids), self._p(d2))
         out = dict(status=st, T=T_out, iterations=res.iterations, converged=bool(res.converged),
                    max_iter_reached=bool(res.max_iter_reached), overlap=res.overlap, residual=res.residual,
                    trim_limit=res.trim_limit, n_kept=res.n_kept, n_finite=res.n_finite,
@@ -261,6 +307,9 @@ class Oracle:
         c = Checker()
         self.lib.orc_checker_init(C.byref(c), C.c_int(max_iters), C.c_double(min_rot), C.c_double(min_trans), C.c_int(smooth))
         return c
+
+    def checker_set_bound(self, c, max_rot, max_trans):
+        self.lib.orc_checker_set_bound(C.byref(c), C.c_double(max_rot), C.c_double(max_trans))
 
     def checker_check(self, c, T):
         T = np.ascontiguousarray(T, dtype=np.float64)

@@ -58,7 +58,8 @@ struct BuildDesc {
     GridDesc<T> g;
     long long pbase, cbase, sbase, fbase;   // fbase: offset of this cloud's FINE cells (+1 sentinel) in the fine table
     long long obase;                        // offset (32-bit words) of this cloud's occupancy bits
-    int ncells, nsc, kx, ncells_f;
+    long long bbase;                        // offset of this cloud's BINS (512 fine cells each) in the build's counting sort
+    int ncells, nsc, kx, ncells_f, nbins;
 };
 
 // Chain parameters as the kernels need them.
@@ -73,6 +74,12 @@ struct ChainDev {
     int smooth;
     double min_rot, min_trans;
     double rank_rel_tol; // 6 * eps(T)
+    // the other modules the chain's slots may hold (ABI 4)
+    int knn;             // KDTreeMatcher.knn: neighbours per reading point; > 1: the top-K matcher, pairs laid out [point][neighbour]
+    int minimizer;       // 0 PointToPlane(WithCov), 1 PointToPoint
+    double bound_rot, bound_trans;   // BoundTransformationChecker limits; <= 0: not in the chain
+    T normal_cos;        // SurfaceNormalOutlierFilter: cos(maxAngle) evaluated in T on the host
+    int use_normals;     // ... and whether it is in the chain
 };
 
 // One ICP problem of a batch.  Lives in device memory; written by the solve
@@ -80,6 +87,8 @@ struct ChainDev {
 struct ProblemDev {
     int map;                 // slot in the MapDev table
     int n;                   // reading points
+    int knn;                 // neighbours per reading point (ChainDev::knn): the per-PAIR arrays (slot, d2, selection keys) hold
+    int pad_knn_;            // n * knn entries from offset off * knn on (pairs_n / pairs_off)
     long long off;           // offset (in points) of this problem in the packed per-point arrays
     double Tpre[16];         // T_refMean^-1 * T_init (applied once per scan, cast to T)
     double T_iter[16];       // accumulated correction in the centred map frame
@@ -98,6 +107,8 @@ struct ProblemDev {
     double rlimit;           // what the matcher must be exact up to for that: max(quantile, limit) -- equal to `limit` for the
                              // TrimmedDist filter; larger with a MedianDist factor below 1 or a MaxDist filter below the quantile
     double prev_limit;       // the `rlimit` the last fast matcher pass derived its search cap from
+    double qraw;             // the order statistic the last selection found (before the filter's scale): the next selection's
+                             // guess -- it compacts only a band of distances around it (k_sel_band); 0: no guess yet
     double sys[kSys];        // final sums of the last iteration
     Checker chk;
 };
@@ -106,9 +117,11 @@ struct ProblemDev {
 #define PGICP_ST_OK 0
 #define PGICP_ST_NO_MATCH 1
 #define PGICP_ST_NAN 2
+#define PGICP_ST_BOUND 3     // BoundTransformationChecker's limit exceeded (PGICP_ERR_BOUND at the ABI)
 
 struct Mat34 { double v[12]; };                    // row-major 3x4, kernel argument
-struct SrcDesc { const void *ptr; int stride; int pad_; };   // where a problem's reading lives (device)
+// where a problem's reading lives (device); nptr: its `normals` descriptor, or null
+struct SrcDesc { const void *ptr; int stride; int nstride; const void *nptr; };
 
 #ifndef PGICP_REDUCE_ROUNDS
 #define PGICP_REDUCE_ROUNDS 2

@@ -219,8 +219,11 @@ PGICP_HD void checker_init(Checker &c)
     c.quat[0][0] = 1.0;   // checkers.init(T_iter = I)
 }
 
-// bit0 keep iterating, bit1 differential stop, bit2 counter stop, bit3 NaN
-PGICP_HD int checker_check(Checker &c, const double *T, int max_iters, double min_rot, double min_trans, int smooth)
+// bit0 keep iterating, bit1 differential stop, bit2 counter stop, bit3 NaN, bit4 BoundTransformationChecker's limit exceeded
+// (bound_rot / bound_trans <= 0: that checker is not in the chain).  The checkers run in the order Counter, Differential,
+// Bound; the Counter's max-iterations condition leaves the check before the Bound is looked at.
+PGICP_HD int checker_check(Checker &c, const double *T, int max_iters, double min_rot, double min_trans, int smooth,
+                           double bound_rot = 0.0, double bound_trans = 0.0)
 {
     int iterate = 1, flags = 0;
     c.count++;
@@ -248,7 +251,100 @@ PGICP_HD int checker_check(Checker &c, const double *T, int max_iters, double mi
         if (rsum != rsum || tsum != tsum) return 8;
         if (rsum < min_rot && tsum < min_trans) { iterate = 0; flags |= 2; }
     }
+    if (!(flags & 4) && (bound_rot > 0.0 || bound_trans > 0.0)) {
+        // the checkers were initialised with T_iter = I: the bound is on the accumulated correction itself
+        const double ident[4] = {1.0, 0.0, 0.0, 0.0};
+        const double *q = c.quat[c.n_hist - 1], *t = c.trans[c.n_hist - 1];
+        const double rot = quat_angular_distance(q, ident), tr = sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+        if ((bound_rot > 0.0 && rot > bound_rot) || (bound_trans > 0.0 && tr > bound_trans)) return 16;
+    }
     return flags | iterate;
+}
+
+// ---- PointToPointErrorMinimizer: weighted Kabsch ------------------------------------------------------------------
+// cyclic Jacobi on a symmetric 3x3 (columns of v: eigenvectors; a's diagonal: eigenvalues)
+PGICP_HD void jacobi3_sym(double a[3][3], double v[3][3])
+{
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) v[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; sweep++) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                for (int r = 0; r < 3; r++) { const double arp = a[r][p], arq = a[r][q]; a[r][p] = c * arp - s * arq; a[r][q] = s * arp + c * arq; }
+                for (int r = 0; r < 3; r++) { const double apr = a[p][r], aqr = a[q][r]; a[p][r] = c * apr - s * aqr; a[q][r] = s * apr + c * aqr; }
+                for (int r = 0; r < 3; r++) { const double vrp = v[r][p], vrq = v[r][q]; v[r][p] = c * vrp - s * vrq; v[r][q] = s * vrp + c * vrq; }
+            }
+    }
+}
+
+// sums of the kept pairs (sys[0..2] sum w p, [3..5] sum w q, [6..14] sum w q_a p_b, [27] sum w) -> the increment: means,
+// M = sum w (q - mq)(p - mp)^T, SVD through the eigen-decomposition of M^T M, R = U V^T (third singular pair negated when
+// that is a reflection), t = mq - R mp.  Returns the rank of M (below 2 no rotation is determined: identity rotation).
+PGICP_HD int solve_p2point(const double *sys, double *T)
+{
+    mat4_identity(T);
+    const double sw = sys[27];
+    if (!(sw > 0.0)) return 0;
+    double mp[3], mq[3], M[3][3], B[3][3], W[3][3];
+    for (int a = 0; a < 3; a++) { mp[a] = sys[a] / sw; mq[a] = sys[3 + a] / sw; }
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) M[a][b] = sys[6 + 3 * a + b] - sw * (mq[a] * mp[b]);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) B[i][j] = (M[0][i] * M[0][j] + M[1][i] * M[1][j]) + M[2][i] * M[2][j];
+    jacobi3_sym(B, W);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; a++)
+        for (int b = a + 1; b < 3; b++)
+            if (B[ord[b]][ord[b]] > B[ord[a]][ord[a]]) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    double S[3], U[3][3], V[3][3];
+    for (int c = 0; c < 3; c++) {
+        const double ev = B[ord[c]][ord[c]];
+        S[c] = ev > 0.0 ? sqrt(ev) : 0.0;
+        for (int r = 0; r < 3; r++) { V[r][c] = W[r][ord[c]]; U[r][c] = 0.0; }
+    }
+    const double tol = 1e-12 * S[0];
+    bool have[3] = {false, false, false};
+    for (int c = 0; c < 3; c++) {
+        if (!(S[c] > tol)) continue;
+        double u[3];
+        for (int r = 0; r < 3; r++) u[r] = ((M[r][0] * V[0][c] + M[r][1] * V[1][c]) + M[r][2] * V[2][c]) / S[c];
+        for (int b = 0; b < c; b++)
+            if (have[b]) {
+                const double d = (u[0] * U[0][b] + u[1] * U[1][b]) + u[2] * U[2][b];
+                for (int r = 0; r < 3; r++) u[r] -= d * U[r][b];
+            }
+        const double nn = sqrt((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2]);
+        if (!(nn > 0.0)) continue;
+        for (int r = 0; r < 3; r++) U[r][c] = u[r] / nn;
+        have[c] = true;
+    }
+    if (have[0] && have[1] && !have[2]) {
+        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+        have[2] = true;
+    }
+    const int rank = S[0] > 0.0 ? (S[2] > tol ? 3 : (S[1] > tol ? 2 : 1)) : 0;
+    double R[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+    if (have[0] && have[1] && have[2]) {
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) R[a][b] = (U[a][0] * V[b][0] + U[a][1] * V[b][1]) + U[a][2] * V[b][2];
+        const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                           R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+        if (det < 0.0)
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) R[a][b] = (U[a][0] * V[b][0] + U[a][1] * V[b][1]) - U[a][2] * V[b][2];
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) T[4 * a + b] = R[a][b];
+        T[4 * a + 3] = mq[a] - ((R[a][0] * mp[0] + R[a][1] * mp[1]) + R[a][2] * mp[2]);
+    }
+    return rank;
 }
 
 // inverse of a general 6x6 (Gauss-Jordan, partial pivoting); returns false if singular

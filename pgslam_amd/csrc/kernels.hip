@@ -94,9 +94,42 @@ template <typename T> __device__ __forceinline__ auto tcur_prev_of(const Problem
     if constexpr (sizeof(T) == 4) return (const float *)P.Tcur_prev_f; else return (const double *)P.Tcur_prev;
 }
 
+// map arrays are reached through pointers stored in a struct, which the compiler can only treat as
+// generic (flat) addresses; they are always device-global memory, and global loads do not occupy
+// the LDS counter
+template <typename V>
+__device__ __forceinline__ const __attribute__((address_space(1))) V *as_global(const V *p)
+{
+    return (const __attribute__((address_space(1))) V *)p;
+}
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Raw4<double> { typedef double type __attribute__((ext_vector_type(4))); };
+// One aligned 16/32-byte global load of a map record.  (A uniform base in SGPRs + a 32-bit byte offset per lane --
+// `global_load_dwordx4 v, v_off, s[base:base+1]`, two VALU instructions fewer per load -- measured neutral, 8.53-8.63 against
+// 8.57-8.64 ms per step, and it would cap the shared point array of a batched build at 2^32 bytes:
+// tools/experiments/r03_e4_*.)
+template <typename T, int K = 0>
+__device__ __forceinline__ typename Vec4<T>::type load_rec(const typename Vec4<T>::type *p, int j)
+{
+    using R4 = typename Raw4<T>::type;
+    const R4 r = as_global(reinterpret_cast<const R4 *>(p))[j + K];
+    return make_v4(r.x, r.y, r.z, r.w);
+}
+// the same for the int tables (the cell tables of ONE map: fewer than 2^30 entries by construction)
+__device__ __forceinline__ int load_tab(const int *p, int i)
+{
+    return as_global(p)[i];
+}
+
+// The per-PAIR arrays (slot, d2, the selection's keys): knn entries per reading point, [point][neighbour]
+__device__ __forceinline__ int pairs_n(const ProblemDev &P) { return P.n * P.knn; }
+__device__ __forceinline__ long long pairs_off(const ProblemDev &P) { return P.off * P.knn; }
+
 // The kernels, by stage (all part of this translation unit):
 #include "k_build.inc"
 #include "k_sort.inc"
+#include "k_mapbuild.inc"
 #include "k_match.inc"
 #include "k_normals.inc"
 #include "k_select.inc"

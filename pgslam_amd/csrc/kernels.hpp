@@ -7,19 +7,22 @@ namespace pgicp {
 template <typename T>
 void launch_centroid_bbox_batch(hipStream_t st, const BuildDesc<T> *descs, int n, int max_m, unsigned long long *stats);
 template <typename T>
-void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_f, long long tot_s,
-                             int max_m, int max_cells, int max_cells_f, int max_nsc, int max_blocks, int *cell_of, int *counts, int *block_sums,
-                             int *cell_start, int *cell_start_f, int *cursor, int *order_tmp, typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
+void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, long long tot_m, long long tot_b, long long tot_s,
+                             int max_m, int max_cells, int max_bins, int max_nsc, int max_blocks, int kx_all4, int *fkey, int *bins_a, int *block_sums,
+                             int *cell_start, int *cell_start_f, int *bins_b, int *arrival, unsigned long long *words,
+                             typename Vec4<T>::type *cpts, typename Vec4<T>::type *cnrm,
+                             typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
                              int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit, unsigned *occ, long long tot_o, float *sc_ext);
 template <typename T>
-void launch_query_sort(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, T *rd_sorted,
-                       int *qrow, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int *cursor, int P,
-                       int max_n, int max_rows, int bin_shift);
+void launch_query_sort(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, const MapDev<T> *maps, typename Vec4<T>::type *rd_pre, T *rd_sorted,
+                       int *qkey, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int P,
+                       int max_n, int max_rows, int bin_shift, typename Vec4<T>::type *nrm_pre, T *nrm_sorted);
+template <typename T>
+int launch_knn_topk(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,
+                    const ChainDev<T> &ch, int P, int max_n, const int *active);
 template <typename T>
 void launch_transform(hipStream_t st, const T *in, int in_stride, T *out, int out_stride, int n, const double *T16,
                       int rotate_only);
-template <typename T>
-void launch_pretransform(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, T *rd_pre, int P, int max_n);
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
@@ -35,8 +38,9 @@ void launch_knn_slow(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, c
                      const int *slow2_idx, int exact_all, T *none_r);
 template <typename T>
 void launch_trim_select(hipStream_t st, ProblemDev *probs, const T *d2, const ChainDev<T> &ch, int P, int max_n, int second,
-                        const int *active, int *tables, void *keys, int *seg_count);
+                        const int *active, int *tables, void *keys, int *seg_count, int guess);
 size_t trim_select_table_bytes(int P);
+int sel_fallbacks_read(int reset);
 int knn_stats_read(unsigned long long out[56], int reset);
 int knn_phase_read(unsigned long long out[48], int reset);   // diagnostics build only: wave cycles per phase of the fast kernel
 int knn_dump_setup(long long total, int passes);              // diagnostics build only: per-query candidate dump
@@ -49,23 +53,25 @@ int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m
                            int out_stride, T *out_eig, int *out_ids, T *out_d2);
 int reduce_blocks(int max_n);
 template <typename T>
-void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
-                   const T *d2, double *partials, int P, int max_n, const int *active);
+void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const T *rd_nrm, const int *slot,
+                   const T *d2, double *partials, int P, int max_n, const int *active, const ChainDev<T> &ch);
 template <typename T>
 void launch_solve(hipStream_t st, ProblemDev *probs, const double *partials, const ChainDev<T> &ch, int *n_done, int P,
                   int max_n, const int *active, int *single_host_flag, int *single_stamp, int *single_queue_counters);
 template <typename T>
-void launch_cov(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const int *slot,
-                const T *d2, double *partials, double *out, int P, int max_n);
+void launch_cov(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const T *rd_nrm, const int *slot,
+                const T *d2, double *partials, double *out, int P, int max_n, const ChainDev<T> &ch);
 void launch_sum_partials(hipStream_t st, const double *partials, int max_blocks, int nt, const ProblemDev *probs,
                          int nb_uniform, double *out, int P);
 template <typename T>
 void launch_trim_raw(hipStream_t st, const T *d2, int n, T ratio, T scale, T *limit_nf, T *w);
 template <typename T>
-void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const int *slot_of, const T *rd, int stride,
-                        const int *ids, const T *w, int n, const T mean[3], double *partials, double *out);
+void launch_slot_of(hipStream_t st, const typename Vec4<T>::type *pts, int first, int m, int *slot_of);
 template <typename T>
-void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int *order, const int *slot, const T *d2, int n,
+void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const int *slot_of, const T *rd, int stride,
+                        const int *ids, const T *w, int n, int knn, const T mean[3], double *partials, double *out, int minimizer);
+template <typename T>
+void launch_unpermute(hipStream_t st, const MapDev<T> *maps, int map, const int *order, const int *slot, const T *d2, int n, int knn,
                       int *ids_out, T *d2_out);
 
 constexpr int kScanChunkHost = 4096;

@@ -61,6 +61,7 @@ struct MapHost {
     int *cell_start_f = nullptr;
     int kx = 1;
     int *slot_of = nullptr;
+    bool slot_of_made = false;      // (filled on first use: error_stats)
     int *sc_count = nullptr;
     int *near = nullptr;
     int *sc_dist = nullptr;
@@ -79,7 +80,7 @@ struct State {
     std::vector<MapHost<T>> maps;
     DevBuf d_maps;                  // MapDev<T>[capacity]
     int d_maps_cap = 0;
-    DevBuf rd_pre, rd_sorted, slot, d2, none_r, staging, stage_aux;
+    DevBuf rd_pre, rd_sorted, slot, d2, none_r, staging, stage_aux, nrm_pre, nrm_sorted;
 };
 
 struct ProfEvent {
@@ -99,7 +100,7 @@ struct pgicp_ctx {
     pgicp_params prm{};
     State<float> f32;
     State<double> f64;
-    DevBuf probs, src, partials, sums, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
+    DevBuf probs, src, partials, sums, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_w, tmp_p, tmp_n;
     DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active, sel_tables, queue;
     // host-input pipeline (pgicp_upload_*): a copy stream and two upload sets used alternately
     struct UploadSet {
@@ -141,6 +142,7 @@ struct pgicp_ctx {
     double cell_scale = 1.0;     // experiment knob PGICP_CELL_SCALE: the automatic grid cell times this
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
+    int bin_shift_add = 0;          // experiment knob PGICP_BIN_SHIFT_ADD: coarser (+) or finer (-) bins of the reading sort
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
     bool prof_on = false;
     std::mutex prof_m;              // prof_events and the sums below: pgicp_profile_process collects from another thread
@@ -274,6 +276,12 @@ ChainDev<T> make_chain(const pgicp_params &p)
     ch.min_rot = p.min_diff_rot;
     ch.min_trans = p.min_diff_trans;
     ch.rank_rel_tol = 6.0 * (double)std::numeric_limits<T>::epsilon();
+    ch.knn = std::max(1, p.knn);
+    ch.minimizer = p.error_minimizer;
+    ch.bound_rot = (p.bound_max_rot > 0.0 && std::isfinite(p.bound_max_rot)) ? p.bound_max_rot : 0.0;
+    ch.bound_trans = (p.bound_max_trans > 0.0 && std::isfinite(p.bound_max_trans)) ? p.bound_max_trans : 0.0;
+    ch.use_normals = p.normal_max_angle > 0.0 ? 1 : 0;
+    ch.normal_cos = std::cos((T)p.normal_max_angle);          // in T, as the filter evaluates `cos(maxAngle)`
     return ch;
 }
 
@@ -542,8 +550,8 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
 
     // ---- phase 2: grids; every cloud gets its slice of ONE allocation and ONE set of build launches ----
     std::vector<MapHost<T>> Ms(n);
-    long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0, tot_o = 0;
-    int max_cells = 0, max_nsc = 0, max_cells_f = 0, max_blocks = 0;
+    long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0, tot_o = 0, tot_b = 0;
+    int max_cells = 0, max_nsc = 0, max_bins = 0, max_blocks = 0;
     const int kx = std::max(1, std::min(8, c->grid_kx));
     bool any_nrm = false;
     for (int k = 0; k < n; k++) {
@@ -595,20 +603,23 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         for (int a = 0; a < 3; a++) d.mean[a] = M.mean[a];
         d.ncells = g.nx * g.ny * g.nz;
         d.nsc = ((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
-        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s; d.fbase = tot_f; d.obase = tot_o;
+        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s; d.fbase = tot_f; d.obase = tot_o; d.bbase = tot_b;
         d.kx = kx; d.ncells_f = d.ncells * kx;
+        d.nbins = (d.ncells_f >> 9) + 1;                 // bins of the build's counting sort: 512 fine cells (kMapBinShift), sentinel included
         M.kx = kx;
         // a first candidate farther than a fraction of maxDist prunes little: do not look for one beyond that
         const double reach_len = std::isfinite(c->prm.max_dist) ? c->near_frac * c->prm.max_dist : 1e30;
         d.near_reach = (int)std::min((double)kNearReach, std::max(2.0, std::ceil(reach_len / (double)g.h)));
-        tot_m += m; tot_c += (long long)d.ncells + 1; tot_s += d.nsc; tot_f += (long long)d.ncells_f + 1;
+        tot_m += m; tot_c += (long long)d.ncells + 1; tot_s += d.nsc;
+        tot_f += ((long long)d.ncells_f + 1 + 3) & ~3LL;     // (every cloud's fine table starts on a 16-byte boundary: k_mfill stores four entries at a time)
         tot_o += (long long)(d.ncells >> 5) + 2;         // (a range test reads one word past the last cell's)
+        tot_b += d.nbins;
         max_cells = std::max(max_cells, d.ncells);
-        max_cells_f = std::max(max_cells_f, d.ncells_f);
+        max_bins = std::max(max_bins, d.nbins);
         max_nsc = std::max(max_nsc, d.nsc);
         max_blocks = std::max(max_blocks, ((g.nx + 1) >> 1) * ((g.ny + 1) >> 1) * ((g.nz + 1) >> 1));
     }
-    if (tot_m > 0x7FFFFFF0LL || tot_f > 0x7FFFFFF0LL) {
+    if (tot_m > 0x7FFFFFF0LL || tot_c > 0x7FFFFFF0LL) {
         // the concatenated index space must fit an int: an oversized batch is built in two halves (each may split again)
         if (n == 1) return fail(c, PGICP_ERR_ARG, "pgicp_map_create: cloud too large");
         const int half = n / 2;
@@ -616,11 +627,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         if (st1) return st1;
         return map_create_batch<T>(c, n - half, src + half, mem, center, map_ids + half);
     }
-    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)tot_m));                               // cell_of
-    HIPC(c, c->tmp_b.ensure(sizeof(int) * (size_t)tot_f));                               // counts (fine cells), then sweep scratch
-    HIPC(c, c->tmp_c.ensure(sizeof(int) * 32 * ((size_t)tot_f / kScanChunkHost + 2)));   // block sums (up to 32 partial copies)
-    HIPC(c, c->tmp_d.ensure(sizeof(int) * (size_t)tot_f));                               // cursor, then sweep scratch
-    HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)tot_m));                               // order_tmp
+    const size_t n_scratch = (size_t)std::max(tot_b + 2, tot_c);
+    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)tot_m));                               // fine-cell keys: by point, then by slot
+    HIPC(c, c->tmp_b.ensure(sizeof(int) * n_scratch));                                   // bin counts, then sweep scratch
+    HIPC(c, c->tmp_c.ensure(sizeof(int) * ((size_t)(tot_b + 1) / kScanChunkHost + 2)));  // the scan's block sums
+    HIPC(c, c->tmp_d.ensure(sizeof(int) * n_scratch));                                   // bin starts, then sweep scratch
+    HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)tot_m));                               // arrival positions
+    HIPC(c, c->tmp_w.ensure(sizeof(unsigned long long) * (size_t)tot_m));                // (fine cell, index) words of the cell sort
+    HIPC(c, c->tmp_p.ensure(sizeof(V4) * 2 * (size_t)tot_m));                            // the records in cloud order: (point, normal) pairs
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
                  b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c),
@@ -657,8 +671,8 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
-        launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_f, tot_s, max_m, max_cells, max_cells_f, max_nsc, max_blocks, c->tmp_a.as<int>(),
-                                   c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), g_pts, g_nrm,
+        launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_b, tot_s, max_m, max_cells, max_bins, max_nsc, max_blocks, kx == 4 ? 1 : 0, c->tmp_a.as<int>(),
+                                   c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), c->tmp_w.as<unsigned long long>(), c->tmp_p.as<V4>(), c->tmp_n.as<V4>(), g_pts, g_nrm,
                                    g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o, g_ext);
     }
     HIPC(c, hipStreamSynchronize(c->stream));          // `descs` (host) feeds an async copy
@@ -695,6 +709,9 @@ struct BatchLayout {
     int max_rows = 1;
     int bin_shift = 2;          // reading-sort bins are (1 << bin_shift)^3 map cells
     long long total = 0;
+    int knn = 1;                // pairs per reading point (ChainDev::knn)
+    bool normals = false;       // the readings' normals travel with them (a SurfaceNormalOutlierFilter is in the chain)
+    int max_pairs() const { return (int)std::min<long long>((long long)max_n * knn, 0x7FFFFFFFLL); }
 };
 
 // Prepare a batch: stage readings, fill + upload ProblemDev, run the prologue
@@ -705,6 +722,12 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     if (P > 65535) return fail(c, PGICP_ERR_ARG, "pgicp: at most 65535 problems per batch (the problem index is a launch-grid dimension)");
     State<T> &S = state<T>(c);
     L.P = P; L.max_n = 0; L.max_rows = 1; L.total = 0;
+    L.knn = std::max(1, c->prm.knn);
+    L.normals = c->prm.normal_max_angle > 0.0;
+    if (L.normals)
+        for (int p = 0; p < P; p++)
+            if (!pr[p].normals || pr[p].nstride < 3)
+                return fail(c, PGICP_ERR_ARG, "SurfaceNormalOutlierFilter: the reading of problem " + std::to_string(p) + " has no normals (pgicp_problem.normals)");
     size_t stage_total = 0;
     double dens = 0.0;                         // largest reading-to-map size ratio of the batch
     for (int p = 0; p < P; p++) {
@@ -715,12 +738,15 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         L.max_n = std::max(L.max_n, pr[p].n);
         dens = std::max(dens, (double)pr[p].n / (double)M->m);
         L.total += pr[p].n;
-        if (pr[p].mem == PGICP_HOST) stage_total += staged_bytes(sizeof(T), pr[p].stride, pr[p].n);
+        if (pr[p].mem == PGICP_HOST) stage_total += staged_bytes(sizeof(T), pr[p].stride, pr[p].n) +
+                                                    (L.normals ? staged_bytes(sizeof(T), pr[p].nstride, pr[p].n) : 0);
     }
+    if ((long long)L.max_n * L.knn > 0x7FFFFFF0LL || L.total * L.knn > 0x7FFFFFF0LL)
+        return fail(c, PGICP_ERR_ARG, "pgicp: points x knn exceeds 2^31: split the batch");
     // Bins of the reading sort are blocks of map cells.  The rank pass costs O(bin population) per
     // point and map cells hold ~17 points where the data is, so a reading as dense as its map gets
     // single-cell bins and a sparse one 4x4x4-cell bins; the bin table is kept under 2^26 entries.
-    L.bin_shift = dens <= 0.25 ? 2 : (dens <= 2.0 ? 1 : 0);
+    L.bin_shift = std::max(0, std::min(4, (dens <= 0.25 ? 2 : (dens <= 2.0 ? 1 : 0)) + c->bin_shift_add));
     for (;; ++L.bin_shift) {
         const int s = L.bin_shift, r = (1 << s) - 1;
         L.max_rows = 1;
@@ -735,12 +761,13 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     if ((long long)L.max_rows * P > 0x7FFFFFFFLL)
         return fail(c, PGICP_ERR_ARG, "pgicp: batch too large for the reading sort (problems x map blocks = " +
                                       std::to_string((long long)L.max_rows * P) + " > 2^31 - 1): split the batch");
-    HIPC(c, S.rd_pre.ensure(sizeof(T) * 3 * (size_t)L.total));
+    HIPC(c, S.rd_pre.ensure(sizeof(typename Vec4<T>::type) * (size_t)L.total));
     HIPC(c, S.rd_sorted.ensure(sizeof(T) * 3 * (size_t)L.total));
     {
         const size_t nbins = (size_t)P * L.max_rows;
         HIPC(c, c->qrow.ensure(sizeof(int) * (size_t)L.total));
-        HIPC(c, c->qtmp.ensure(sizeof(unsigned long long) * (size_t)L.total));
+        // (the sort's words; afterwards the selection's key list: one key per PAIR)
+        HIPC(c, c->qtmp.ensure(std::max(sizeof(unsigned long long) * (size_t)L.total, sizeof(T) * (size_t)L.total * L.knn)));
         HIPC(c, c->order.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
         HIPC(c, c->slow_lb.ensure(sizeof(T) * (size_t)L.total));
@@ -748,16 +775,19 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         HIPC(c, c->slow2.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->active.ensure(sizeof(int) * (size_t)P));
         HIPC(c, c->qcounts.ensure(sizeof(int) * nbins));
-        HIPC(c, c->qcursor.ensure(sizeof(int) * nbins));
         HIPC(c, c->qstart.ensure(sizeof(int) * (nbins + 1)));
         HIPC(c, c->qblock.ensure(sizeof(int) * (nbins / kScanChunkHost + 2)));
     }
-    HIPC(c, S.slot.ensure(sizeof(int) * (size_t)L.total));
-    HIPC(c, S.d2.ensure(sizeof(T) * (size_t)L.total));
+    HIPC(c, S.slot.ensure(sizeof(int) * (size_t)L.total * L.knn));
+    HIPC(c, S.d2.ensure(sizeof(T) * (size_t)L.total * L.knn));
+    if (L.normals) {
+        HIPC(c, S.nrm_pre.ensure(sizeof(typename Vec4<T>::type) * (size_t)L.total));
+        HIPC(c, S.nrm_sorted.ensure(sizeof(T) * 3 * (size_t)L.total));
+    }
     HIPC(c, S.none_r.ensure(sizeof(T) * (size_t)L.total));
     HIPC(c, c->probs.ensure(sizeof(ProblemDev) * (size_t)P));
     HIPC(c, c->src.ensure(sizeof(SrcDesc) * (size_t)P));
-    HIPC(c, c->partials.ensure(sizeof(double) * (size_t)P * reduce_blocks(L.max_n) * kCovTerms));
+    HIPC(c, c->partials.ensure(sizeof(double) * (size_t)P * reduce_blocks(L.max_pairs()) * kCovTerms));
     HIPC(c, c->sums.ensure(sizeof(double) * (size_t)P * kCovTerms));
     HIPC(c, c->small.ensure(256));
     HIPC(c, c->sel_tables.ensure(trim_select_table_bytes(P)));
@@ -776,10 +806,18 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         int st = to_device<T>(c, (const T *)pr[p].reading, pr[p].stride, pr[p].n, pr[p].mem, S.staging, soff, &d_rd);
         if (st) return st;
         if (pr[p].mem == PGICP_HOST) soff += staged_bytes(sizeof(T), pr[p].stride, pr[p].n);
-        hs[p].ptr = d_rd; hs[p].stride = pr[p].stride; hs[p].pad_ = 0;
+        hs[p].ptr = d_rd; hs[p].stride = pr[p].stride; hs[p].nptr = nullptr; hs[p].nstride = 0;
+        if (L.normals) {
+            const T *d_nr = nullptr;
+            if (pr[p].mem == PGICP_DEVICE && (c->up[0].pending || c->up[1].pending)) up_mask |= upload_wait(c, pr[p].normals);
+            st = to_device<T>(c, (const T *)pr[p].normals, pr[p].nstride, pr[p].n, pr[p].mem, S.staging, soff, &d_nr);
+            if (st) return st;
+            if (pr[p].mem == PGICP_HOST) soff += staged_bytes(sizeof(T), pr[p].nstride, pr[p].n);
+            hs[p].nptr = d_nr; hs[p].nstride = pr[p].nstride;
+        }
         ProblemDev &D = hp[p];
         std::memset(&D, 0, sizeof D);
-        D.map = map_index<T>(c, pr[p].map_id); D.n = pr[p].n; D.off = off;
+        D.map = map_index<T>(c, pr[p].map_id); D.n = pr[p].n; D.off = off; D.knn = L.knn;
         off += pr[p].n;
         Tpre_of(p, D.Tpre);
         mat4_identity(D.T_iter); mat4_identity(D.T_prev); mat4_identity(D.dT);
@@ -800,14 +838,15 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     HIPC(c, hipMemsetAsync(c->sel_tables.p, 0, trim_select_table_bytes(P), c->stream));
     {
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
-        launch_pretransform<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.rd_pre.template as<T>(), P, L.max_n);
-        upload_consumed(c, up_mask);                 // the pre-transform is the only kernel that reads the readings where they lie
-        c->up_seen = 0;
-        // order each reading by (map row, x) once: waves stay spatially coherent for every iteration
-        launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(),
-                             S.rd_pre.template as<T>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<unsigned long long>(),
+        // pre-transform + ordering of each reading by (block of map cells, cell, index), once per scan: waves stay spatially
+        // coherent for every iteration
+        launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.d_maps.template as<MapDev<T>>(),
+                             S.rd_pre.template as<typename Vec4<T>::type>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<unsigned long long>(),
                              c->order.as<int>(), c->qcounts.as<int>(), c->qblock.as<int>(), c->qstart.as<int>(),
-                             c->qcursor.as<int>(), P, L.max_n, L.max_rows, L.bin_shift);
+                             P, L.max_n, L.max_rows, L.bin_shift, L.normals ? S.nrm_pre.template as<typename Vec4<T>::type>() : nullptr,
+                             L.normals ? S.nrm_sorted.template as<T>() : nullptr);
+        upload_consumed(c, up_mask);                 // its first kernel is the only one that reads the readings where they lie
+        c->up_seen = 0;
     }
     // (no synchronisation here: hp is the caller's, hs / ident are context members, and every caller ends with
     // a stream synchronisation before it returns -- a wait at this point idles the GPU for ~25 us per scan)
@@ -831,6 +870,30 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
     State<T> &S = state<T>(c);
     const MapDev<T> *maps = S.d_maps.template as<MapDev<T>>();
     ProblemDev *probs = c->probs.as<ProblemDev>();
+    const T *rd_nrm = L.normals ? S.nrm_sorted.template as<T>() : nullptr;
+    if (L.knn > 1) {
+        // KDTreeMatcher.knn > 1: the top-K matcher finds every pair exactly (no queue, no lazy resolution), one selection
+        // over the knn * N distances, the minimiser over the knn * N pairs
+        {
+            ProfScope ps(c, PGICP_PROF_KNN_GRID, act_units, act_probs);
+            (void)launch_knn_topk<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(), ch, nA, L.max_n, active);
+        }
+        {
+            ProfScope ps(c, PGICP_PROF_TRIM, act_units, act_probs);
+            launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_pairs(), 0, active, c->sel_tables.as<int>(), c->qtmp.p, nullptr, use_seed);
+        }
+        {
+            ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
+            launch_reduce<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), rd_nrm, S.slot.template as<int>(), S.d2.template as<T>(),
+                             c->partials.as<double>(), nA, L.max_pairs(), active, ch);
+        }
+        if (with_solve) {
+            ProfScope ps(c, PGICP_PROF_SOLVE, act_units, act_probs);
+            launch_solve<T>(c->stream, probs, c->partials.as<double>(), ch, c->small.as<int>(), nA, L.max_pairs(), active, nullptr, nullptr, nullptr);
+            launch_compact_active(c->stream, probs, L.P, c->active.as<int>(), c->h_flag, c->stamp_dev, c->small.as<int>() + 16);
+        }
+        return;
+    }
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
@@ -844,7 +907,7 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
         // (with the grid matcher this selection also clears the matcher's segmented queue counters for the next iteration)
         const bool grid = c->prm.matcher == PGICP_MATCHER_GRID;
         launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 0, active, c->sel_tables.as<int>(), c->qtmp.p,
-                              grid ? (int *)c->queue.p : nullptr);
+                              grid ? (int *)c->queue.p : nullptr, use_seed);      // (every selection but a run's first starts from the last one's result: ProblemDev::qraw)
         c->seg_clean = grid ? 1 : 0;
     }
     if (c->prm.matcher == PGICP_MATCHER_GRID) {
@@ -869,12 +932,12 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
             }
         }
         ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 1, active, c->sel_tables.as<int>(), c->qtmp.p, nullptr);
+        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 1, active, c->sel_tables.as<int>(), c->qtmp.p, nullptr, 1);
     }
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
-        launch_reduce<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(),
-                         c->partials.as<double>(), nA, L.max_n, active);
+        launch_reduce<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), rd_nrm, S.slot.template as<int>(), S.d2.template as<T>(),
+                         c->partials.as<double>(), nA, L.max_n, active, ch);
     }
     if (with_solve) {
         ProfScope ps(c, PGICP_PROF_SOLVE, act_units, act_probs);
@@ -990,7 +1053,8 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     for (int p = 0; p < P; p++) {
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_align: unknown map id");
-        if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp_align: reference has no normals descriptor");
+        if (!M->has_nrm && (prm.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE || prm.normal_max_angle > 0.0))
+            return fail(c, PGICP_ERR_ARG, "pgicp_align: reference has no normals descriptor");
     }
     static const bool host_timing = std::getenv("PGICP_HOST_TIMING") != nullptr;      // diagnostics
     const auto ht0 = std::chrono::steady_clock::now();
@@ -1025,12 +1089,13 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         }
     }
     const auto ht2 = std::chrono::steady_clock::now();
-    {
+    const bool with_cov = prm.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE;      // (PointToPoint: the base class's zeros)
+    if (with_cov) {
         ProfScope ps(c, PGICP_PROF_COV, L.total, P);
         launch_cov<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(), S.rd_sorted.template as<T>(),
-                      S.slot.template as<int>(), S.d2.template as<T>(), c->partials.as<double>(), c->sums.as<double>(), P,
-                      L.max_n);
-    }
+                      L.normals ? S.nrm_sorted.template as<T>() : nullptr, S.slot.template as<int>(), S.d2.template as<T>(),
+                      c->partials.as<double>(), c->sums.as<double>(), P, L.max_pairs(), ch);
+    } else HIPC(c, hipMemsetAsync(c->sums.p, 0, sizeof(double) * (size_t)P * kCovTerms, c->stream));
     std::vector<double> cs((size_t)P * kCovTerms);
     { const int pst = pinned_ensure(c, &c->h_down, &c->h_down_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
     HIPC(c, hipMemcpyAsync(c->h_down, c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
@@ -1051,7 +1116,8 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         std::memset(&s, 0, sizeof s);
         s.status = D.status;
         s.iterations = D.iters; s.converged = D.converged; s.max_iter_reached = D.max_iter_reached;
-        s.overlap = D.sys[27] / (double)D.n; s.residual = D.sys[29]; s.trim_limit = D.limit;
+        s.status = D.status == PGICP_ST_BOUND ? PGICP_ERR_BOUND : D.status;
+        s.overlap = D.sys[27] / ((double)D.n * L.knn); s.residual = D.sys[29]; s.trim_limit = D.limit;
         s.n_kept = D.n_kept; s.n_finite = D.n_finite;
         if (D.status == PGICP_ST_OK) {
             double t1[16];
@@ -1060,7 +1126,8 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
             double H[36], G[36], Hi[36], tmp[36];
             sys_to_full(cs.data() + (size_t)p * kCovTerms, H);
             sys_to_full(cs.data() + (size_t)p * kCovTerms + 21, G);
-            if (inverse6(H, Hi)) {
+            if (!with_cov) { /* zeros */ }
+            else if (inverse6(H, Hi)) {
                 const double s2 = prm.sensor_std_dev * prm.sensor_std_dev;
                 for (int i = 0; i < 6; i++)
                     for (int j = 0; j < 6; j++) {
@@ -1078,13 +1145,14 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
                 for (int i = 0; i < 6; i++) s.cov[i * 6 + i] = std::numeric_limits<double>::max();
         } else {
             mat4_identity(To);
-            if (worst == PGICP_OK) worst = D.status;
+            if (worst == PGICP_OK) worst = s.status;
         }
         if (stats) stats[p] = s;
     }
     if (worst != PGICP_OK)
-        return fail(c, worst, worst == PGICP_ST_NO_MATCH ? "ICP: no point to minimize (ConvergenceError)"
-                                                         : "ICP: NaN in transformation checker (ConvergenceError)");
+        return fail(c, worst, worst == PGICP_ERR_NO_MATCH ? "ICP: no point to minimize (ConvergenceError)"
+                           : worst == PGICP_ERR_BOUND ? "ICP: BoundTransformationChecker: limit exceeded (ConvergenceError)"
+                                                      : "ICP: NaN in transformation checker (ConvergenceError)");
     return PGICP_OK;
 }
 
@@ -1096,6 +1164,7 @@ int icp_pair(pgicp_ctx *c, const T *reading, int rd_stride, int n, const T *ref_
     int st = map_create<T>(c, ref_xyz, ref_stride, ref_nrm, nrm_stride, m, mem, 1, &id);
     if (st) return st;
     pgicp_problem pr;
+    std::memset(&pr, 0, sizeof pr);
     pr.map_id = id; pr.reading = reading; pr.stride = rd_stride; pr.n = n; pr.mem = mem;
     std::memcpy(pr.T_init, T_init, sizeof pr.T_init);
     st = align_batch<T>(c, 1, &pr, T_out, stats);
@@ -1112,9 +1181,13 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     MapHost<T> *M = get_map<T>(c, map_id);
     if (!M) return fail(c, PGICP_ERR_ARG, "pgicp: unknown map id");
     pgicp_problem pr;
+    std::memset(&pr, 0, sizeof pr);
     pr.map_id = map_id; pr.reading = reading; pr.stride = stride; pr.n = n; pr.mem = mem;
     mat4_identity(pr.T_init);
     if (Tmove) std::memcpy(pr.T_init, Tmove, sizeof pr.T_init);
+    // (the matcher alone: no outlier filter runs here, so a SurfaceNormalOutlierFilter's normals are not asked for)
+    struct NoNormals { pgicp_ctx *c; double a; ~NoNormals() { c->prm.normal_max_angle = a; } } restore{c, c->prm.normal_max_angle};
+    c->prm.normal_max_angle = 0.0;
     int st = batch_begin<T>(c, 1, &pr, [&](int, double *Tpre) {
         double mean[3] = {(double)M->mean[0], (double)M->mean[1], (double)M->mean[2]};
         double Tm_inv[16];
@@ -1126,6 +1199,13 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     const ChainDev<T> ch = make_chain<T>(c->prm);
     const MapDev<T> *maps = S.d_maps.template as<MapDev<T>>();
     ProblemDev *probs = c->probs.as<ProblemDev>();
+    if (L.knn > 1) {
+        ProfScope ps(c, PGICP_PROF_KNN_GRID, n);
+        if (launch_knn_topk<T>(c->stream, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(), S.d2.template as<T>(), ch, 1, n,
+                               c->active.as<int>()) != 0)
+            return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.knn exceeds PGICP_MAX_KNN");
+        return PGICP_OK;
+    }
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
@@ -1151,13 +1231,14 @@ int match(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem
     int st = run_partial<T>(c, map_id, reading, stride, n, mem, Tm, L, hp);
     if (st) return st;
     State<T> &S = state<T>(c);
-    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)n));
-    HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)n));
+    const size_t np = (size_t)n * L.knn;                     // knn entries per reading point
+    HIPC(c, c->tmp_a.ensure(sizeof(int) * np));
+    HIPC(c, c->tmp_b.ensure(sizeof(T) * np));
     launch_unpermute<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), c->order.as<int>(),
-                        S.slot.template as<int>(), S.d2.template as<T>(), n, c->tmp_a.as<int>(), c->tmp_b.as<T>());
+                        S.slot.template as<int>(), S.d2.template as<T>(), n, L.knn, c->tmp_a.as<int>(), c->tmp_b.as<T>());
     const hipMemcpyKind k = mem == PGICP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * (size_t)n, k, c->stream));
-    HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * (size_t)n, k, c->stream));
+    HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * np, k, c->stream));
+    HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * np, k, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
     return PGICP_OK;
@@ -1173,7 +1254,8 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
     for (int p = 0; p < P; p++) {
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_partial_chain: unknown map id");
-        if (!M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
+        if (!M->has_nrm && (c->prm.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE || c->prm.normal_max_angle > 0.0))
+            return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
     }
     BatchLayout L;
     std::vector<ProblemDev> hp;
@@ -1187,7 +1269,7 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
     if (st) return st;
     const ChainDev<T> ch = make_chain<T>(c->prm);
     one_iteration<T>(c, L, ch, false, L.total, P, 0);
-    launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(L.max_n), kSys, c->probs.as<ProblemDev>(), 0,
+    launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(L.max_pairs()), kSys, c->probs.as<ProblemDev>(), 0,
                         c->sums.as<double>(), P);
     std::vector<double> sys((size_t)P * kSys);
     HIPC(c, hipMemcpyAsync(sys.data(), c->sums.p, sizeof(double) * sys.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1202,7 +1284,7 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
         const bool ok = hp[p].n_finite != 0 && s[28] > 0.0;
         if (status) status[p] = ok ? PGICP_OK : PGICP_ERR_NO_MATCH;
         if (!ok) worst = PGICP_ERR_NO_MATCH;
-        if (ratio) ratio[p] = ok ? s[27] / (double)pr[p].n : 0.0;
+        if (ratio) ratio[p] = ok ? s[27] / ((double)pr[p].n * L.knn) : 0.0;
         if (residual) residual[p] = ok ? s[29] : 0.0;
     }
     if (worst != PGICP_OK) return fail(c, worst, "no point to minimize (ConvergenceError)");
@@ -1215,6 +1297,7 @@ int partial_chain(pgicp_ctx *c, int map_id, const T *reading, int stride, int n,
 {
     if (!c || !reading || n <= 0) return fail(c, PGICP_ERR_ARG, "pgicp_partial_chain: bad argument");
     pgicp_problem pr;
+    std::memset(&pr, 0, sizeof pr);
     pr.map_id = map_id; pr.reading = reading; pr.stride = stride; pr.n = n; pr.mem = mem;
     mat4_identity(pr.T_init);
     if (Tm) std::memcpy(pr.T_init, Tm, sizeof pr.T_init);
@@ -1259,8 +1342,9 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     if (!c || !reading || !ids || !w || n <= 0 || stride < 3) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: bad argument");
     HIPC(c, hipSetDevice(c->device));
     MapHost<T> *M = get_map<T>(c, map_id);
-    if (!M || !M->has_nrm) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: unknown map or no normals");
+    if (!M || (!M->has_nrm && c->prm.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE)) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: unknown map or no normals");
     State<T> &S = state<T>(c);
+    const int K = std::max(1, c->prm.knn);                   // ids / w: knn entries per reading point
     const T *d_rd = reading, *d_w = w;
     const int *d_ids = ids;
     UploadUse use(c);
@@ -1269,20 +1353,24 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         HIPC(c, S.staging.ensure(staged_bytes(sizeof(T), stride, n)));
         int st = to_device<T>(c, reading, stride, n, mem, S.staging, 0, &d_rd);
         if (st) return st;
-        HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)n));
-        HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)n));
-        HIPC(c, hipMemcpyAsync(c->tmp_a.p, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(c->tmp_b.p, w, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)n * K));
+        HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)n * K));
+        HIPC(c, hipMemcpyAsync(c->tmp_a.p, ids, sizeof(int) * (size_t)n * K, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->tmp_b.p, w, sizeof(T) * (size_t)n * K, hipMemcpyHostToDevice, c->stream));
         d_ids = c->tmp_a.as<int>();
         d_w = c->tmp_b.as<T>();
     }
-    const int nb = (n + kReduceSpan - 1) / kReduceSpan;
+    if (!M->slot_of_made) {
+        launch_slot_of<T>(c->stream, M->pts, M->first, M->m, M->slot_of);
+        M->slot_of_made = true;
+    }
+    const int nb = (int)(((long long)n * K + kReduceSpan - 1) / kReduceSpan);
     HIPC(c, c->partials.ensure(sizeof(double) * (size_t)nb * kSys));
     HIPC(c, c->sums.ensure(sizeof(double) * kCovTerms));
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, n);
-        launch_error_stats<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), M->slot_of, d_rd, stride, d_ids, d_w, n,
-                              M->mean, c->partials.as<double>(), c->sums.as<double>());
+        launch_error_stats<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), M->slot_of, d_rd, stride, d_ids, d_w, n, K,
+                              M->mean, c->partials.as<double>(), c->sums.as<double>(), c->prm.error_minimizer);
     }
     double sys[kSys];
     HIPC(c, hipMemcpyAsync(sys, c->sums.p, sizeof sys, hipMemcpyDeviceToHost, c->stream));
@@ -1290,7 +1378,7 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     HIPC(c, hipGetLastError());
     if (sys_out) std::memcpy(sys_out, sys, sizeof sys);
     if (!(sys[28] > 0.0)) return fail(c, PGICP_ERR_NO_MATCH, "no point to minimize (ConvergenceError)");
-    if (ratio) *ratio = sys[27] / (double)n;
+    if (ratio) *ratio = sys[27] / ((double)n * K);
     if (residual) *residual = sys[29];
     return PGICP_OK;
 }
@@ -1476,13 +1564,14 @@ int debug_last_matches(pgicp_ctx *c, int problem, int32_t *ids, T *dist2)
     State<T> &S = state<T>(c);
     ProblemDev D;
     HIPC(c, hipMemcpy(&D, c->probs.as<ProblemDev>() + problem, sizeof D, hipMemcpyDeviceToHost));
-    HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)D.n));
-    HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)D.n));
+    const size_t np = (size_t)D.n * D.knn;                   // (knn entries per point)
+    HIPC(c, c->tmp_a.ensure(sizeof(int) * np));
+    HIPC(c, c->tmp_b.ensure(sizeof(T) * np));
     // `order` holds positions in the batch-wide sorted arrays: point the kernel at this problem's slice
     launch_unpermute<T>(c->stream, S.d_maps.template as<MapDev<T>>(), D.map, c->order.as<int>() + D.off,
-                        S.slot.template as<int>() + D.off, S.d2.template as<T>() + D.off, D.n, c->tmp_a.as<int>(), c->tmp_b.as<T>());
-    HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * (size_t)D.n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * (size_t)D.n, hipMemcpyDeviceToHost, c->stream));
+                        S.slot.template as<int>() + D.off * D.knn, S.d2.template as<T>() + D.off * D.knn, D.n, D.knn, c->tmp_a.as<int>(), c->tmp_b.as<T>());
+    HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * np, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * np, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return PGICP_OK;
 }
@@ -1621,6 +1710,10 @@ void pgicp_default_params(pgicp_params *p)
     p->matcher = PGICP_MATCHER_GRID;
     p->grid_cell = 0.0;
     p->check_every = 1;
+    p->error_minimizer = PGICP_MINIMIZER_POINT_TO_PLANE;
+    p->bound_max_rot = 0.0;
+    p->bound_max_trans = 0.0;
+    p->normal_max_angle = 0.0;
 }
 
 int pgicp_ctx_create(int device, pgicp_ctx **out)
@@ -1637,6 +1730,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     if (const char *e = std::getenv("PGICP_KX")) c->grid_kx = std::atoi(e);
     if (const char *e = std::getenv("PGICP_CELL_SCALE")) { const double v = std::atof(e); if (v > 0.05 && v < 20.0) c->cell_scale = v; }
     if (const char *e = std::getenv("PGICP_NEAR_FRAC")) c->near_frac = std::atof(e);
+    if (const char *e = std::getenv("PGICP_BIN_SHIFT_ADD")) c->bin_shift_add = std::atoi(e);
     if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_POLL_US")) c->poll_us = std::atoi(e);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
@@ -1711,8 +1805,8 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     }
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
-                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e,
-                      &c->f32.rd_sorted, &c->f64.rd_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
+                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e, &c->tmp_w, &c->tmp_p, &c->tmp_n,
+                      &c->f32.rd_sorted, &c->f64.rd_sorted, &c->f32.nrm_pre, &c->f32.nrm_sorted, &c->f64.nrm_pre, &c->f64.nrm_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
                       &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->sel_tables, &c->queue, &c->f32.none_r, &c->f64.none_r})
         b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -1759,6 +1853,7 @@ const char *pgicp_status_string(int status)
     case PGICP_ERR_HIP: return "HIP runtime error";
     case PGICP_ERR_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
     case PGICP_ERR_NOT_RIGID: return "transformation is not rigid";
+    case PGICP_ERR_BOUND: return "BoundTransformationChecker: limit exceeded (ConvergenceError)";
     default: return "unknown status";
     }
 }
@@ -1777,7 +1872,12 @@ int pgicp_ctx_synchronize(pgicp_ctx *c)
 int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
 {
     if (!c || !p) return PGICP_ERR_ARG;
-    if (p->knn != 1) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.knn: only 1 is supported");
+    if (p->knn < 1 || p->knn > PGICP_MAX_KNN) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.knn must be in [1, " + std::to_string(PGICP_MAX_KNN) + "]");
+    if (p->error_minimizer != PGICP_MINIMIZER_POINT_TO_PLANE && p->error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT)
+        return fail(c, PGICP_ERR_ARG, "unknown error minimizer");
+    if (p->bound_max_rot < 0.0 || p->bound_max_rot != p->bound_max_rot || p->bound_max_trans < 0.0 || p->bound_max_trans != p->bound_max_trans)
+        return fail(c, PGICP_ERR_ARG, "BoundTransformationChecker limits must be >= 0");
+    if (p->normal_max_angle < 0.0 || p->normal_max_angle != p->normal_max_angle) return fail(c, PGICP_ERR_ARG, "SurfaceNormalOutlierFilter.maxAngle must be >= 0");
     if (p->epsilon != 0.0) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.epsilon: only 0 (exact search) is supported");
     if (!(p->max_dist > 0.0)) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.maxDist must be > 0");
     if (!(p->trim_ratio > 0.0 && p->trim_ratio <= 1.0)) return fail(c, PGICP_ERR_ARG, "TrimmedDistOutlierFilter.ratio must be in (0,1]");
@@ -1845,6 +1945,7 @@ int pgicp_map_size(pgicp_ctx *c, int id, int *m)
 static pgicp_problem one_problem(int map_id, const void *rd, int stride, int n, int mem, const double *T)
 {
     pgicp_problem p;
+    std::memset(&p, 0, sizeof p);
     p.map_id = map_id; p.reading = rd; p.stride = stride; p.n = n; p.mem = mem;
     if (T) std::memcpy(p.T_init, T, sizeof p.T_init); else mat4_identity(p.T_init);
     return p;
@@ -1970,6 +2071,7 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
 {
     if (!c || !out) return PGICP_ERR_ARG;
     HIPC(c, hipMemcpy(out, c->small.as<int>() + (c->counters_clean ? 24 : 16), 4 * sizeof(int), hipMemcpyDeviceToHost));
+    out[3] = sel_fallbacks_read(1);       // selections whose guess was off (k_sel_final2) since the last call, all contexts of the device
     if (std::getenv("PGICP_KNN_STATS_DUMP")) {          // diagnostics builds only
         unsigned long long s[56];
         (void)hipDeviceSynchronize();

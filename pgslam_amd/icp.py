@@ -24,7 +24,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGICP_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libpgicp.so")
 
-OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID = range(7)
+OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID, ERR_BOUND = range(8)
+MINIMIZER_POINT_TO_PLANE, MINIMIZER_POINT_TO_POINT = 0, 1
 HOST, DEVICE, HOST_PINNED = 0, 1, 2
 MATCHER_GRID, MATCHER_BRUTE = 0, 1
 PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_update", "pretransform",
@@ -55,7 +56,8 @@ class Params(C.Structure):
                 ("max_iters", C.c_int), ("min_diff_rot", C.c_double), ("min_diff_trans", C.c_double),
                 ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double), ("matcher", C.c_int),
                 ("grid_cell", C.c_double), ("check_every", C.c_int), ("outlier_max_dist", C.c_double),
-                ("quantile_scale", C.c_double)]
+                ("quantile_scale", C.c_double), ("error_minimizer", C.c_int), ("bound_max_rot", C.c_double),
+                ("bound_max_trans", C.c_double), ("normal_max_angle", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -72,7 +74,7 @@ class Stats(C.Structure):
 
 class Problem(C.Structure):
     _fields_ = [("map_id", C.c_int), ("reading", C.c_void_p), ("stride", C.c_int), ("n", C.c_int), ("mem", C.c_int),
-                ("T_init", C.c_double * 16)]
+                ("T_init", C.c_double * 16), ("normals", C.c_void_p), ("nstride", C.c_int)]
 
 
 class Edge(C.Structure):
@@ -92,7 +94,7 @@ class PgicpError(RuntimeError):
 
 
 class ConvergenceError(PgicpError):
-    """PM::ConvergenceError: 'no point to minimize' / NaN in the checkers."""
+    """PM::ConvergenceError: 'no point to minimize' / NaN in the checkers / BoundTransformationChecker's limit exceeded."""
 
 
 _lib = None
@@ -125,9 +127,10 @@ def load_library() -> C.CDLL:
 _TORCH_DTYPES = {}          # torch dtype -> numpy dtype (the string round trip costs microseconds per reading of a batch)
 
 # numpy views of the two ctypes records a batch call exchanges (same layout: ctypes' natural alignment)
-_PROBLEM_DTYPE = np.dtype({"names": ["map_id", "reading", "stride", "n", "mem", "T_init"],
-                           "formats": ["<i4", "<u8", "<i4", "<i4", "<i4", ("<f8", (16,))],
-                           "offsets": [0, 8, 16, 20, 24, 32], "itemsize": 160})
+_PROBLEM_DTYPE = np.dtype({"names": ["map_id", "reading", "stride", "n", "mem", "T_init", "normals", "nstride"],
+                           "formats": ["<i4", "<u8", "<i4", "<i4", "<i4", ("<f8", (16,)), "<u8", "<i4"],
+                           "offsets": [0, 8, 16, 20, 24, 32, 160, 168], "itemsize": 176})
+assert C.sizeof(Problem) == _PROBLEM_DTYPE.itemsize
 _STATS_DTYPE = np.dtype({"names": ["status", "iterations", "converged", "max_iter_reached", "overlap", "residual", "trim_limit",
                                    "n_kept", "n_finite", "cov"],
                          "formats": ["<i4", "<i4", "<i4", "<i4", "<f8", "<f8", "<f8", "<i4", "<i4", ("<f8", (36,))],
@@ -298,7 +301,7 @@ class Context:
         if st == OK:
             return
         msg = self.lib.pgicp_last_error(self.h).decode()
-        if st in (ERR_NO_MATCH, ERR_NAN):
+        if st in (ERR_NO_MATCH, ERR_NAN, ERR_BOUND):
             raise ConvergenceError(st, msg)
         raise PgicpError(st, msg)
 
@@ -389,7 +392,11 @@ class Context:
         return m.value
 
     # ---- full ICP -----------------------------------------------------------
-    def align(self, map_id, reading, T_init, dtype=None):
+    def align(self, map_id, reading, T_init, dtype=None, normals=None):
+        """normals: the reading's `normals` descriptor (a SurfaceNormalOutlierFilter in the chain needs it)"""
+        if normals is not None:
+            T, st = self.align_batch(map_id, [reading], [T_init], dtype=dtype, normals=[normals])
+            return T[0], st[0]
         r = _Buf(reading, dtype)
         T_out = (C.c_double * 16)()
         st = Stats()
@@ -398,11 +405,12 @@ class Context:
                        _T16(T_init), T_out, C.byref(st)))
         return np.array(T_out[:]).reshape(4, 4), st.as_dict()
 
-    def align_batch(self, map_ids, readings, T_inits, dtype=None, raise_on_error=True):
+    def align_batch(self, map_ids, readings, T_inits, dtype=None, raise_on_error=True, normals=None):
         P = len(readings)
         if isinstance(map_ids, int):
             map_ids = [map_ids] * P
         bufs = [_Buf(r, dtype) for r in readings]
+        nbufs = [_Buf(v, bufs[0].dtype) for v in normals] if normals is not None else None
         # the records are filled and read back through numpy views, column by column: per-problem attribute access on
         # ctypes structures cost ~9 us a problem, 1.2 ms of a 15 ms step at 128 problems
         pa = np.zeros(P, dtype=_PROBLEM_DTYPE)
@@ -412,13 +420,17 @@ class Context:
         pa["n"] = [b.n for b in bufs]
         pa["mem"] = [b.mem for b in bufs]
         pa["T_init"] = np.asarray(T_inits, dtype=np.float64).reshape(P, 16)
+        if nbufs is not None:
+            assert all(nb.n == b.n and nb.mem == b.mem for nb, b in zip(nbufs, bufs))
+            pa["normals"] = [b.ptr for b in nbufs]
+            pa["nstride"] = [b.stride for b in nbufs]
         T_out = np.empty((P, 4, 4), dtype=np.float64)
         sa = np.zeros(P, dtype=_STATS_DTYPE)
         fn = getattr(self.lib, "pgicp_align_batch" + self._sfx(bufs[0].dtype))
         rc = fn(self.h, C.c_int(P), C.c_void_p(pa.ctypes.data), C.c_void_p(T_out.ctypes.data), C.c_void_p(sa.ctypes.data))
         if raise_on_error:
             self._check(rc)
-        elif rc not in (OK, ERR_NO_MATCH, ERR_NAN):
+        elif rc not in (OK, ERR_NO_MATCH, ERR_NAN, ERR_BOUND):
             self._check(rc)
         cov = sa["cov"].reshape(P, 6, 6)
         cols = [sa[k].tolist() for k in ("status", "iterations", "converged", "max_iter_reached", "overlap", "residual", "trim_limit",
@@ -446,15 +458,17 @@ class Context:
         r = _Buf(reading, dtype)
         fn = getattr(self.lib, "pgicp_match" + self._sfx(r.dtype))
         Tp = _T16(T) if T is not None else None
+        k = max(1, int(self.params.knn))
+        shape = (r.n,) if k == 1 else (r.n, k)              # knn entries per reading point
         if r.mem == DEVICE:
             import torch
-            ids = torch.empty(r.n, dtype=torch.int32, device=r.keep.device)
-            d2 = torch.empty(r.n, dtype=r.keep.dtype, device=r.keep.device)
+            ids = torch.empty(shape, dtype=torch.int32, device=r.keep.device)
+            d2 = torch.empty(shape, dtype=r.keep.dtype, device=r.keep.device)
             self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem),
                            Tp, C.c_void_p(ids.data_ptr()), C.c_void_p(d2.data_ptr())))
             return ids, d2
-        ids = np.empty(r.n, dtype=np.int32)
-        d2 = np.empty(r.n, dtype=r.dtype)
+        ids = np.empty(shape, dtype=np.int32)
+        d2 = np.empty(shape, dtype=r.dtype)
         self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem), Tp,
                        C.c_void_p(ids.ctypes.data), C.c_void_p(d2.ctypes.data)))
         return ids, d2
@@ -595,8 +609,9 @@ class Context:
 
     def debug_last_matches(self, n, problem=0, dtype=np.float32):
         """Correspondences of the last iteration of the last align call (diagnostics; see pgicp.h)."""
-        ids = np.empty(n, dtype=np.int32)
-        d2 = np.empty(n, dtype=dtype)
+        k = max(1, int(self.params.knn))
+        ids = np.empty(n if k == 1 else (n, k), dtype=np.int32)
+        d2 = np.empty(n if k == 1 else (n, k), dtype=dtype)
         fn = getattr(self.lib, "pgicp_debug_last_matches" + self._sfx(dtype))
         self._check(fn(self.h, C.c_int(problem), C.c_void_p(ids.ctypes.data), C.c_void_p(d2.ctypes.data)))
         return ids, d2

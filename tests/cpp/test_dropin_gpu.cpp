@@ -198,6 +198,52 @@ void run(const char *name)
         CHECK(pose_diff(Tb, truth[1]) < 2e-2);
     }
 
+    // --- the chain's other modules from YAML (round 4): knn > 1, PointToPointErrorMinimizer, SurfaceNormalOutlierFilter,
+    //     BoundTransformationChecker -- any of them may stand in a pgslam user's config (Localizer.hpp:70, LoopCloser.hpp:73)
+    {
+        auto chain = [](const char *matcher, const char *outliers, const char *minimizer, const char *checkers) {
+            return std::string("matcher:\n  KDTreeMatcher:\n    maxDist: 2.0\n") + matcher + "outlierFilters:\n  - TrimmedDistOutlierFilter:\n      ratio: 0.85\n" +
+                   outliers + "errorMinimizer:\n  " + minimizer + "\ntransformationCheckers:\n  - CounterTransformationChecker:\n      maxIterationCount: 30\n"
+                   "  - DifferentialTransformationChecker:\n      minDiffRotErr: 0.001\n      minDiffTransErr: 0.01\n      smoothLength: 3\n" + checkers;
+        };
+        ICP k3;
+        { std::istringstream iss(chain("    knn: 3\n", "", "PointToPlaneWithCovErrorMinimizer", "")); k3.loadFromYaml(iss); }
+        CHECK(pose_diff(k3(reading, map, guess), P) < 1e-2 && k3.matcher->knn == 3);
+        CHECK(k3.errorMinimizer->getOverlap() > T(0.84) && k3.errorMinimizer->getOverlap() <= T(0.8501));
+        // ... and through the hand-driven partial chain: knn x N matches, weights, error elements
+        k3.matcher->init(map);
+        const typename PM::Matches m3(k3.matcher->findClosests(moved));
+        CHECK(m3.ids.rows() == 3 && m3.ids.cols() == (int)moved.getNbPoints());
+        for (int j : {0, 7, 1000}) CHECK(m3.dists(0, j) <= m3.dists(1, j) && m3.dists(1, j) <= m3.dists(2, j) && m3.ids(0, j) == matches.ids(0, j));
+        const typename PM::OutlierWeights w3(k3.outlierFilters.compute(moved, map, m3));
+        typename PM::ErrorMinimizer::ErrorElements el3(moved, map, w3, m3);
+        CHECK(std::fabs((double)el3.weightedPointUsedRatio - 0.85) < 0.01);
+        CHECK(k3.errorMinimizer->getResidualError(moved, map, w3, m3) >= 0);
+
+        ICP p2p;
+        { std::istringstream iss(chain("", "", "PointToPointErrorMinimizer", "")); p2p.loadFromYaml(iss); }
+        CHECK(pose_diff(p2p(reading, map, guess), P) < 3e-2);
+        CHECK(p2p.errorMinimizer->getCovariance()(0, 0) == T(0));          // the base class's covariance: zeros
+
+        ICP nrm;
+        { std::istringstream iss(chain("", "  - SurfaceNormalOutlierFilter:\n      maxAngle: 0.6\n", "PointToPlaneErrorMinimizer", "")); nrm.loadFromYaml(iss); }
+        CHECK(pose_diff(nrm(reading, map, guess), P) < 1e-2);
+        CHECK(nrm.errorMinimizer->getOverlap() <= overlap);                 // the filter only removes pairs
+        const typename PM::OutlierWeights wn(nrm.outlierFilters.compute(moved, reference, matches));
+        int dropped = 0;
+        for (int j = 0; j < wn.cols(); j++) dropped += (wn(0, j) == T(0) && w(0, j) != T(0));
+        CHECK(dropped >= 0);
+
+        ICP bound;
+        { std::istringstream iss(chain("", "", "PointToPlaneErrorMinimizer", "  - BoundTransformationChecker:\n      maxRotationNorm: 0.5\n      maxTranslationNorm: 0.02\n")); bound.loadFromYaml(iss); }
+        bool bthrew = false;
+        try { bound(reading, map, guess); } catch (const typename PM::ConvergenceError &) { bthrew = true; }
+        CHECK(bthrew);                                                       // the guess is 10 cm off: the correction leaves a 2 cm bound
+        ICP bound_ok;
+        { std::istringstream iss(chain("", "", "PointToPlaneErrorMinimizer", "  - BoundTransformationChecker:\n      maxRotationNorm: 0.5\n      maxTranslationNorm: 0.5\n")); bound_ok.loadFromYaml(iss); }
+        CHECK(pose_diff(bound_ok(reading, map, guess), T1) < 1e-6);
+    }
+
     // --- ConvergenceError propagates like libpointmatcher's
     bool threw = false;
     try { seq(reading, pose<T>(500, 0, 0, 0)); } catch (const typename PM::ConvergenceError &) { threw = true; }

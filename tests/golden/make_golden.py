@@ -140,6 +140,122 @@ def np_icp(reading, ref, nrm, T_init, chain):
     return out
 
 
+def np_icp_ex(reading, ref, nrm, T_init, chain, reading_nrm=None):
+    """The same float64 restatement with the other modules the chain's slots may hold:
+    KDTreeMatcher.knn > 1 (matches knn x N; the quantile runs over all knn * N distances, every pair is a constraint),
+    PointToPointErrorMinimizer (weighted Kabsch through numpy.linalg.svd; residual = sum of |p - q|; zero covariance),
+    SurfaceNormalOutlierFilter (reading normal, rotated with the reading, against the matched reference normal) and
+    BoundTransformationChecker (angle and translation of the accumulated correction; exceeding either is an error)."""
+    K = int(chain.get("knn", 1))
+    p2point = int(chain.get("error_minimizer", 0)) == 1
+    max_angle = float(chain.get("normal_max_angle", 0.0))
+    b_rot, b_tr = float(chain.get("bound_max_rot", 0.0)), float(chain.get("bound_max_trans", 0.0))
+    rd = reading.astype(np.float64)
+    rn = None if reading_nrm is None else reading_nrm.astype(np.float64)
+    ref = ref.astype(np.float64)
+    nrm = nrm.astype(np.float64)
+    tree = cKDTree(ref)
+    T = np.array(T_init, dtype=np.float64)
+    T_iter = np.eye(4)
+    quats = [np.array([1.0, 0, 0, 0])]
+    trans = [np.zeros(3)]
+    out = dict(converged=False, max_iter_reached=False, status=0)
+    it = 0
+    N = rd.shape[0]
+    while True:
+        Tc = T_iter @ T
+        p = rd @ Tc[:3, :3].T + Tc[:3, 3]
+        d, idx = tree.query(p, k=K)
+        d = d.reshape(N, K); idx = idx.reshape(N, K)
+        d2 = d * d
+        finite = d2 <= chain["max_dist"] ** 2
+        vals = d2[finite]
+        nf = vals.size
+        k = min(int(nf * chain["trim_ratio"]), nf - 1) if chain["trim_ratio"] < 1 else nf - 1
+        limit = np.partition(vals, k)[k]
+        keep = finite & (d2 <= limit)
+        if rn is not None and max_angle > 0:
+            a = rn @ Tc[:3, :3].T
+            a = a / np.linalg.norm(a, axis=1, keepdims=True)
+            bq = nrm[np.where(finite, idx, 0)]
+            bq = bq / np.linalg.norm(bq, axis=2, keepdims=True)
+            keep &= np.einsum("ni,nki->nk", a, bq) >= math.cos(max_angle)
+        ii, kk = np.nonzero(keep)
+        pk, qk, nk = p[ii], ref[idx[ii, kk]], nrm[idx[ii, kk]]
+        if p2point:
+            mp, mq = pk.mean(0), qk.mean(0)
+            M = (qk - mq).T @ (pk - mp)
+            U, S, Vt = np.linalg.svd(M)
+            R = U @ Vt
+            if np.linalg.det(R) < 0:
+                Vt = Vt.copy(); Vt[2] *= -1
+                R = U @ Vt
+            dT = np.eye(4); dT[:3, :3] = R; dT[:3, 3] = mq - R @ mp
+            residual = float(np.sum(np.linalg.norm(pk - qk, axis=1)))
+        else:
+            e = np.sum(nk * (pk - qk), axis=1)
+            J = np.column_stack([np.cross(pk, nk), nk])
+            dT = rodrigues(np.linalg.solve(J.T @ J, -J.T @ e))
+            residual = float(np.sum(e * e))
+        T_iter = dT @ T_iter
+        it += 1
+        out.update(overlap=keep.sum() / (N * K), residual=residual, trim_limit=float(limit), n_kept=int(keep.sum()), n_finite=int(nf))
+        quats.append(quat_from_R(T_iter[:3, :3]))
+        trans.append(T_iter[:3, 3].copy())
+        stop = False
+        if it >= chain["max_iters"]:
+            out["max_iter_reached"] = True
+            stop = True
+        s = chain["smooth_length"]
+        if len(quats) > s:
+            r = np.mean([abs(quat_angle(quats[-1 - i], quats[-2 - i])) for i in range(s)])
+            tt = np.mean([np.linalg.norm(trans[-1 - i] - trans[-2 - i]) for i in range(s)])
+            if r < chain["min_diff_rot"] and tt < chain["min_diff_trans"]:
+                out["converged"] = True
+                stop = True
+        if not out["max_iter_reached"] and (b_rot > 0 or b_tr > 0):
+            ang = abs(quat_angle(quats[-1], quats[0]))
+            if (b_rot > 0 and ang > b_rot) or (b_tr > 0 and np.linalg.norm(trans[-1]) > b_tr):
+                out["status"] = 7
+                break
+        if stop:
+            mean = ref.mean(axis=0)
+            out["cov"] = np.zeros((6, 6)) if p2point else censi_cov(pk - mean, qk - mean, nk, dT, chain["sensor_std_dev"])
+            break
+    out["T"] = T_iter @ T if out["status"] == 0 else np.eye(4)
+    out["iterations"] = it
+    return out
+
+
+def main_variants():
+    """tests/golden/chain_variants_small.npz: one scan-to-map problem through the chain with its other modules"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    w = synth.make_scan_to_map(n_scan=3000, n_map=16000, n_queries=1, n_map_poses=4, rings=16)
+    rd, T0 = w.scans_xyz[0], w.T_init[0]
+    # reading normals for the SurfaceNormalOutlierFilter: the normals of the reading's nearest map points at the true pose,
+    # expressed in the reading's frame, every seventh one turned by 60 degrees (pairs the filter must drop)
+    Tt = w.T_truth[0]
+    pt = rd.astype(np.float64) @ Tt[:3, :3].T + Tt[:3, 3]
+    _, j = cKDTree(w.map_xyz.astype(np.float64)).query(pt)
+    rn = w.map_nrm[j].astype(np.float64) @ Tt[:3, :3]
+    c, s_ = math.cos(math.pi / 3), math.sin(math.pi / 3)
+    Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]]); Rx = np.array([[1.0, 0, 0], [0, c, -s_], [0, s_, c]])
+    rn[::7] = rn[::7] @ (Rz @ Rx).T
+    rn = rn.astype(np.float32)
+    fix = dict(map_xyz=w.map_xyz, map_nrm=w.map_nrm, reading=rd, reading_nrm=rn, T_init=T0, T_truth=Tt)
+    variants = dict(knn3=dict(CHAIN, knn=3), p2point=dict(CHAIN, error_minimizer=1), p2point_knn2=dict(CHAIN, error_minimizer=1, knn=2),
+                    normals=dict(CHAIN, normal_max_angle=0.5), bound_ok=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=1.0),
+                    bound_hit=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=0.05))
+    for name, ch in variants.items():
+        r = np_icp_ex(rd, w.map_xyz, w.map_nrm, T0, ch, reading_nrm=rn if "normal_max_angle" in ch else None)
+        for k in ("T", "iterations", "converged", "status", "overlap", "residual", "trim_limit", "n_kept", "n_finite"):
+            fix[f"{name}_{k}"] = r[k]
+        if "cov" in r:
+            fix[f"{name}_cov"] = r["cov"]
+        print(name, "status", r["status"], "iterations", r["iterations"], "kept", r["n_kept"], "overlap", round(r["overlap"], 4))
+    np.savez_compressed(os.path.join(here, "chain_variants_small.npz"), **fix)
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     # ---- scan-to-map, small ------------------------------------------------
@@ -197,5 +313,8 @@ def main():
     print("wrote fixtures:", [f for f in os.listdir(here) if f.endswith(".npz")])
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "variants":
+    main_variants()
+    sys.exit(0)
 if __name__ == "__main__":
     main()

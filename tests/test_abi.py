@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_sizes():
     lib = icp.load_library()
-    assert lib.pgicp_abi_version() == 3
+    assert lib.pgicp_abi_version() == 4
     assert ctypes.sizeof(icp.Edge) == 512
     p = icp.Params()
     lib.pgicp_default_params(ctypes.byref(p))

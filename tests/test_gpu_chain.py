@@ -1,0 +1,142 @@
+"""GPU parity of the chain's other modules (round 4): KDTreeMatcher.knn > 1, PointToPointErrorMinimizer,
+SurfaceNormalOutlierFilter, BoundTransformationChecker -- the HIP path through the C ABI against the CPU oracle on the same
+inputs, and against the independent float64 chain of tests/golden/make_golden.py (chain_variants_small.npz).
+A pgslam user's YAML may name any of them (loadFromYaml at /root/reference/src/pgslam/Localizer.hpp:70, LoopCloser.hpp:73)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from pgslam_amd import icp, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01,
+             smooth_length=3, sensor_std_dev=0.01)
+RESET = dict(knn=1, error_minimizer=0, bound_max_rot=0.0, bound_max_trans=0.0, normal_max_angle=0.0, outlier_max_dist=0.0,
+             quantile_scale=1.0)
+VARIANTS = dict(knn3=dict(knn=3), p2point=dict(error_minimizer=1), p2point_knn2=dict(error_minimizer=1, knn=2),
+                normals=dict(normal_max_angle=0.5), bound_ok=dict(bound_max_rot=0.2, bound_max_trans=1.0),
+                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05))
+
+
+def pose_error(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    c = min(1.0, max(-1.0, (np.trace(d[:3, :3]) - 1.0) / 2.0))
+    return np.linalg.norm(d[:3, 3]), math.acos(c)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "chain_variants_small.npz"))
+
+
+@pytest.mark.parametrize("k", [2, 3, 5, 8])
+@pytest.mark.parametrize("max_dist", [2.0, 0.25, float("inf")])
+def test_match_knn_bit_exact(ctx, oracle32, gold, k, max_dist):
+    """knn neighbours per point in (distance, index) order, -1 / +inf where fewer lie within maxDist: bit for bit."""
+    ctx.set_params(**{**CHAIN, **RESET, "max_dist": max_dist, "knn": k})
+    mid = ctx.set_map(gold["map_xyz"], None, center=False)
+    ids, d2 = ctx.match(mid, gold["reading"], T=gold["T_init"])
+    ctx.destroy_map(mid)
+    q = oracle32.transform(gold["T_init"], gold["reading"])
+    oid, od2 = oracle32.knn_k(gold["map_xyz"], q, k, max_dist)
+    assert ids.shape == (len(q), k)
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+    ctx.set_params(**dict(CHAIN, **RESET))
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_chain_variant_against_oracle_and_golden(ctx, oracle32, oracle64, gold, name, dtype):
+    z = gold
+    o = oracle32 if dtype == np.float32 else oracle64
+    chain = dict(CHAIN, **VARIANTS[name])
+    ctx.set_params(**dict(CHAIN, **RESET))
+    ctx.set_params(**chain)
+    rd, mx, mn = z["reading"].astype(dtype), z["map_xyz"].astype(dtype), z["map_nrm"].astype(dtype)
+    rn = z["reading_nrm"].astype(dtype) if name == "normals" else None
+    mid = ctx.set_map(mx, mn, center=True, dtype=dtype)
+    r = o.icp(rd, mx, mn, z["T_init"], reading_nrm=rn, **chain)
+    if name == "bound_hit":
+        with pytest.raises(icp.ConvergenceError) as e:
+            ctx.align(mid, rd, z["T_init"], dtype=dtype)
+        assert e.value.code == icp.ERR_BOUND and r["status"] == 7 and int(z[f"{name}_status"]) == 7
+    else:
+        T, st = ctx.align(mid, rd, z["T_init"], dtype=dtype, normals=rn)
+        assert st["status"] == 0 and r["status"] == 0
+        dt, dr = pose_error(r["T"], T)
+        assert dt < 1e-5 and dr < 1e-5, (dt, dr)
+        assert st["iterations"] == r["iterations"] and st["converged"] == r["converged"]
+        assert st["n_finite"] == r["n_finite"] and st["n_kept"] == r["n_kept"]
+        if dtype == np.float32:
+            assert np.float32(st["trim_limit"]) == np.float32(r["trim_limit"])
+        else:       # (the solved transforms agree to ~1e-15: a double distance may differ in its last bits)
+            assert st["trim_limit"] == pytest.approx(r["trim_limit"], rel=1e-9)
+        assert st["overlap"] == pytest.approx(r["overlap"], rel=1e-12)
+        assert st["residual"] == pytest.approx(r["residual"], rel=1e-6)
+        if chain.get("error_minimizer", 0) == 1:
+            assert not np.any(st["cov"])                      # PointToPoint: the base class's getCovariance
+        else:
+            np.testing.assert_allclose(st["cov"], r["cov"], rtol=1e-5, atol=1e-14)
+        # ... and the independent float64 chain
+        gt, gr = pose_error(z[f"{name}_T"], T)
+        assert gt < 1e-4 and gr < 1e-5, (gt, gr)
+        assert st["iterations"] == int(z[f"{name}_iterations"]) and abs(st["n_kept"] - int(z[f"{name}_n_kept"])) <= 2
+    ctx.destroy_map(mid)
+    ctx.set_params(**dict(CHAIN, **RESET))
+
+
+def test_knn_matcher_state_after_every_iteration(ctx, oracle32, gold):
+    """knn = 3: ids and squared distances of ALL pairs bit for bit after 1, 2 and 3 iterations."""
+    z = gold
+    for iters in (1, 2, 3):
+        chain = dict(CHAIN, knn=3, max_iters=iters, min_diff_rot=0.0, min_diff_trans=0.0)
+        ctx.set_params(**dict(CHAIN, **RESET))
+        ctx.set_params(**chain)
+        mid = ctx.set_map(z["map_xyz"], z["map_nrm"], center=True)
+        T, st = ctx.align(mid, z["reading"], z["T_init"])
+        ids, d2 = ctx.debug_last_matches(len(z["reading"]))
+        ctx.destroy_map(mid)
+        r = oracle32.icp(z["reading"], z["map_xyz"], z["map_nrm"], z["T_init"], **chain)
+        assert st["iterations"] == iters == r["iterations"]
+        assert np.array_equal(ids, r["last_ids"])
+        assert np.array_equal(d2.view(np.uint32), r["last_d2"].view(np.uint32))
+        assert st["n_kept"] == r["n_kept"] and st["n_finite"] == r["n_finite"]
+    ctx.set_params(**dict(CHAIN, **RESET))
+
+
+def test_batch_of_variants_and_partial_chain(ctx, oracle32, gold):
+    """knn = 2 in a batch (two problems, one map), and the partial chain (ComputeOverlapWith) with knn = 2."""
+    z = gold
+    chain = dict(CHAIN, knn=2)
+    ctx.set_params(**dict(CHAIN, **RESET))
+    ctx.set_params(**chain)
+    mid = ctx.set_map(z["map_xyz"], z["map_nrm"], center=True)
+    T0 = [z["T_init"], z["T_init"] @ synth.se3(x=0.03, yaw=0.004)]
+    rds = [z["reading"], z["reading"][:2500]]
+    Ts, sts = ctx.align_batch(mid, rds, T0)
+    for b in range(2):
+        r = oracle32.icp(rds[b], z["map_xyz"], z["map_nrm"], T0[b], **chain)
+        dt, dr = pose_error(r["T"], Ts[b])
+        assert dt < 1e-5 and dr < 1e-5
+        assert sts[b]["iterations"] == r["iterations"] and sts[b]["n_kept"] == r["n_kept"]
+    ctx.destroy_map(mid)
+    rid = ctx.set_map(z["map_xyz"], z["map_nrm"], center=False)
+    ov, res = ctx.partial_chain(rid, z["reading"], T=z["T_truth"])
+    po = oracle32.partial_chain(z["reading"], z["map_xyz"], z["map_nrm"], z["T_truth"], **chain)
+    assert ov == pytest.approx(po["overlap"], rel=1e-12) and res == pytest.approx(po["residual"], rel=1e-6)
+    ctx.destroy_map(rid)
+    ctx.set_params(**dict(CHAIN, **RESET))
+
+
+def test_normals_filter_needs_reading_normals(ctx, gold):
+    ctx.set_params(**{**CHAIN, **RESET, "normal_max_angle": 0.5})
+    mid = ctx.set_map(gold["map_xyz"], gold["map_nrm"], center=True)
+    with pytest.raises(icp.PgicpError):
+        ctx.align(mid, gold["reading"], gold["T_init"])
+    ctx.destroy_map(mid)
+    ctx.set_params(**dict(CHAIN, **RESET))

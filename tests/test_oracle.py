@@ -322,3 +322,139 @@ def test_median_dist_outlier_filter_restatement(oracle32, oracle64):
     a = oracle32.icp(t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], t["T_init"], **dict(CHAIN, trim_ratio=0.5, quantile_scale=3.0))
     b = oracle32.icp(t["reading_xyz"], t["ref_xyz"], t["ref_nrm"], t["T_init"], **dict(CHAIN, trim_ratio=0.5))
     assert a["status"] == 0 and a["n_kept"] > b["n_kept"] and a["trim_limit"] > b["trim_limit"]
+
+
+# ------------------------------------------------------------------ round 4: the chain's other modules (knn > 1, PointToPoint,
+# SurfaceNormalOutlierFilter, BoundTransformationChecker) -- each against the independent float64 chain of make_golden.py
+# (np_icp_ex: scipy k-d tree, numpy.linalg.svd / solve), never against the oracle itself
+VARIANTS = dict(knn3=dict(knn=3), p2point=dict(error_minimizer=1), p2point_knn2=dict(error_minimizer=1, knn=2),
+                normals=dict(normal_max_angle=0.5), bound_ok=dict(bound_max_rot=0.2, bound_max_trans=1.0),
+                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05))
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_oracle_matches_golden_chain_variants(oracle32, oracle64, name):
+    z = np.load(os.path.join(GOLD, "chain_variants_small.npz"))
+    chain = dict(CHAIN, **VARIANTS[name])
+    for o in (oracle32, oracle64):
+        r = o.icp(z["reading"], z["map_xyz"], z["map_nrm"], z["T_init"], reading_nrm=z["reading_nrm"] if name == "normals" else None,
+                  **chain)
+        assert r["status"] == int(z[f"{name}_status"])
+        assert r["iterations"] == int(z[f"{name}_iterations"])
+        if r["status"] != 0:
+            assert r["status"] == 7                       # BoundTransformationChecker: ConvergenceError
+            continue
+        dt, dr = pose_error(z[f"{name}_T"], r["T"])
+        assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+        assert r["converged"] == bool(z[f"{name}_converged"])
+        assert r["n_finite"] == int(z[f"{name}_n_finite"])
+        assert abs(r["n_kept"] - int(z[f"{name}_n_kept"])) <= 2
+        assert r["overlap"] == pytest.approx(float(z[f"{name}_overlap"]), abs=1e-3)
+        assert r["trim_limit"] == pytest.approx(float(z[f"{name}_trim_limit"]), rel=1e-3)
+        assert r["residual"] == pytest.approx(float(z[f"{name}_residual"]), rel=1e-2)
+        np.testing.assert_allclose(r["cov"], z[f"{name}_cov"], rtol=1e-3, atol=1e-12)
+        gt, gr = pose_error(z["T_truth"], r["T"])
+        assert gt < 0.03 and gr < 0.003
+
+
+def test_knn_k_against_scipy_and_brute(oracle32, oracle64):
+    """KDTreeMatcher.knn > 1 (A.3): the k-d tree and the brute-force restatement agree bit for bit; both agree with
+    scipy.cKDTree(k) wherever float rounding cannot reorder neighbours."""
+    for o, dt in ((oracle32, np.float32), (oracle64, np.float64)):
+        m = rng_cloud(61, 2500).astype(dt)
+        m = np.concatenate([m, m[:100]])                 # duplicates -> ties, resolved by index
+        q = rng_cloud(62, 700, 1.3).astype(dt)
+        for md in (np.inf, 0.12):
+            ib, db = o.knn_brute_k(q, m, 4, md)
+            ik, dk = o.knn_k(m, q, 4, md)
+            assert np.array_equal(ib, ik) and np.array_equal(db, dk)
+            d, idx = cKDTree(m.astype(np.float64)).query(q.astype(np.float64), k=5)
+            clear = np.all(np.diff(d, axis=1) > 1e-5, axis=1) & (np.abs(d[:, :4] - md) > 1e-5).all(axis=1)
+            want = np.where(d[:, :4] <= md, idx[:, :4], -1)
+            assert clear.mean() > 0.8
+            assert np.array_equal(ib[clear], want[clear])
+            fin = (want >= 0) & clear[:, None]
+            np.testing.assert_allclose(np.sqrt(db[fin].astype(np.float64)), d[:, :4][fin], rtol=2e-4, atol=2e-6)
+            assert np.all(np.isinf(db[(want < 0) & clear[:, None]]))
+
+
+def test_point_to_point_against_numpy_svd(oracle32, oracle64):
+    """PointToPointErrorMinimizer: the sums, and the increment against a weighted Kabsch through numpy.linalg.svd; a
+    reflection is turned into the second-best rotation; the residual is the sum of the pairs' distances."""
+    rng = np.random.default_rng(5)
+    for o, dt in ((oracle32, np.float32), (oracle64, np.float64)):
+        q = rng.normal(size=(400, 3))
+        Rt = synth.se3(x=0.3, y=-0.2, z=0.1, yaw=0.2, pitch=-0.1, roll=0.05)
+        p = ((q - Rt[:3, 3]) @ Rt[:3, :3] + 0.01 * rng.normal(size=q.shape)).astype(dt)      # q ~ R p + t
+        q = q.astype(dt)
+        ids = rng.permutation(400).astype(np.int32)
+        w = (rng.random(400) > 0.2).astype(dt)
+        st, sys_ = o.p2point_system(p, q, ids, w)
+        assert st == 0
+        keep = w != 0
+        pk, qk = p[keep].astype(np.float64), q[ids[keep]].astype(np.float64)
+        np.testing.assert_allclose(sys_[0:3], pk.sum(0), rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(sys_[3:6], qk.sum(0), rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(sys_[6:15].reshape(3, 3), qk.T @ pk, rtol=1e-12, atol=1e-9)
+        assert sys_[27] == keep.sum() and sys_[28] == keep.sum()
+        assert sys_[29] == pytest.approx(np.linalg.norm(pk - qk, axis=1).sum(), rel=1e-6)
+        # pairs in order: the transform is recovered
+        st, sys_ = o.p2point_system(p, q, np.arange(400, dtype=np.int32), np.ones(400, dtype=dt))
+        T, rank = o.solve_p2point(sys_)
+        mp, mq = p.astype(np.float64).mean(0), q.astype(np.float64).mean(0)
+        U, S, Vt = np.linalg.svd((q.astype(np.float64) - mq).T @ (p.astype(np.float64) - mp))
+        R = U @ Vt
+        assert np.linalg.det(R) > 0 and rank == 3
+        np.testing.assert_allclose(T[:3, :3], R, atol=1e-9)
+        np.testing.assert_allclose(T[:3, 3], mq - R @ mp, atol=1e-9)
+        dt_, dr_ = pose_error(Rt, T)
+        assert dt_ < 5e-3 and dr_ < 5e-3
+    # a planar set mirrored through its plane: U V^T is a reflection; the answer must be a rotation (det +1)
+    a = rng.normal(size=(200, 3)); a[:, 2] = 0.0
+    b = a.copy(); b[:, 0] = -b[:, 0]
+    st, sys_ = oracle64.p2point_system(a, b, np.arange(200, dtype=np.int32), np.ones(200))
+    T, rank = oracle64.solve_p2point(sys_)
+    assert rank == 2 and np.linalg.det(T[:3, :3]) == pytest.approx(1.0, abs=1e-9)
+    np.testing.assert_allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-9)
+
+
+def test_surface_normal_outlier_filter_restatement(oracle32, oracle64):
+    """SurfaceNormalOutlierFilter: weight 0 where the angle between the (normalised) normals exceeds maxAngle or the
+    match is invalid; it multiplies into the weights it is given."""
+    rng = np.random.default_rng(9)
+    for o, dt in ((oracle32, np.float32), (oracle64, np.float64)):
+        a = rng.normal(size=(500, 3)).astype(dt) * 3.0          # not unit length: the filter normalises
+        b = rng.normal(size=(300, 3)).astype(dt) * 0.2
+        ids = rng.integers(-1, 300, size=(500, 2)).astype(np.int32)
+        w0 = (rng.random((500, 2)) > 0.3).astype(dt)
+        for ang in (0.4, 1.2, 2.5):
+            w = o.normal_weights(a, b, ids, ang, w0)
+            an = a.astype(np.float64) / np.linalg.norm(a.astype(np.float64), axis=1, keepdims=True)
+            bn = b.astype(np.float64) / np.linalg.norm(b.astype(np.float64), axis=1, keepdims=True)
+            cosv = np.einsum("ni,nki->nk", an, bn[np.maximum(ids, 0)])
+            want = w0 * ((cosv >= math.cos(ang)) & (ids >= 0))
+            clear = np.abs(cosv - math.cos(ang)) > 1e-5           # float rounding may flip a pair that sits on the limit
+            assert np.array_equal(w[clear], want.astype(dt)[clear])
+        assert np.array_equal(o.normal_weights(a, b, ids, 0.0, w0), w0)   # maxAngle <= 0: not in the chain
+
+
+def test_bound_checker_scripted(oracle32):
+    """BoundTransformationChecker (Appendix B.7 style): scripted corrections with known angle / translation."""
+    def Rz(a):
+        T = np.eye(4); T[0, 0] = T[1, 1] = math.cos(a); T[0, 1] = -math.sin(a); T[1, 0] = math.sin(a)
+        return T
+    c = oracle32.checker(50, 0.0, 0.0, 3)
+    oracle32.checker_set_bound(c, 0.3, 0.5)
+    T = Rz(0.1); T[0, 3] = 0.2
+    assert oracle32.checker_check(c, T) & 1 and not oracle32.checker_check(c, T) & 16
+    T = Rz(0.29); T[0, 3] = 0.49
+    assert not oracle32.checker_check(c, T) & 16
+    assert oracle32.checker_check(c, Rz(0.31)) == 16                  # rotation beyond the bound
+    c = oracle32.checker(50, 0.0, 0.0, 3)
+    oracle32.checker_set_bound(c, 0.3, 0.5)
+    T = np.eye(4); T[:3, 3] = [0.3, 0.3, 0.3]                        # |t| = 0.52
+    assert oracle32.checker_check(c, T) == 16
+    # the Counter's condition leaves the check before the Bound is looked at
+    c = oracle32.checker(1, 0.0, 0.0, 3)
+    oracle32.checker_set_bound(c, 0.3, 0.5)
+    assert oracle32.checker_check(c, T) == 4
