@@ -220,6 +220,17 @@ int pgicp_align_batch_f32(pgicp_ctx *ctx, int n_problems, const pgicp_problem *p
                           pgicp_stats *stats);
 int pgicp_align_batch_f64(pgicp_ctx *ctx, int n_problems, const pgicp_problem *problems, double *T_out,
                           pgicp_stats *stats);
+/* pgicp_align_residual_batch = the numeric part of LoopCloser::ProcessVertex for a batch of candidates
+ * (LoopCloser.hpp:83-110): ICP::operator() per pair (:98), then -- for CheckIcpResult (:308-340) -- ComputeResidualError's
+ * chain on the result (:343-365: the reading moved by the result, matched, weighted, getResidualError), FUSED: the residual
+ * pass starts from the last iteration's correspondences instead of searching from scratch (they are candidates only; the
+ * matches are the exact ones).  residual[p] = getResidualError (+inf when the ICP of p failed or nothing is kept), ratio[p]
+ * (optional) = weightedPointUsedRatio of that pass, status[p] (optional) = PGICP_OK / PGICP_ERR_NO_MATCH.  The maps are the
+ * ICP's (centred) indices: against pgicp_partial_chain_batch on an un-centred index the figures agree to float rounding. */
+int pgicp_align_residual_batch_f32(pgicp_ctx *ctx, int n_problems, const pgicp_problem *problems, double *T_out, pgicp_stats *stats,
+                                   double *residual, double *ratio, int *status);
+int pgicp_align_residual_batch_f64(pgicp_ctx *ctx, int n_problems, const pgicp_problem *problems, double *T_out, pgicp_stats *stats,
+                                   double *residual, double *ratio, int *status);
 int pgicp_icp_pair_f32(pgicp_ctx *ctx, const float *reading, int rd_stride, int n, const float *ref_xyz,
                        int ref_stride, const float *ref_nrm, int nrm_stride, int m, int mem,
                        const double T_init[16], double T_out[16], pgicp_stats *stats);

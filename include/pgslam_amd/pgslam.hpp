@@ -464,26 +464,12 @@ public:
         }
         std::vector<double> Tout((size_t)16 * P);
         std::vector<pgicp_stats> st(P);
-        const int rc = sizeof(T) == 4 ? pgicp_align_batch_f32(ctx, P, pr.data(), Tout.data(), st.data())
-                                      : pgicp_align_batch_f64(ctx, P, pr.data(), Tout.data(), st.data());
-        if (rc != PGICP_OK && rc != PGICP_ERR_NO_MATCH && rc != PGICP_ERR_NAN) PM::check(ctx, rc);
-        // ComputeResidualError (LoopCloser.hpp:343-365) of every aligned pair, one device pass
-        std::vector<pgicp_problem> chk;
-        std::vector<int> chk_of;
-        for (int k = 0; k < P; k++)
-            if (st[k].status == PGICP_OK) {
-                pgicp_problem q = pr[k];
-                std::memcpy(q.T_init, Tout.data() + 16 * k, sizeof q.T_init);
-                chk.push_back(q); chk_of.push_back(k);
-            }
-        std::vector<double> residual(P, 1.0 / 0.0), res(chk.size());
-        std::vector<int> cst(chk.size());
-        if (!chk.empty()) {
-            const int prc = sizeof(T) == 4 ? pgicp_partial_chain_batch_f32(ctx, (int)chk.size(), chk.data(), nullptr, res.data(), cst.data())
-                                           : pgicp_partial_chain_batch_f64(ctx, (int)chk.size(), chk.data(), nullptr, res.data(), cst.data());
-            if (prc != PGICP_OK && prc != PGICP_ERR_NO_MATCH) PM::check(ctx, prc);
-            for (size_t i = 0; i < chk.size(); i++) if (cst[i] == PGICP_OK) residual[chk_of[i]] = res[i];
-        }
+        // ICP::operator() of every pair (LoopCloser.hpp:98) and ComputeResidualError (LoopCloser.hpp:343-365) of every result
+        // in one device call: the residual pass starts from the last iteration's correspondences
+        std::vector<double> residual(P, 1.0 / 0.0);
+        const int rc = sizeof(T) == 4 ? pgicp_align_residual_batch_f32(ctx, P, pr.data(), Tout.data(), st.data(), residual.data(), nullptr, nullptr)
+                                      : pgicp_align_residual_batch_f64(ctx, P, pr.data(), Tout.data(), st.data(), residual.data(), nullptr, nullptr);
+        if (rc != PGICP_OK && rc != PGICP_ERR_NO_MATCH && rc != PGICP_ERR_NAN && rc != PGICP_ERR_BOUND) PM::check(ctx, rc);
         for (int k = 0; k < P; k++) {
             const Candidate &c = queue_[mine[k]];
             pgicp_edge &e = edges[k];

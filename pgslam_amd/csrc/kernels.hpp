@@ -46,6 +46,7 @@ int knn_phase_read(unsigned long long out[48], int reset);   // diagnostics buil
 int knn_dump_setup(long long total, int passes);              // diagnostics build only: per-query candidate dump
 int knn_dump_read(unsigned *cnt, float *d2, long long n);
 int knn_trace_set(int sorted_index);                       // diagnostics build only   // diagnostics build (-DPGICP_KNN_STATS) only
+void launch_reopen(hipStream_t st, ProblemDev *probs, int P);
 void launch_compact_active(hipStream_t st, const ProblemDev *probs, int P, int *active, int *host_flag, int *stamp_counter,
                            int *queue_counters);
 template <typename T>

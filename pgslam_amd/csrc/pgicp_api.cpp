@@ -100,7 +100,7 @@ struct pgicp_ctx {
     pgicp_params prm{};
     State<float> f32;
     State<double> f64;
-    DevBuf probs, src, partials, sums, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_w, tmp_p, tmp_n;
+    DevBuf probs, src, partials, sums, sums2, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_w, tmp_p, tmp_n;
     DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active, sel_tables, queue;
     // host-input pipeline (pgicp_upload_*): a copy stream and two upload sets used alternately
     struct UploadSet {
@@ -1040,8 +1040,11 @@ static int wait_iteration_flag(pgicp_ctx *c)
     return __atomic_load_n(&c->h_flag[0], __ATOMIC_RELAXED);
 }
 
+// `residual` / `res_ratio` / `res_status` (optional, P entries each): after the ICP, LoopCloser::ComputeResidualError's chain
+// on the result (LoopCloser.hpp:343-365) -- see pgicp_align_residual_batch_*.
 template <typename T>
-int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgicp_stats *stats)
+int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgicp_stats *stats, double *residual = nullptr,
+                double *res_ratio = nullptr, int *res_status = nullptr)
 {
     if (!c || P <= 0 || !pr || !T_out) return fail(c, PGICP_ERR_ARG, "pgicp_align_batch: bad argument");
     HIPC(c, hipSetDevice(c->device));
@@ -1100,9 +1103,32 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     { const int pst = pinned_ensure(c, &c->h_down, &c->h_down_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
     HIPC(c, hipMemcpyAsync(c->h_down, c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipMemcpyAsync(cs.data(), c->sums.p, sizeof(double) * cs.size(), hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> rsys;
+    if (residual || res_ratio || res_status) {
+        // The residual check of the result: one more pass of the chain WITHOUT a solve, with the final transform (it is in
+        // ProblemDev::Tcur) -- transform, match, outlier weights, error elements.  The pass is SEEDED with the last
+        // iteration's correspondences, which the final increment (below the convergence thresholds) hardly moves: as a
+        // separate, unseeded chain it cost a fifth of a loop-closure batch.  Seeds are candidates only: the matches are exact.
+        launch_reopen(c->stream, c->probs.as<ProblemDev>(), P);
+        HIPC(c, hipMemcpyAsync(c->active.p, c->h_ident.data(), sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
+        c->prof_next_m = total_m;
+        one_iteration<T>(c, L, ch, false, L.total, P, 1);
+        HIPC(c, c->sums2.ensure(sizeof(double) * (size_t)P * kSys));
+        launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(L.max_pairs()), kSys, c->probs.as<ProblemDev>(), 0,
+                            c->sums2.as<double>(), P);
+        rsys.resize((size_t)P * kSys);
+        HIPC(c, hipMemcpyAsync(rsys.data(), c->sums2.p, sizeof(double) * rsys.size(), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
     std::memcpy(hp.data(), c->h_down, sizeof(ProblemDev) * (size_t)P);
+    for (int p = 0; p < P && !rsys.empty(); p++) {
+        const double *rs = rsys.data() + (size_t)p * kSys;
+        const bool ok = hp[p].status == PGICP_ST_OK && rs[28] > 0.0;
+        if (res_status) res_status[p] = ok ? PGICP_OK : PGICP_ERR_NO_MATCH;
+        if (res_ratio) res_ratio[p] = ok ? rs[27] / ((double)pr[p].n * L.knn) : 0.0;
+        if (residual) residual[p] = ok ? rs[29] : std::numeric_limits<double>::infinity();
+    }
     if (host_timing) {
         const auto ht3 = std::chrono::steady_clock::now();
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1805,7 +1831,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     }
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
-                      &c->probs, &c->src, &c->partials, &c->sums, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e, &c->tmp_w, &c->tmp_p, &c->tmp_n,
+                      &c->probs, &c->src, &c->partials, &c->sums, &c->sums2, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e, &c->tmp_w, &c->tmp_p, &c->tmp_n,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->f32.nrm_pre, &c->f32.nrm_sorted, &c->f64.nrm_pre, &c->f64.nrm_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
                       &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->sel_tables, &c->queue, &c->f32.none_r, &c->f64.none_r})
         b->release();
@@ -1969,6 +1995,19 @@ int pgicp_align_batch_f32(pgicp_ctx *c, int P, const pgicp_problem *pr, double *
 { return align_batch<float>(c, P, pr, T_out, stats); }
 int pgicp_align_batch_f64(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgicp_stats *stats)
 { return align_batch<double>(c, P, pr, T_out, stats); }
+
+int pgicp_align_residual_batch_f32(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgicp_stats *stats, double *residual,
+                                   double *ratio, int *status)
+{
+    if (!residual) return fail(c, PGICP_ERR_ARG, "pgicp_align_residual_batch: residual is null");
+    return align_batch<float>(c, P, pr, T_out, stats, residual, ratio, status);
+}
+int pgicp_align_residual_batch_f64(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgicp_stats *stats, double *residual,
+                                   double *ratio, int *status)
+{
+    if (!residual) return fail(c, PGICP_ERR_ARG, "pgicp_align_residual_batch: residual is null");
+    return align_batch<double>(c, P, pr, T_out, stats, residual, ratio, status);
+}
 
 int pgicp_icp_pair_f32(pgicp_ctx *c, const float *rd, int rs, int n, const float *rx, int xs, const float *rn, int ns, int m,
                        int mem, const double T_init[16], double T_out[16], pgicp_stats *stats)

@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "pgicp_map_create_f32", "pgicp_map_create_f64", "pgicp_map_create_batch_f32", "pgicp_map_create_batch_f64",
     "pgicp_map_destroy", "pgicp_map_size", "pgicp_map_transfer",
     "pgicp_align_f32", "pgicp_align_f64", "pgicp_align_batch_f32", "pgicp_align_batch_f64",
+    "pgicp_align_residual_batch_f32", "pgicp_align_residual_batch_f64",
     "pgicp_icp_pair_f32", "pgicp_icp_pair_f64", "pgicp_match_f32", "pgicp_match_f64",
     "pgicp_outlier_weights_f32", "pgicp_outlier_weights_f64", "pgicp_error_stats_f32", "pgicp_error_stats_f64",
     "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_partial_chain_batch_f32",
@@ -405,7 +406,13 @@ class Context:
                        _T16(T_init), T_out, C.byref(st)))
         return np.array(T_out[:]).reshape(4, 4), st.as_dict()
 
-    def align_batch(self, map_ids, readings, T_inits, dtype=None, raise_on_error=True, normals=None):
+    def align_residual_batch(self, map_ids, readings, T_inits, dtype=None, normals=None):
+        """pgicp_align_residual_batch: the ICPs of a batch of loop-closure candidates and, fused, the residual check of every
+        result (LoopCloser.hpp:98, 343-365).  Returns (T (P,4,4), stats, residual (P,), ratio (P,), status (P,)); never raises
+        for a failed candidate (its residual is +inf)."""
+        return self.align_batch(map_ids, readings, T_inits, dtype=dtype, raise_on_error=False, normals=normals, _residual=True)
+
+    def align_batch(self, map_ids, readings, T_inits, dtype=None, raise_on_error=True, normals=None, _residual=False):
         P = len(readings)
         if isinstance(map_ids, int):
             map_ids = [map_ids] * P
@@ -426,8 +433,14 @@ class Context:
             pa["nstride"] = [b.stride for b in nbufs]
         T_out = np.empty((P, 4, 4), dtype=np.float64)
         sa = np.zeros(P, dtype=_STATS_DTYPE)
-        fn = getattr(self.lib, "pgicp_align_batch" + self._sfx(bufs[0].dtype))
-        rc = fn(self.h, C.c_int(P), C.c_void_p(pa.ctypes.data), C.c_void_p(T_out.ctypes.data), C.c_void_p(sa.ctypes.data))
+        if _residual:
+            res, ratio, rst = np.zeros(P), np.zeros(P), np.zeros(P, dtype=np.int32)
+            fn = getattr(self.lib, "pgicp_align_residual_batch" + self._sfx(bufs[0].dtype))
+            rc = fn(self.h, C.c_int(P), C.c_void_p(pa.ctypes.data), C.c_void_p(T_out.ctypes.data), C.c_void_p(sa.ctypes.data),
+                    C.c_void_p(res.ctypes.data), C.c_void_p(ratio.ctypes.data), C.c_void_p(rst.ctypes.data))
+        else:
+            fn = getattr(self.lib, "pgicp_align_batch" + self._sfx(bufs[0].dtype))
+            rc = fn(self.h, C.c_int(P), C.c_void_p(pa.ctypes.data), C.c_void_p(T_out.ctypes.data), C.c_void_p(sa.ctypes.data))
         if raise_on_error:
             self._check(rc)
         elif rc not in (OK, ERR_NO_MATCH, ERR_NAN, ERR_BOUND):
@@ -438,6 +451,8 @@ class Context:
         stats = [dict(status=st, iterations=it, converged=bool(cv), max_iter_reached=bool(mx), overlap=ov, residual=rs, trim_limit=tl,
                       n_kept=nk, n_finite=nf, cov=cov[p])
                  for p, (st, it, cv, mx, ov, rs, tl, nk, nf) in enumerate(zip(*cols))]
+        if _residual:
+            return T_out, stats, res, ratio, rst
         return T_out, stats
 
     def icp_pair(self, reading, ref_xyz, ref_nrm, T_init, dtype=None):

@@ -68,20 +68,16 @@ def make_edge(from_id, to_id, T, stats, residual, cfg: LoopClosureConfig) -> np.
 
 def align_local(ctx: icp.Context, cands, cfg: LoopClosureConfig):
     """Run this rank's candidates as ONE device batch: ICP::operator() per pair (centred index per
-    candidate map), then ComputeResidualError's partial chain with the result (LoopCloser.hpp:343-365)."""
+    candidate map) and ComputeResidualError's chain on the result (LoopCloser.hpp:343-365), fused."""
     if cfg.chain:
         ctx.set_params(**cfg.chain)
     if not cands:
         return np.zeros(0, dtype=EDGE_DTYPE)
     map_ids = ctx.set_maps([c.ref_xyz for c in cands], [c.ref_nrm for c in cands], center=True)
     readings = [c.reading for c in cands]
-    Ts, stats = ctx.align_batch(map_ids, readings, [c.T_init for c in cands], raise_on_error=False)
-    ok = [k for k in range(len(cands)) if stats[k]["status"] == 0]
-    residual = np.full(len(cands), np.inf)
-    if ok:
-        _, res, st = ctx.partial_chain_batch([map_ids[k] for k in ok], [readings[k] for k in ok], [Ts[k] for k in ok],
-                                             raise_on_error=False)
-        residual[ok] = np.where(st == 0, res, np.inf)
+    # ICP and residual check of the result in one device call (pgicp_align_residual_batch: the residual pass is seeded with
+    # the last iteration's correspondences)
+    Ts, stats, residual, _, _ = ctx.align_residual_batch(map_ids, readings, [c.T_init for c in cands])
     # the edge records column by column (512 per-candidate record assignments were a tenth of a step)
     edges = np.zeros(len(cands), dtype=EDGE_DTYPE)
     edges["from_id"] = [c.from_id for c in cands]

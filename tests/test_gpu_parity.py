@@ -355,6 +355,34 @@ def test_loop_closure_batch_against_oracle(ctx, oracle32):
     assert len(lc.accepted_constraints(edges)) == int(edges["accepted"].sum())
 
 
+def test_fused_residual_pass_equals_the_separate_chain(ctx, oracle32):
+    """pgicp_align_residual_batch: the ICPs are those of pgicp_align_batch, bit for bit; the residual pass -- seeded with the
+    last iteration's correspondences -- gives what the separate (unseeded) partial chain gives on the result."""
+    ps = synth.make_pairs(6, n_pts=5000, n_keyframes=6, rings=16)
+    ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
+    rds = [ps.reading_xyz[k] for k in range(6)]
+    T0 = [ps.T_init[k] for k in range(6)]
+    T0[3] = T0[3] @ synth.se3(x=500.0)                     # a candidate that cannot be aligned: its ICP fails, its residual is +inf
+    ids = ctx.set_maps([ps.ref_xyz[k] for k in range(6)], [ps.ref_nrm[k] for k in range(6)], center=True)
+    Ta, sa = ctx.align_batch(ids, rds, T0, raise_on_error=False)
+    Tb, sb, res, ratio, rst = ctx.align_residual_batch(ids, rds, T0)
+    assert np.array_equal(Ta, Tb)
+    for a, b in zip(sa, sb):
+        assert (a["status"], a["iterations"], a["n_kept"], a["n_finite"], a["trim_limit"], a["overlap"], a["residual"]) == \
+               (b["status"], b["iterations"], b["n_kept"], b["n_finite"], b["trim_limit"], b["overlap"], b["residual"])
+        assert np.array_equal(a["cov"], b["cov"])
+    ok = [k for k in range(6) if sa[k]["status"] == 0]
+    assert 3 not in ok and len(ok) == 5 and np.isinf(res[3]) and rst[3] != 0
+    r2, e2, s2 = ctx.partial_chain_batch([ids[k] for k in ok], [rds[k] for k in ok], [Ta[k] for k in ok])
+    for j, k in enumerate(ok):
+        assert rst[k] == 0 and s2[j] == 0
+        assert res[k] == pytest.approx(e2[j], rel=1e-4) and ratio[k] == pytest.approx(r2[j], rel=1e-9)
+        po = oracle32.partial_chain(rds[k], ps.ref_xyz[k], ps.ref_nrm[k], Ta[k], **CHAIN)
+        assert res[k] == pytest.approx(po["residual"], rel=1e-3) and ratio[k] == pytest.approx(po["overlap"], rel=1e-9)
+    for m in ids:
+        ctx.destroy_map(m)
+
+
 def test_batch_entry_points_equal_single_calls(ctx):
     """pgicp_map_create_batch / pgicp_partial_chain_batch give bit-identical results to the per-object calls."""
     ps = synth.make_pairs(4, n_pts=4000, n_keyframes=5, rings=16)
