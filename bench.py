@@ -571,7 +571,7 @@ def main_slam(args, collect=False):
     rec = f"/tmp/pgslam_amd_replay_{rank}.bin"
 
     def run(record):
-        cmd = [exe, seq] + (["--record", str(args.slam_record), rec] if record else [])
+        cmd = [exe, seq, "--filters", args.slam_filters] + (["--record", str(args.slam_record), rec] if record else [])
         t0 = time.perf_counter()
         out = subprocess.run(cmd, env=dict(env, PGICP_PROFILE_ALL="1") if record else env, capture_output=True, text=True, check=True)
         return json.loads(out.stdout.strip().splitlines()[-1]), time.perf_counter() - t0
@@ -627,7 +627,8 @@ def main_slam(args, collect=False):
             "ms_per_step": slam_s * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"full pose-graph SLAM, {res['scans']} scans of {res['points_per_scan']} pts, {args.slam_step} m apart "
-                                   f"(BASELINE.json configs[3]), host clouds through pgslam::PoseGraphSlam<float> (C++ facade)",
+                                   f"(BASELINE.json configs[3]), host clouds through pgslam::PoseGraphSlam<float> (C++ facade), input filters: "
+                                   f"{res.get('input_filters')}",
                        "parallelism": f"{world} independent replica(s), one process per GPU"},
             "slam": res, "replay_vs_oracle": replay, "cpu_baseline": cpu, "roofline": slam_roofline(res_prof)})
     if collect:
@@ -891,18 +892,106 @@ def main_stream(args, collect=False):
     dist_end()
 
 
+def main_f64(args, collect=False):
+    """PointMatcher<double> (the reference instantiates it on equal footing, /root/reference/tests/instantiation.cpp:12-18):
+    the headline's workload -- the same scans, map, initial guesses and chain -- with every scalar a double.  Algorithmic
+    bytes double with the scalars: the matcher kernel 40 N + 24 M per active problem."""
+    import torch
+    from pgslam_amd import icp, synth
+    world, rank, local_rank = ranks()
+    require_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    w = build_workload(args.n_scan, args.n_map, args.queries)
+    chain = dict(CHAIN)
+    ctx = icp.Context(local_rank, **chain, matcher=icp.MATCHER_GRID, check_every=args.check_every)
+    d_map_xyz = torch.from_numpy(w.map_xyz.astype(np.float64)).to(dev)
+    d_map_nrm = torch.from_numpy(w.map_nrm.astype(np.float64)).to(dev)
+    d_scans = [torch.from_numpy(s.astype(np.float64)).to(dev) for s in w.scans_xyz]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    map_id = ctx.set_map(d_map_xyz, d_map_nrm, center=True)
+    t_setmap = time.perf_counter() - t0
+    B = args.batch
+    readings = [d_scans[b % len(d_scans)] for b in range(B)]
+    T_inits = [w.T_truth[b % len(d_scans)] @ synth.perturbation(1000 * rank + b) for b in range(B)]
+
+    def step():
+        return ctx.align_batch(map_id, readings, T_inits, raise_on_error=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    converged, iters, last = 0, [], None
+    for _ in range(args.steps):
+        T, st = step()
+        converged += sum(1 for s in st if s["status"] == 0 and s["converged"])
+        iters += [s["iterations"] for s in st]
+        last = (T, st)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    T, st = last
+    err_t = [float(np.linalg.norm((np.linalg.inv(w.T_truth[b % len(d_scans)]) @ T[b])[:3, 3])) for b in range(B) if st[b]["status"] == 0]
+    # roofline of the matcher kernel: HIP events on the context's stream around every launch of a replay of the timed steps
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    ctx.profile_enable(False)
+    k = ctx.profile()["knn_grid"]
+    roofline = None
+    if k["launches"]:
+        alg = 40.0 * k["units"] + 24.0 * args.n_map * k["problems"]
+        avg_s = k["total_ms"] * 1e-3 / k["launches"]
+        roofline = dict(bound="hbm", kernel="knn_grid<double>", achieved=alg / k["launches"] / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=alg / k["launches"] / avg_s / 1e9 / HBM_PEAK_GBS, traffic=None, avg_launch_us=avg_s * 1e6, launches=k["launches"],
+                        active_problems_per_launch=k["problems"] / k["launches"], algorithmic_bytes_per_launch=alg / k["launches"])
+    cpu = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle import Oracle
+        o = Oracle(np.float64)
+        t0 = time.perf_counter()
+        m = o.map_create(w.map_xyz.astype(np.float64), w.map_nrm.astype(np.float64), center=True, use_kdtree=True)
+        t_build = time.perf_counter() - t0
+        n_cpu = 4
+        t0 = time.perf_counter()
+        rs = [o.icp_map(m, w.scans_xyz[q].astype(np.float64), w.T_init[q], **CHAIN) for q in range(n_cpu)]
+        dt = time.perf_counter() - t0
+        o.map_free(m)
+        cpu = dict(value=sum(1 for r in rs if r["status"] == 0 and r["converged"]) / dt, unit="scans/s", cores=1, kind="port",
+                   sample=f"{n_cpu} of the benchmark's scans vs the 1M-pt map through the float64 CPU oracle (k-d tree port of the chain) on one "
+                          f"core; index build ({t_build:.2f} s) excluded; host has {os.cpu_count()} cores", index_build_s=t_build)
+    ctx.destroy_map(map_id)
+    ctx.close()
+    del d_map_xyz, d_map_nrm, d_scans, readings
+    torch.cuda.empty_cache()
+    out = dict(metric="ICP-converged scans/sec at 100k-pt scan vs 1M-pt local map, PointMatcher<double>", value=converged / elapsed, unit="scans/s",
+               n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed * 1e3 / args.steps, higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=f"scan-to-map ICP, {args.n_scan}-pt scan vs {args.n_map}-pt map, <=30 iterations (BASELINE.json configs[1]) "
+                                    f"with double scalars", batch_scans_per_step=B, parallelism="1 replica"),
+               mean_iterations=float(np.mean(iters)), converged_fraction=converged / max(1, args.steps * B), set_map_ms=t_setmap * 1e3,
+               median_translation_error_m=float(np.median(err_t)) if err_t else None, roofline=roofline, cpu_baseline=cpu)
+    if collect:
+        return out
+    emit(out)
+
+
 def compact_leg(d, wall_s):
     """What a leg contributes to the headline's line: the figure, its roofline and its CPU baseline, a few facts."""
     if d is None:
         return None
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "cpu_baseline",
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "cpu_baseline", "dtype",
+            "set_map_ms", "median_translation_error_m",
             "mean_iterations", "converged_fraction", "final_position_error_m", "host_input", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
             "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size",
             "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "replay_vs_oracle")
     out = {k: d[k] for k in keep if k in d}
     if "slam" in d:
         out["slam"] = {k: d["slam"].get(k) for k in ("scans", "points_per_scan", "keyframes", "loops_closed", "loop_candidates_tried",
-                                                     "map_rebuilds", "mean_icp_iterations", "tracking_error_rms_m", "localizer_host_s")}
+                                                     "map_rebuilds", "mean_icp_iterations", "tracking_error_rms_m", "localizer_host_s",
+                                                     "input_filters", "device_input_stages", "device_readings_used", "points_after_filters_last_scan")}
     r = out.get("roofline")
     if r:
         out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches",
@@ -940,8 +1029,12 @@ def workload_legs(args, world, rank):
 
     lc_leg = run("loop_closure", main_loopclosure, steps=2, warmup=1, pairs=512, pair_chunk=512)
     if world == 1:
+        run("f64", main_f64, steps=3, warmup=1)
         run("stream", main_stream, steps=1, warmup=1, streams=1, fleet=False)
         run("slam", main_slam, steps=1, warmup=0)
+        # the same facade at SENSOR size: 100 k-pt scans (64 rings, an HDL-64E's), a shorter drive (the sequence file is 2.4 MB a
+        # scan), the input filters a driver would configure -- every scan through the device input stage
+        run("slam_100k", main_slam, steps=1, warmup=0, slam_scans=600, slam_points=100_000, slam_filters="sensor", slam_record=8)
     return (legs if rank == 0 else None), lc_leg
 
 
@@ -984,8 +1077,10 @@ def main():
     ap.add_argument("--slam-scans", type=int, default=4500, help="slam: scans of the sequence (KITTI-00 has 4541)")
     ap.add_argument("--slam-points", type=int, default=10_000, help="slam: points per scan (16 rings)")
     ap.add_argument("--slam-step", type=float, default=0.8, help="slam: metres between scans (10 Hz at 8 m/s)")
+    ap.add_argument("--slam-filters", choices=["identity", "sensor"], default="identity",
+                    help="slam: the localizer's input filters (sensor: RemoveNaN, range cut, vehicle box -- through the device input stage)")
     ap.add_argument("--slam-record", type=int, default=32, help="slam: ICP calls recorded for the replay through the CPU oracle")
-    ap.add_argument("--workload", choices=["scan2map", "loopclosure", "stream", "slam"], default="scan2map",
+    ap.add_argument("--workload", choices=["scan2map", "loopclosure", "stream", "slam", "f64"], default="scan2map",
                     help="scan2map = BASELINE configs[1] (the headline metric); loopclosure = configs[4]: --pairs candidate "
                          "scan pairs (100k vs 100k) sharded over the ranks, all-gather of the SE(3) edges")
     ap.add_argument("--pairs", type=int, default=512)
@@ -1015,6 +1110,8 @@ def main():
         return
     if args.workload == "loopclosure":
         return main_loopclosure(args)
+    if args.workload == "f64":
+        return main_f64(args)
 
     import torch
     import torch.distributed as dist

@@ -312,6 +312,35 @@ int pgicp_surface_normals_f32(pgicp_ctx *ctx, const float *xyz, int stride, int 
 int pgicp_surface_normals_f64(pgicp_ctx *ctx, const double *xyz, int stride, int n, int mem, int knn, double max_dist,
                               double *out_nrm, int out_stride, double *out_eig, int32_t *out_ids, double *out_d2);
 
+/* pgicp_filter_cloud = the localizer's input stage on the device: input_filters_.apply(cloud) (Localizer.hpp:103) for the
+ * filters that only drop points, then rigid_transformation_->compute(cloud, T_robot_sensor) (Localizer.hpp:106), in one pass
+ * over the uploaded scan.  `features`: frows x n column-major (a point = frows contiguous values, xyz first); `descriptors`
+ * (may be NULL): drows x n; both HOST.  The filters run in list order, each on what the one before it kept (FixStep /
+ * RandomSampling see the points' indices in THAT cloud); the kept points are those libpointmatcher's filters keep, in order.
+ * T (16 doubles, row major; NULL: none) moves the kept points (R p + t) and rotates the descriptor rows [rotate_row0, +3) and
+ * [rotate_row1, +3) (`normals`, `observationDirections`; -1: none).  out_features / out_descriptors (HOST, room for n points;
+ * may alias the inputs: the call is synchronous) receive the n_out kept points, kept_idx (optional) their input indices.
+ * dev_features (optional) receives the DEVICE address of the filtered features (stride frows): a reading for pgicp_align_*
+ * with mem = PGICP_DEVICE that needs no second upload; valid for the next three pgicp_filter_cloud calls on the context. */
+#define PGICP_FILTER_IDENTITY 0
+#define PGICP_FILTER_MAX_DIST 1         /* p[0] = limit: keeps |p|^2 < limit^2 (MaxDistDataPointsFilter, dim = -1) */
+#define PGICP_FILTER_MIN_DIST 2         /* p[0] = limit: keeps the others (MinDistDataPointsFilter) */
+#define PGICP_FILTER_BOUNDING_BOX 3     /* p[0..2] = min xyz, p[3..5] = max xyz, p[6] = removeInside */
+#define PGICP_FILTER_REMOVE_NAN 4
+#define PGICP_FILTER_FIX_STEP 5         /* p[0] = step: keeps points 0, step, 2 step, ... */
+#define PGICP_FILTER_RANDOM_SAMPLING 6  /* p[0] = prob, p[1] = seed: the counter-based sampler of pointmatcher.hpp */
+#define PGICP_MAX_FILTERS 8
+typedef struct pgicp_filter {
+    int type;
+    double p[8];
+} pgicp_filter;
+int pgicp_filter_cloud_f32(pgicp_ctx *ctx, int n_filters, const pgicp_filter *filters, const float *features, int frows,
+                           const float *descriptors, int drows, int n, const double *T, int rotate_row0, int rotate_row1,
+                           float *out_features, float *out_descriptors, int32_t *kept_idx, int *n_out, const float **dev_features);
+int pgicp_filter_cloud_f64(pgicp_ctx *ctx, int n_filters, const pgicp_filter *filters, const double *features, int frows,
+                           const double *descriptors, int drows, int n, const double *T, int rotate_row0, int rotate_row1,
+                           double *out_features, double *out_descriptors, int32_t *kept_idx, int *n_out, const double **dev_features);
+
 /* ---- loop-closure dispatcher helpers (host logic, no GPU needed) -------
  * pgicp_shard_pairs: deterministic longest-processing-time split of n_pairs
  * candidate ICPs (cost[i] ~ N_i + M_i) over world_size ranks; writes the pair

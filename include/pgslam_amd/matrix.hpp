@@ -39,6 +39,10 @@ public:
     // keeps the leading block, like Eigen's conservativeResize
     void conservativeResize(int rows, int cols)
     {
+        if (rows == r_) {                       // column-major: dropping or adding trailing columns keeps the leading ones in place
+            if (cols != c_) { v_.resize((size_t)rows * cols, T(0)); c_ = cols; }
+            return;
+        }
         Mat m(rows, cols);
         for (int j = 0; j < std::min(cols, c_); j++)
             for (int i = 0; i < std::min(rows, r_); i++) m(i, j) = (*this)(i, j);

@@ -191,11 +191,29 @@ public:
         DP reading(reading_in);
         temp_icp.readingDataPointsFilters.init();
         temp_icp.readingDataPointsFilters.apply(reading);
+        // Localizer.hpp:325-326: the step filters act on the filtered reading in its own frame, before it is moved (they
+        // are pure functions of the cloud here: pointmatcher.hpp alignOnMap)
+        temp_icp.readingStepDataPointsFilters.init();
+        temp_icp.readingStepDataPointsFilters.apply(reading);
         double Tm[16], ratio = 0, residual = 0;
         pgslam_amd::to_row_major16(T_world_robot, Tm);
         temp_icp.pushParams();
         PM::check(temp_icp.ctx, pgslam_amd::Abi<T>::partial(temp_icp.ctx, temp_icp.matcher->mapId, reading.xyzPtr(), reading.xyzStride(),
                                                            (int)reading.getNbPoints(), Tm, &ratio, &residual));
+        return (T)ratio;
+    }
+    //! the same for a reading that is on the device already (the localizer's input stage left it there): no copy of the
+    //! cloud, no upload -- when the chain's reading filters change nothing; else the host cloud goes the usual way
+    T ComputeOverlapAgainstPrepared(const typename PM::ICPChainBase::DeviceReading &reading, const Matrix &T_world_robot)
+    {
+        if (!temp_icp_) throw std::logic_error("ComputeOverlapAgainstPrepared: no reference prepared");
+        typename PM::ICP &temp_icp = *temp_icp_;
+        if (!reading || !temp_icp.deviceReadingEquivalent()) return ComputeOverlapAgainstPrepared(*reading.filtered, T_world_robot);
+        double Tm[16], ratio = 0, residual = 0;
+        pgslam_amd::to_row_major16(T_world_robot, Tm);
+        temp_icp.pushParams();
+        PM::check(temp_icp.ctx, pgslam_amd::Abi<T>::partial_dev(temp_icp.ctx, temp_icp.matcher->mapId, reading.dev, reading.filtered->xyzStride(),
+                                                               (int)reading.filtered->getNbPoints(), Tm, &ratio, &residual));
         return (T)ratio;
     }
     const Matrix &T_refkf_robot() const { return T_refkf_robot_; }

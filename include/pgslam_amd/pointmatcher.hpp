@@ -89,6 +89,7 @@ template <> struct Abi<float> {
     static int map_create_batch(pgicp_ctx *c, int k, const float *const *x, const int *xs, const float *const *n, const int *ns, const int *m, int center, int *ids) { return pgicp_map_create_batch_f32(c, k, x, xs, n, ns, m, PGICP_HOST, center, ids); }
     static int normals(pgicp_ctx *c, const float *x, int xs, int n, int knn, double md, float *out, int os, float *eig) { return pgicp_surface_normals_f32(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, nullptr, nullptr); }
     static int partial(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
+    static int partial_dev(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_DEVICE, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const float *in, int is, float *out, int os, int n, int ro) { return pgicp_transform_f32(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
 };
@@ -111,6 +112,7 @@ template <> struct Abi<double> {
     static int map_create_batch(pgicp_ctx *c, int k, const double *const *x, const int *xs, const double *const *n, const int *ns, const int *m, int center, int *ids) { return pgicp_map_create_batch_f64(c, k, x, xs, n, ns, m, PGICP_HOST, center, ids); }
     static int normals(pgicp_ctx *c, const double *x, int xs, int n, int knn, double md, double *out, int os, double *eig) { return pgicp_surface_normals_f64(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, nullptr, nullptr); }
     static int partial(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
+    static int partial_dev(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_DEVICE, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const double *in, int is, double *out, int os, int n, int ro) { return pgicp_transform_f64(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
 };
@@ -305,12 +307,24 @@ struct PointMatcher {
         virtual ~DataPointsFilter() {}
         virtual void init() {}
         virtual void inPlaceFilter(DataPoints &cloud) = 0;
+        //! the filter as an entry of pgicp_filter_cloud's list (the device pass keeps the points this host version keeps);
+        //! false: the filter has no device form (it adds descriptors, or needs neighbours)
+        virtual bool deviceSpec(pgicp_filter &) const { return false; }
     };
-    struct IdentityDataPointsFilter : DataPointsFilter { void inPlaceFilter(DataPoints &) override {} };
+    struct IdentityDataPointsFilter : DataPointsFilter {
+        void inPlaceFilter(DataPoints &) override {}
+        bool deviceSpec(pgicp_filter &f) const override { std::memset(&f, 0, sizeof f); f.type = PGICP_FILTER_IDENTITY; return true; }
+    };
     //! keeps points whose distance to the origin is below (MaxDist) / above (MinDist) a limit -- host side, O(N)
     struct DistLimitDataPointsFilter : DataPointsFilter {
         T limit; bool keepInside;
         DistLimitDataPointsFilter(T l, bool inside) : limit(l), keepInside(inside) {}
+        bool deviceSpec(pgicp_filter &f) const override
+        {
+            std::memset(&f, 0, sizeof f);
+            f.type = keepInside ? PGICP_FILTER_MAX_DIST : PGICP_FILTER_MIN_DIST; f.p[0] = (double)limit;
+            return true;
+        }
         void inPlaceFilter(DataPoints &c) override
         {
             const int n = c.features.cols();
@@ -351,6 +365,14 @@ struct PointMatcher {
     struct BoundingBoxDataPointsFilter : DataPointsFilter {
         T lo[3], hi[3]; bool removeInside;
         BoundingBoxDataPointsFilter(const T l[3], const T h[3], bool rm) : removeInside(rm) { for (int a = 0; a < 3; a++) { lo[a] = l[a]; hi[a] = h[a]; } }
+        bool deviceSpec(pgicp_filter &f) const override
+        {
+            std::memset(&f, 0, sizeof f);
+            f.type = PGICP_FILTER_BOUNDING_BOX;
+            for (int a = 0; a < 3; a++) { f.p[a] = (double)lo[a]; f.p[3 + a] = (double)hi[a]; }
+            f.p[6] = removeInside ? 1.0 : 0.0;
+            return true;
+        }
         void inPlaceFilter(DataPoints &c) override
         {
             compactColumns(c, [&](int j) {
@@ -362,6 +384,7 @@ struct PointMatcher {
     };
     //! [EXT] RemoveNaNDataPointsFilter: drops points with a NaN coordinate
     struct RemoveNaNDataPointsFilter : DataPointsFilter {
+        bool deviceSpec(pgicp_filter &f) const override { std::memset(&f, 0, sizeof f); f.type = PGICP_FILTER_REMOVE_NAN; return true; }
         void inPlaceFilter(DataPoints &c) override
         {
             compactColumns(c, [&](int j) {
@@ -406,6 +429,7 @@ struct PointMatcher {
     struct FixStepSamplingDataPointsFilter : DataPointsFilter {
         int step;
         explicit FixStepSamplingDataPointsFilter(int s) : step(s < 1 ? 1 : s) {}
+        bool deviceSpec(pgicp_filter &f) const override { std::memset(&f, 0, sizeof f); f.type = PGICP_FILTER_FIX_STEP; f.p[0] = (double)step; return true; }
         void inPlaceFilter(DataPoints &c) override
         {
             compactColumns(c, [&](int j) { return j % step == 0; });
@@ -418,6 +442,13 @@ struct PointMatcher {
     struct RandomSamplingDataPointsFilter : DataPointsFilter {
         T prob; unsigned long long seed;
         RandomSamplingDataPointsFilter(T p, unsigned long long s) : prob(p), seed(s) {}
+        bool deviceSpec(pgicp_filter &f) const override
+        {
+            if (seed >= (1ULL << 53)) return false;              // (the seed crosses the ABI as a double)
+            std::memset(&f, 0, sizeof f);
+            f.type = PGICP_FILTER_RANDOM_SAMPLING; f.p[0] = (double)prob; f.p[1] = (double)seed;
+            return true;
+        }
         static unsigned long long mix(unsigned long long z)
         {
             z += 0x9E3779B97F4A7C15ULL; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
@@ -507,7 +538,53 @@ struct PointMatcher {
         }
         void init() { for (auto &f : *this) f->init(); }
         void apply(DataPoints &cloud) { for (auto &f : *this) f->inPlaceFilter(cloud); }
+        //! every filter of the list has a device form (and the list fits pgicp_filter_cloud): the list as its argument
+        bool deviceSpecs(std::vector<pgicp_filter> &out) const
+        {
+            out.clear();
+            if (this->size() > PGICP_MAX_FILTERS) return false;
+            for (auto &f : *this) { pgicp_filter s; if (!f->deviceSpec(s)) return false; out.push_back(s); }
+            return true;
+        }
+        bool allIdentity() const
+        {
+            for (auto &f : *this) if (!std::dynamic_pointer_cast<IdentityDataPointsFilter>(f)) return false;
+            return true;
+        }
     };
+    //! Localizer.hpp:103-106 in ONE device pass (pgicp_filter_cloud): filters.apply(cloud), in place, then
+    //! cloud = RigidTransformation::compute(cloud, T).  `dev` receives the device address of the resulting features (a reading
+    //! that needs no second upload; valid for the next three calls on `c`).  false: some filter has no device form, nothing
+    //! was done (the caller applies the host filters and the transformation one after the other).
+    static bool filterAndTransformOnDevice(pgicp_ctx *c, const DataPointsFilters &filters, DataPoints &cloud, const TransformationParameters &Tm,
+                                           const T **dev = nullptr)
+    {
+        std::vector<pgicp_filter> specs;
+        const int n = (int)cloud.getNbPoints();
+        if (n == 0 || cloud.features.rows() < 3 || !filters.deviceSpecs(specs)) return false;
+        RigidTransformation check_t;
+        if (!check_t.checkParameters(Tm)) throw std::runtime_error("RigidTransformation: the transformation is not rigid");
+        double T16[16];
+        pgslam_amd::to_row_major16(Tm, T16);
+        const int drows = (int)cloud.descriptors.rows();
+        const int r0 = cloud.descriptorExists("normals") && cloud.getDescriptorDimension("normals") == 3 ? cloud.getDescriptorStartingRow("normals") : -1;
+        const int r1 = cloud.descriptorExists("observationDirections") && cloud.getDescriptorDimension("observationDirections") == 3
+                           ? cloud.getDescriptorStartingRow("observationDirections") : -1;
+        int kept = 0;
+        const T *d = nullptr;
+        const int rc = sizeof(T) == 4
+            ? pgicp_filter_cloud_f32(c, (int)specs.size(), specs.data(), (const float *)cloud.features.data(), (int)cloud.features.rows(),
+                                     drows ? (const float *)cloud.descriptors.data() : nullptr, drows, n, T16, r0, r1, (float *)cloud.features.data(),
+                                     drows ? (float *)cloud.descriptors.data() : nullptr, nullptr, &kept, (const float **)&d)
+            : pgicp_filter_cloud_f64(c, (int)specs.size(), specs.data(), (const double *)cloud.features.data(), (int)cloud.features.rows(),
+                                     drows ? (const double *)cloud.descriptors.data() : nullptr, drows, n, T16, r0, r1, (double *)cloud.features.data(),
+                                     drows ? (double *)cloud.descriptors.data() : nullptr, nullptr, &kept, (const double **)&d);
+        check(c, rc);
+        cloud.features.conservativeResize(cloud.features.rows(), kept);
+        if (drows) cloud.descriptors.conservativeResize(drows, kept);
+        if (dev) *dev = d;
+        return true;
+    }
 
     struct ICPChainBase;
 
@@ -899,6 +976,13 @@ struct PointMatcher {
             std::shared_ptr<DataPoints> filtered;         // the host copy after the chain's reading filters (what was uploaded)
             explicit operator bool() const { return dev != nullptr; }
         };
+        //! a device copy of a cloud may stand for the cloud itself in operator(): the chain's reading filters change nothing
+        //! and no outlier filter looks at the reading's descriptors
+        bool deviceReadingEquivalent() const
+        {
+            for (auto &f : outlierFilters) if (std::dynamic_pointer_cast<SurfaceNormalOutlierFilter>(f)) return false;
+            return readingDataPointsFilters.allIdentity() && readingStepDataPointsFilters.allIdentity();
+        }
         DeviceReading uploadReading(const DataPoints &readingIn)
         {
             DeviceReading r;

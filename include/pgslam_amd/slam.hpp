@@ -724,7 +724,7 @@ public:
         using clk = std::chrono::steady_clock;
         const auto t0 = clk::now();
         input_cloud_ = cloud;
-        PreProcess(input_T_robot_sensor, cloud);
+        typename PM::ICPChainBase::DeviceReading direct = PreProcess(input_T_robot_sensor, cloud);
         const auto t1 = clk::now();
         phase_s_[0] += std::chrono::duration<double>(t1 - t0).count();
         auto &g = map_manager_->GetGraph();
@@ -743,6 +743,8 @@ public:
         // (only THIS cloud's slot is consumed: the slot of the scan after it, whose transfer is under way, stays)
         typename PM::ICPChainBase::DeviceReading ahead;
         if (Prefetched *slot = FindPrefetched(cloud.get())) { ahead = slot->reading; *slot = Prefetched(); }   // (freed even if the ICP throws)
+        if (!ahead && direct) ahead = direct;                    // the device copy the input stage left behind (no second upload)
+        input_device_ = ahead && ahead.filtered.get() == cloud.get() ? ahead : typename PM::ICPChainBase::DeviceReading();
         if (ahead) { T_refkf_robot_ = icp_sequence_(ahead, T_refkf_robot_ * d); device_readings_used_++; }
         else T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);
         const auto t2 = clk::now();
@@ -760,17 +762,30 @@ public:
     }
     //! Localizer.hpp:103-106: the input filters in place, then sensor frame -> robot frame.  Once per cloud (a cloud whose
     //! upload was prefetched has been through it already).
-    void PreProcess(const Matrix &input_T_robot_sensor, DPPtr cloud)
+    //! Returns the device copy of the pre-processed cloud when the input stage ran on the device (pgicp_filter_cloud: filters
+    //! and transform in one pass over the uploaded scan) and that copy can stand for the cloud in the ICP; empty otherwise.
+    typename PM::ICPChainBase::DeviceReading PreProcess(const Matrix &input_T_robot_sensor, DPPtr cloud)
     {
         // per-cloud state: while scan k aligns, scan k + 1 has been through here already (Prefetch) -- one "last cloud"
         // memo would alternate between the two and send every prefetched cloud through the filters and the sensor
         // transform a second time, in place
+        typename PM::ICPChainBase::DeviceReading direct;
         Prefetched *slot = FindPrefetched(cloud.get());
-        if (slot && slot->preprocessed) return;
-        input_filters_.apply(*cloud);
-        (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
+        if (slot && slot->preprocessed) return direct;
+        const T *dev = nullptr;
+        if (device_input_stage_ && PM::filterAndTransformOnDevice(icp_sequence_.ctx, input_filters_, *cloud, input_T_robot_sensor, &dev)) {
+            device_input_stages_++;
+            if (icp_sequence_.deviceReadingEquivalent()) { direct.dev = dev; direct.filtered = cloud; }
+        } else {
+            input_filters_.apply(*cloud);
+            (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
+        }
         if (slot) slot->preprocessed = true;
+        return direct;
     }
+    //! scans whose input filters + sensor transform ran as one device pass
+    size_t device_input_stages() const { return device_input_stages_; }
+    void SetDeviceInputStage(bool on) { device_input_stage_ = on; }
     //! The NEXT scan, already queued (LocalizerMT.hpp:27-40): pre-process it and start its transfer to the device on the ICP
     //! context's copy stream (pgicp_upload_*), so that it travels while the current scan aligns.  Needs a map (the chain
     //! aligns device readings only against one) -- before the first keyframe nothing is prefetched.
@@ -781,8 +796,8 @@ public:
         Prefetched *slot = FindPrefetched(nullptr);
         if (!slot) return;
         slot->cloud = cloud.get();
-        PreProcess(input_T_robot_sensor, cloud);
-        slot->reading = icp_sequence_.uploadReading(*cloud);
+        const auto direct = PreProcess(input_T_robot_sensor, cloud);
+        slot->reading = direct ? direct : icp_sequence_.uploadReading(*cloud);
         prefetches_++;
     }
     size_t prefetches() const { return prefetches_; }
@@ -812,7 +827,9 @@ protected:
         for (auto &p : prefetched_) if (p.cloud == cloud) return &p;
         return nullptr;
     }
-    size_t prefetches_ = 0, device_readings_used_ = 0;
+    size_t prefetches_ = 0, device_readings_used_ = 0, device_input_stages_ = 0;
+    typename PM::ICPChainBase::DeviceReading input_device_;      // the current scan's device copy (while it is valid: this ProcessData)
+    bool device_input_stage_ = std::getenv("PGSLAM_HOST_INPUT_STAGE") == nullptr;
     bool resync_before_update_ = false;              // the MT flavour re-reads the graph before every update
     unsigned long long synced_version_ = 0;
     void Rebuild()
@@ -846,6 +863,8 @@ protected:
             probe_comp_ = comp;
             probe_version_ = map_manager_->Version();
         }
+        // (the scan is on the device already when the input stage ran there: the probe reads that copy)
+        if (input_device_ && input_device_.filtered.get() == input_cloud_.get()) return probe_->ComputeOverlapAgainstPrepared(input_device_, T_world_robot_);
         return probe_->ComputeOverlapAgainstPrepared(*input_cloud_, T_world_robot_);
     }
     //! Localizer.hpp:393-483

@@ -134,6 +134,7 @@ __device__ __forceinline__ long long pairs_off(const ProblemDev &P) { return P.o
 #include "k_normals.inc"
 #include "k_select.inc"
 #include "k_minimise.inc"
+#include "k_filter.inc"
 #include "k_launch.inc"
 
 }  // namespace pgicp

@@ -67,6 +67,10 @@ void launch_sum_partials(hipStream_t st, const double *partials, int max_blocks,
 template <typename T>
 void launch_trim_raw(hipStream_t st, const T *d2, int n, T ratio, T scale, T *limit_nf, T *w);
 template <typename T>
+void launch_filter_cloud(hipStream_t st, const T *feat, int fstride, int frows, const T *desc, int drows, int n, int n_filters,
+                         const int *types, const double *params, const double *T16, int rot0, int rot1, int *keep, int *pos,
+                         int *block_sums, T *out_feat, T *out_desc, int *kept_idx);
+template <typename T>
 void launch_slot_of(hipStream_t st, const typename Vec4<T>::type *pts, int first, int m, int *slot_of);
 template <typename T>
 void launch_error_stats(hipStream_t st, const MapDev<T> *maps, int map, const int *slot_of, const T *rd, int stride,

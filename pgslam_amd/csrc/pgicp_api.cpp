@@ -113,6 +113,11 @@ struct pgicp_ctx {
         bool pending = false, has_consumer = false;
     } up[2];
     hipStream_t copy_stream = nullptr;
+    // pgicp_filter_cloud: four sets of device buffers used in turn (the filtered features of a call stay valid, as a device
+    // reading, for the next three calls: a localizer that pre-processes scan k + 1 while scan k aligns, and now and then a
+    // scan that was not pre-processed ahead, has three calls between making a reading and aligning it)
+    struct FilterSet { DevBuf in_f, in_d, keep, pos, bsum, out_f, out_d, idx; } fset[4];
+    int fset_next = 0;
     int up_next = 0;
     int up_seen = 0;            // upload sets whose device pointers the running call was handed (see UploadUse)
     int *h_pinned = nullptr;        // pinned scratch for small D2H polls (64 ints)
@@ -1567,6 +1572,80 @@ int surface_normals(pgicp_ctx *c, const T *xyz, int stride, int n, int mem, int 
     return PGICP_OK;
 }
 
+template <typename T>
+int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int frows, const T *desc, int drows, int n, const double *T16,
+                 int rot0, int rot1, T *out_feat, T *out_desc, int32_t *kept_idx, int *n_out, const T **dev_feat)
+{
+    if (!c || nf < 0 || nf > PGICP_MAX_FILTERS || (nf && !f) || !feat || frows < 3 || n <= 0 || (desc && drows <= 0) || !out_feat || !n_out ||
+        (desc && !out_desc) || (rot0 >= 0 && (!desc || rot0 + 3 > drows)) || (rot1 >= 0 && (!desc || rot1 + 3 > drows)))
+        return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: bad argument");
+    if (T16 && !is_rigid(T16)) return fail(c, PGICP_ERR_NOT_RIGID, "pgicp_filter_cloud: transformation is not rigid");
+    int types[PGICP_MAX_FILTERS];
+    double params[8 * PGICP_MAX_FILTERS];
+    for (int k = 0; k < nf; k++) {
+        if (f[k].type < PGICP_FILTER_IDENTITY || f[k].type > PGICP_FILTER_RANDOM_SAMPLING) return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: unknown filter type");
+        if (f[k].type == PGICP_FILTER_FIX_STEP && !(f[k].p[0] >= 1.0)) return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: FixStep needs step >= 1");
+        types[k] = f[k].type;
+        std::memcpy(params + 8 * k, f[k].p, sizeof f[k].p);
+    }
+    HIPC(c, hipSetDevice(c->device));
+    pgicp_ctx::FilterSet &S = c->fset[c->fset_next];
+    c->fset_next = (c->fset_next + 1) & 3;
+    // Without a transformation (none, or the identity -- a sensor at the robot's origin) the kept points are the input's
+    // own: only the features travel (the predicates look at nothing else, and the ICP wants them on the device anyway), and
+    // what comes back is the list of kept indices, if anything was dropped at all -- the host copies compact themselves.
+    bool ident = T16 == nullptr;
+    if (T16) {
+        ident = true;
+        for (int i = 0; i < 12; i++) ident = ident && T16[i] == (i % 5 == 0 ? 1.0 : 0.0);
+    }
+    const bool dev_desc = desc && !ident;
+    const size_t bf = sizeof(T) * (size_t)frows * n, bd = dev_desc ? sizeof(T) * (size_t)drows * n : 0;
+    HIPC(c, S.in_f.ensure(bf)); HIPC(c, S.out_f.ensure(bf));
+    if (dev_desc) { HIPC(c, S.in_d.ensure(bd)); HIPC(c, S.out_d.ensure(bd)); }
+    HIPC(c, S.keep.ensure(sizeof(int) * ((size_t)n + 1))); HIPC(c, S.pos.ensure(sizeof(int) * ((size_t)n + 1)));
+    HIPC(c, S.bsum.ensure(sizeof(int) * ((size_t)n / kScanChunkHost + 4)));
+    const bool want_idx = kept_idx || ident;
+    if (want_idx) HIPC(c, S.idx.ensure(sizeof(int) * (size_t)n));
+    HIPC(c, hipMemcpyAsync(S.in_f.p, feat, bf, hipMemcpyHostToDevice, c->stream));
+    if (dev_desc) HIPC(c, hipMemcpyAsync(S.in_d.p, desc, bd, hipMemcpyHostToDevice, c->stream));
+    launch_filter_cloud<T>(c->stream, S.in_f.as<T>(), frows, frows, dev_desc ? S.in_d.as<T>() : nullptr, drows, n, nf, types, params,
+                           ident ? nullptr : T16, rot0, rot1, S.keep.as<int>(), S.pos.as<int>(), S.bsum.as<int>(), S.out_f.as<T>(),
+                           dev_desc ? S.out_d.as<T>() : nullptr, want_idx ? S.idx.as<int>() : nullptr);
+    int kept = 0;
+    HIPC(c, hipMemcpyAsync(&kept, S.pos.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    *n_out = kept;
+    if (ident) {
+        std::vector<int> hidx;
+        const int *idx = nullptr;
+        if (kept < n || kept_idx) {
+            int *dst = kept_idx;
+            if (!dst) { hidx.resize((size_t)std::max(kept, 1)); dst = hidx.data(); }
+            if (kept > 0) HIPC(c, hipMemcpy(dst, S.idx.p, sizeof(int) * (size_t)kept, hipMemcpyDeviceToHost));
+            idx = dst;
+        }
+        if (kept == n) {
+            if (out_feat != feat) std::memcpy(out_feat, feat, bf);
+            if (desc && out_desc != desc) std::memcpy(out_desc, desc, sizeof(T) * (size_t)drows * n);
+        } else {
+            // (ascending indices: compaction in place moves every point towards the front)
+            for (int k = 0; k < kept; k++) {
+                std::memmove(out_feat + (size_t)k * frows, feat + (size_t)idx[k] * frows, sizeof(T) * (size_t)frows);
+                if (desc) std::memmove(out_desc + (size_t)k * drows, desc + (size_t)idx[k] * drows, sizeof(T) * (size_t)drows);
+            }
+        }
+    } else if (kept > 0) {
+        HIPC(c, hipMemcpyAsync(out_feat, S.out_f.p, sizeof(T) * (size_t)frows * kept, hipMemcpyDeviceToHost, c->stream));
+        if (desc) HIPC(c, hipMemcpyAsync(out_desc, S.out_d.p, sizeof(T) * (size_t)drows * kept, hipMemcpyDeviceToHost, c->stream));
+        if (kept_idx) HIPC(c, hipMemcpyAsync(kept_idx, S.idx.p, sizeof(int) * (size_t)kept, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    if (dev_feat) *dev_feat = S.out_f.as<T>();
+    return PGICP_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1841,6 +1920,8 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (std::getenv("PGICP_GRAPH_DEBUG"))
         std::fprintf(stderr, "pgicp context %p: %lld iteration graphs captured, %lld replayed, %d failures\n", (void *)c, c->graph_captures, c->graph_launches, c->graph_failures);
+    for (auto &fs : c->fset)
+        for (DevBuf *b : {&fs.in_f, &fs.in_d, &fs.keep, &fs.pos, &fs.bsum, &fs.out_f, &fs.out_d, &fs.idx}) b->release();
     for (auto &g : c->iter_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (c->stamp_dev) (void)hipFree(c->stamp_dev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2063,6 +2144,13 @@ int pgicp_build_local_map_f32(pgicp_ctx *c, int n_kf, const float *const *xyz, c
 int pgicp_build_local_map_f64(pgicp_ctx *c, int n_kf, const double *const *xyz, const double *const *nrm, const int *sx,
                               const int *sn, const int *counts, const double *T_ref_kf, double *ox, int os, double *on, int ons, int mem)
 { return build_local_map<double>(c, n_kf, xyz, nrm, sx, sn, counts, T_ref_kf, ox, os, on, ons, mem); }
+
+int pgicp_filter_cloud_f32(pgicp_ctx *c, int nf, const pgicp_filter *f, const float *feat, int frows, const float *desc, int drows, int n,
+                           const double *T, int r0, int r1, float *of, float *od, int32_t *idx, int *n_out, const float **dev)
+{ return filter_cloud<float>(c, nf, f, feat, frows, desc, drows, n, T, r0, r1, of, od, idx, n_out, dev); }
+int pgicp_filter_cloud_f64(pgicp_ctx *c, int nf, const pgicp_filter *f, const double *feat, int frows, const double *desc, int drows, int n,
+                           const double *T, int r0, int r1, double *of, double *od, int32_t *idx, int *n_out, const double **dev)
+{ return filter_cloud<double>(c, nf, f, feat, frows, desc, drows, n, T, r0, r1, of, od, idx, n_out, dev); }
 
 int pgicp_shard_pairs(int n_pairs, const int64_t *cost, int world, int rank, int *out_idx, int cap, int *n_out)
 {

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "pgicp_map_create_f32", "pgicp_map_create_f64", "pgicp_map_create_batch_f32", "pgicp_map_create_batch_f64",
     "pgicp_map_destroy", "pgicp_map_size", "pgicp_map_transfer",
     "pgicp_align_f32", "pgicp_align_f64", "pgicp_align_batch_f32", "pgicp_align_batch_f64",
-    "pgicp_align_residual_batch_f32", "pgicp_align_residual_batch_f64",
+    "pgicp_align_residual_batch_f32", "pgicp_align_residual_batch_f64", "pgicp_filter_cloud_f32", "pgicp_filter_cloud_f64",
     "pgicp_icp_pair_f32", "pgicp_icp_pair_f64", "pgicp_match_f32", "pgicp_match_f64",
     "pgicp_outlier_weights_f32", "pgicp_outlier_weights_f64", "pgicp_error_stats_f32", "pgicp_error_stats_f64",
     "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_partial_chain_batch_f32",
@@ -76,6 +76,13 @@ class Stats(C.Structure):
 class Problem(C.Structure):
     _fields_ = [("map_id", C.c_int), ("reading", C.c_void_p), ("stride", C.c_int), ("n", C.c_int), ("mem", C.c_int),
                 ("T_init", C.c_double * 16), ("normals", C.c_void_p), ("nstride", C.c_int)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("type", C.c_int), ("p", C.c_double * 8)]
+
+
+FILTER_IDENTITY, FILTER_MAX_DIST, FILTER_MIN_DIST, FILTER_BOUNDING_BOX, FILTER_REMOVE_NAN, FILTER_FIX_STEP, FILTER_RANDOM_SAMPLING = range(7)
 
 
 class Edge(C.Structure):
@@ -612,6 +619,33 @@ class Context:
         new_id = C.c_int(-1)
         self._check(self.lib.pgicp_map_transfer(other.h, C.c_int(map_id), self.h, C.byref(new_id)))
         return new_id.value
+
+    def filter_cloud(self, filters, features, descriptors=None, T=None, rotate_rows=(-1, -1), want_idx=True):
+        """pgicp_filter_cloud: `filters` = [(type, p0, p1, ...)], `features` (n, frows) host array (a point per row),
+        `descriptors` (n, drows) or None.  Returns (features_out, descriptors_out, kept_idx, DevPtr of the device copy)."""
+        f = np.ascontiguousarray(features)
+        assert f.dtype in (np.float32, np.float64) and f.ndim == 2
+        n, frows = f.shape
+        d = np.ascontiguousarray(descriptors, dtype=f.dtype) if descriptors is not None else None
+        drows = d.shape[1] if d is not None else 0
+        fl = (Filter * max(1, len(filters)))()
+        for k, spec in enumerate(filters):
+            fl[k].type = int(spec[0])
+            for j, v in enumerate(spec[1:]):
+                fl[k].p[j] = float(v)
+        of = np.empty_like(f)
+        od = np.empty_like(d) if d is not None else None
+        idx = np.empty(n, dtype=np.int32) if want_idx else None
+        n_out = C.c_int(0)
+        dev = C.c_void_p()
+        fn = getattr(self.lib, "pgicp_filter_cloud" + self._sfx(f.dtype))
+        self._check(fn(self.h, C.c_int(len(filters)), fl, C.c_void_p(f.ctypes.data), C.c_int(frows),
+                       C.c_void_p(d.ctypes.data) if d is not None else None, C.c_int(drows), C.c_int(n), _T16(T) if T is not None else None,
+                       C.c_int(rotate_rows[0]), C.c_int(rotate_rows[1]), C.c_void_p(of.ctypes.data),
+                       C.c_void_p(od.ctypes.data) if od is not None else None, C.c_void_p(idx.ctypes.data) if idx is not None else None,
+                       C.byref(n_out), C.byref(dev)))
+        k = n_out.value
+        return of[:k], (od[:k] if od is not None else None), (idx[:k] if idx is not None else None), DevPtr(dev.value, frows, k, f.dtype)
 
     # ---- measurement --------------------------------------------------------
     def profile_enable(self, on=True):

@@ -121,15 +121,22 @@ void run_mt_sensor_pose(const char *name)
     };
     const unsigned n_raw = sensor_cloud(0)->getNbPoints();
     std::vector<Matrix> st_poses;
-    {
+    for (int device_stage = 0; device_stage < 2; device_stage++) {
+        // the input stage (filters + sensor transform) on the host, filter by filter, and as ONE device pass
+        // (pgicp_filter_cloud): the same kept points, the same arithmetic -- the same poses, bit for bit
         pgslam::PoseGraphSlam<T> slam;
         slam.SetIcpConfigFromStrings(filters, kIcpYaml, kIcpYaml);
         slam.localizer().SetOverlapThreshold(T(0.9));
+        slam.localizer().SetDeviceInputStage(device_stage != 0);
         for (int s = 0; s < S; s++) {
-            slam.AddData((unsigned long long)s, "world", odom[s], T_robot_sensor, sensor_cloud(s));
-            st_poses.push_back(slam.localizer().T_world_robot());
-            CHECK(pose_diff(st_poses.back(), truth[s]) < 3e-2);
+            auto cloud = sensor_cloud(s);
+            slam.AddData((unsigned long long)s, "world", odom[s], T_robot_sensor, cloud);
+            CHECK(cloud->getNbPoints() == (n_raw + 1) / 2);
+            if (device_stage == 0) st_poses.push_back(slam.localizer().T_world_robot());
+            else CHECK(pose_diff(slam.localizer().T_world_robot(), st_poses[s]) == 0.0);
+            CHECK(pose_diff(slam.localizer().T_world_robot(), truth[s]) < 3e-2);
         }
+        CHECK(slam.localizer().device_input_stages() == (device_stage ? (size_t)S : 0));
     }
     pgslam::PoseGraphSlamMT<T> slam;
     slam.SetIcpConfigFromStrings(filters, kIcpYaml, kIcpYaml);
@@ -144,7 +151,8 @@ void run_mt_sensor_pose(const char *name)
     slam.WaitIdle();
     CHECK(slam.localizer().processed() == (size_t)S);
     CHECK(slam.localizer().prefetches() > (size_t)S / 2);
-    CHECK(slam.localizer().device_readings_used() == slam.localizer().prefetches());     // every prefetched upload was the one aligned
+    CHECK(slam.localizer().device_readings_used() >= slam.localizer().prefetches());     // every prefetched upload was the one aligned
+    CHECK(slam.localizer().device_input_stages() == (size_t)S);                          // (the input stage of every scan ran on the device)
     for (int s = 0; s < S; s++) CHECK(clouds[s]->getNbPoints() == (n_raw + 1) / 2);      // filtered once, in place
     CHECK(pose_diff(slam.localizer().T_world_robot(), truth[S - 1]) < 3e-2);
     CHECK(pose_diff(slam.localizer().T_world_robot(), st_poses[S - 1]) < 1e-4);

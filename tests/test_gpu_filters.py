@@ -1,0 +1,101 @@
+"""The localizer's input stage on the device (pgicp_filter_cloud): input_filters_.apply + the sensor transform
+(/root/reference/src/pgslam/Localizer.hpp:103-106) in one pass.  The kept points must be those the host filters of
+include/pgslam_amd/pointmatcher.hpp keep (restated here in numpy, the same arithmetic), index for index; the moved
+coordinates those of pgicp_transform; and the device copy must serve as an ICP reading."""
+import numpy as np
+import pytest
+
+from pgslam_amd import icp, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def splitmix(z):
+    z = (z + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def host_filters(filters, f):
+    """the filters of pointmatcher.hpp, one after the other, on the (n, frows) features; returns the kept input indices"""
+    idx = np.arange(f.shape[0])
+    for spec in filters:
+        t, p = spec[0], spec[1:]
+        x = f[idx]
+        if t in (icp.FILTER_MAX_DIST, icp.FILTER_MIN_DIST):
+            lim = float(f.dtype.type(p[0]))
+            r2 = (x[:, 0].astype(np.float64) ** 2 + x[:, 1].astype(np.float64) ** 2) + x[:, 2].astype(np.float64) ** 2
+            keep = (r2 < lim * lim) == (t == icp.FILTER_MAX_DIST)
+        elif t == icp.FILTER_BOUNDING_BOX:
+            lo, hi = np.asarray(p[0:3], dtype=f.dtype), np.asarray(p[3:6], dtype=f.dtype)
+            inside = np.all((lo < x[:, :3]) & (x[:, :3] < hi), axis=1)
+            keep = inside != bool(p[6])
+        elif t == icp.FILTER_REMOVE_NAN:
+            keep = ~np.any(np.isnan(x), axis=1)
+        elif t == icp.FILTER_FIX_STEP:
+            keep = np.arange(len(idx)) % int(p[0]) == 0
+        elif t == icp.FILTER_RANDOM_SAMPLING:
+            seed = int(p[1])
+            u = np.array([(splitmix((seed * 0x100000001B3 + j) & 0xFFFFFFFFFFFFFFFF) >> 11) / 9007199254740992.0 for j in range(len(idx))])
+            keep = u < float(f.dtype.type(p[0]))
+        else:
+            keep = np.ones(len(idx), dtype=bool)
+        idx = idx[keep]
+    return idx
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_filter_chain_keeps_what_the_host_filters_keep(ctx, oracle32, oracle64, dtype):
+    o = oracle32 if dtype == np.float32 else oracle64
+    w = synth.make_two_scans(6000, rings=16)
+    xyz, nrm = w["ref_xyz"].astype(dtype), w["ref_nrm"].astype(dtype)
+    n = len(xyz)
+    f = np.concatenate([xyz, np.ones((n, 1), dtype=dtype)], axis=1)
+    f[17, 1] = np.nan
+    f[4000, 3] = np.nan                                         # a NaN in the homogeneous row counts too
+    obs = (np.array([0.1, 0.2, 1.7], dtype=dtype) - xyz).astype(dtype)
+    d = np.concatenate([nrm, obs, np.arange(n, dtype=dtype)[:, None]], axis=1)     # normals | observationDirections | an id row
+    T = synth.se3(x=0.4, y=-0.2, z=1.1, yaw=0.3, pitch=0.05, roll=-0.02)
+    chains = [
+        [(icp.FILTER_IDENTITY,)],
+        [(icp.FILTER_REMOVE_NAN,), (icp.FILTER_MAX_DIST, 25.0), (icp.FILTER_MIN_DIST, 1.5)],
+        [(icp.FILTER_BOUNDING_BOX, -2.0, -1.5, -3.0, 2.0, 1.5, 3.0, 1.0), (icp.FILTER_FIX_STEP, 3)],
+        [(icp.FILTER_FIX_STEP, 2), (icp.FILTER_RANDOM_SAMPLING, 0.6, 7), (icp.FILTER_MAX_DIST, 30.0), (icp.FILTER_FIX_STEP, 5)],
+        [(icp.FILTER_REMOVE_NAN,), (icp.FILTER_RANDOM_SAMPLING, 0.25, 123456789), (icp.FILTER_BOUNDING_BOX, -50, -50, -50, 50, 50, 50, 0.0)],
+    ]
+    for filters in chains:
+        for Tm in (None, T):
+            of, od, idx, dev = ctx.filter_cloud(filters, f, d, T=Tm, rotate_rows=(0, 3))
+            want = host_filters(filters, f)
+            assert np.array_equal(idx, want), filters
+            assert len(of) == len(want) and dev.n == len(want)
+            if Tm is None:
+                assert np.array_equal(of.view(np.uint8), f[want].view(np.uint8)) and np.array_equal(od.view(np.uint8), d[want].view(np.uint8))
+            else:
+                clean = ~np.any(np.isnan(f[want, :3]), axis=1)
+                assert np.array_equal(of[clean, :3], o.transform(Tm, f[want][clean, :3]))        # RigidTransformation: R p + t
+                assert np.array_equal(of[:, 3:].view(np.uint8), f[want][:, 3:].view(np.uint8))
+                assert np.array_equal(od[:, 0:3], o.transform(Tm, d[want][:, 0:3], rotate_only=True))    # normals rotate
+                assert np.array_equal(od[:, 3:6], o.transform(Tm, d[want][:, 3:6], rotate_only=True))
+                assert np.array_equal(od[:, 6], d[want][:, 6])
+
+
+def test_filtered_cloud_is_an_icp_reading_without_a_second_upload(ctx, oracle32):
+    """the device copy of the filtered, transformed scan aligns like the host copy of it"""
+    chain = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01, smooth_length=3, sensor_std_dev=0.01)
+    w = synth.make_scan_to_map(n_scan=6000, n_map=40_000, n_queries=1, n_map_poses=4, rings=16)
+    ctx.set_params(**chain)
+    mid = ctx.set_map(w.map_xyz, w.map_nrm, center=True)
+    T_rs = synth.se3(x=0.3, y=-0.1, z=0.2, yaw=0.1)
+    sensor = oracle32.transform(synth.se3_inv(T_rs), w.scans_xyz[0])             # the scan as the sensor sees it
+    f = np.concatenate([sensor, np.ones((len(sensor), 1), dtype=np.float32)], axis=1)
+    filters = [(icp.FILTER_MAX_DIST, 60.0), (icp.FILTER_FIX_STEP, 2)]
+    of, _, idx, dev = ctx.filter_cloud(filters, f, None, T=T_rs)
+    Ta, sa = ctx.align(mid, dev, w.T_init[0])
+    Tb, sb = ctx.align(mid, np.ascontiguousarray(of[:, :3]), w.T_init[0])
+    assert np.array_equal(Ta, Tb) and sa["iterations"] == sb["iterations"] and sa["n_kept"] == sb["n_kept"]
+    r = oracle32.icp(of[:, :3], w.map_xyz, w.map_nrm, w.T_init[0], **chain)
+    d = np.linalg.inv(r["T"]) @ Ta
+    assert np.linalg.norm(d[:3, 3]) < 1e-5 and sa["iterations"] == r["iterations"]
+    ctx.destroy_map(mid)

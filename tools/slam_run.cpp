@@ -3,7 +3,11 @@
 // the host), as a C++ pgslam user would run it: host clouds in, poses out.  Driver of `bench.py --workload slam` and of
 // tests/test_slam_replay.py; not part of the library.
 //
-//   slam_run SEQUENCE [--record N FILE] [--limit S] [--mt]
+//   slam_run SEQUENCE [--record N FILE] [--limit S] [--mt] [--filters identity|sensor]
+//
+// --filters sensor: the input filters a range sensor's driver would configure (Localizer.hpp:77,103): RemoveNaN, a range cut
+// just inside the sensor's reach, the box of the vehicle itself -- they drop next to nothing of the synthetic scans, but every
+// scan goes through the localizer's input stage at full size (one device pass: pgicp_filter_cloud).
 //
 // --mt: the multi-thread flavour (pgslam::PoseGraphSlamMT): scans are queued as fast as they are read, the three workers
 // run freely (the loop closer drains its queue into device batches); poses are compared at the end only.
@@ -33,6 +37,12 @@ static const char *kIcpYaml =
     "transformationCheckers:\n  - CounterTransformationChecker:\n      maxIterationCount: 30\n"
     "  - DifferentialTransformationChecker:\n      minDiffRotErr: 0.001\n      minDiffTransErr: 0.01\n      smoothLength: 3\n"
     "inspector:\n  NullInspector\nlogger:\n  NullLogger\n";
+
+static const char *kSensorFilters =
+    "- RemoveNaNDataPointsFilter\n"
+    "- MaxDistDataPointsFilter:\n    maxDist: 79.9\n"
+    "- BoundingBoxDataPointsFilter:\n    xMin: -1.2\n    xMax: 1.2\n    yMin: -0.9\n    yMax: 0.9\n    zMin: -2.0\n    zMax: 0.5\n    removeInside: 1\n";
+static const char *g_filters = "- IdentityDataPointsFilter\n";
 
 static Matrix from_rows(const double *r)
 {
@@ -108,7 +118,7 @@ static int count_revisits(size_t n, P pos, double thr, size_t gap)
 static int run_mt(FILE *f, int S, int N)
 {
     pgslam::PoseGraphSlamMT<T> slam;
-    slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+    slam.SetIcpConfigFromStrings(g_filters, kIcpYaml, kIcpYaml);
     slam.Run();
     std::vector<double> Tt(16), To(16);
     std::vector<float> xyz((size_t)N * 3), nrm((size_t)N * 3);
@@ -158,6 +168,7 @@ int main(int argc, char **argv)
         if (!std::strcmp(argv[a], "--record") && a + 2 < argc) { rec_n = std::atoi(argv[a + 1]); rec_path = argv[a + 2]; a += 2; }
         else if (!std::strcmp(argv[a], "--limit") && a + 1 < argc) { limit = std::atoi(argv[a + 1]); a += 1; }
         else if (!std::strcmp(argv[a], "--mt")) mt = true;
+        else if (!std::strcmp(argv[a], "--filters") && a + 1 < argc) { g_filters = !std::strcmp(argv[a + 1], "sensor") ? kSensorFilters : "- IdentityDataPointsFilter\n"; a += 1; }
     }
     FILE *f = std::fopen(argv[1], "rb");
     if (!f) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
@@ -167,7 +178,7 @@ int main(int argc, char **argv)
 
     if (mt) return run_mt(f, S, N);
     pgslam::PoseGraphSlam<T> slam;
-    slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+    slam.SetIcpConfigFromStrings(g_filters, kIcpYaml, kIcpYaml);
     Recorder rec;
     if (rec_path) {
         rec.open(rec_path, rec_n, S);
@@ -184,6 +195,7 @@ int main(int argc, char **argv)
     long long icp_iterations = 0;
     int not_converged = 0;
     const Matrix I4 = Matrix::Identity(4, 4);
+    unsigned last_cloud_points = 0;
     const auto t_begin = std::chrono::steady_clock::now();
     for (int s = 0; s < S; s++) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -198,6 +210,7 @@ int main(int argc, char **argv)
         rec.scan = s;
         slam.AddData((unsigned long long)s, "world", from_rows(To.data()), I4, cloud);
         t_icp_loop += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        last_cloud_points = cloud->getNbPoints();
         truth.push_back(from_rows(Tt.data()));
         last_odom = from_rows(To.data());
         while (kf_scan.size() < slam.map_manager().GetGraph().NumVertices()) kf_scan.push_back((size_t)s);
@@ -240,6 +253,7 @@ int main(int argc, char **argv)
                 "\"tracking_error_max_m\": %.5f, \"tracking_error_last_m\": %.5f, \"odometry_error_last_m\": %.5f, "
                 "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d, "
                 "\"localizer_host_s\": {\"filters_and_sensor_transform\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f}, "
+                "\"input_filters\": \"%s\", \"device_input_stages\": %zu, \"device_readings_used\": %zu, \"points_after_filters_last_scan\": %u, "
                 "\"keyframes_revisiting_within_3m_by_truth\": %d, \"keyframes_revisiting_within_3m_by_estimate\": %d, "
                 "\"knn_profile\": {\"launches\": %lld, \"total_ms\": %.4f, \"reading_points\": %lld, \"problems\": %lld, \"map_points\": %lld}}\n",
                 S, N, wall, t_icp_loop, t_io, (S - 1) / t_icp_loop, g.NumVertices(), loops, slam.loop_closer().candidates_tried(),
@@ -248,6 +262,8 @@ int main(int argc, char **argv)
                 std::sqrt(e_sum2 / std::max<size_t>(1, err_track.size())), e_max, e_last, odo_last,
                 std::sqrt(kf_sum2 / std::max<size_t>(1, kf_scan.size())), kf_max, rec.written, rec.written_kind[1],
                 slam.localizer().phase_seconds()[0], slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2],
+                g_filters == kSensorFilters ? "RemoveNaN, MaxDist 79.9, BoundingBox (vehicle)" : "Identity", slam.localizer().device_input_stages(),
+                slam.localizer().device_readings_used(), last_cloud_points,
                 count_revisits(std::min(g.NumVertices(), kf_scan.size()), [&](size_t v, int a) { return (double)truth[kf_scan[v]](a, 3); }, 3.0, 4),
                 count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4),
                 kp_l, kp_ms, kp_u, kp_p, kp_m);
