@@ -364,8 +364,9 @@ def main_loopclosure(args, collect=False):
             avg_s = k["total_ms"] * 1e-3 / k["launches"]
             ach = alg / k["launches"] / avg_s / 1e9
             roofline = dict(bound="hbm", kernel="knn_grid", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                            traffic=None, avg_launch_us=avg_s * 1e6, launches=k["launches"], profiled_steps=args.steps,
-                            algorithmic_bytes_per_launch=alg / k["launches"], active_problems_per_launch=k["problems"] / k["launches"])
+                            avg_launch_us=avg_s * 1e6, launches=k["launches"], profiled_steps=args.steps,
+                            algorithmic_bytes_per_launch=alg / k["launches"], active_problems_per_launch=k["problems"] / k["launches"],
+                            **recorded_traffic("knn_traffic_loopclosure", n_scan=args.n_scan, batch=args.pairs))
     # ---- strong-scaling reference, same run: rank 0 aligns ALL pairs alone while the others wait
     single = None
     if distributed:
@@ -527,6 +528,22 @@ def read_replay(path):
                             max_iter_reached=int(h[7]), overlap=ov, T_init=t[:16].reshape(4, 4), T_out=t[16:].reshape(4, 4),
                             reading=rd, ref_xyz=rx, ref_nrm=rn))
     return out
+
+
+def recorded_traffic(name, **match):
+    """HBM-fabric bytes per fast-matcher launch of a workload, from profiles/<name>.json (written by tools/pmc_traffic.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command; MI355X_MICROARCH.md's unit and gfx950 corrections).
+    Returns the fields to merge into a roofline object: the record is used only when its workload keys equal this run's."""
+    path = os.path.join(ROOT, "profiles", name + ".json")
+    try:
+        tj = json.load(open(path))
+    except (OSError, ValueError):
+        return dict(traffic=None)
+    if any(tj.get(k) != v for k, v in match.items()):
+        return dict(traffic=None, traffic_source="profiles/%s.json is of another workload size" % name)
+    return dict(traffic=tj.get("hbm_bytes_per_launch"), traffic_uncorrected=tj.get("hbm_bytes_per_launch_uncorrected"),
+                traffic_source="NOT measured in this run: profiles/%s.json, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               "this command (tools/r4_pmc.sh); %s" % (name, tj.get("note", "")))
 
 
 def slam_roofline(res):
@@ -765,11 +782,13 @@ def main_stream(args, collect=False):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = 0.0
+    pass_s = []
     for k in range(args.steps):
         t0 = time.perf_counter()
         res = step()
         torch.cuda.synchronize()
-        elapsed += time.perf_counter() - t0
+        pass_s.append(time.perf_counter() - t0)
+        elapsed += pass_s[-1]
         if k + 1 < args.steps:
             for v in vehicles:                      # rewinding the vehicles is not part of the feed
                 v.reset()
@@ -795,8 +814,9 @@ def main_stream(args, collect=False):
             avg_s = k["total_ms"] * 1e-3 / k["launches"]
             achieved = alg / k["launches"] / avg_s / 1e9
             roofline = dict(bound="hbm", kernel="knn_grid", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                            traffic=None, avg_launch_us=avg_s * 1e6, launches=k["launches"],
+                            avg_launch_us=avg_s * 1e6, launches=k["launches"],
                             algorithmic_bytes_per_launch=alg / k["launches"], active_problems_per_launch=k["problems"] / k["launches"],
+                            **recorded_traffic("knn_traffic_stream", n_scan=args.n_scan, n_map=m_map, batch=args.streams if args.fleet else 1),
                             note="one small launch per vehicle (or one per fleet step): the kernel cannot fill the chip; see DESIGN.md section 5")
     # ---- PCIe-inclusive companion (never `value`): the caller owns HOST scans (Localizer.hpp:103-126); the mapper uploads
     #      scan k + 1 on the context's copy stream while scan k aligns (LocalizerMT.hpp:27-40 has it queued by then)
@@ -877,6 +897,9 @@ def main_stream(args, collect=False):
                                    f"{args.streams} vehicle(s) per GPU, {mode}",
                        "parallelism": f"{world} GPU(s) x {args.streams} independent vehicles (replicas)"},
             "ms_per_scan_per_vehicle": elapsed * 1e3 / (args.steps * (n_total - first - 1)),
+            # `value` is the contract's figure (all timed passes / their time); the passes one by one, and their median
+            "scans_per_s_each_pass": [per_step * world / t for t in pass_s],
+            "scans_per_s_median_pass": float(np.median([per_step * world / t for t in pass_s])),
             "mean_iterations": its / per_step, "converged_fraction": conv / per_step,
             "new_keyframes_per_vehicle": res[0][2], "map_rebuilds_per_vehicle": res[0][3], "final_position_error_m": res[0][4],
             "host_input": host_input, "roofline": roofline, "cpu_baseline": cpu})
@@ -944,8 +967,9 @@ def main_f64(args, collect=False):
         alg = 40.0 * k["units"] + 24.0 * args.n_map * k["problems"]
         avg_s = k["total_ms"] * 1e-3 / k["launches"]
         roofline = dict(bound="hbm", kernel="knn_grid<double>", achieved=alg / k["launches"] / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=alg / k["launches"] / avg_s / 1e9 / HBM_PEAK_GBS, traffic=None, avg_launch_us=avg_s * 1e6, launches=k["launches"],
-                        active_problems_per_launch=k["problems"] / k["launches"], algorithmic_bytes_per_launch=alg / k["launches"])
+                        frac=alg / k["launches"] / avg_s / 1e9 / HBM_PEAK_GBS, avg_launch_us=avg_s * 1e6, launches=k["launches"],
+                        active_problems_per_launch=k["problems"] / k["launches"], algorithmic_bytes_per_launch=alg / k["launches"],
+                        **recorded_traffic("knn_traffic_f64", n_scan=args.n_scan, n_map=args.n_map, batch=B))
     cpu = None
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -986,7 +1010,7 @@ def compact_leg(d, wall_s):
             "set_map_ms", "median_translation_error_m",
             "mean_iterations", "converged_fraction", "final_position_error_m", "host_input", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
             "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size",
-            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "replay_vs_oracle")
+            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "replay_vs_oracle", "scans_per_s_each_pass", "scans_per_s_median_pass")
     out = {k: d[k] for k in keep if k in d}
     if "slam" in d:
         out["slam"] = {k: d["slam"].get(k) for k in ("scans", "points_per_scan", "keyframes", "loops_closed", "loop_candidates_tried",
@@ -1030,7 +1054,7 @@ def workload_legs(args, world, rank):
     lc_leg = run("loop_closure", main_loopclosure, steps=2, warmup=1, pairs=512, pair_chunk=512)
     if world == 1:
         run("f64", main_f64, steps=3, warmup=1)
-        run("stream", main_stream, steps=1, warmup=1, streams=1, fleet=False)
+        run("stream", main_stream, steps=3, warmup=1, streams=1, fleet=False)
         run("slam", main_slam, steps=1, warmup=0)
         # the same facade at SENSOR size: 100 k-pt scans (64 rings, an HDL-64E's), a shorter drive (the sequence file is 2.4 MB a
         # scan), the input filters a driver would configure -- every scan through the device input stage
@@ -1252,9 +1276,31 @@ def main():
                                        "WRITE_SIZE passes of this command (tools/measure_round.sh); " + str(tj.get("note", "")))
                 except (OSError, ValueError):
                     pass
+            # what the kernel is actually bound by (unit counters, profiles/knn_pmc.json: separate rocprofv3 --pmc passes of this
+            # command) and the same fraction for the launches that had no correspondences to start from, and for the rest
+            pmc = None
+            ppath = os.path.join(ROOT, "profiles", "knn_pmc.json")
+            if os.path.exists(ppath):
+                try:
+                    pmc = json.load(open(ppath))
+                except (OSError, ValueError):
+                    pmc = None
+            split = {}
+            ku = prof.get("knn_grid_unseeded")
+            if kname == "knn_grid" and ku and ku["launches"] and k["launches"] > ku["launches"]:
+                def frac_of(units, problems, launches, ms):
+                    return (20.0 * units + 12.0 * args.n_map * problems) / launches / (ms * 1e-3 / launches) / 1e9 / HBM_PEAK_GBS
+                split = dict(frac_unseeded_launches=frac_of(ku["units"], ku["problems"], ku["launches"], ku["total_ms"]),
+                             avg_unseeded_launch_us=ku["total_ms"] * 1e3 / ku["launches"],
+                             frac_seeded_launches=frac_of(k["units"] - ku["units"], k["problems"] - ku["problems"], k["launches"] - ku["launches"],
+                                                          k["total_ms"] - ku["total_ms"]),
+                             avg_seeded_launch_us=(k["total_ms"] - ku["total_ms"]) * 1e3 / (k["launches"] - ku["launches"]))
             roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_uncorrected=traffic_raw,
                             traffic_source=traffic_src,
+                            bound_measured=(pmc or {}).get("bound_measured", "valu"),
+                            bound_measured_evidence=(pmc or {"note": "profiles/knn_pmc.json not found: see DESIGN.md section 4 (VALU 68-94 % busy)"}),
+                            **split,
                             achieved_shared_map=achieved_shared, frac_shared_map=achieved_shared / HBM_PEAK_GBS,
                             compulsory_bytes_per_launch_shared_map=shared_bytes / k["launches"],
                             avg_launch_us=avg_s * 1e6, launches=k["launches"], profiled_steps=args.steps,

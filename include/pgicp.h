@@ -397,7 +397,8 @@ int pgicp_allgather_edges(pgicp_comm *comm, const pgicp_edge *local, const int *
 #define PGICP_PROF_GRID_BUILD 7
 #define PGICP_PROF_KNN_SLOW 8
 #define PGICP_PROF_NORMALS 9
-#define PGICP_PROF_COUNT 10
+#define PGICP_PROF_KNN_GRID_UNSEEDED 10   /* the launches of id 0 that had no previous correspondences to start from (an ICP's first pass) */
+#define PGICP_PROF_COUNT 11
 /* diagnostics of the last kNN launch: [0] queries queued by the fast path, [1] queued queries
  * resolved because their existence was unknown, [2] resolved because their lower bound was
  * within the trim threshold, [3] outlier-filter selections since the last call (all contexts of the device) whose

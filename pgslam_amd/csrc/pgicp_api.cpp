@@ -86,6 +86,7 @@ struct State {
 struct ProfEvent {
     hipEvent_t a, b;
     int kid;
+    int kid2 = -1;          // a second account the launch also goes to (-1: none)
     long long units;
     long long problems;
     long long map_points;
@@ -226,6 +227,7 @@ struct ProfScope {
         if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(ev.a, c->stream);
     }
+    void also(int kid2) { ev.kid2 = kid2; }
     ~ProfScope();
 };
 
@@ -237,11 +239,14 @@ void prof_collect_locked(pgicp_ctx *c)
     for (auto &e : c->prof_events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-            c->prof_launches[e.kid] += 1;
-            c->prof_ms[e.kid] += ms;
-            c->prof_units[e.kid] += e.units;
-            c->prof_problems[e.kid] += e.problems;
-            c->prof_map_points[e.kid] += e.map_points;
+            for (int kid : {e.kid, e.kid2}) {
+                if (kid < 0) continue;
+                c->prof_launches[kid] += 1;
+                c->prof_ms[kid] += ms;
+                c->prof_units[kid] += e.units;
+                c->prof_problems[kid] += e.problems;
+                c->prof_map_points[kid] += e.map_points;
+            }
         }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -901,6 +906,7 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
     }
     {
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, act_units, act_probs);
+        if (!use_seed && c->prm.matcher == PGICP_MATCHER_GRID) ps.also(PGICP_PROF_KNN_GRID_UNSEEDED);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
                       c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active, S.none_r.template as<T>(),

@@ -29,7 +29,7 @@ MINIMIZER_POINT_TO_PLANE, MINIMIZER_POINT_TO_POINT = 0, 1
 HOST, DEVICE, HOST_PINNED = 0, 1, 2
 MATCHER_GRID, MATCHER_BRUTE = 0, 1
 PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_update", "pretransform",
-              "covariance", "grid_build", "knn_slow", "surface_normals"]
+              "covariance", "grid_build", "knn_slow", "surface_normals", "knn_grid_unseeded"]
 
 # every symbol include/pgicp.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
