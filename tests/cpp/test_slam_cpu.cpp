@@ -1,6 +1,7 @@
 // CPU checks of include/pgslam_amd/slam.hpp (no GPU): graph search, SE(3) maps, pose-graph least squares,
 // loop-closure candidate search.  The least-squares problem and its solution are printed so that the Python
 // side can solve the same cost with scipy and compare (tests/test_slam.py).
+#include <cstdlib>
 #include "common.hpp"
 #include <chrono>
 #include <pgslam_amd/slam.hpp>
@@ -164,7 +165,9 @@ int main()
         for (int i = 0; i < N; i++) worst = std::max(worst, pose_diff(se3::to_matrix<pgslam_amd::Mat<double>>(big.X[i]), truth[i]));
         std::printf("pose graph of %d keyframes, %zu edges: %d LM iterations, %.3f s, cost %.3g -> %.3g, worst pose error %.2e\n", N,
                     big.factors.size(), big.iterations, secs, big.initial_error, big.final_error, worst);
-        CHECK(worst < 1e-4 && big.final_error < 1e-6 * big.initial_error && secs < 2.0);
+        // (the time limit is for the plain build; an instrumented one -- tools/sanitize/run.sh -- stretches it)
+        const char *slow = std::getenv("PGSLAM_TEST_TIME_SCALE");
+        CHECK(worst < 1e-4 && big.final_error < 1e-6 * big.initial_error && secs < 2.0 * (slow ? std::atof(slow) : 1.0));
     }
     std::puts("slam cpu tests ok");
     return 0;
