@@ -1015,7 +1015,7 @@ def compact_leg(d, wall_s):
     if "slam" in d:
         out["slam"] = {k: d["slam"].get(k) for k in ("scans", "points_per_scan", "keyframes", "loops_closed", "loop_candidates_tried",
                                                      "map_rebuilds", "mean_icp_iterations", "tracking_error_rms_m", "localizer_host_s",
-                                                     "input_filters", "device_input_stages", "device_readings_used", "points_after_filters_last_scan")}
+                                                     "input_filters", "device_input_stages", "device_readings_used", "device_map_rebuilds", "points_after_filters_last_scan")}
     r = out.get("roofline")
     if r:
         out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches",

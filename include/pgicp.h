@@ -172,6 +172,18 @@ int pgicp_upload_f64(pgicp_ctx *ctx, int n_readings, const double *const *host, 
                      const double **dev_ptrs);
 int pgicp_host_alloc(pgicp_ctx *ctx, size_t bytes, void **out);
 int pgicp_host_free(pgicp_ctx *ctx, void *p);
+/* Device memory a caller owns between calls: the keyframe clouds of a local map (LocalMap.hpp:209-224 walks them at every
+ * rebuild; Keyframe, types.h:31-44) stay in HBM, pgicp_build_local_map(mem = PGICP_DEVICE) assembles the next map from
+ * them into a buffer of this kind and pgicp_map_create(mem = PGICP_DEVICE) indexes it -- no cloud crosses PCIe at a rebuild.
+ * Plain buffers on the context's device, usable by every context of that device.  pgicp_device_copy returns when the copy
+ * is complete (it is ordered after the context's queued work).  pgicp_device_free waits for the device; its context may be
+ * NULL (an owner that outlives its context). */
+#define PGICP_COPY_TO_DEVICE 0
+#define PGICP_COPY_FROM_DEVICE 1
+#define PGICP_COPY_ON_DEVICE 2
+int pgicp_device_alloc(pgicp_ctx *ctx, size_t bytes, void **out);
+int pgicp_device_free(pgicp_ctx *ctx, void *p);
+int pgicp_device_copy(pgicp_ctx *ctx, void *dst, const void *src, size_t bytes, int kind);
 
 void pgicp_default_params(pgicp_params *p);
 /* replaces ICP::loadFromYaml / setDefault for the supported chain */

@@ -46,6 +46,10 @@ struct Types {
         Matrix T_world_kf;
         Matrix optimized_T_world_kf;
         Time update_time;
+        //! (not in the reference) the keyframe's cloud in device memory, made when a local map is first assembled from it on
+        //! the device (EnsureKeyframeOnDevice): keyframe clouds are immutable, so it is uploaded once and walked from HBM at
+        //! every rebuild.  Shared by the copies of the keyframe made after that.
+        std::shared_ptr<pgslam_amd::DeviceCloud<T>> device_cloud;
     };
     struct Constraint {
         enum Type { kOdomConstraint, kLoopConstraint };
@@ -106,6 +110,57 @@ typename Types<T>::DP BuildLocalMapCloud(const std::vector<typename Types<T>::Ke
     PMT::check(ctx, pgslam_amd::Abi<T>::local_map(ctx, k, xs.data(), all_normals ? ns.data() : nullptr, sx.data(), sn.data(), cnt.data(), Ts.data(),
                                                    out.features.data(), 4, all_normals ? out.descriptors.data() : nullptr, 3));
     return out;
+}
+
+//! the keyframe's cloud goes to device memory once (points and normals, host strides kept)
+template <typename T>
+void EnsureKeyframeOnDevice(typename Types<T>::Keyframe &kf)
+{
+    if (kf.device_cloud) return;
+    auto dc = std::make_shared<pgslam_amd::DeviceCloud<T>>();
+    const auto &c = *kf.cloud_ptr;
+    dc->upload(pgslam_amd::default_context(), c.xyzPtr(), c.xyzStride(), c.descriptorExists("normals") ? c.normalsPtr() : nullptr, c.normalsStride(), (int)c.getNbPoints());
+    kf.device_cloud = dc;
+}
+
+//! BuildLocalMapCloud over keyframes whose clouds are resident (EnsureKeyframeOnDevice), INTO device memory: the same
+//! device pass (pgicp_build_local_map), inputs and output in HBM; `out` is an assembly buffer the caller reuses.  Optionally
+//! the assembled cloud is then moved by `T_then` (LocalMap::CloudInWorldFrame, LocalMap.hpp:95-98) in a second pass, as the
+//! host flow does -- two roundings, the same two.  Same values as the host flow, bit for bit.
+template <typename T>
+void BuildLocalMapOnDevice(pgicp_ctx *ctx, const std::vector<typename Types<T>::Keyframe> &keyframes, pgslam_amd::DeviceCloud<T> &out,
+                           const typename Types<T>::Matrix *T_then = nullptr)
+{
+    using PMT = PointMatcher<T>;
+    if (keyframes.empty()) throw std::logic_error("BuildLocalMapOnDevice: no keyframes");
+    const auto T_refkf_world = keyframes[0].optimized_T_world_kf.inverse();
+    const int k = (int)keyframes.size();
+    bool all_normals = true;
+    long long total = 0;
+    for (auto &kf : keyframes) {
+        if (!kf.device_cloud) throw std::logic_error("BuildLocalMapOnDevice: a keyframe is not on the device");
+        all_normals = all_normals && kf.device_cloud->hasNormals();
+        total += kf.device_cloud->n;
+    }
+    std::vector<const T *> xs(k), ns(k);
+    std::vector<int> sx(k), sn(k), cnt(k);
+    std::vector<double> Ts((size_t)16 * k, 0.0);
+    for (int i = 0; i < k; i++) {
+        const auto &c = *keyframes[i].device_cloud;
+        xs[i] = c.xyz; sx[i] = c.xs; ns[i] = all_normals ? c.nrm : nullptr; sn[i] = all_normals ? c.ns : 3;
+        cnt[i] = c.n;
+        const auto Tk = (i == 0) ? PMT::Matrix::Identity(4, 4) : T_refkf_world * keyframes[i].optimized_T_world_kf;
+        pgslam_amd::to_row_major16(Tk, Ts.data() + 16 * i);
+    }
+    out.reserve(ctx, (int)total, 3, all_normals, 3);
+    PMT::check(ctx, pgslam_amd::Abi<T>::local_map_dev(ctx, k, xs.data(), all_normals ? ns.data() : nullptr, sx.data(), sn.data(), cnt.data(), Ts.data(),
+                                                       out.xyz, 3, all_normals ? out.nrm : nullptr, 3));
+    if (T_then) {
+        double T16[16];
+        pgslam_amd::to_row_major16(*T_then, T16);
+        PMT::check(ctx, pgslam_amd::Abi<T>::transform_dev(ctx, T16, out.xyz, 3, out.xyz, 3, (int)total, 0));
+        if (all_normals) PMT::check(ctx, pgslam_amd::Abi<T>::transform_dev(ctx, T16, out.nrm, 3, out.nrm, 3, (int)total, 1));
+    }
 }
 
 template <typename T>
@@ -182,6 +237,29 @@ public:
         temp_icp.referenceDataPointsFilters.init();
         temp_icp.referenceDataPointsFilters.apply(reference);
         temp_icp.matcher->init(reference);
+    }
+    //! the same for a candidate map that is in device memory already (assembled there from resident keyframe clouds): no
+    //! upload; only when the chain's reference filters change nothing (false: the caller takes the host flow)
+    bool PrepareOverlapReference(const pgslam_amd::DeviceCloud<T> &candidate_map_in_world_frame)
+    {
+        if (!temp_icp_) {
+            temp_icp_.reset(new typename PM::ICP());
+            std::istringstream iss(icp_config_buffer_);
+            temp_icp_->loadFromYaml(iss);
+        }
+        if (!temp_icp_->referenceDataPointsFilters.allIdentity()) return false;
+        temp_icp_->matcher->initDevice(candidate_map_in_world_frame, 0);
+        return true;
+    }
+    //! the context the probe's chain computes on (device-side assembly of its reference runs on the same stream)
+    pgicp_ctx *OverlapContext()
+    {
+        if (!temp_icp_) {
+            temp_icp_.reset(new typename PM::ICP());
+            std::istringstream iss(icp_config_buffer_);
+            temp_icp_->loadFromYaml(iss);
+        }
+        return temp_icp_->ctx;
     }
     //! the reading half (Localizer.hpp:319-334) against the reference prepared last
     T ComputeOverlapAgainstPrepared(const DP &reading_in, const Matrix &T_world_robot)
@@ -263,6 +341,14 @@ public:
         order.push_back(data_.back());
         for (size_t i = data_.size() - 1; i-- > 0;) order.push_back(data_[i]);
         cloud_ = BuildLocalMapCloud<T>(order);
+    }
+    //! the same order, for the device-side assembly (BuildLocalMapOnDevice)
+    std::vector<Keyframe> AssemblyOrder() const
+    {
+        std::vector<Keyframe> order;
+        order.push_back(data_.back());
+        for (size_t i = data_.size() - 1; i-- > 0;) order.push_back(data_[i]);
+        return order;
     }
 
 private:

@@ -69,6 +69,58 @@ struct LazyContext {
     void destroy() { if (p) { pgicp_ctx_destroy(p); p = nullptr; } }
 };
 
+//! A cloud that stays in device memory between calls (pgicp_device_alloc): points as [n][xs], normals (optional) as [n][ns].
+//! What a keyframe of the local map keeps (LocalMap.hpp:209-224 walks the keyframes at every rebuild; here the walk is one
+//! device pass over resident clouds: pgicp_build_local_map with mem = PGICP_DEVICE) and what an assembled map is handed to
+//! ICPSequence::setMap as.  Grow-only when reused as an assembly buffer.
+template <typename T>
+struct DeviceCloud {
+    T *xyz = nullptr, *nrm = nullptr;
+    int n = 0, xs = 3, ns = 3;
+    size_t cap_x = 0, cap_n = 0;                    // elements allocated
+    DeviceCloud() {}
+    DeviceCloud(const DeviceCloud &) = delete;
+    DeviceCloud &operator=(const DeviceCloud &) = delete;
+    ~DeviceCloud() { release(); }
+    void release()
+    {
+        if (xyz) pgicp_device_free(nullptr, xyz);
+        if (nrm) pgicp_device_free(nullptr, nrm);
+        xyz = nrm = nullptr; n = 0; cap_x = cap_n = 0;
+    }
+    static void fail(pgicp_ctx *c, int st, const char *what)
+    {
+        if (st != PGICP_OK) throw std::runtime_error(std::string(what) + ": " + pgicp_status_string(st) + " (" + pgicp_last_error(c) + ")");
+    }
+    //! room for `count` points (and normals) at the given strides; contents are undefined afterwards
+    void reserve(pgicp_ctx *c, int count, int xstride, bool normals, int nstride)
+    {
+        const size_t need_x = (size_t)count * xstride, need_n = normals ? (size_t)count * nstride : 0;
+        if (need_x > cap_x) {
+            if (xyz) pgicp_device_free(c, xyz);
+            xyz = nullptr; cap_x = 0;
+            fail(c, pgicp_device_alloc(c, sizeof(T) * (need_x + need_x / 8), (void **)&xyz), "DeviceCloud: device allocation");
+            cap_x = need_x + need_x / 8;
+        }
+        if (need_n > cap_n) {
+            if (nrm) pgicp_device_free(c, nrm);
+            nrm = nullptr; cap_n = 0;
+            fail(c, pgicp_device_alloc(c, sizeof(T) * (need_n + need_n / 8), (void **)&nrm), "DeviceCloud: device allocation");
+            cap_n = need_n + need_n / 8;
+        }
+        n = count; xs = xstride; ns = nstride;
+    }
+    bool hasNormals() const { return nrm != nullptr && cap_n >= (size_t)n * ns && n > 0; }
+    //! host -> device, strides kept as they are on the host (`x` holds (count - 1) * xstride + 3 elements at least)
+    void upload(pgicp_ctx *c, const T *x, int xstride, const T *nr, int nstride, int count)
+    {
+        reserve(c, count, xstride, nr != nullptr, nstride);
+        if (count <= 0) return;
+        fail(c, pgicp_device_copy(c, xyz, x, sizeof(T) * ((size_t)(count - 1) * xstride + 3), PGICP_COPY_TO_DEVICE), "DeviceCloud: upload");
+        if (nr) fail(c, pgicp_device_copy(c, nrm, nr, sizeof(T) * ((size_t)(count - 1) * nstride + 3), PGICP_COPY_TO_DEVICE), "DeviceCloud: upload");
+    }
+};
+
 template <typename T> struct Abi;
 template <> struct Abi<float> {
     static int map_create(pgicp_ctx *c, const float *x, int xs, const float *n, int ns, int m, int center, int *id) { return pgicp_map_create_f32(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
@@ -92,6 +144,9 @@ template <> struct Abi<float> {
     static int partial_dev(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_DEVICE, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const float *in, int is, float *out, int os, int n, int ro) { return pgicp_transform_f32(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
+    static int local_map_dev(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_DEVICE); }
+    static int map_create_dev(pgicp_ctx *c, const float *x, int xs, const float *n, int ns, int m, int center, int *id) { return pgicp_map_create_f32(c, x, xs, n, ns, m, PGICP_DEVICE, center, id); }
+    static int transform_dev(pgicp_ctx *c, const double *T16, const float *in, int is, float *out, int os, int n, int rotate_only) { return pgicp_transform_f32(c, T16, in, is, out, os, n, rotate_only, PGICP_DEVICE); }
 };
 template <> struct Abi<double> {
     static int map_create(pgicp_ctx *c, const double *x, int xs, const double *n, int ns, int m, int center, int *id) { return pgicp_map_create_f64(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
@@ -115,6 +170,9 @@ template <> struct Abi<double> {
     static int partial_dev(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_DEVICE, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const double *in, int is, double *out, int os, int n, int ro) { return pgicp_transform_f64(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
+    static int local_map_dev(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_DEVICE); }
+    static int map_create_dev(pgicp_ctx *c, const double *x, int xs, const double *n, int ns, int m, int center, int *id) { return pgicp_map_create_f64(c, x, xs, n, ns, m, PGICP_DEVICE, center, id); }
+    static int transform_dev(pgicp_ctx *c, const double *T16, const double *in, int is, double *out, int os, int n, int rotate_only) { return pgicp_transform_f64(c, T16, in, is, out, os, n, rotate_only, PGICP_DEVICE); }
 };
 
 }  // namespace pgslam_amd
@@ -605,6 +663,14 @@ struct PointMatcher {
             check(chain->ctx, A::map_create(chain->ctx, ref.xyzPtr(), ref.xyzStride(), ref.normalsPtr(), ref.normalsStride(), (int)ref.getNbPoints(), center, &mapId));
             mapSize = (int)ref.getNbPoints();
         }
+        //! the same over a cloud that is in device memory already (DeviceCloud): no upload
+        void initDevice(const pgslam_amd::DeviceCloud<T> &ref, int center)
+        {
+            release();
+            chain->pushParams();
+            check(chain->ctx, A::map_create_dev(chain->ctx, ref.xyz, ref.xs, ref.hasNormals() ? ref.nrm : nullptr, ref.ns, ref.n, center, &mapId));
+            mapSize = ref.n;
+        }
         //! Localizer.hpp:328, LoopCloser.hpp:358
         virtual Matches findClosests(const DataPoints &filteredReading)
         {
@@ -791,6 +857,21 @@ struct PointMatcher {
         std::function<void(const DataPoints &, const DataPoints &, const TransformationParameters &, const TransformationParameters &,
                            const pgicp_stats &)> onAlign;
         const DataPoints *currentReference = nullptr;
+        //! optional gate of the observer: asked once per completed alignment BEFORE the observer's arguments are made; false
+        //! skips the observer for that call (a map that lives only in device memory is downloaded for the observer's sake)
+        std::function<bool()> onAlignWanted;
+        //! the host copy of a device-resident reference, made when an observer asks for it (ICPSequence::setMap(DeviceCloud))
+        std::function<DataPoints()> lazyReference;
+        DataPoints lazyReferenceCloud;
+        const DataPoints *observedReference()
+        {
+            if (currentReference) return currentReference;
+            if (!lazyReference) return nullptr;
+            lazyReferenceCloud = lazyReference();
+            lazyReference = nullptr;
+            currentReference = &lazyReferenceCloud;
+            return currentReference;
+        }
 
         explicit ICPChainBase(int device = 0) : ctx(device)
         {
@@ -1007,7 +1088,8 @@ struct PointMatcher {
             storeStats(st);
             check(ctx, rc);
             const TransformationParameters T_out = pgslam_amd::from_row_major16<T>(To);
-            if (onAlign && currentReference) onAlign(*r.filtered, *currentReference, T_init, T_out, st);
+            if (onAlign && (currentReference || lazyReference) && (!onAlignWanted || onAlignWanted()))
+                if (const DataPoints *ref = observedReference()) onAlign(*r.filtered, *ref, T_init, T_out, st);
             return T_out;
         }
         TransformationParameters alignOnMap(const DataPoints &readingIn, const TransformationParameters &T_init)
@@ -1036,7 +1118,8 @@ struct PointMatcher {
             storeStats(st);
             check(ctx, rc);
             const TransformationParameters T_out = pgslam_amd::from_row_major16<T>(To);
-            if (onAlign && currentReference) onAlign(reading, *currentReference, T_init, T_out, st);
+            if (onAlign && (currentReference || lazyReference) && (!onAlignWanted || onAlignWanted()))
+                if (const DataPoints *ref = observedReference()) onAlign(reading, *ref, T_init, T_out, st);
             return T_out;
         }
     };
@@ -1066,7 +1149,25 @@ struct PointMatcher {
 
     struct ICPSequence : ICP {
         explicit ICPSequence(int device = 0) : ICP(device) {}
-        bool hasMap() const { return mapPointCloud.getNbPoints() != 0; }
+        bool hasMap() const { return mapPointCloud.getNbPoints() != 0 || mapOnDevice; }
+        //! a map that is in device memory already (the localizer assembles it there from resident keyframe clouds) may stand
+        //! for setMap(cloud): the chain's reference filters change nothing
+        bool deviceMapEquivalent() const { return this->referenceDataPointsFilters.allIdentity(); }
+        //! setMap for such a map: mean-centre + index build, no cloud crosses PCIe.  `hostCopy` makes the host cloud if an
+        //! observer (onAlign) or getPrefilteredMap() asks for it.
+        bool setMap(const pgslam_amd::DeviceCloud<T> &deviceCloud, std::function<DataPoints()> hostCopy)
+        {
+            if (!deviceMapEquivalent()) throw std::logic_error("ICPSequence::setMap(DeviceCloud): the chain has reference filters");
+            if (!deviceCloud.hasNormals() && !(this->errorMinimizer && this->errorMinimizer->pointToPoint))
+                throw std::runtime_error("PointToPlaneErrorMinimizer: the map has no 'normals' descriptor");
+            mapPointCloud = DataPoints();
+            this->prefilteredReferencePtsCount = deviceCloud.n;
+            this->matcher->initDevice(deviceCloud, 1);
+            mapOnDevice = true;
+            this->currentReference = nullptr;
+            this->lazyReference = hostCopy;
+            return true;
+        }
         //! Localizer.hpp:148,168,254 -- copy, reference filters, mean-centre, build the index; stays resident in HBM
         bool setMap(const DataPoints &inputCloud)
         {
@@ -1078,10 +1179,16 @@ struct PointMatcher {
                 throw std::runtime_error("PointToPlaneErrorMinimizer: the map has no 'normals' descriptor");
             this->matcher->initImpl(mapPointCloud, 1);
             this->currentReference = &mapPointCloud;
+            this->lazyReference = nullptr;
+            mapOnDevice = false;
             return true;
         }
-        void clearMap() { mapPointCloud = DataPoints(); this->currentReference = nullptr; this->matcher->release(); }
-        const DataPoints &getPrefilteredMap() const { return mapPointCloud; }
+        void clearMap() { mapPointCloud = DataPoints(); this->currentReference = nullptr; this->lazyReference = nullptr; mapOnDevice = false; this->matcher->release(); }
+        const DataPoints &getPrefilteredMap()
+        {
+            if (mapOnDevice) if (const DataPoints *ref = this->observedReference()) return *ref;
+            return mapPointCloud;
+        }
         TransformationParameters operator()(const DataPoints &cloudIn) { return (*this)(cloudIn, Matrix::Identity(4, 4)); }
         //! Localizer.hpp:126.  Without a map the first cloud becomes the map and identity is returned
         TransformationParameters operator()(const DataPoints &cloudIn, const TransformationParameters &initialTransformationParameters)
@@ -1097,6 +1204,7 @@ struct PointMatcher {
         }
     private:
         DataPoints mapPointCloud;
+        bool mapOnDevice = false;
     };
 
     // ------------------------------------------------------------------ registrar (PM::get().REG(Transformation).create(...))

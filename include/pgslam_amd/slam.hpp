@@ -786,6 +786,9 @@ public:
     //! scans whose input filters + sensor transform ran as one device pass
     size_t device_input_stages() const { return device_input_stages_; }
     void SetDeviceInputStage(bool on) { device_input_stage_ = on; }
+    //! local maps assembled from device-resident keyframe clouds (default) or through the host, as upstream does
+    void SetDeviceLocalMap(bool on) { device_local_map_ = on; }
+    size_t device_rebuilds() const { return device_rebuilds_; }
     //! The NEXT scan, already queued (LocalizerMT.hpp:27-40): pre-process it and start its transfer to the device on the ICP
     //! context's copy stream (pgicp_upload_*), so that it travels while the current scan aligns.  Needs a map (the chain
     //! aligns device readings only against one) -- before the first keyframe nothing is prefetched.
@@ -830,15 +833,29 @@ protected:
     size_t prefetches_ = 0, device_readings_used_ = 0, device_input_stages_ = 0;
     typename PM::ICPChainBase::DeviceReading input_device_;      // the current scan's device copy (while it is valid: this ProcessData)
     bool device_input_stage_ = std::getenv("PGSLAM_HOST_INPUT_STAGE") == nullptr;
+    bool device_local_map_ = std::getenv("PGSLAM_HOST_LOCAL_MAP") == nullptr;      // keyframe clouds resident, maps assembled in HBM
+    pgslam_amd::DeviceCloud<T> map_assembly_, probe_assembly_;                   // assembly buffers (grow-only), one per chain
+    size_t device_rebuilds_ = 0;
     bool resync_before_update_ = false;              // the MT flavour re-reads the graph before every update
     unsigned long long synced_version_ = 0;
     void Rebuild()
     {
         auto &g = map_manager_->GetGraph();
         LocalMap<T> lm(capacity_);
-        for (size_t v : comp_) lm.PushKeyframe(g[v]);
-        lm.BuildCloudFromData();
-        icp_sequence_.setMap(lm.Cloud());
+        // Keyframe clouds are immutable: each goes to device memory once, and a rebuild assembles the map THERE and indexes it
+        // in place -- no cloud crosses PCIe (the host flow uploads the keyframes, downloads the assembled map and uploads it
+        // again: 24 MB per rebuild at 100 k-pt scans).  Same values bit for bit; the host copy is made when somebody asks.
+        if (device_local_map_ && icp_sequence_.deviceMapEquivalent()) {
+            for (size_t v : comp_) { EnsureKeyframeOnDevice<T>(g[v]); lm.PushKeyframe(g[v]); }
+            const std::vector<Keyframe> order = lm.AssemblyOrder();
+            BuildLocalMapOnDevice<T>(icp_sequence_.ctx, order, map_assembly_);
+            icp_sequence_.setMap(map_assembly_, [order]() { return BuildLocalMapCloud<T>(order); });
+            device_rebuilds_++;
+        } else {
+            for (size_t v : comp_) lm.PushKeyframe(g[v]);
+            lm.BuildCloudFromData();
+            icp_sequence_.setMap(lm.Cloud());
+        }
         rebuilds_++;
     }
     T OverlapWith(const std::vector<size_t> &comp)                          // ComputeOverlapWith, Localizer.hpp:282-348
@@ -856,10 +873,20 @@ protected:
         static const bool always_rebuild = std::getenv("PGSLAM_PROBE_REBUILD") != nullptr;   // tests: the reference's own flow
         if (always_rebuild || probe_comp_ != comp || probe_version_ != map_manager_->Version()) {
             LocalMap<T> lm(capacity_);
-            for (size_t v : comp) lm.PushKeyframe(g[v]);
-            lm.BuildCloudFromData();
-            const DP world_map = rigid_->compute(lm.Cloud(), g[comp.back()].optimized_T_world_kf);
-            probe_->PrepareOverlapReference(world_map);
+            bool prepared = false;
+            if (device_local_map_) {                    // (as Rebuild: assembled and moved to the world frame in device memory)
+                for (size_t v : comp) { EnsureKeyframeOnDevice<T>(g[v]); lm.PushKeyframe(g[v]); }
+                const Matrix T_world_ref = g[comp.back()].optimized_T_world_kf;
+                BuildLocalMapOnDevice<T>(probe_->OverlapContext(), lm.AssemblyOrder(), probe_assembly_, &T_world_ref);
+                prepared = probe_->PrepareOverlapReference(probe_assembly_);
+            } else {
+                for (size_t v : comp) lm.PushKeyframe(g[v]);
+            }
+            if (!prepared) {
+                lm.BuildCloudFromData();
+                const DP world_map = rigid_->compute(lm.Cloud(), g[comp.back()].optimized_T_world_kf);
+                probe_->PrepareOverlapReference(world_map);
+            }
             probe_comp_ = comp;
             probe_version_ = map_manager_->Version();
         }

@@ -1956,6 +1956,34 @@ int pgicp_host_free(pgicp_ctx *c, void *p)
     return PGICP_OK;
 }
 
+int pgicp_device_alloc(pgicp_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || bytes == 0) return fail(c, PGICP_ERR_ARG, "pgicp_device_alloc: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    if (hipMalloc(out, bytes) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(c, PGICP_ERR_HIP, "pgicp_device_alloc: out of device memory"); }
+    return PGICP_OK;
+}
+int pgicp_device_free(pgicp_ctx *c, void *p)
+{
+    // (the context may be NULL: an owner that outlives its context -- a keyframe freed at process exit -- still frees)
+    if (!p) return PGICP_OK;
+    if (!c) return hipFree(p) == hipSuccess ? PGICP_OK : PGICP_ERR_HIP;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipFree(p));
+    return PGICP_OK;
+}
+int pgicp_device_copy(pgicp_ctx *c, void *dst, const void *src, size_t bytes, int kind)
+{
+    if (!c || (bytes && (!dst || !src)) || kind < PGICP_COPY_TO_DEVICE || kind > PGICP_COPY_ON_DEVICE)
+        return fail(c, PGICP_ERR_ARG, "pgicp_device_copy: bad argument");
+    if (!bytes) return PGICP_OK;
+    HIPC(c, hipSetDevice(c->device));
+    const hipMemcpyKind k = kind == PGICP_COPY_TO_DEVICE ? hipMemcpyHostToDevice : kind == PGICP_COPY_FROM_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIPC(c, hipMemcpyAsync(dst, src, bytes, k, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return PGICP_OK;
+}
+
 const char *pgicp_status_string(int status)
 {
     switch (status) {

@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "pgicp_map_destroy", "pgicp_map_size", "pgicp_map_transfer",
     "pgicp_align_f32", "pgicp_align_f64", "pgicp_align_batch_f32", "pgicp_align_batch_f64",
     "pgicp_align_residual_batch_f32", "pgicp_align_residual_batch_f64", "pgicp_filter_cloud_f32", "pgicp_filter_cloud_f64",
+    "pgicp_device_alloc", "pgicp_device_free", "pgicp_device_copy",
     "pgicp_icp_pair_f32", "pgicp_icp_pair_f64", "pgicp_match_f32", "pgicp_match_f64",
     "pgicp_outlier_weights_f32", "pgicp_outlier_weights_f64", "pgicp_error_stats_f32", "pgicp_error_stats_f64",
     "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_partial_chain_batch_f32",

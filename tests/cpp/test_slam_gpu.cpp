@@ -160,8 +160,67 @@ void run_mt_sensor_pose(const char *name)
                 slam.localizer().device_readings_used(), S, pose_diff(slam.localizer().T_world_robot(), st_poses[S - 1]));
 }
 
+// Local maps assembled from keyframe clouds that STAY in device memory (GraphLocalizer::Rebuild, OverlapWith: one upload per
+// keyframe, pgicp_build_local_map + pgicp_map_create on device pointers) against the host flow (LocalMap.hpp:209-224 through the
+// host at every rebuild): the same kernels on the same values -- poses, keyframes, loop edges and the map itself bit for bit.
+template <typename T>
+void run_device_local_map(const char *name)
+{
+    IMPORT_PGSLAM_TYPES(T)
+    TransformationPtr rigid = PM::get().REG(Transformation).create("RigidTransformation");
+    const int S = 15;
+    std::vector<Matrix> truth, odom;
+    for (int s = 0; s < S; s++) {
+        const double a = 2 * M_PI * s / (S - 1);
+        truth.push_back(pose<T>(1.5 + 0.5 * std::cos(a), 1.5 + 0.5 * std::sin(a), 0.0, a * 0.2));
+    }
+    odom.push_back(truth[0]);
+    for (int s = 1; s < S; s++) odom.push_back(odom[s - 1] * (truth[s - 1].inverse() * truth[s]) * pose<T>(0.012, -0.009, 0.0, 0.005));
+    std::vector<Matrix> host_poses, host_kf;
+    DP host_map;
+    int host_loops = 0, host_rebuilds = 0;
+    for (int on_device = 0; on_device < 2; on_device++) {
+        pgslam::PoseGraphSlam<T> slam;
+        slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+        // (threshold 0.8: some scans join the current map, some become keyframes, and the neighbour-composition probe runs)
+        slam.localizer().SetOverlapThreshold(T(0.8));
+        slam.localizer().SetDeviceLocalMap(on_device != 0);
+        slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
+        slam.loop_closer().SetGeometricalDistanceThreshold(T(0.3));
+        for (int s = 0; s < S; s++) {
+            auto cloud = std::make_shared<DP>(rigid->compute(make_corner<T>(2000, 70 + s, 0.004), truth[s].inverse()));
+            slam.AddData((unsigned long long)s, "world", odom[s], Matrix::Identity(4, 4), cloud);
+            if (!on_device) host_poses.push_back(slam.localizer().T_world_robot());
+            else CHECK(pose_diff(slam.localizer().T_world_robot(), host_poses[s]) == 0.0);
+        }
+        auto &g = slam.map_manager().GetGraph();
+        int loops = 0;
+        for (size_t e = 0; e < g.NumEdges(); e++) loops += g.Edge(e).c.type == Constraint::kLoopConstraint;
+        const DP &map = slam.localizer().icp().getPrefilteredMap();          // (device flow: the host copy is made here, on demand)
+        if (!on_device) {
+            for (size_t v = 0; v < g.NumVertices(); v++) host_kf.push_back(g[v].optimized_T_world_kf);
+            host_loops = loops; host_rebuilds = slam.localizer().rebuilds(); host_map = map;
+            CHECK(slam.localizer().device_rebuilds() == 0);
+        } else {
+            CHECK(g.NumVertices() == host_kf.size() && loops == host_loops && slam.localizer().rebuilds() == host_rebuilds);
+            for (size_t v = 0; v < g.NumVertices(); v++) CHECK(pose_diff(g[v].optimized_T_world_kf, host_kf[v]) == 0.0);
+            CHECK(slam.localizer().device_rebuilds() == (size_t)host_rebuilds);
+            CHECK(map.getNbPoints() == host_map.getNbPoints() && map.getNbPoints() > 0);
+            bool same = true;
+            for (unsigned i = 0; i < map.getNbPoints() && same; i++)
+                for (int a = 0; a < 3; a++)
+                    same = same && map.features(a, (int)i) == host_map.features(a, (int)i) && map.normalsPtr()[(size_t)i * map.normalsStride() + a] == host_map.normalsPtr()[(size_t)i * host_map.normalsStride() + a];
+            CHECK(same);
+            std::printf("%s: ok  (%zu keyframes, %d rebuilds all in device memory, %d loop edges; poses, keyframes and the map equal the host flow's bit for bit)\n",
+                        name, g.NumVertices(), host_rebuilds, loops);
+        }
+    }
+}
+
 int main()
 {
+    run_device_local_map<float>("local maps from device-resident keyframes, PoseGraphSlam<float>");
+    run_device_local_map<double>("local maps from device-resident keyframes, PoseGraphSlam<double>");
     run_mt_sensor_pose<float>("PoseGraphSlamMT<float>, sensor off the robot's origin + sampling input filter");
     run_mt<float>("PoseGraphSlamMT<float>");
     run<float>("PoseGraphSlam<float>");

@@ -67,7 +67,6 @@ struct Recorder {
     void operator()(int k, const DP &reading, const DP &reference, const Matrix &Ti, const Matrix &To, const pgicp_stats &st)
     {
         if (!f || written_kind[k] >= want) return;
-        if (k == 0 && (calls++ % every) != 0) return;
         const int n = (int)reading.getNbPoints(), m = (int)reference.getNbPoints();
         const int head[8] = {k, scan, n, m, st.iterations, st.converged, st.status, st.max_iter_reached};
         std::fwrite(head, sizeof head, 1, f);
@@ -87,6 +86,13 @@ struct Recorder {
         dump(reference.normalsPtr(), reference.normalsStride(), m);
         written++;
         written_kind[k]++;
+    }
+    //! asked before the observer's arguments are made (ICPChainBase::onAlignWanted): a local map that lives in device memory
+    //! is downloaded only for the calls that are written
+    bool wanted(int k)
+    {
+        if (!f || written_kind[k] >= want) return false;
+        return k != 0 || (calls++ % every) == 0;
     }
     void close()
     {
@@ -184,6 +190,8 @@ int main(int argc, char **argv)
         rec.open(rec_path, rec_n, S);
         slam.localizer().icp().onAlign = [&](const DP &r, const DP &m, const Matrix &a, const Matrix &b, const pgicp_stats &s) { rec(0, r, m, a, b, s); };
         slam.loop_closer().icp().onAlign = [&](const DP &r, const DP &m, const Matrix &a, const Matrix &b, const pgicp_stats &s) { rec(1, r, m, a, b, s); };
+        slam.localizer().icp().onAlignWanted = [&]() { return rec.wanted(0); };
+        slam.loop_closer().icp().onAlignWanted = [&]() { return rec.wanted(1); };
     }
     std::vector<double> Tt(16), To(16);
     std::vector<float> xyz((size_t)N * 3), nrm((size_t)N * 3);
@@ -253,7 +261,7 @@ int main(int argc, char **argv)
                 "\"tracking_error_max_m\": %.5f, \"tracking_error_last_m\": %.5f, \"odometry_error_last_m\": %.5f, "
                 "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d, "
                 "\"localizer_host_s\": {\"filters_and_sensor_transform\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f}, "
-                "\"input_filters\": \"%s\", \"device_input_stages\": %zu, \"device_readings_used\": %zu, \"points_after_filters_last_scan\": %u, "
+                "\"input_filters\": \"%s\", \"device_input_stages\": %zu, \"device_readings_used\": %zu, \"device_map_rebuilds\": %zu, \"points_after_filters_last_scan\": %u, "
                 "\"keyframes_revisiting_within_3m_by_truth\": %d, \"keyframes_revisiting_within_3m_by_estimate\": %d, "
                 "\"knn_profile\": {\"launches\": %lld, \"total_ms\": %.4f, \"reading_points\": %lld, \"problems\": %lld, \"map_points\": %lld}}\n",
                 S, N, wall, t_icp_loop, t_io, (S - 1) / t_icp_loop, g.NumVertices(), loops, slam.loop_closer().candidates_tried(),
@@ -263,7 +271,7 @@ int main(int argc, char **argv)
                 std::sqrt(kf_sum2 / std::max<size_t>(1, kf_scan.size())), kf_max, rec.written, rec.written_kind[1],
                 slam.localizer().phase_seconds()[0], slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2],
                 g_filters == kSensorFilters ? "RemoveNaN, MaxDist 79.9, BoundingBox (vehicle)" : "Identity", slam.localizer().device_input_stages(),
-                slam.localizer().device_readings_used(), last_cloud_points,
+                slam.localizer().device_readings_used(), slam.localizer().device_rebuilds(), last_cloud_points,
                 count_revisits(std::min(g.NumVertices(), kf_scan.size()), [&](size_t v, int a) { return (double)truth[kf_scan[v]](a, 3); }, 3.0, 4),
                 count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4),
                 kp_l, kp_ms, kp_u, kp_p, kp_m);
