@@ -811,6 +811,7 @@ struct PointMatcher {
         T sensorStdDev = T(0.01);
         bool withCov = false;
         bool pointToPoint = false;       //!< PointToPointErrorMinimizer (Kabsch); else PointToPlane(WithCov)
+        bool force4DOF = false;          //!< PointToPlane[WithCov]ErrorMinimizer{force4DOF: 1}: rotation about z + translation only
         // state of the last ICP run / compute()
         T lastOverlap = 0; T lastResidual = 0; Matrix lastCov = Matrix::Zero(6, 6);
         explicit ErrorMinimizer(ICPChainBase *c) : chain(c) {}
@@ -964,6 +965,7 @@ struct PointMatcher {
                 else if (m.name != "PointToPlaneErrorMinimizer") throw std::runtime_error("loadFromYaml: unsupported error minimizer " + m.name);
                 for (auto &kv : m.params) {
                     if (kv.first == "sensorStdDev") errorMinimizer->sensorStdDev = (T)to_double(kv.second, "sensorStdDev");
+                    else if (kv.first == "force4DOF" && !errorMinimizer->pointToPoint) errorMinimizer->force4DOF = !(kv.second == "0" || kv.second == "false");
                     else if ((kv.first == "force2D" || kv.first == "force4DOF") && (kv.second == "0" || kv.second == "false")) {}
                     else throw std::runtime_error(m.name + ": unsupported parameter " + kv.first);
                 }
@@ -1012,7 +1014,8 @@ struct PointMatcher {
             }
             if (errorMinimizer) {
                 p.sensor_std_dev = (double)errorMinimizer->sensorStdDev;
-                p.error_minimizer = errorMinimizer->pointToPoint ? PGICP_MINIMIZER_POINT_TO_POINT : PGICP_MINIMIZER_POINT_TO_PLANE;
+                p.error_minimizer = errorMinimizer->pointToPoint ? PGICP_MINIMIZER_POINT_TO_POINT
+                                    : errorMinimizer->force4DOF ? PGICP_MINIMIZER_POINT_TO_PLANE_4DOF : PGICP_MINIMIZER_POINT_TO_PLANE;
             }
             for (auto &f : outlierFilters)
                 if (auto sn = std::dynamic_pointer_cast<SurfaceNormalOutlierFilter>(f))

@@ -90,7 +90,8 @@ typedef struct {
     /* ---- round 4: the rest of the chain slots a pgslam user's YAML may fill (Localizer.hpp:70, LoopCloser.hpp:73) ---- */
     int knn;                /* [A.3] KDTreeMatcher.knn: neighbours per reading point (<= 1: one).  Matches are knn x N; every
                              * later stage sees knn * N pairs */
-    int minimizer;          /* 0: PointToPlane(WithCov)ErrorMinimizer [A.6]; 1: PointToPointErrorMinimizer (Kabsch / SVD) */
+    int minimizer;          /* 0: PointToPlane(WithCov)ErrorMinimizer [A.6]; 1: PointToPointErrorMinimizer (Kabsch / SVD);
+                             * 2: PointToPlane with force4DOF (orc_solve_4dof) */
     double bound_max_rot;   /* [A.9] BoundTransformationChecker.maxRotationNorm (rad); <= 0 or inf: not in the chain */
     double bound_max_trans; /* [A.9] BoundTransformationChecker.maxTranslationNorm; <= 0 or inf: not in the chain */
     real normal_max_angle;  /* [A.4] SurfaceNormalOutlierFilter.maxAngle (rad); <= 0: not in the chain */
@@ -739,6 +740,72 @@ int FN(orc_solve6)(const double *sys, double *x, int *rank_out)
     return ORC_OK;
 }
 
+/* [EXT] PointToPlaneErrorMinimizer{force4DOF: 1} (libpointmatcher ErrorMinimizers/PointToPlane.cpp): only the z component
+ * of p x n enters F, the unknowns are [rz tx ty tz], the system is 4 x 4 -- the [2..5] block of the 6 x 6 normal equations,
+ * since dropping rows of F drops the matching rows and columns of F F^T -- and the increment is AngleAxis(x0, unitZ) plus the
+ * translation.  Solved like [A.6]: Cholesky with the relative pivot test on the block, else the minimal-norm solution.
+ * x comes back as [0 0 rz tx ty tz]. */
+int FN(orc_solve_4dof)(const double *sys, double *x, int *rank_out)
+{
+    double A[16], L[16], b[4];
+    static const int pk[4][4] = {{11, 12, 13, 14}, {12, 15, 16, 17}, {13, 16, 18, 19}, {14, 17, 19, 20}};   /* packed upper triangle */
+    for (int i = 0; i < 4; i++) { b[i] = sys[21 + 2 + i]; for (int j = 0; j < 4; j++) A[i * 4 + j] = sys[pk[i][j]]; }
+#ifdef ORC_DOUBLE
+    const double rel = 6.0 * DBL_EPSILON;
+#else
+    const double rel = 6.0 * (double)FLT_EPSILON;
+#endif
+    double dmax = 0.0;
+    for (int i = 0; i < 4; i++) if (fabs(A[i * 4 + i]) > dmax) dmax = fabs(A[i * 4 + i]);
+    memset(L, 0, sizeof L);
+    int ok = 1;
+    for (int j = 0; j < 4 && ok; j++) {
+        double d = A[j * 4 + j];
+        for (int m = 0; m < j; m++) d -= L[j * 4 + m] * L[j * 4 + m];
+        if (!(d > dmax * rel)) { ok = 0; break; }
+        L[j * 4 + j] = sqrt(d);
+        for (int i = j + 1; i < 4; i++) {
+            double t = A[i * 4 + j];
+            for (int m = 0; m < j; m++) t -= L[i * 4 + m] * L[j * 4 + m];
+            L[i * 4 + j] = t / L[j * 4 + j];
+        }
+    }
+    double y[4], z[4] = {0, 0, 0, 0};
+    int rank = 4;
+    if (ok) {
+        for (int i = 0; i < 4; i++) {
+            double t = b[i];
+            for (int m = 0; m < i; m++) t -= L[i * 4 + m] * y[m];
+            y[i] = t / L[i * 4 + i];
+        }
+        for (int i = 3; i >= 0; i--) {
+            double t = y[i];
+            for (int m = i + 1; m < 4; m++) t -= L[m * 4 + i] * z[m];
+            z[i] = t / L[i * 4 + i];
+        }
+    } else {
+        /* minimal-norm solution: the block embedded in a 6 x 6 of zeros has the block's eigen-pairs and two null ones */
+        double A6[36], V[36], ev[6];
+        memset(A6, 0, sizeof A6);
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) A6[(i + 2) * 6 + (j + 2)] = A[i * 4 + j];
+        jacobi6(A6, V, ev);
+        double emax = 0.0;
+        for (int i = 0; i < 6; i++) if (fabs(ev[i]) > emax) emax = fabs(ev[i]);
+        rank = 0;
+        for (int e = 0; e < 6; e++) {
+            if (!(ev[e] > emax * rel)) continue;
+            rank++;
+            double dot = 0.0;
+            for (int i = 0; i < 4; i++) dot += V[(i + 2) * 6 + e] * b[i];
+            for (int i = 0; i < 4; i++) z[i] += dot / ev[e] * V[(i + 2) * 6 + e];
+        }
+    }
+    x[0] = 0.0; x[1] = 0.0;
+    for (int i = 0; i < 4; i++) x[2 + i] = z[i];
+    if (rank_out) *rank_out = rank;
+    return ORC_OK;
+}
+
 /* [A.6] x = [rx ry rz tx ty tz] -> 4x4; AngleAxis(|r|, r/|r|); NaN => R = I */
 void FN(orc_delta_T)(const double *x, double *T)
 {
@@ -1157,7 +1224,8 @@ int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *r
             status = FN(p2plane_system_k)(step, n, K, ref, ref_nrm, ids, w, sys);
             if (status != ORC_OK) break;
             double x[6]; int rank;
-            FN(orc_solve6)(sys, x, &rank);
+            if (prm->minimizer == 2) FN(orc_solve_4dof)(sys, x, &rank);
+            else FN(orc_solve6)(sys, x, &rank);
             FN(orc_delta_T)(x, dT);
         }
         memcpy(T_prev, T_iter, sizeof T_iter);

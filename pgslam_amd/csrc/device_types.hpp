@@ -77,6 +77,7 @@ struct ChainDev {
     // the other modules the chain's slots may hold (ABI 4)
     int knn;             // KDTreeMatcher.knn: neighbours per reading point; > 1: the top-K matcher, pairs laid out [point][neighbour]
     int minimizer;       // 0 PointToPlane(WithCov), 1 PointToPoint
+    int force4dof;       // PointToPlane{force4DOF}: the increment is a rotation about z and a translation
     double bound_rot, bound_trans;   // BoundTransformationChecker limits; <= 0: not in the chain
     T normal_cos;        // SurfaceNormalOutlierFilter: cos(maxAngle) evaluated in T on the host
     int use_normals;     // ... and whether it is in the chain

@@ -145,6 +145,22 @@ PGICP_HD int min_norm_solve6(const double *Ain, const double *b, double rel_tol,
     return rank;
 }
 
+// PointToPlaneErrorMinimizer{force4DOF} ([EXT] ErrorMinimizers/PointToPlane.cpp: F's first row is the z component of
+// p x n alone, the system is 4 x 4 in [rz tx ty tz], the increment AngleAxis(x0, unitZ) + translation): the 4 x 4 system is
+// the [2..5] block of the 6 x 6 one, so the 6 x 6 is made block diagonal -- rows and columns of rx, ry cleared, their
+// diagonal set to the block's largest diagonal entry (the pivot test's scale stays the block's), b0 = b1 = 0 -- and solved
+// as usual: x0 = x1 = 0 exactly, the rest is the 4 x 4 solve.
+PGICP_HD void constrain_4dof(double *sys)
+{
+    // packed upper triangle, row by row: (0,0..5) = 0..5, (1,1..5) = 6..10, (2,2..5) = 11..14, (3,3..5) = 15..17, (4,4..5) = 18..19, (5,5) = 20
+    const double dmax = fmax(fmax(fabs(sys[11]), fabs(sys[15])), fmax(fabs(sys[18]), fabs(sys[20])));
+    for (int k = 0; k <= 10; k++) sys[k] = 0.0;
+    sys[0] = dmax > 0.0 ? dmax : 1.0;
+    sys[6] = sys[0];
+    sys[21] = 0.0;
+    sys[22] = 0.0;
+}
+
 // solvePossiblyUnderdeterminedLinearSystem.
 PGICP_HD int solve6(const double *sys, double rel_tol, double *x)
 {

@@ -287,7 +287,8 @@ ChainDev<T> make_chain(const pgicp_params &p)
     ch.min_trans = p.min_diff_trans;
     ch.rank_rel_tol = 6.0 * (double)std::numeric_limits<T>::epsilon();
     ch.knn = std::max(1, p.knn);
-    ch.minimizer = p.error_minimizer;
+    ch.minimizer = p.error_minimizer == PGICP_MINIMIZER_POINT_TO_POINT ? 1 : 0;
+    ch.force4dof = p.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE_4DOF ? 1 : 0;
     ch.bound_rot = (p.bound_max_rot > 0.0 && std::isfinite(p.bound_max_rot)) ? p.bound_max_rot : 0.0;
     ch.bound_trans = (p.bound_max_trans > 0.0 && std::isfinite(p.bound_max_trans)) ? p.bound_max_trans : 0.0;
     ch.use_normals = p.normal_max_angle > 0.0 ? 1 : 0;
@@ -1067,7 +1068,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     for (int p = 0; p < P; p++) {
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_align: unknown map id");
-        if (!M->has_nrm && (prm.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE || prm.normal_max_angle > 0.0))
+        if (!M->has_nrm && (prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT || prm.normal_max_angle > 0.0))
             return fail(c, PGICP_ERR_ARG, "pgicp_align: reference has no normals descriptor");
     }
     static const bool host_timing = std::getenv("PGICP_HOST_TIMING") != nullptr;      // diagnostics
@@ -1103,7 +1104,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         }
     }
     const auto ht2 = std::chrono::steady_clock::now();
-    const bool with_cov = prm.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE;      // (PointToPoint: the base class's zeros)
+    const bool with_cov = prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT;      // (PointToPoint: the base class's zeros)
     if (with_cov) {
         ProfScope ps(c, PGICP_PROF_COV, L.total, P);
         launch_cov<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(), S.rd_sorted.template as<T>(),
@@ -1291,7 +1292,7 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
     for (int p = 0; p < P; p++) {
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_partial_chain: unknown map id");
-        if (!M->has_nrm && (c->prm.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE || c->prm.normal_max_angle > 0.0))
+        if (!M->has_nrm && (c->prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT || c->prm.normal_max_angle > 0.0))
             return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
     }
     BatchLayout L;
@@ -1379,7 +1380,7 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     if (!c || !reading || !ids || !w || n <= 0 || stride < 3) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: bad argument");
     HIPC(c, hipSetDevice(c->device));
     MapHost<T> *M = get_map<T>(c, map_id);
-    if (!M || (!M->has_nrm && c->prm.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE)) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: unknown map or no normals");
+    if (!M || (!M->has_nrm && c->prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT)) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: unknown map or no normals");
     State<T> &S = state<T>(c);
     const int K = std::max(1, c->prm.knn);                   // ids / w: knn entries per reading point
     const T *d_rd = reading, *d_w = w;
@@ -2014,7 +2015,8 @@ int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
 {
     if (!c || !p) return PGICP_ERR_ARG;
     if (p->knn < 1 || p->knn > PGICP_MAX_KNN) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.knn must be in [1, " + std::to_string(PGICP_MAX_KNN) + "]");
-    if (p->error_minimizer != PGICP_MINIMIZER_POINT_TO_PLANE && p->error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT)
+    if (p->error_minimizer != PGICP_MINIMIZER_POINT_TO_PLANE && p->error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT &&
+        p->error_minimizer != PGICP_MINIMIZER_POINT_TO_PLANE_4DOF)
         return fail(c, PGICP_ERR_ARG, "unknown error minimizer");
     if (p->bound_max_rot < 0.0 || p->bound_max_rot != p->bound_max_rot || p->bound_max_trans < 0.0 || p->bound_max_trans != p->bound_max_trans)
         return fail(c, PGICP_ERR_ARG, "BoundTransformationChecker limits must be >= 0");

@@ -225,6 +225,18 @@ void run(const char *name)
         CHECK(pose_diff(p2p(reading, map, guess), P) < 3e-2);
         CHECK(p2p.errorMinimizer->getCovariance()(0, 0) == T(0));          // the base class's covariance: zeros
 
+        // PointToPlaneErrorMinimizer{force4DOF: 1}: the correction is a rotation about z and a translation -- the z axis of the
+        // result is the z axis of the guess, whatever the scene asks for
+        ICP dof4;
+        { std::istringstream iss(chain("", "", "PointToPlaneErrorMinimizer:\n    force4DOF: 1", "")); dof4.loadFromYaml(iss); }
+        CHECK(dof4.errorMinimizer->force4DOF);
+        {
+            const typename PM::TransformationParameters T4 = dof4(reading, map, guess);
+            const typename PM::TransformationParameters D = T4 * guess.inverse();
+            CHECK(std::fabs((double)D(2, 2) - 1.0) < 1e-5 && std::fabs((double)D(0, 2)) < 1e-5 && std::fabs((double)D(2, 1)) < 1e-5);
+            CHECK(pose_diff(T4, P) < 5e-2);
+        }
+
         ICP nrm;
         { std::istringstream iss(chain("", "  - SurfaceNormalOutlierFilter:\n      maxAngle: 0.6\n", "PointToPlaneErrorMinimizer", "")); nrm.loadFromYaml(iss); }
         CHECK(pose_diff(nrm(reading, map, guess), P) < 1e-2);

@@ -145,9 +145,11 @@ def np_icp_ex(reading, ref, nrm, T_init, chain, reading_nrm=None):
     KDTreeMatcher.knn > 1 (matches knn x N; the quantile runs over all knn * N distances, every pair is a constraint),
     PointToPointErrorMinimizer (weighted Kabsch through numpy.linalg.svd; residual = sum of |p - q|; zero covariance),
     SurfaceNormalOutlierFilter (reading normal, rotated with the reading, against the matched reference normal) and
-    BoundTransformationChecker (angle and translation of the accumulated correction; exceeding either is an error)."""
+    BoundTransformationChecker (angle and translation of the accumulated correction; exceeding either is an error),
+    PointToPlaneErrorMinimizer{force4DOF} (the increment is a rotation about z and a translation: a 4 x 4 system)."""
     K = int(chain.get("knn", 1))
     p2point = int(chain.get("error_minimizer", 0)) == 1
+    force4dof = int(chain.get("error_minimizer", 0)) == 2          # PointToPlaneErrorMinimizer{force4DOF}: [rz tx ty tz] only
     max_angle = float(chain.get("normal_max_angle", 0.0))
     b_rot, b_tr = float(chain.get("bound_max_rot", 0.0)), float(chain.get("bound_max_trans", 0.0))
     rd = reading.astype(np.float64)
@@ -195,7 +197,12 @@ def np_icp_ex(reading, ref, nrm, T_init, chain, reading_nrm=None):
         else:
             e = np.sum(nk * (pk - qk), axis=1)
             J = np.column_stack([np.cross(pk, nk), nk])
-            dT = rodrigues(np.linalg.solve(J.T @ J, -J.T @ e))
+            if force4dof:
+                J4 = J[:, 2:]                                       # the z component of p x n, and n
+                x4 = np.linalg.solve(J4.T @ J4, -J4.T @ e)
+                dT = rodrigues(np.concatenate([[0.0, 0.0], x4]))
+            else:
+                dT = rodrigues(np.linalg.solve(J.T @ J, -J.T @ e))
             residual = float(np.sum(e * e))
         T_iter = dT @ T_iter
         it += 1
@@ -245,7 +252,7 @@ def main_variants():
     fix = dict(map_xyz=w.map_xyz, map_nrm=w.map_nrm, reading=rd, reading_nrm=rn, T_init=T0, T_truth=Tt)
     variants = dict(knn3=dict(CHAIN, knn=3), p2point=dict(CHAIN, error_minimizer=1), p2point_knn2=dict(CHAIN, error_minimizer=1, knn=2),
                     normals=dict(CHAIN, normal_max_angle=0.5), bound_ok=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=1.0),
-                    bound_hit=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=0.05))
+                    bound_hit=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(CHAIN, error_minimizer=2))
     for name, ch in variants.items():
         r = np_icp_ex(rd, w.map_xyz, w.map_nrm, T0, ch, reading_nrm=rn if "normal_max_angle" in ch else None)
         for k in ("T", "iterations", "converged", "status", "overlap", "residual", "trim_limit", "n_kept", "n_finite"):

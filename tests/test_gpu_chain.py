@@ -19,7 +19,7 @@ RESET = dict(knn=1, error_minimizer=0, bound_max_rot=0.0, bound_max_trans=0.0, n
              quantile_scale=1.0)
 VARIANTS = dict(knn3=dict(knn=3), p2point=dict(error_minimizer=1), p2point_knn2=dict(error_minimizer=1, knn=2),
                 normals=dict(normal_max_angle=0.5), bound_ok=dict(bound_max_rot=0.2, bound_max_trans=1.0),
-                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05))
+                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(error_minimizer=2))
 
 
 def pose_error(Ta, Tb):

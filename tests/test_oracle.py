@@ -329,7 +329,7 @@ def test_median_dist_outlier_filter_restatement(oracle32, oracle64):
 # (np_icp_ex: scipy k-d tree, numpy.linalg.svd / solve), never against the oracle itself
 VARIANTS = dict(knn3=dict(knn=3), p2point=dict(error_minimizer=1), p2point_knn2=dict(error_minimizer=1, knn=2),
                 normals=dict(normal_max_angle=0.5), bound_ok=dict(bound_max_rot=0.2, bound_max_trans=1.0),
-                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05))
+                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(error_minimizer=2))
 
 
 @pytest.mark.parametrize("name", sorted(VARIANTS))
@@ -353,6 +353,14 @@ def test_oracle_matches_golden_chain_variants(oracle32, oracle64, name):
         assert r["trim_limit"] == pytest.approx(float(z[f"{name}_trim_limit"]), rel=1e-3)
         assert r["residual"] == pytest.approx(float(z[f"{name}_residual"]), rel=1e-2)
         np.testing.assert_allclose(r["cov"], z[f"{name}_cov"], rtol=1e-3, atol=1e-12)
+        if name == "force4dof":
+            # PointToPlane{force4DOF}: every increment is a rotation about z plus a translation, so the accumulated correction
+            # leaves the z axis where it was -- and the result is NOT the six-degree-of-freedom one (the initial error has roll and pitch)
+            dR = r["T"][:3, :3] @ np.asarray(z["T_init"])[:3, :3].T
+            assert abs(dR[2, 2] - 1.0) < 1e-9 and abs(dR[0, 2]) < 1e-9 and abs(dR[2, 1]) < 1e-9
+            full = o.icp(z["reading"], z["map_xyz"], z["map_nrm"], z["T_init"], **CHAIN)
+            assert pose_error(full["T"], r["T"])[1] > 1e-3
+            continue
         gt, gr = pose_error(z["T_truth"], r["T"])
         assert gt < 0.03 and gr < 0.003
 
