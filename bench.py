@@ -898,6 +898,7 @@ def main_stream(args, collect=False):
                        "parallelism": f"{world} GPU(s) x {args.streams} independent vehicles (replicas)"},
             "ms_per_scan_per_vehicle": elapsed * 1e3 / (args.steps * (n_total - first - 1)),
             # `value` is the contract's figure (all timed passes / their time); the passes one by one, and their median
+            "selection_guess_misses_per_scan": vehicles[0].ctx.debug_counters()[3] / max(1.0, float(per_step) / max(1, args.streams) * (args.steps + args.warmup)),
             "scans_per_s_each_pass": [per_step * world / t for t in pass_s],
             "scans_per_s_median_pass": float(np.median([per_step * world / t for t in pass_s])),
             "mean_iterations": its / per_step, "converged_fraction": conv / per_step,
@@ -1010,7 +1011,7 @@ def compact_leg(d, wall_s):
             "set_map_ms", "median_translation_error_m",
             "mean_iterations", "converged_fraction", "final_position_error_m", "host_input", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
             "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size",
-            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "replay_vs_oracle", "scans_per_s_each_pass", "scans_per_s_median_pass")
+            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "replay_vs_oracle", "scans_per_s_each_pass", "scans_per_s_median_pass", "selection_guess_misses_per_scan")
     out = {k: d[k] for k in keep if k in d}
     if "slam" in d:
         out["slam"] = {k: d["slam"].get(k) for k in ("scans", "points_per_scan", "keyframes", "loops_closed", "loop_candidates_tried",

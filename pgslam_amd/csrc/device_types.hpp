@@ -110,6 +110,9 @@ struct ProblemDev {
     double prev_limit;       // the `rlimit` the last fast matcher pass derived its search cap from
     double qraw;             // the order statistic the last selection found (before the filter's scale): the next selection's
                              // guess -- it compacts only a band of distances around it (k_sel_band); 0: no guess yet
+    double qraw1;            // the same of the last FIRST selection of an iteration: the next first selection's guess.  (A first
+                             // selection sees upper bounds where queries are still queued -- a scan that runs ahead of its map has
+                             // thousands -- so its result sits well above the iteration's final one, iteration after iteration.)
     double sys[kSys];        // final sums of the last iteration
     Checker chk;
 };

@@ -3,7 +3,7 @@
 import csv, glob, sys
 rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_pretransform" in r["Kernel_Name"]][-1]
+idx = [i for i, r in enumerate(rows) if "k_qbin" in r["Kernel_Name"] or "k_pretransform" in r["Kernel_Name"]][-1]
 t0 = int(rows[idx]["Start_Timestamp"]); prev_end = t0
 tot_gap = 0
 for r in rows[idx:]:
