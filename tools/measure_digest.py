@@ -25,9 +25,19 @@ for f in ('bench_stream_1', 'bench_stream_4', 'bench_stream_fleet16'):
 s = json.load(open(M + 'bench_slam.json'))
 print('slam', round(s['value'], 1), 'scans/s', {k: s['slam'][k] for k in ('keyframes', 'loops_closed', 'map_rebuilds', 'mean_icp_iterations', 'optimizer_host_s', 'localizer_host_s')})
 print('  replay', s['replay_vs_oracle'], 'cpu', round(s['cpu_baseline']['value'], 1), s['cpu_baseline']['unit'])
+try:
+    s1 = json.load(open(M + 'bench_slam100k.json'))
+    print('slam 100k-pt scans', round(s1['value'], 1), 'scans/s', {k: s1['slam'].get(k) for k in ('keyframes', 'map_rebuilds', 'device_map_rebuilds', 'device_input_stages', 'localizer_host_s', 'input_filters')})
+    f = json.load(open(M + 'bench_f64.json'))
+    print('f64', round(f['value'], 1), 'scans/s', round(f['ms_per_step'], 2), 'ms/step, frac', round(f['roofline']['frac'], 4), 'launch', round(f['roofline']['avg_launch_us'], 1), 'us; x of f32:', round(f['value'] / d['value'], 3))
+    print('pmc', {k: v for k, v in json.load(open(M + 'pmc/knn_pmc.json')).items() if k != 'per_launch' and k != 'how' and k != 'note'})
+    for leg in ('knn_traffic', 'knn_traffic_loopclosure', 'knn_traffic_stream', 'knn_traffic_f64'):
+        t = json.load(open(M + 'pmc/' + leg + '.json'))
+        print(' ', leg, 'bytes per launch', round(t['hbm_bytes_per_launch'] / 1e6, 2), 'MB (uncorrected', round(t['hbm_bytes_per_launch_uncorrected'] / 1e6, 2), 'MB), launches', t['launches'])
+except Exception as e:
+    print('round-4 legs:', type(e).__name__, e)
 print('slam mt', open(M + 'slam_mt.json').read()[:400])
 n = json.load(open(M + 'bench_normals.json'))
 print('normals', {k: (round(v['kernel_ms'], 2) if isinstance(v, dict) else round(v, 1)) for k, v in n.items()})
-print(open(M + 'pmc.log').read().strip().splitlines()[-1][:300])
 print(open(M + 'trace_summary.txt').read()[:700])
 print(open(M + 'host_input_overlap.txt').read())

@@ -14,6 +14,8 @@ python3 bench.py --workload stream --streams 1 --steps 2 --warmup 1 2>/dev/null 
 python3 bench.py --workload stream --streams 4 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_4.json
 python3 bench.py --workload stream --streams 16 --fleet --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_fleet16.json
 python3 bench.py --workload slam --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_slam.json
+python3 bench.py --workload slam --slam-scans 600 --slam-points 100000 --slam-filters sensor --slam-record 8 --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_slam100k.json
+python3 bench.py --workload f64 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_f64.json
 ./tools/slam_run /tmp/pgslam_amd_seq_4500_10000_0.8.bin --mt > $OUT/slam_mt.json 2>/dev/null
 python3 tools/bench_normals.py 2>/dev/null | grep -v amdgpu > $OUT/bench_normals.json
 REPO=$PWD
@@ -23,13 +25,15 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/t
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace_lc -o t -- python3 $REPO/bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $REPO/$OUT/trace_lc.log 2>&1
 # the copy / compute overlap of the host-input pipeline: kernels and memory copies on one time line
 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$OUT/trace_host -o t -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-fixed30 --no-cpu-baseline --no-profile --no-workloads > $REPO/$OUT/trace_host.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 --no-host-input --no-workloads > $REPO/$OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o p -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-fixed30 --no-host-input --no-workloads > $REPO/$OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace_stream -o t -- python3 $REPO/bench.py --workload stream --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host-input > $REPO/$OUT/trace_stream.log 2>&1
 cd $REPO
 python3 tools/trace_summary.py $OUT/trace > $OUT/trace_summary.txt 2>&1
 python3 tools/trace_summary.py $OUT/trace_lc > $OUT/trace_lc_summary.txt 2>&1
 python3 tools/overlap_summary.py $OUT/trace_host > $OUT/host_input_overlap.txt 2>&1
-python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/knn_traffic.json 100000 1000000 128 > $OUT/pmc.log 2>&1
-rm -rf $OUT/pmc_fetch/*/*.db $OUT/trace/*.db $OUT/trace_lc/*.db $OUT/trace_host/*.db 2>/dev/null
+python3 tools/trace_summary.py $OUT/trace_stream > $OUT/trace_stream_summary.txt 2>&1
+python3 tools/timeline.py $OUT/trace_stream > $OUT/stream_timeline_last_scan.txt 2>&1
+rm -rf $OUT/trace/*.db $OUT/trace_lc/*.db $OUT/trace_host/*.db $OUT/trace_stream/*.db 2>/dev/null
+# counters: every --pmc pass its own run (tools/r4_pmc.sh) -> knn_traffic*.json, knn_pmc.json
+bash tools/r4_pmc.sh measure/pmc > $OUT/pmc.log 2>&1
 for f in $OUT/bench_*.json $OUT/slam_mt.json; do echo "$f: $(cut -c1-300 $f)"; done
-cat $OUT/pmc.log | tail -2; head -8 $OUT/trace_summary.txt; cat $OUT/host_input_overlap.txt
+tail -6 $OUT/pmc.log | cut -c1-300; head -8 $OUT/trace_summary.txt; cat $OUT/host_input_overlap.txt

@@ -15,5 +15,10 @@ cp $M/trace_lc_summary.txt $P/${R}_loopclosure_trace_summary.txt
 cp $M/trace/t_kernel_stats.csv $P/${R}_rocprofv3_kernel_stats.csv
 cp $M/trace_summary.txt $P/${R}_trace_summary.txt
 cp $M/slam_mt.json $P/${R}_slam_run_mt.json
-cp $M/knn_traffic.json $P/knn_traffic.json
+cp $M/bench_slam100k.json $P/${R}_bench_slam100k.json
+cp $M/bench_f64.json $P/${R}_bench_f64.json
+cp $M/trace_stream_summary.txt $P/${R}_stream_kernel_totals.txt
+cp $M/stream_timeline_last_scan.txt $P/${R}_stream_timeline_last_scan.txt
+for f in knn_traffic knn_pmc knn_traffic_loopclosure knn_traffic_stream knn_traffic_f64; do cp $M/pmc/$f.json $P/$f.json; done
+mkdir -p $P/${R}_pmc; cp $M/pmc/*_all_kernels.txt $M/pmc/head_*_per_dispatch.txt $M/pmc/digest.log $P/${R}_pmc/
 python3 tools/measure_digest.py $M > $P/${R}_digest.txt 2>&1

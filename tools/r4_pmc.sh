@@ -2,7 +2,7 @@
 # Round-4 counter record (GPU box, through gpurun): every rocprofv3 --pmc pass is its own run, no trace domains with it.
 #   headline: FETCH_SIZE | WRITE_SIZE | GRBM+TA | SQ instruction mix      -> knn_traffic.json, knn_pmc.json
 #   loop closing, streaming, f64: FETCH_SIZE | WRITE_SIZE                    -> knn_traffic_<leg>.json
-OUT=gpurun_out/${1:-r4pmc}; mkdir -p $OUT
+OUT=gpurun_out/${1:-r4pmc}; mkdir -p $OUT; rm -f $OUT/passes.log
 python3 bench.py --prepare-only > /dev/null 2>&1
 python3 bench.py --workload stream --prepare-only > /dev/null 2>&1
 R=$PWD
