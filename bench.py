@@ -760,6 +760,7 @@ def main_stream(args, collect=False):
             self.new()
 
     vehicles = [Fleet()] if args.fleet else [Vehicle() for _ in range(args.streams)]
+    vehicles[0].ctx.debug_counters()                # (reading them resets them: the guess misses below are this leg's)
 
     def step():
         outs = [[] for _ in vehicles]

@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGICP_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libpgicp.so")
 
 OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID, ERR_BOUND = range(8)
-MINIMIZER_POINT_TO_PLANE, MINIMIZER_POINT_TO_POINT = 0, 1
+MINIMIZER_POINT_TO_PLANE, MINIMIZER_POINT_TO_POINT, MINIMIZER_POINT_TO_PLANE_4DOF = 0, 1, 2
 HOST, DEVICE, HOST_PINNED = 0, 1, 2
 MATCHER_GRID, MATCHER_BRUTE = 0, 1
 PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_update", "pretransform",
@@ -331,6 +331,36 @@ class Context:
         p = self._pinned.pop(a.ctypes.data)
         self._check(self.lib.pgicp_host_free(self.h, C.c_void_p(p)))
 
+    # ---- device memory the caller owns between calls (keyframe clouds of a local map stay in HBM) ----
+    def device_empty(self, n, stride=3, dtype=np.float32):
+        """pgicp_device_alloc: room for n points at `stride` elements each; a DevPtr (release it with device_free)."""
+        dtype = np.dtype(dtype)
+        p = C.c_void_p()
+        self._check(self.lib.pgicp_device_alloc(self.h, C.c_size_t(max(1, n * stride) * dtype.itemsize), C.byref(p)))
+        return DevPtr(p.value, stride, n, dtype)
+
+    def device_cloud(self, xyz, dtype=None):
+        """A host cloud copied to device memory of its own (pgicp_device_alloc + pgicp_device_copy); strides as on the host."""
+        b = _Buf(xyz, dtype)
+        assert b.mem == HOST
+        d = self.device_empty(b.n, b.stride, b.dtype)
+        if b.n:
+            nbytes = ((b.n - 1) * b.stride + 3) * b.dtype.itemsize
+            self._check(self.lib.pgicp_device_copy(self.h, C.c_void_p(d.ptr), C.c_void_p(b.ptr), C.c_size_t(nbytes), C.c_int(0)))
+        return d
+
+    def device_download(self, d):
+        """numpy (n, 3) copy of a DevPtr cloud"""
+        out = np.zeros((d.n, d.stride), dtype=d.dtype)
+        if d.n:
+            nbytes = ((d.n - 1) * d.stride + 3) * d.dtype.itemsize
+            self._check(self.lib.pgicp_device_copy(self.h, C.c_void_p(out.ctypes.data), C.c_void_p(d.ptr), C.c_size_t(nbytes), C.c_int(1)))
+        return out[:, :3]
+
+    def device_free(self, d):
+        self._check(self.lib.pgicp_device_free(self.h, C.c_void_p(d.ptr)))
+        d.ptr = None
+
     def upload(self, readings, pinned=False, dtype=None):
         """pgicp_upload_*: start the H2D transfer of host readings on the copy stream, return DevPtr handles at once."""
         bufs = [_Buf(r, dtype) for r in readings]
@@ -569,7 +599,10 @@ class Context:
         sn = (C.c_int * k)(*[b.stride for b in ns])
         Ts = np.ascontiguousarray(np.stack([np.asarray(t, dtype=np.float64).reshape(4, 4) for t in T_ref_kf]))
         total = sum(b.n for b in xs)
-        if mem == DEVICE:
+        if mem == DEVICE and isinstance(clouds_xyz[0], DevPtr):
+            out_x, out_n = self.device_empty(total, 3, dtype), self.device_empty(total, 3, dtype)     # (the caller frees them)
+            px, pn = out_x.ptr, out_n.ptr
+        elif mem == DEVICE:
             import torch
             like = clouds_xyz[0]
             out_x = torch.empty((total, 3), dtype=like.dtype, device=like.device)

@@ -99,3 +99,32 @@ def test_filtered_cloud_is_an_icp_reading_without_a_second_upload(ctx, oracle32)
     d = np.linalg.inv(r["T"]) @ Ta
     assert np.linalg.norm(d[:3, 3]) < 1e-5 and sa["iterations"] == r["iterations"]
     ctx.destroy_map(mid)
+
+
+def test_local_map_from_device_resident_keyframes_equals_the_host_flow(ctx, oracle32):
+    """Keyframe clouds kept in device memory of the caller's own (pgicp_device_alloc / _copy), the map assembled from them
+    there (pgicp_build_local_map, mem = DEVICE) and indexed in place (pgicp_map_create, mem = DEVICE): the same cloud and the
+    same alignment as through the host (LocalMap.hpp:209-224 + setMap), bit for bit -- what the C++ facade's localizer does."""
+    chain = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01, smooth_length=3, sensor_std_dev=0.01)
+    ctx.set_params(**chain)
+    w = synth.make_scan_to_map(n_scan=5000, n_map=30_000, n_queries=1, n_map_poses=3, rings=16)
+    third = len(w.map_xyz) // 3
+    kx = [w.map_xyz[i * third:(i + 1) * third] for i in range(3)]
+    kn = [w.map_nrm[i * third:(i + 1) * third] for i in range(3)]
+    Ts = [np.eye(4), synth.se3(x=0.4, y=-0.2, yaw=0.05), synth.se3(x=-0.3, z=0.1, yaw=-0.02)]
+    hx, hn = ctx.build_local_map(kx, kn, Ts)                                  # through the host
+    dx = [ctx.device_cloud(c) for c in kx]
+    dn = [ctx.device_cloud(c) for c in kn]
+    mx, mn = ctx.build_local_map(dx, dn, Ts)                                  # in device memory
+    assert np.array_equal(ctx.device_download(mx), hx) and np.array_equal(ctx.device_download(mn), hn)
+    ox, on = oracle32.build_local_map(kx, kn, Ts)
+    assert np.array_equal(hx, ox) and np.array_equal(hn, on)
+    mid_h = ctx.set_map(hx, hn, center=True)
+    mid_d = ctx.set_map(mx, mn, center=True)
+    Th, sh = ctx.align(mid_h, w.scans_xyz[0], w.T_init[0])
+    Td, sd = ctx.align(mid_d, w.scans_xyz[0], w.T_init[0])
+    assert np.array_equal(Th, Td) and sh["iterations"] == sd["iterations"] and sh["n_kept"] == sd["n_kept"] and sh["residual"] == sd["residual"]
+    for d in dx + dn + [mx, mn]:
+        ctx.device_free(d)
+    ctx.destroy_map(mid_h)
+    ctx.destroy_map(mid_d)
