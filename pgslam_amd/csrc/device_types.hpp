@@ -27,7 +27,8 @@ struct GridDesc {
 template <typename T>
 struct MapDev {
     const typename Vec4<T>::type *pts;   // (x, y, z, bit-cast original index) cell-sorted, centred
-    const typename Vec4<T>::type *nrm;   // (nx, ny, nz, 0) same order; may be null
+    const typename Vec4<T>::type *nrm;   // the minimiser's records, same order: entry 2 s = the point again, 2 s + 1 = (nx, ny, nz, 0) -- one
+                                         // 32-byte gather per pair instead of two 16-byte ones from two arrays; may be null
     const int *cell_start;               // ncells + 1 exclusive prefix sums
     const int *cell_start_f;             // the same prefix sums on cells kx times finer in x (== cell_start when kx == 1)
     int kx;                              // points of a cell are ordered by fine x cell, so fine ranges are contiguous too

@@ -647,7 +647,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     HIPC(c, c->tmp_w.ensure(sizeof(unsigned long long) * (size_t)tot_m));                // (fine cell, index) words of the cell sort
     HIPC(c, c->tmp_p.ensure(sizeof(V4) * 2 * (size_t)tot_m));                            // the records in cloud order: (point, normal) pairs
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? b_pts : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
+    const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? up(2 * sizeof(V4) * (size_t)tot_m) : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
                  b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c),
                  b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0, b_occ = up(sizeof(unsigned) * (size_t)tot_o),
                  b_ext = up(sizeof(float) * 6 * (size_t)tot_s);
