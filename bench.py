@@ -1330,6 +1330,38 @@ def main():
         for c in ctxs:
             c.set_params(min_diff_rot=chain["min_diff_rot"], min_diff_trans=chain["min_diff_trans"])
 
+    # ---- companion figure: the same steps with the batch split over TWO contexts (two HIP streams, two host threads, a resident
+    #      copy of the map each): the last, nearly empty iterations of one half overlap the other half's work.  Never `value`:
+    #      the roofline above describes the launches of ONE context, which is what the metric is quoted on.
+    two_ctx = None
+    if S == 1 and B >= 64 and not args.no_fixed30 and not args.fixed_iters and world == 1:
+        c2 = [ctx, icp.Context(local_rank, **chain, matcher=icp.MATCHER_GRID if args.matcher == "grid" else icp.MATCHER_BRUTE,
+                               grid_cell=args.grid_cell, check_every=args.check_every)]
+        m2 = [map_id, c2[1].set_map(d_map_xyz, d_map_nrm, center=True)]
+
+        def step2():
+            out = [None, None]
+            def work(k):
+                out[k] = c2[k].align_batch(m2[k], readings[k::2], T_inits[k::2], raise_on_error=False)
+            th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            return out
+        step2(); step2()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n2 = 0
+        for _ in range(args.steps):
+            o2 = step2()
+            n2 += sum(1 for h in o2 for s_ in h[1] if s_["status"] == 0 and s_["converged"])
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        two_ctx = dict(scans_per_s=n2 / dt2, ms_per_step=dt2 * 1e3 / args.steps, over_one_context=(n2 / dt2) / (converged / elapsed),
+                       note="the batch as two sub-batches of %d on two contexts (two HIP streams); same results" % (B // 2))
+        c2[1].close()
+
     # ---- PCIe-inclusive companion figure: the caller owns HOST clouds (Localizer.hpp:103-126); step k+1's scans travel on
     #      the copy stream while step k aligns (pgicp_upload_f32), the compute stream waits for them on the device
     host_input = None
@@ -1415,6 +1447,7 @@ def main():
             "scans_total": scans_all,
             "scans_converged": converged_all,
             "fixed_30_iterations": fixed30,
+            "two_contexts": two_ctx,
             "host_input": host_input,
             "mean_iterations": iters_all / max(1, scans_all),
             "selection_guess_misses_per_step": sel_fallbacks / max(1, args.steps + args.warmup),
