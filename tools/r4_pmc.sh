@@ -28,7 +28,7 @@ pass f64_fetch FETCH_SIZE $F64
 pass f64_write WRITE_SIZE $F64
 cd $R
 python3 tools/pmc_traffic.py $OUT/head_fetch $OUT/head_write $OUT/knn_traffic.json 100000 1000000 128 > $OUT/digest.log 2>&1
-python3 tools/pmc_valu.py $OUT/head_grbm $OUT/head_sq $OUT/knn_pmc.json 12800000 >> $OUT/digest.log 2>&1
+python3 tools/pmc_valu.py $OUT/head_grbm $OUT/head_sq $OUT/knn_pmc.json 12800000 k_knn_grid 6.4921875 >> $OUT/digest.log 2>&1
 python3 tools/pmc_traffic.py $OUT/lc_fetch $OUT/lc_write $OUT/knn_traffic_loopclosure.json 100000 100000 512 k_knn_grid loopclosure >> $OUT/digest.log 2>&1
 python3 tools/pmc_traffic.py $OUT/st_fetch $OUT/st_write $OUT/knn_traffic_stream.json 100000 2000000 1 k_knn_grid stream >> $OUT/digest.log 2>&1
 python3 tools/pmc_traffic.py $OUT/f64_fetch $OUT/f64_write $OUT/knn_traffic_f64.json 100000 1000000 128 k_knn_grid f64 >> $OUT/digest.log 2>&1
