@@ -546,7 +546,7 @@ def recorded_traffic(name, **match):
                                "this command (tools/r4_pmc.sh); %s" % (name, tj.get("note", "")))
 
 
-def slam_roofline(res):
+def slam_roofline(res, points=None):
     """Fast-matcher roofline of a slam_run pass made with PGICP_PROFILE_ALL=1: 20 N + 12 M per active problem
     over every context of the facade (pgicp_profile_process), HIP events on the contexts' streams."""
     k = (res or {}).get("knn_profile")
@@ -555,9 +555,10 @@ def slam_roofline(res):
     alg = 20.0 * k["reading_points"] + 12.0 * k["map_points"]
     avg_s = k["total_ms"] * 1e-3 / k["launches"]
     ach = alg / k["launches"] / avg_s / 1e9
-    return dict(bound="hbm", kernel="knn_grid", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+    return dict(bound="hbm", kernel="knn_grid", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                 avg_launch_us=avg_s * 1e6, launches=k["launches"], algorithmic_bytes_per_launch=alg / k["launches"],
                 active_problems_per_launch=k["problems"] / k["launches"],
+                **recorded_traffic("knn_traffic_slam", n_scan=points, batch=1),
                 note="one 10k-pt scan against a 30k-pt local map per launch: launch-latency-bound, the kernel cannot fill the chip; "
                      "measured in the recorded pass (every context profiling), not in the timed one")
 
@@ -647,7 +648,7 @@ def main_slam(args, collect=False):
                                    f"(BASELINE.json configs[3]), host clouds through pgslam::PoseGraphSlam<float> (C++ facade), input filters: "
                                    f"{res.get('input_filters')}",
                        "parallelism": f"{world} independent replica(s), one process per GPU"},
-            "slam": res, "replay_vs_oracle": replay, "cpu_baseline": cpu, "roofline": slam_roofline(res_prof)})
+            "slam": res, "replay_vs_oracle": replay, "cpu_baseline": cpu, "roofline": slam_roofline(res_prof, args.slam_points)})
     if collect:
         return out
     if out is not None:

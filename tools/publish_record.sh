@@ -19,6 +19,6 @@ cp $M/bench_slam100k.json $P/${R}_bench_slam100k.json
 cp $M/bench_f64.json $P/${R}_bench_f64.json
 cp $M/trace_stream_summary.txt $P/${R}_stream_kernel_totals.txt
 cp $M/stream_timeline_last_scan.txt $P/${R}_stream_timeline_last_scan.txt
-for f in knn_traffic knn_pmc knn_traffic_loopclosure knn_traffic_stream knn_traffic_f64; do cp $M/pmc/$f.json $P/$f.json; done
+for f in knn_traffic knn_pmc knn_traffic_loopclosure knn_traffic_stream knn_traffic_f64 knn_traffic_slam; do cp $M/pmc/$f.json $P/$f.json; done
 mkdir -p $P/${R}_pmc; cp $M/pmc/*_all_kernels.txt $M/pmc/head_*_per_dispatch.txt $M/pmc/digest.log $P/${R}_pmc/
 python3 tools/measure_digest.py $M > $P/${R}_digest.txt 2>&1
