@@ -2233,7 +2233,10 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
 int pgicp_debug_counters(pgicp_ctx *c, int out[4])
 {
     if (!c || !out) return PGICP_ERR_ARG;
-    HIPC(c, hipMemcpy(out, c->small.as<int>() + (c->counters_clean ? 24 : 16), 4 * sizeof(int), hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = out[3] = 0;
+    HIPC(c, hipSetDevice(c->device));
+    if (c->small.p)           // (a context that has not aligned anything yet has no counters)
+        HIPC(c, hipMemcpy(out, c->small.as<int>() + (c->counters_clean ? 24 : 16), 4 * sizeof(int), hipMemcpyDeviceToHost));
     out[3] = sel_fallbacks_read(1);       // selections whose guess was off (k_sel_final2) since the last call, all contexts of the device
     if (std::getenv("PGICP_KNN_STATS_DUMP")) {          // diagnostics builds only
         unsigned long long s[56];

@@ -3,7 +3,7 @@ strided / homogeneous inputs, bad arguments.  Every result is checked against th
 import numpy as np
 import pytest
 
-from pgslam_amd import synth
+from pgslam_amd import icp, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -287,3 +287,12 @@ def test_crowded_cells_overflow_the_item_pool(ctx, oracle32):
     from test_gpu_matcher_state import check_state
     T0 = synth.se3(x=0.05, y=0.04, z=-0.02, yaw=np.deg2rad(0.8))
     check_state(ctx, oracle32, q, ref, nrm, T0, (1, 2, 4))
+
+
+def test_debug_counters_on_a_context_that_has_not_aligned_anything():
+    """a fresh context has no matcher counters yet: the call answers zeros instead of failing (bench.py's stream leg reads
+    -- and thereby resets -- the selection's guess-miss counter before its first scan)"""
+    c = icp.Context(0, max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01, smooth_length=3, sensor_std_dev=0.01)
+    out = c.debug_counters()
+    assert list(out[:3]) == [0, 0, 0]
+    c.close()
