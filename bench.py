@@ -1056,7 +1056,7 @@ def workload_legs(args, world, rank):
 
     lc_leg = run("loop_closure", main_loopclosure, steps=2, warmup=1, pairs=512, pair_chunk=512)
     if world == 1:
-        run("f64", main_f64, steps=3, warmup=1)
+        run("f64", main_f64, steps=5, warmup=2)
         run("stream", main_stream, steps=3, warmup=1, streams=1, fleet=False)
         run("slam", main_slam, steps=1, warmup=0)
         # the same facade at SENSOR size: 100 k-pt scans (64 rings, an HDL-64E's), a shorter drive (the sequence file is 2.4 MB a

@@ -1,0 +1,50 @@
+"""The bench line's contract, checked on the round's recorded line (profiles/rNN_bench_n1.json, written by `python bench.py --steps 20
+--warmup 5` on the GPU box): the fields the driver reads, the roofline and cpu_baseline objects, and their arithmetic."""
+import glob, json, os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def latest():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_n1.json")))
+    if not files:
+        pytest.skip("no recorded bench line")
+    return json.load(open(files[-1])), json.load(open(os.path.join(ROOT, "BASELINE.json")))
+
+
+def test_recorded_line_keeps_the_contract():
+    d, base = latest()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    assert d["unit"] == "scans/s" and isinstance(d["value"], float) and d["value"] > 0
+    # value = converged scans of all steps / the timed region; ms_per_step the same region per step
+    batch = d["config"]["batch_scans_per_step"]
+    assert d["value"] == pytest.approx(d["scans_converged"] / (d["steps"] * d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["scans_total"] == d["steps"] * batch
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    # achieved = algorithmic bytes per launch / the kernel's average launch duration (HIP events on the context's stream)
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9, rel=1e-6)
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["bound_measured"] == "valu" and 0.0 < r["frac_unseeded_launches"] < r["frac"] < r["frac_seeded_launches"] < 1.0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    # the companion legs: never `value`, each with its own roofline
+    for leg in ("loop_closure", "stream", "slam", "f64", "slam_100k"):
+        w = d["workloads"][leg]
+        assert "error" not in w, (leg, w)
+        assert w["value"] > 0 and "roofline" in w and 0.0 < w["roofline"]["frac"] < 1.0
+    assert d["workloads"]["f64"]["value"] >= 0.45 * d["value"]           # the double path at about half the float rate (0.48-0.51 by run)
+    assert len(d["workloads"]["stream"]["scans_per_s_each_pass"]) >= 3
+
+
+def test_metric_is_baselines():
+    d, base = latest()
+    assert base["metric"].split()[0].lower() in d["metric"].lower() or "scans/sec" in d["metric"]
