@@ -128,3 +128,41 @@ def test_local_map_from_device_resident_keyframes_equals_the_host_flow(ctx, orac
         ctx.device_free(d)
     ctx.destroy_map(mid_h)
     ctx.destroy_map(mid_d)
+
+
+def test_filter_chain_edge_cases(ctx):
+    """a chain that keeps nothing, a one-point cloud, a chain of the maximum length, refused arguments"""
+    f = np.array([[0.1, 0.2, 0.3, 1.0], [5.0, 0.0, 0.0, 1.0], [0.0, 9.0, 0.0, 1.0]], dtype=np.float32)
+    # everything inside the box, removeInside: nothing is left
+    of, od, idx, dev = ctx.filter_cloud([(icp.FILTER_BOUNDING_BOX, -20, -20, -20, 20, 20, 20, 1.0)], f, None)
+    assert len(idx) == 0 and of.shape[0] == 0
+    # one point, kept / dropped
+    of, od, idx, dev = ctx.filter_cloud([(icp.FILTER_MAX_DIST, 1.0)], f[:1], None)
+    assert list(idx) == [0] and np.array_equal(of[0, :3], f[0, :3])
+    of, od, idx, dev = ctx.filter_cloud([(icp.FILTER_MIN_DIST, 1.0)], f[:1], None)
+    assert len(idx) == 0
+    # the longest chain the ABI takes (eight filters), each a no-op here
+    of, od, idx, dev = ctx.filter_cloud([(icp.FILTER_IDENTITY,)] * 4 + [(icp.FILTER_MAX_DIST, 100.0)] * 4, f, None)
+    assert list(idx) == [0, 1, 2]
+    with pytest.raises(icp.PgicpError):
+        ctx.filter_cloud([(icp.FILTER_IDENTITY,)] * 9, f, None)                      # more than PGICP_MAX_FILTERS
+    with pytest.raises(icp.PgicpError):
+        ctx.filter_cloud([(99,)], f, None)                                           # unknown filter type
+    with pytest.raises(icp.PgicpError):
+        ctx.filter_cloud([(icp.FILTER_FIX_STEP, 0)], f, None)                        # a step below one
+
+
+def test_device_memory_calls_refuse_bad_arguments(ctx):
+    import ctypes as C
+    p = C.c_void_p()
+    assert ctx.lib.pgicp_device_alloc(ctx.h, C.c_size_t(0), C.byref(p)) == icp.ERR_ARG
+    d = ctx.device_empty(4, 3, np.float32)
+    host = np.zeros(12, dtype=np.float32)
+    assert ctx.lib.pgicp_device_copy(ctx.h, C.c_void_p(d.ptr), C.c_void_p(host.ctypes.data), C.c_size_t(48), C.c_int(7)) == icp.ERR_ARG
+    assert ctx.lib.pgicp_device_copy(ctx.h, C.c_void_p(d.ptr), None, C.c_size_t(48), C.c_int(0)) == icp.ERR_ARG
+    assert ctx.lib.pgicp_device_copy(ctx.h, C.c_void_p(d.ptr), C.c_void_p(host.ctypes.data), C.c_size_t(0), C.c_int(0)) == icp.OK
+    host[:] = np.arange(12)
+    assert ctx.lib.pgicp_device_copy(ctx.h, C.c_void_p(d.ptr), C.c_void_p(host.ctypes.data), C.c_size_t(48), C.c_int(0)) == icp.OK
+    assert np.array_equal(ctx.device_download(d).ravel(), host)
+    ctx.device_free(d)
+    assert ctx.lib.pgicp_device_free(None, None) == icp.OK                            # nothing to free, no context: fine
