@@ -2,7 +2,7 @@
 1-3 maps of random scenes, whole ICP runs against the CPU oracle -- with a random chain per batch: KDTreeMatcher.knn 1-4,
 PointToPlane / PointToPoint / PointToPlane{force4DOF}, a SurfaceNormalOutlierFilter (reading normals from the scan generator, a
 share of them turned), a BoundTransformationChecker (loose or tight: PGICP_ERR_BOUND must come from both sides), MedianDist or
-TrimmedDist, a MaxDistOutlierFilter.  Status, iteration count, n_finite, n_kept, threshold (bit for bit in float), transform to
+TrimmedDist, a MaxDistOutlierFilter; three batches of ten with double scalars against the double oracle.  Status, iteration count, n_finite, n_kept, threshold (bit for bit in float), transform to
 1e-5 m / 1e-5 rad.  tools/stress_chain.py [seconds] [seed]"""
 import sys, time, importlib
 import numpy as np
@@ -13,6 +13,7 @@ CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, mi
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 o32 = orc.Oracle(np.float32)
+o64 = orc.Oracle(np.float64)
 world = synth.make_world()
 
 
@@ -56,28 +57,31 @@ while time.time() - t0 < budget:
     if b < 0.2: chain.update(bound_max_rot=0.5, bound_max_trans=1.0)
     elif b < 0.35: chain.update(bound_max_rot=0.02, bound_max_trans=0.03)
     use_nrm = chain["normal_max_angle"] > 0
+    DT = np.float64 if rng.random() < 0.3 else np.float32               # PointMatcher<double> in three batches of ten
+    oo = o64 if DT == np.float64 else o32
     ctx = icp.Context(0, **chain)
     scenes = [scene() for _ in range(int(rng.integers(1, 4)))]
-    mids = [ctx.set_map(s[0], s[1]) for s in scenes]
+    mids = [ctx.set_map(s[0].astype(DT), s[1].astype(DT), dtype=DT) for s in scenes]
     P = int(rng.choice([1, 2, 5, 9, 16]))
     which = [int(rng.integers(0, len(scenes))) for _ in range(P)]
     rds, rns, T0s = zip(*[scenes[w][2]() for w in which])
     ok = [k for k in range(P) if len(rds[k]) >= 50]
     if not ok: ctx.close(); continue
-    Ts, st = ctx.align_batch([mids[which[k]] for k in ok], [rds[k] for k in ok], [T0s[k] for k in ok], raise_on_error=False,
-                             normals=[rns[k] for k in ok] if use_nrm else None)
+    Ts, st = ctx.align_batch([mids[which[k]] for k in ok], [rds[k].astype(DT) for k in ok], [T0s[k] for k in ok], raise_on_error=False,
+                             normals=[rns[k].astype(DT) for k in ok] if use_nrm else None, dtype=DT)
     for j, k in enumerate(ok):
         s = scenes[which[k]]
-        o = o32.icp(rds[k], s[0], s[1], T0s[k], reading_nrm=rns[k] if use_nrm else None, **chain)
+        o = oo.icp(rds[k].astype(DT), s[0].astype(DT), s[1].astype(DT), T0s[k], reading_nrm=rns[k].astype(DT) if use_nrm else None, **chain)
         try:
             assert st[j]["status"] == o["status"]
             if o["status"] == 0:
                 assert st[j]["iterations"] == o["iterations"] and st[j]["n_finite"] == o["n_finite"] and st[j]["n_kept"] == o["n_kept"]
-                assert np.float32(st[j]["trim_limit"]) == np.float32(o["trim_limit"])
+                if DT == np.float32: assert np.float32(st[j]["trim_limit"]) == np.float32(o["trim_limit"])
+                else: assert abs(st[j]["trim_limit"] - o["trim_limit"]) <= 1e-9 * o["trim_limit"]
                 dt, dr = pose_error(o["T"], Ts[j])
                 assert dt < 1e-5 and dr < 1e-5, (dt, dr)
         except AssertionError:
-            print("MISMATCH batch", n, "problem", j, "of", len(ok), "chain", chain, "device", st[j]["status"], st[j]["iterations"], st[j]["n_finite"], st[j]["n_kept"],
+            print("MISMATCH batch", n, "problem", j, "of", len(ok), "dtype", DT.__name__, "chain", chain, "device", st[j]["status"], st[j]["iterations"], st[j]["n_finite"], st[j]["n_kept"],
                   st[j]["trim_limit"], "oracle", o["status"], o["iterations"], o["n_finite"], o["n_kept"], o["trim_limit"], file=sys.stderr)
             raise
         kinds[o["status"]] = kinds.get(o["status"], 0) + 1
