@@ -67,7 +67,8 @@ typedef struct pgicp_params {
     int knn;                 /* KDTreeMatcher.knn, 1 .. PGICP_MAX_KNN.  With knn > 1 the matches are knn x N ([point][neighbour], in
                               * (distance, index) order), the quantile filter runs over all knn * N distances, every pair is a
                               * constraint of the minimiser and the ratios are over knn * N */
-    double epsilon;          /* KDTreeMatcher.epsilon; only 0 (exact) is supported */
+    double epsilon;          /* KDTreeMatcher.epsilon >= 0: libnabo's allowance for an approximate neighbour ((1 + epsilon) x the nearest
+                              * distance).  Accepted; the search is exact, which meets every allowance: results are those of epsilon = 0 */
     double max_dist;         /* KDTreeMatcher.maxDist, metres; +inf allowed */
     double trim_ratio;       /* TrimmedDistOutlierFilter.ratio */
     int max_iters;           /* CounterTransformationChecker.maxIterationCount */

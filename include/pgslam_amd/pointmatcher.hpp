@@ -559,7 +559,8 @@ struct PointMatcher {
                     this->push_back(std::make_shared<DistLimitDataPointsFilter>(lim, m.name == "MaxDistDataPointsFilter"));
                 } else if (m.name == "SurfaceNormalDataPointsFilter") {
                     auto get = [&](const char *k, const char *def) { return m.params.count(k) ? m.params.at(k) : std::string(def); };
-                    if (to_double(get("epsilon", "0"), m.name) != 0.0) throw std::runtime_error(m.name + ": only epsilon = 0 (exact search) is supported");
+                    // (epsilon > 0 allows an approximate neighbour search upstream; the exact search here meets every allowance)
+                    if (!(to_double(get("epsilon", "0"), m.name) >= 0.0)) throw std::runtime_error(m.name + ": epsilon must be >= 0");
                     for (const char *k : {"keepDensities", "keepEigenVectors", "keepMatchedIds", "keepMeanDist", "smoothNormals"})
                         if (to_double(get(k, "0"), m.name) != 0.0) throw std::runtime_error(m.name + ": " + k + " is not supported");
                     const int knn = (int)to_double(get("knn", "5"), m.name);

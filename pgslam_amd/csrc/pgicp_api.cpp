@@ -2021,7 +2021,9 @@ int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
     if (p->bound_max_rot < 0.0 || p->bound_max_rot != p->bound_max_rot || p->bound_max_trans < 0.0 || p->bound_max_trans != p->bound_max_trans)
         return fail(c, PGICP_ERR_ARG, "BoundTransformationChecker limits must be >= 0");
     if (p->normal_max_angle < 0.0 || p->normal_max_angle != p->normal_max_angle) return fail(c, PGICP_ERR_ARG, "SurfaceNormalOutlierFilter.maxAngle must be >= 0");
-    if (p->epsilon != 0.0) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.epsilon: only 0 (exact search) is supported");
+    // (libnabo's epsilon ALLOWS a neighbour up to (1 + epsilon) times farther than the nearest; the exact neighbour meets that
+    // for every epsilon >= 0, so the value is accepted and the search stays exact: the results are those of epsilon = 0)
+    if (!(p->epsilon >= 0.0)) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.epsilon must be >= 0");
     if (!(p->max_dist > 0.0)) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.maxDist must be > 0");
     if (!(p->trim_ratio > 0.0 && p->trim_ratio <= 1.0)) return fail(c, PGICP_ERR_ARG, "TrimmedDistOutlierFilter.ratio must be in (0,1]");
     if (!(p->quantile_scale > 0.0) || !std::isfinite(p->quantile_scale)) return fail(c, PGICP_ERR_ARG, "MedianDistOutlierFilter.factor (quantile_scale) must be positive and finite");

@@ -129,9 +129,12 @@ void yaml_and_matrix()
         try { PointMatcher<float>::DataPointsFilters v(vs); } catch (const std::runtime_error &) { threw = true; }
         CHECK(threw);                                                          // a varying step is not restated
     }
+    // an epsilon > 0 (libnabo's allowance for an approximate search, common in libpointmatcher's example configurations) is
+    // accepted: the exact search meets it
+    { std::istringstream ok("- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: 3.16\n"); PointMatcher<float>::DataPointsFilters g(ok); CHECK(g.size() == 1); }
     // anything outside the supported set is refused at load time, never ignored
     for (const char *txt : {"- MaxPointCountDataPointsFilter:\n    maxCount: 100\n",
-                            "- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: 3.16\n",
+                            "- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: -1\n",
                             "- SurfaceNormalDataPointsFilter:\n    knn: 64\n"}) {
         std::istringstream bad(txt);
         threw = false;

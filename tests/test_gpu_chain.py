@@ -140,3 +140,22 @@ def test_normals_filter_needs_reading_normals(ctx, gold):
         ctx.align(mid, gold["reading"], gold["T_init"])
     ctx.destroy_map(mid)
     ctx.set_params(**dict(CHAIN, **RESET))
+
+
+def test_epsilon_above_zero_is_accepted_and_the_search_stays_exact(ctx, gold):
+    """KDTreeMatcher.epsilon allows libnabo an approximate neighbour ((1 + epsilon) x the nearest distance); the exact one
+    meets every allowance -- a configuration with epsilon 3.16 (libpointmatcher's example files) gives the results of epsilon 0"""
+    z = gold
+    ctx.set_params(**dict(CHAIN, **RESET))
+    mid = ctx.set_map(z["map_xyz"], z["map_nrm"], center=True)
+    T0, s0 = ctx.align(mid, z["reading"], z["T_init"])
+    ids0, d0 = ctx.match(mid, z["reading"], z["T_init"])
+    ctx.set_params(epsilon=3.16)
+    T1, s1 = ctx.align(mid, z["reading"], z["T_init"])
+    ids1, d1 = ctx.match(mid, z["reading"], z["T_init"])
+    assert np.array_equal(T0, T1) and s0["iterations"] == s1["iterations"] and s0["n_kept"] == s1["n_kept"]
+    assert np.array_equal(ids0, ids1) and np.array_equal(d0, d1)
+    with pytest.raises(icp.PgicpError):
+        ctx.set_params(epsilon=-0.5)
+    ctx.set_params(epsilon=0.0)
+    ctx.destroy_map(mid)
