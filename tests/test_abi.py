@@ -85,3 +85,25 @@ def test_numpy_views_of_the_batch_records_match_the_ctypes_structures():
         assert icp._STATS_DTYPE.fields[name][1] == getattr(icp.Stats, name).offset, name
     assert set(icp._PROBLEM_DTYPE.names) == {f[0] for f in icp.Problem._fields_}
     assert set(icp._STATS_DTYPE.names) == {f[0] for f in icp.Stats._fields_}
+
+
+def test_header_is_plain_c99_and_its_records_are_the_bindings(tmp_path):
+    """include/pgicp.h is what a cgo / JNI / ctypes binding reads: it must compile as strict C99, link from C, and its records
+    must have the sizes the ctypes mirror in pgslam_amd/icp.py assumes (no compute: pgicp_device_count answers 0 without a GPU)."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "pgicp.h"\n#include <stdio.h>\nint main(void)\n{\n    pgicp_params p;\n    pgicp_default_params(&p);\n'
+                   '    printf("%d %d %zu %zu %zu %zu %zu\\n", pgicp_abi_version(), p.knn, sizeof(pgicp_params), sizeof(pgicp_stats), sizeof(pgicp_problem),\n'
+                   '           sizeof(pgicp_edge), sizeof(pgicp_filter));\n    return pgicp_device_count() >= 0 ? 0 : 1;\n}\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "pgslam_amd", "lib")
+    exe = str(tmp_path / "abi")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"), str(src), "-o", exe,
+                           "-L" + lib, "-lpgicp", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
+    assert out.returncode == 0, out.stderr
+    abi, knn, s_params, s_stats, s_problem, s_edge, s_filter = (int(v) for v in out.stdout.split())
+    assert abi == 4 and knn == 1
+    assert (s_params, s_stats, s_problem, s_edge, s_filter) == (C.sizeof(icp.Params), C.sizeof(icp.Stats), C.sizeof(icp.Problem), C.sizeof(icp.Edge),
+                                                                C.sizeof(icp.Filter))
