@@ -380,6 +380,49 @@ def main_loopclosure(args, collect=False):
             torch.cuda.synchronize()
             single = args.steps * len(cands) / (time.perf_counter() - t1)
         dist.barrier()
+    # ---- ONE-GPU PROXY of the multi-GPU target (north_star: >= 3.5x at 8 GPUs on this workload; no 8-GPU node is available to
+    #      this run).  The path shards with no data exchange before the final all-gather, so rank r of a
+    #      W-rank job does exactly what this GPU does when handed rank r's LPT shard: the per-batch fixed costs (the unseeded
+    #      first matcher launch over a smaller batch, the convergence tail, the index build at P = 512 / W maps) are all in the
+    #      shard's time.  T(512) and every rank's shard are timed here back to back on the same box;
+    #      predicted_speedup(W) = T(512) / (max_r T(shard r of W) + t_allgather), t_allgather = the world-1 collective's
+    #      latency (pack + ncclAllGather + unpack of the same 512 records; over xGMI the 256 KiB are latency-bound too).
+    #      What the proxy cannot see: 8 host processes sharing the box's cores and PCIe, and RCCL's multi-rank latency.
+    shard_proxy = None
+    if world == 1 and (args.shard_proxy or collect) and len(cands) >= 16:
+        import statistics
+
+        def time_shard(idx, reps):
+            align_shard(idx)                                       # warm-up of this batch size (pool blocks, scratch sizes)
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                align_shard(idx)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            return statistics.median(ts)
+
+        every = list(range(len(cands)))
+        reps = max(2, args.steps)
+        t_all = time_shard(every, reps)
+        loc = align_shard(mine)
+        tg = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            lc.allgather_edges_rccl(comm, loc, mine, costs)
+            tg.append(time.perf_counter() - t1)
+        t_gather = statistics.median(tg)
+        per_world, predicted = {}, {}
+        for W in (2, 4, 8):
+            tr = [time_shard(list(lc.shard(costs, W, r)), reps) for r in range(W)]
+            per_world[str(W)] = dict(shard_pairs=[int(len(lc.shard(costs, W, r))) for r in range(W)], shard_ms=[round(t * 1e3, 3) for t in tr],
+                                     max_shard_ms=max(tr) * 1e3)
+            predicted[str(W)] = t_all / (max(tr) + t_gather)
+        shard_proxy = dict(pairs=len(cands), t_all_pairs_ms=t_all * 1e3, allgather_world1_ms=t_gather * 1e3, per_world=per_world,
+                           predicted_speedup=predicted, repetitions=reps,
+                           how="rank r's LPT shard (pgicp_shard_pairs) of a W-rank job aligned alone on this GPU, every r, W in {2, 4, 8}; "
+                               "predicted_speedup(W) = T(all pairs) / (max_r T(shard) + world-1 all-gather latency); medians")
     seen = sorted(set(int(v) - 1 for v in np.asarray(edges["reserved"])[:, 1] if v > 0))
     comm_world, comm_rank = comm.info()
     cpu = None
@@ -418,6 +461,7 @@ def main_loopclosure(args, collect=False):
             "pairs_ok": ok, "pairs_accepted": int(np.sum(edges["accepted"] == 1)),
             "mean_iterations": float(np.mean(edges["iterations"])),
             "rccl_ranks_seen": len(seen), "ranks_that_reported_edges": seen, "comm_world_size": comm_world,
+            "shard_proxy": shard_proxy,
             "pairs_per_s_one_gpu_same_run": single,
             "speedup_vs_one_gpu": (args.steps * len(cands) / elapsed) / single if single else None})
     comm.close()
@@ -1016,7 +1060,7 @@ def compact_leg(d, wall_s):
             "set_map_ms", "median_translation_error_m",
             "mean_iterations", "converged_fraction", "final_position_error_m", "host_input", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
             "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size",
-            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "replay_vs_oracle", "scans_per_s_each_pass", "scans_per_s_median_pass", "selection_guess_misses_per_scan")
+            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "shard_proxy", "replay_vs_oracle", "scans_per_s_each_pass", "scans_per_s_median_pass", "selection_guess_misses_per_scan")
     out = {k: d[k] for k in keep if k in d}
     if "slam" in d:
         out["slam"] = {k: d["slam"].get(k) for k in ("scans", "points_per_scan", "keyframes", "loops_closed", "loop_candidates_tried",
@@ -1120,6 +1164,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=512)
     ap.add_argument("--pair-chunk", type=int, default=512,
                     help="pairs aligned per device batch (measured at 512 pairs on one GPU: 64 -> 4 260, 128 -> 4 820, 256 -> 5 180, 512 -> 5 440 pairs/s)")
+    ap.add_argument("--shard-proxy", action="store_true",
+                    help="loopclosure at N = 1: also time every rank's LPT shard of a 2-, 4- and 8-rank job alone on this GPU and report "
+                         "the predicted multi-GPU speed-up (`shard_proxy`; always on in the default line's loop_closure leg)")
     ap.add_argument("--no-workloads", action="store_true",
                     help="scan2map: skip the `workloads` legs the default line carries next to the headline (stream, loop closure, "
                          "SLAM -- BASELINE.json configs[2..4], each with its own roofline and cpu_baseline, never `value`)")
@@ -1306,6 +1353,8 @@ def main():
                                                           k["total_ms"] - ku["total_ms"]),
                              avg_seeded_launch_us=(k["total_ms"] - ku["total_ms"]) * 1e3 / (k["launches"] - ku["launches"]))
             roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                            bound_means="`bound` names the roofline the fraction is QUOTED against (BASELINE.json north_star: achieved fraction of the "
+                                        "HBM roofline, SURVEY.md 8(d) algorithmic bytes); `bound_measured` is what the unit counters say limits the kernel",
                             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_uncorrected=traffic_raw,
                             traffic_source=traffic_src,
                             bound_measured=(pmc or {}).get("bound_measured", "valu"),
@@ -1473,6 +1522,21 @@ def main():
         }
         if cpu and cpu["value"] > 0:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        # LAST key, compact (the driver keeps the tail of the line): every leg's figure and its roofline fraction under the
+        # same clock -- [value, frac] per leg; the long form of each is in `workloads` above
+        def vf(d_, key="value"):
+            if not d_ or "error" in d_:
+                return None
+            r_ = d_.get("roofline") or {}
+            return [round(float(d_[key]), 1), round(float(r_["frac"]), 4) if r_.get("frac") is not None else None]
+        lg = legs or {}
+        out["legs"] = {"unit": "[value, roofline.frac]; scans/s except loop_closure: pairs/s",
+                       "headline": [round(value, 1), round(roofline["frac"], 4) if roofline else None],
+                       "fixed30": [round(fixed30["scans_per_s"], 1), None] if fixed30 else None,
+                       "f64": vf(lg.get("f64")), "stream": vf(lg.get("stream")), "slam": vf(lg.get("slam")),
+                       "slam_100k": vf(lg.get("slam_100k")), "loop_closure": vf(lg.get("loop_closure")),
+                       "loop_closure_predicted_speedup_8": ((lg.get("loop_closure") or {}).get("shard_proxy") or {}).get("predicted_speedup", {}).get("8"),
+                       "cpu_port_all_cores": round(cpu["value"], 2) if cpu else None}
         emit(out)
     dist_end()
 

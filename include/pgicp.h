@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PGICP_ABI_VERSION 4
+#define PGICP_ABI_VERSION 5
 
 /* status codes (pgslam sees PM::ConvergenceError for 1, 2 and 7 through the C++ shim) */
 #define PGICP_OK 0
@@ -337,12 +337,17 @@ int pgicp_surface_normals_f64(pgicp_ctx *ctx, const double *xyz, int stride, int
  * dev_features (optional) receives the DEVICE address of the filtered features (stride frows): a reading for pgicp_align_*
  * with mem = PGICP_DEVICE that needs no second upload; valid for the next three pgicp_filter_cloud calls on the context. */
 #define PGICP_FILTER_IDENTITY 0
-#define PGICP_FILTER_MAX_DIST 1         /* p[0] = limit: keeps |p|^2 < limit^2 (MaxDistDataPointsFilter, dim = -1) */
-#define PGICP_FILTER_MIN_DIST 2         /* p[0] = limit: keeps the others (MinDistDataPointsFilter) */
+#define PGICP_FILTER_MAX_DIST 1         /* p[0] = maxDist, p[1] = dim + 1 (0: dim = -1, the radius): keeps |p| < |maxDist| -- the norm in T, strict --
+                                         * or features(dim) < maxDist ([EXT] MaxDistDataPointsFilter) */
+#define PGICP_FILTER_MIN_DIST 2         /* p[0] = minDist, p[1] = dim + 1: keeps |p| > |minDist| or features(dim) > minDist (MinDistDataPointsFilter);
+                                         * a NaN coordinate fails both filters' comparisons: dropped */
 #define PGICP_FILTER_BOUNDING_BOX 3     /* p[0..2] = min xyz, p[3..5] = max xyz, p[6] = removeInside */
 #define PGICP_FILTER_REMOVE_NAN 4
-#define PGICP_FILTER_FIX_STEP 5         /* p[0] = step: keeps points 0, step, 2 step, ... */
+#define PGICP_FILTER_FIX_STEP 5         /* p[0] = step: keeps points 0, step, 2 step, ... (upstream starts at rand() % step: the phase is not
+                                         * reproducible there; here it is 0.  A step that changes from call to call -- stepMult -- is the caller's state) */
 #define PGICP_FILTER_RANDOM_SAMPLING 6  /* p[0] = prob, p[1] = seed: the counter-based sampler of pointmatcher.hpp */
+#define PGICP_FILTER_MAX_POINT_COUNT 7  /* (ABI 5) p[0] = maxCount, p[1] = seed: when more than maxCount points arrive, the same sampler with
+                                         * prob = T(maxCount) / T(N) ([EXT] MaxPointCountDataPointsFilter; like RandomSampling not rand()-parity) */
 #define PGICP_MAX_FILTERS 8
 typedef struct pgicp_filter {
     int type;
@@ -418,6 +423,10 @@ int pgicp_allgather_edges(pgicp_comm *comm, const pgicp_edge *local, const int *
  * within the trim threshold, [3] outlier-filter selections since the last call (all contexts of the device) whose
  * guess -- the last selection's result -- was off, so that one block selected over all of a problem's distances. */
 int pgicp_debug_counters(pgicp_ctx *ctx, int out[4]);
+/* (ABI 5) Process-wide count and summed host nanoseconds of the library's hipMalloc [0,1], hipFree [2,3], hipHostMalloc [4,5] and
+ * hipHostFree [6,7] calls: their cost is the HOST's (1 ms on some boxes, 45 ms on others; hipFree waits for the whole device),
+ * so a caller's slow pass can be told apart from a slow GPU.  No context needed. */
+int pgicp_debug_alloc_stats(long long out[8]);
 /* Diagnostics: the correspondences the LAST iteration of problem `problem` of the last align call
  * ended with, in reading order (host buffers of n entries).  ids: reference index, -1 = no neighbour
  * within maxDist, -2 = a neighbour exists but was not located (lazy resolution: its distance is an

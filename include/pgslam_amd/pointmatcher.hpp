@@ -368,38 +368,12 @@ struct PointMatcher {
         //! the filter as an entry of pgicp_filter_cloud's list (the device pass keeps the points this host version keeps);
         //! false: the filter has no device form (it adds descriptors, or needs neighbours)
         virtual bool deviceSpec(pgicp_filter &) const { return false; }
+        //! called once after a device pass that stood in for inPlaceFilter (filters whose parameters evolve from cloud to cloud)
+        virtual void afterDevicePass() {}
     };
     struct IdentityDataPointsFilter : DataPointsFilter {
         void inPlaceFilter(DataPoints &) override {}
         bool deviceSpec(pgicp_filter &f) const override { std::memset(&f, 0, sizeof f); f.type = PGICP_FILTER_IDENTITY; return true; }
-    };
-    //! keeps points whose distance to the origin is below (MaxDist) / above (MinDist) a limit -- host side, O(N)
-    struct DistLimitDataPointsFilter : DataPointsFilter {
-        T limit; bool keepInside;
-        DistLimitDataPointsFilter(T l, bool inside) : limit(l), keepInside(inside) {}
-        bool deviceSpec(pgicp_filter &f) const override
-        {
-            std::memset(&f, 0, sizeof f);
-            f.type = keepInside ? PGICP_FILTER_MAX_DIST : PGICP_FILTER_MIN_DIST; f.p[0] = (double)limit;
-            return true;
-        }
-        void inPlaceFilter(DataPoints &c) override
-        {
-            const int n = c.features.cols();
-            int k = 0;
-            for (int j = 0; j < n; j++) {
-                const double r2 = (double)c.features(0, j) * c.features(0, j) + (double)c.features(1, j) * c.features(1, j) + (double)c.features(2, j) * c.features(2, j);
-                const bool in = r2 < (double)limit * limit;
-                if (in != keepInside) continue;
-                if (k != j) {
-                    for (int i = 0; i < c.features.rows(); i++) c.features(i, k) = c.features(i, j);
-                    for (int i = 0; i < c.descriptors.rows(); i++) c.descriptors(i, k) = c.descriptors(i, j);
-                }
-                k++;
-            }
-            c.features.conservativeResize(c.features.rows(), k);
-            if (c.descriptors.rows()) c.descriptors.conservativeResize(c.descriptors.rows(), k);
-        }
     };
     //! keeps the columns for which `keep(j)` holds, in order (features and descriptors)
     template <typename Pred>
@@ -418,6 +392,29 @@ struct PointMatcher {
         c.features.conservativeResize(c.features.rows(), k);
         if (c.descriptors.rows()) c.descriptors.conservativeResize(c.descriptors.rows(), k);
     }
+    //! [EXT] MaxDistDataPointsFilter{maxDist, dim} / MinDistDataPointsFilter{minDist, dim} (DataPointsFilters/MaxDist.cpp, MinDist.cpp):
+    //! dim = -1: keeps points whose distance to the origin -- features.col(i).head(3).norm() in T -- is below |maxDist| (above
+    //! |minDist|), strictly; dim = 0..2: keeps features(dim, i) < maxDist (> minDist).  A NaN fails either comparison.
+    struct DistLimitDataPointsFilter : DataPointsFilter {
+        T limit; bool keepInside; int dim;
+        DistLimitDataPointsFilter(T l, bool inside, int d = -1) : limit(l), keepInside(inside), dim(d) {}
+        bool deviceSpec(pgicp_filter &f) const override
+        {
+            std::memset(&f, 0, sizeof f);
+            f.type = keepInside ? PGICP_FILTER_MAX_DIST : PGICP_FILTER_MIN_DIST; f.p[0] = (double)limit; f.p[1] = (double)(dim + 1);
+            return true;
+        }
+        void inPlaceFilter(DataPoints &c) override
+        {
+            const T al = limit < (T)0 ? -limit : limit;
+            compactColumns(c, [&](int j) {
+                if (dim >= 0) return keepInside ? c.features(dim, j) < limit : c.features(dim, j) > limit;
+                const T x = c.features(0, j), y = c.features(1, j), z = c.features(2, j);
+                const T r = std::sqrt((x * x + y * y) + z * z);          // Eigen's .norm() of the three coordinates, in T
+                return keepInside ? r < al : r > al;
+            });
+        }
+    };
     //! [EXT] BoundingBoxDataPointsFilter{xMin..zMax, removeInside}: a point is inside when every coordinate lies
     //! strictly between its bounds; removeInside = 1 (the default) drops the inside, 0 keeps only the inside
     struct BoundingBoxDataPointsFilter : DataPointsFilter {
@@ -483,14 +480,28 @@ struct PointMatcher {
             }
         }
     };
-    //! [EXT] FixStepSamplingDataPointsFilter{startStep (= endStep, stepMult = 1)}: keeps points 0, step, 2 step, ... -- deterministic
+    //! [EXT] FixStepSamplingDataPointsFilter{startStep, endStep, stepMult} (DataPointsFilters/FixStepSampling.cpp): keeps points
+    //! phase, phase + step, ...; after every cloud step *= stepMult, clamped at endStep in the direction of travel; init() goes back
+    //! to startStep.  Upstream draws phase = rand() % step from the C library's global generator -- like RandomSampling there is
+    //! nothing to be bit-exact against; here the phase is 0 (documented as NOT parity with upstream's sample, same density).
     struct FixStepSamplingDataPointsFilter : DataPointsFilter {
-        int step;
-        explicit FixStepSamplingDataPointsFilter(int s) : step(s < 1 ? 1 : s) {}
-        bool deviceSpec(pgicp_filter &f) const override { std::memset(&f, 0, sizeof f); f.type = PGICP_FILTER_FIX_STEP; f.p[0] = (double)step; return true; }
+        double startStep, endStep, stepMult, step;
+        explicit FixStepSamplingDataPointsFilter(double s, double e = -1, double m = 1) : startStep(s < 1 ? 1 : s), endStep(e < 1 ? startStep : e), stepMult(m), step(startStep) {}
+        void init() override { step = startStep; }
+        bool deviceSpec(pgicp_filter &f) const override { std::memset(&f, 0, sizeof f); f.type = PGICP_FILTER_FIX_STEP; f.p[0] = (double)(int)step; return true; }
+        void afterDevicePass() override { advance(); }
+        void advance()
+        {
+            const double delta = startStep * stepMult - startStep;
+            step *= stepMult;
+            if (delta < 0 && step < endStep) step = endStep;
+            if (delta > 0 && step > endStep) step = endStep;
+        }
         void inPlaceFilter(DataPoints &c) override
         {
-            compactColumns(c, [&](int j) { return j % step == 0; });
+            const int iStep = (int)step;
+            compactColumns(c, [&](int j) { return j % iStep == 0; });
+            advance();
         }
     };
     //! [EXT] RandomSamplingDataPointsFilter{prob}: upstream keeps a point when rand() / RAND_MAX < prob -- the C library's
@@ -515,6 +526,27 @@ struct PointMatcher {
         void inPlaceFilter(DataPoints &c) override
         {
             compactColumns(c, [&](int j) { return (double)(mix(seed * 0x100000001B3ULL + (unsigned long long)j) >> 11) / 9007199254740992.0 < (double)prob; });
+        }
+    };
+    //! [EXT] MaxPointCountDataPointsFilter{maxCount, seed} (DataPointsFilters/MaxPointCount.cpp as of the libpointmatcher pgslam was
+    //! written against): when more than maxCount points arrive, a random sample with prob = T(maxCount) / T(N) -- about maxCount
+    //! points survive.  The draw is RandomSampling's build-owned one (not rand()-parity, see there).
+    struct MaxPointCountDataPointsFilter : DataPointsFilter {
+        unsigned maxCount; unsigned long long seed;
+        MaxPointCountDataPointsFilter(unsigned m, unsigned long long s) : maxCount(m < 1 ? 1 : m), seed(s) {}
+        bool deviceSpec(pgicp_filter &f) const override
+        {
+            if (seed >= (1ULL << 53)) return false;
+            std::memset(&f, 0, sizeof f);
+            f.type = PGICP_FILTER_MAX_POINT_COUNT; f.p[0] = (double)maxCount; f.p[1] = (double)seed;
+            return true;
+        }
+        void inPlaceFilter(DataPoints &c) override
+        {
+            const int n = (int)c.features.cols();
+            if (!((double)n > (double)maxCount)) return;
+            const double prob = (double)((T)maxCount / (T)n);
+            compactColumns(c, [&](int j) { return (double)(RandomSamplingDataPointsFilter::mix(seed * 0x100000001B3ULL + (unsigned long long)j) >> 11) / 9007199254740992.0 < prob; });
         }
     };
     //! [EXT] SurfaceNormalDataPointsFilter{knn, maxDist, epsilon, keepNormals, keepEigenValues}: normals (and,
@@ -554,9 +586,10 @@ struct PointMatcher {
             for (auto &m : mods) {
                 if (m.name == "IdentityDataPointsFilter") this->push_back(std::make_shared<IdentityDataPointsFilter>());
                 else if (m.name == "MaxDistDataPointsFilter" || m.name == "MinDistDataPointsFilter") {
-                    if (m.params.count("dim") && m.params.at("dim") != "-1") throw std::runtime_error(m.name + ": only dim = -1 (radius) is supported");
+                    const int dim = m.params.count("dim") ? (int)to_double(m.params.at("dim"), m.name) : -1;
+                    if (dim < -1 || dim > 2) throw std::runtime_error(m.name + ": dim must be -1 (radius), 0, 1 or 2");
                     const T lim = (T)to_double(m.params.count("maxDist") ? m.params.at("maxDist") : m.params.count("minDist") ? m.params.at("minDist") : "1", m.name);
-                    this->push_back(std::make_shared<DistLimitDataPointsFilter>(lim, m.name == "MaxDistDataPointsFilter"));
+                    this->push_back(std::make_shared<DistLimitDataPointsFilter>(lim, m.name == "MaxDistDataPointsFilter", dim));
                 } else if (m.name == "SurfaceNormalDataPointsFilter") {
                     auto get = [&](const char *k, const char *def) { return m.params.count(k) ? m.params.at(k) : std::string(def); };
                     // (epsilon > 0 allows an approximate neighbour search upstream; the exact search here meets every allowance)
@@ -582,17 +615,24 @@ struct PointMatcher {
                         to_double(m.params.count("towardCenter") ? m.params.at("towardCenter") : std::string("1"), m.name) != 0.0));
                 } else if (m.name == "FixStepSamplingDataPointsFilter") {
                     auto get = [&](const char *k, const char *def) { return to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
-                    const int start = (int)get("startStep", "10");
-                    if ((m.params.count("endStep") && (int)get("endStep", "10") != start) || get("stepMult", "1") != 1.0)
-                        throw std::runtime_error(m.name + ": only a constant step (endStep = startStep, stepMult = 1) is supported");
-                    this->push_back(std::make_shared<FixStepSamplingDataPointsFilter>(start));
+                    const double start = get("startStep", "10"), end = get("endStep", "10"), mult = get("stepMult", "1");
+                    if (!(start >= 1.0 && start <= 2147483647.0) || !(end >= 1.0 && end <= 2147483647.0) || !(mult > 0.0))
+                        throw std::runtime_error(m.name + ": startStep and endStep must be in [1, INT_MAX], stepMult positive");
+                    this->push_back(std::make_shared<FixStepSamplingDataPointsFilter>(start, m.params.count("endStep") ? end : start, mult));
                 } else if (m.name == "RandomSamplingDataPointsFilter") {
                     auto get = [&](const char *k, const char *def) { return to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
-                    this->push_back(std::make_shared<RandomSamplingDataPointsFilter>((T)get("prob", "0.75"), (unsigned long long)get("seed", "1")));
+                    const double prob = get("prob", "0.75"), seed = get("seed", "1");
+                    if (!(prob >= 0.0 && prob <= 1.0) || !(seed >= 0.0 && seed < 9007199254740992.0)) throw std::runtime_error(m.name + ": prob must be in [0, 1], seed in [0, 2^53)");
+                    this->push_back(std::make_shared<RandomSamplingDataPointsFilter>((T)prob, (unsigned long long)seed));
+                } else if (m.name == "MaxPointCountDataPointsFilter") {
+                    auto get = [&](const char *k, const char *def) { return to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
+                    const double mc = get("maxCount", "1000"), seed = get("seed", "1");
+                    if (!(mc >= 1.0 && mc <= 2147483647.0) || !(seed >= 0.0 && seed < 9007199254740992.0)) throw std::runtime_error(m.name + ": maxCount must be in [1, INT_MAX], seed in [0, 2^53)");
+                    this->push_back(std::make_shared<MaxPointCountDataPointsFilter>((unsigned)mc, (unsigned long long)seed));
                 } else
                     throw std::runtime_error("DataPointsFilters: unsupported filter '" + m.name +
                                              "' (supported: Identity, MinDist, MaxDist, BoundingBox, RemoveNaN, SurfaceNormal, "
-                                             "ObservationDirection, OrientNormals, FixStepSampling, RandomSampling (seeded, not bit-parity))");
+                                             "ObservationDirection, OrientNormals, FixStepSampling, RandomSampling, MaxPointCount (seeded samplers, not rand()-parity))");
             }
         }
         void init() { for (auto &f : *this) f->init(); }
@@ -639,6 +679,7 @@ struct PointMatcher {
                                      drows ? (const double *)cloud.descriptors.data() : nullptr, drows, n, T16, r0, r1, (double *)cloud.features.data(),
                                      drows ? (double *)cloud.descriptors.data() : nullptr, nullptr, &kept, (const double **)&d);
         check(c, rc);
+        for (auto &f : filters) f->afterDevicePass();               // (a FixStep filter's step moves on, as after inPlaceFilter)
         cloud.features.conservativeResize(cloud.features.rows(), kept);
         if (drows) cloud.descriptors.conservativeResize(drows, kept);
         if (dev) *dev = d;

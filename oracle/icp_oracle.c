@@ -50,6 +50,21 @@
  *   - centroid: fixed-point (2^-24) integer sum => order independent;
  *   - normal equations, residual, covariance: double accumulation;
  *   - 6x6 solve, SE(3) composition and convergence checks: double.
+ *
+ * SENSITIVITY VARIANTS (round 5; oracle/Makefile builds one extra library per flag, tests/test_sensitivity.py and
+ * tools/sensitivity_envelope.py compare them with the default build -- they answer "how far does the result move under the
+ * assumptions nobody can check here"; none of them is the contract the HIP path is held to):
+ *   -DORC_ACCUM_T        everything libpointmatcher's PointMatcher<T> does in T is done in `real`: the normal equations
+ *                        A = wF F^T, b = -(wF dot^T) and the residual accumulated in `real` in pair (column) order, the
+ *                        Cholesky solve in `real`, the AngleAxis increment in `real`, T_iter = dT * T_iter, the pre- and
+ *                        post-multiplication with T_refIn_refMean in `real` ([EXT] ICP.cpp computeWithTransformedReference
+ *                        keeps TransformationParameters = Matrix of T), the reference mean as 8 running `real` lane sums
+ *                        (an Eigen packet reduction).  The checkers see the `real`-rounded T_iter (their own quaternion
+ *                        arithmetic stays double).
+ *   -DORC_TIE_HIGH       among candidates at exactly the same squared distance the HIGHEST index wins (libnabo's order is
+ *                        traversal dependent; lowest / highest index are its two extremes).
+ *   -DORC_FMA_TRANSFORM  the rigid transform contracts to fused multiply-adds, as an Eigen 4x4 * 4xN product compiled with
+ *                        FMA enabled would: fma(r02, z, fma(r01, y, r00 * x)) + tx.
  */
 #include <math.h>
 #include <stdint.h>
@@ -65,6 +80,26 @@ typedef double real;
 typedef float real;
 #define REAL_EPS FLT_EPSILON
 #define FN(name) name##_f32
+#endif
+
+#ifdef ORC_DOUBLE
+#define FMA_R(a, b, c) fma((a), (b), (c))
+#define SQRT_R(a) sqrt(a)
+#define COS_R(a) cos(a)
+#define SIN_R(a) sin(a)
+#else
+#define FMA_R(a, b, c) fmaf((a), (b), (c))
+#define SQRT_R(a) sqrtf(a)
+#define COS_R(a) cosf(a)
+#define SIN_R(a) sinf(a)
+#endif
+/* which index wins among candidates at exactly the same squared distance (see ORC_TIE_HIGH above) */
+#ifdef ORC_TIE_HIGH
+#define TIE_WINS(j, bi) ((j) > (bi))
+#define TIE_NONE (-1)                 /* "no candidate yet": loses every tie */
+#else
+#define TIE_WINS(j, bi) ((j) < (bi))
+#define TIE_NONE INT32_MAX
 #endif
 
 #define ORC_OK 0
@@ -123,7 +158,7 @@ typedef struct {
 /* --------------------------------------------------------------------------
  * small dense helpers (double, row-major 4x4 / 6x6)
  * ------------------------------------------------------------------------ */
-static void mat4_mul(const double *a, const double *b, double *c)
+__attribute__((unused)) static void mat4_mul(const double *a, const double *b, double *c)
 {
     double t[16];
     for (int i = 0; i < 4; i++)
@@ -133,6 +168,23 @@ static void mat4_mul(const double *a, const double *b, double *c)
             t[i * 4 + j] = s;
         }
     memcpy(c, t, sizeof t);
+}
+
+/* a product of two TransformationParameters of the ICP loop: double by contract; Matrix of T under ORC_ACCUM_T */
+static void mat4_mul_chain(const double *a, const double *b, double *c)
+{
+#ifdef ORC_ACCUM_T
+    double t[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            real s = (real)0;
+            for (int k = 0; k < 4; k++) s += (real)a[i * 4 + k] * (real)b[k * 4 + j];
+            t[i * 4 + j] = (double)s;
+        }
+    memcpy(c, t, sizeof t);
+#else
+    mat4_mul(a, b, c);
+#endif
 }
 
 static void mat4_identity(double *a)
@@ -160,9 +212,15 @@ void FN(orc_transform)(const double *T, const real *in, real *out, int n, int ro
     const real r20 = (real)T[8], r21 = (real)T[9], r22 = (real)T[10], tz = (real)T[11];
     for (int i = 0; i < n; i++) {
         const real x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+#ifdef ORC_FMA_TRANSFORM
+        real ox = FMA_R(r02, z, FMA_R(r01, y, r00 * x));
+        real oy = FMA_R(r12, z, FMA_R(r11, y, r10 * x));
+        real oz = FMA_R(r22, z, FMA_R(r21, y, r20 * x));
+#else
         real ox = (r00 * x + r01 * y) + r02 * z;
         real oy = (r10 * x + r11 * y) + r12 * z;
         real oz = (r20 * x + r21 * y) + r22 * z;
+#endif
         if (!rotate_only) { ox = ox + tx; oy = oy + ty; oz = oz + tz; }
         out[3 * i] = ox; out[3 * i + 1] = oy; out[3 * i + 2] = oz;
     }
@@ -171,6 +229,16 @@ void FN(orc_transform)(const double *T, const real *in, real *out, int n, int ro
 /* [A.2] centroid of the reference, order-independent fixed-point definition. */
 void FN(orc_centroid)(const real *xyz, int n, real *mean)
 {
+#ifdef ORC_ACCUM_T
+    /* reference.features.rowwise().sum() / N in T: eight running lane sums per row, folded at the end */
+    for (int a = 0; a < 3; a++) {
+        real lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n; i++) lane[i & 7] += xyz[3 * i + a];
+        const real s = ((lane[0] + lane[4]) + (lane[2] + lane[6])) + ((lane[1] + lane[5]) + (lane[3] + lane[7]));
+        mean[a] = s / (real)n;
+    }
+    return;
+#endif
     for (int a = 0; a < 3; a++) {
         int64_t s = 0;
         for (int i = 0; i < n; i++) s += llrint((double)xyz[3 * i + a] * 16777216.0);
@@ -197,6 +265,79 @@ void FN(orc_build_local_map)(int n_kf, const real *const *xyz, const real *const
 }
 
 /* --------------------------------------------------------------------------
+ * Input filters that only drop points -- input_filters_.apply(cloud) at Localizer.hpp:103, the reading / reference filters at
+ * Localizer.hpp:314-326 -- restated from [EXT] libpointmatcher DataPointsFilters/{MaxDist,MinDist,BoundingBox,RemoveNaN,
+ * FixStepSampling,RandomSampling,MaxPointCount}.cpp.  `feat`: n points of `frows` values (xyz first, then the homogeneous row).
+ * The filters run in list order, each on what the one before it kept; kept_idx receives the surviving input indices.
+ *   type 1 MaxDist {maxDist = p[0], dim = p[1] - 1}: dim -1: keep when features.col(i).head(3).norm() < |maxDist| (the norm in T:
+ *          sqrt((x x + y y) + z z)); dim 0..2: keep when features(dim, i) < maxDist
+ *   type 2 MinDist {minDist, dim}: norm > |minDist|; features(dim, i) > minDist       (strict both; a NaN fails either)
+ *   type 3 BoundingBox {xMin yMin zMin xMax yMax zMax removeInside}: inside = every coordinate strictly between its bounds
+ *   type 4 RemoveNaN: drops a point when any FEATURE value (the padding row too) is NaN
+ *   type 5 FixStepSampling {step = p[0]}: points phase, phase + step, ...; upstream draws phase = rand() % step (the C library's
+ *          global generator: nothing to be bit-exact against) -- phase 0 here and in the build; the step's evolution over calls
+ *          (startStep, endStep, stepMult) is the caller's state, see orc_fixstep_next
+ *   type 6 RandomSampling {prob = p[0]}: upstream keeps when rand() / RAND_MAX < prob; here the build's counter-based draw
+ *          (SplitMix64 of seed p[1] and the point's index) -- same distribution, documented as NOT rand()-parity
+ *   type 7 MaxPointCount {maxCount = p[0], seed = p[1]}: only when maxCount < N: the same draw with prob = T(maxCount) / T(N)
+ * ------------------------------------------------------------------------ */
+static uint64_t orc_splitmix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+int FN(orc_filter_chain)(int n_filters, const int *types, const double *params /* 8 per filter */, const real *feat, int frows, int n,
+                         int *kept_idx, int *n_out)
+{
+    int cur = n;
+    for (int i = 0; i < n; i++) kept_idx[i] = i;
+    for (int k = 0; k < n_filters; k++) {
+        const double *p = params + 8 * k;
+        const int t = types[k];
+        int out = 0;
+        for (int j = 0; j < cur; j++) {
+            const real *q = feat + (size_t)kept_idx[j] * frows;
+            int keep = 1;
+            if (t == 1 || t == 2) {
+                const int dim = (int)p[1] - 1;
+                const real lim = (real)p[0];
+                if (dim < 0) {
+                    const real r = SQRT_R((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]), al = lim < (real)0 ? -lim : lim;
+                    keep = t == 1 ? r < al : r > al;
+                } else keep = t == 1 ? q[dim] < lim : q[dim] > lim;
+            } else if (t == 3) {
+                const int in = (real)p[0] < q[0] && q[0] < (real)p[3] && (real)p[1] < q[1] && q[1] < (real)p[4] && (real)p[2] < q[2] && q[2] < (real)p[5];
+                keep = in != (p[6] != 0.0);
+            } else if (t == 4) {
+                for (int r = 0; r < frows; r++) if (q[r] != q[r]) keep = 0;
+            } else if (t == 5) {
+                keep = j % (int)p[0] == 0;
+            } else if (t == 6 || t == 7) {
+                double prob = p[0];
+                if (t == 7) prob = (double)cur > p[0] ? (double)((real)p[0] / (real)cur) : 2.0;
+                const double u = (double)(orc_splitmix((uint64_t)p[1] * 0x100000001B3ULL + (uint64_t)j) >> 11) / 9007199254740992.0;
+                keep = u < prob;
+            } else if (t != 0) return ORC_ERR_ARG;
+            if (keep) kept_idx[out++] = kept_idx[j];
+        }
+        cur = out;
+    }
+    *n_out = cur;
+    return ORC_OK;
+}
+/* [EXT] FixStepSampling.cpp, the end of inPlaceFilter: step *= stepMult, clamped at endStep in the direction of travel */
+#ifndef ORC_DOUBLE
+double orc_fixstep_next(double step, double start_step, double end_step, double step_mult)
+{
+    const double delta = start_step * step_mult - start_step;
+    step *= step_mult;
+    if (delta < 0 && step < end_step) step = end_step;
+    if (delta > 0 && step > end_step) step = end_step;
+    return step;
+}
+#endif
+
+/* --------------------------------------------------------------------------
  * [A.3] matcher: brute force (ground truth) and kd-tree (identical results)
  * ------------------------------------------------------------------------ */
 static inline real dist2(const real *q, const real *m)
@@ -213,7 +354,11 @@ void FN(orc_knn_brute)(const real *q, int nq, const real *m, int nm, real max_di
         int bi = -1;
         for (int j = 0; j < nm; j++) {
             const real d = dist2(q + 3 * i, m + 3 * j);
+#ifdef ORC_TIE_HIGH
+            if (d <= best) { best = d; bi = j; }     /* the other extreme: highest index wins ties */
+#else
             if (d < best) { best = d; bi = j; }      /* strict <: lowest index wins ties */
+#endif
         }
         if (bi >= 0 && best <= md2) { ids[i] = bi; d2[i] = best; }
         else { ids[i] = -1; d2[i] = INFINITY; }
@@ -302,7 +447,7 @@ static void kd_search(const kdtree *t, int node, const real *q, real *best, int 
         for (int i = t->node_lo[node]; i < t->node_hi[node]; i++) {
             const int j = t->perm[i];
             const real d = dist2(q, t->pts + 3 * j);
-            if (d < *best || (d == *best && j < *bi)) { *best = d; *bi = j; }
+            if (d < *best || (d == *best && TIE_WINS(j, *bi))) { *best = d; *bi = j; }
         }
         return;
     }
@@ -325,9 +470,9 @@ void FN(orc_kdtree_knn)(const void *h, const real *q, int nq, real max_dist, int
         if (t->n > 0) {
             /* seed with maxDist so far subtrees are pruned early; keep exactness:
              * anything with d2 > md2 is rejected below anyway. */
-            best = md2; bi = INT32_MAX;
+            best = md2; bi = TIE_NONE;
             kd_search(t, 0, q + 3 * i, &best, &bi);
-            if (bi == INT32_MAX) bi = -1;
+            if (bi == TIE_NONE) bi = -1;
         }
         if (bi >= 0 && best <= md2) { ids[i] = bi; d2[i] = best; }
         else { ids[i] = -1; d2[i] = INFINITY; }
@@ -344,9 +489,9 @@ typedef struct { real *d; int *i; int k; } kbest;
 static inline void kbest_push(kbest *b, real d, int j)
 {
     const int k = b->k;
-    if (!(d < b->d[k - 1] || (d == b->d[k - 1] && j < b->i[k - 1]))) return;
+    if (!(d < b->d[k - 1] || (d == b->d[k - 1] && TIE_WINS(j, b->i[k - 1])))) return;
     int p = k - 1;
-    while (p > 0 && (d < b->d[p - 1] || (d == b->d[p - 1] && j < b->i[p - 1]))) { b->d[p] = b->d[p - 1]; b->i[p] = b->i[p - 1]; --p; }
+    while (p > 0 && (d < b->d[p - 1] || (d == b->d[p - 1] && TIE_WINS(j, b->i[p - 1])))) { b->d[p] = b->d[p - 1]; b->i[p] = b->i[p - 1]; --p; }
     b->d[p] = d; b->i[p] = j;
 }
 
@@ -373,10 +518,10 @@ void FN(orc_kdtree_knn_k)(const void *h, const real *q, int nq, int k, real max_
     const real md2 = max_dist * max_dist;
     for (int i = 0; i < nq; i++) {
         kbest b = { d2 + (size_t)i * k, ids + (size_t)i * k, k };
-        for (int j = 0; j < k; j++) { b.d[j] = md2; b.i[j] = INT32_MAX; }   /* anything beyond maxDist is useless */
+        for (int j = 0; j < k; j++) { b.d[j] = md2; b.i[j] = TIE_NONE; }   /* anything beyond maxDist is useless */
         if (t->n > 0) kd_search_k(t, 0, q + 3 * i, &b);
         for (int j = 0; j < k; j++)
-            if (b.i[j] == INT32_MAX || !(b.d[j] <= md2)) { b.i[j] = -1; b.d[j] = INFINITY; }
+            if (b.i[j] == TIE_NONE || !(b.d[j] <= md2)) { b.i[j] = -1; b.d[j] = INFINITY; }
     }
 }
 
@@ -386,10 +531,10 @@ void FN(orc_knn_brute_k)(const real *q, int nq, const real *m, int nm, int k, re
     const real md2 = max_dist * max_dist;
     for (int i = 0; i < nq; i++) {
         kbest b = { d2 + (size_t)i * k, ids + (size_t)i * k, k };
-        for (int j = 0; j < k; j++) { b.d[j] = md2; b.i[j] = INT32_MAX; }
+        for (int j = 0; j < k; j++) { b.d[j] = md2; b.i[j] = TIE_NONE; }
         for (int j = 0; j < nm; j++) kbest_push(&b, dist2(q + 3 * i, m + 3 * j), j);
         for (int j = 0; j < k; j++)
-            if (b.i[j] == INT32_MAX || !(b.d[j] <= md2)) { b.i[j] = -1; b.d[j] = INFINITY; }
+            if (b.i[j] == TIE_NONE || !(b.d[j] <= md2)) { b.i[j] = -1; b.d[j] = INFINITY; }
     }
 }
 
@@ -534,6 +679,44 @@ static int FN(p2plane_system_k)(const real *p, int n, int K, const real *ref_xyz
                                 const int *ids, const real *w, double *sys)
 {
     for (int i = 0; i < 30; i++) sys[i] = 0.0;
+#ifdef ORC_ACCUM_T
+    /* PointMatcher<T>: cross = p x n, wF = w .* F, A = wF F^T, dot = sum_rows(deltas .* normals), b = -(wF dot^T), all Matrix
+     * of T; the products accumulated here pair by pair (column order) in `real` */
+    {
+        real acc[30];
+        for (int i = 0; i < 30; i++) acc[i] = (real)0;
+        for (int k = 0; k < K; k++)
+        for (int i = 0; i < n; i++) {
+            const size_t pe = (size_t)i * K + k;
+            if (w[pe] == (real)0 || ids[pe] < 0) continue;
+            const int j = ids[pe];
+            const real wi = w[pe];
+            const real px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+            const real nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
+            const real dx = px - ref_xyz[3 * j], dy = py - ref_xyz[3 * j + 1], dz = pz - ref_xyz[3 * j + 2];
+            const real e = (dx * nx + dy * ny) + dz * nz;
+            real J[6], wJ[6];
+            J[0] = py * nz - pz * ny;
+            J[1] = pz * nx - px * nz;
+            J[2] = px * ny - py * nx;
+            J[3] = nx; J[4] = ny; J[5] = nz;
+            for (int a = 0; a < 6; a++) wJ[a] = wi * J[a];
+            int q = 0;
+            for (int a = 0; a < 6; a++)
+                for (int b = a; b < 6; b++) acc[q++] += wJ[a] * J[b];
+            for (int a = 0; a < 6; a++) acc[21 + a] -= wJ[a] * e;
+            acc[27] += wi;
+            acc[28] += (real)1;
+            acc[29] += wi * (e * e);
+        }
+        for (int i = 0; i < 30; i++) sys[i] = (double)acc[i];
+        /* (the kept count must stay exact: a float counter saturates at 2^24) */
+        double kept = 0.0;
+        for (size_t pe = 0; pe < (size_t)n * K; pe++) if (!(w[pe] == (real)0 || ids[pe] < 0)) kept += 1.0;
+        sys[28] = kept;
+        return sys[28] > 0 ? ORC_OK : ORC_ERR_NO_MATCH;
+    }
+#endif
     for (int k = 0; k < K; k++)
     for (int i = 0; i < n; i++) {
         const size_t pe = (size_t)i * K + k;
@@ -679,6 +862,47 @@ static void jacobi6(double *a /* 36, destroyed */, double *v /* 36 */, double *e
  * lambda > 6*eps(T)*lambda_max.  (Assumption-ledger item: rank threshold.) */
 int FN(orc_solve6)(const double *sys, double *x, int *rank_out)
 {
+#ifdef ORC_ACCUM_T
+    /* A.llt().solve(b) on Matrix / Vector of T: the factorisation and both substitutions in `real` (the rank test is the
+     * default build's, on the same pivots) */
+    {
+        real Ar[36], Lr[36], yr[6], xr[6];
+        int q = 0;
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) { Ar[a * 6 + b] = (real)sys[q]; Ar[b * 6 + a] = (real)sys[q]; q++; }
+        real dmax_r = (real)0;
+        for (int i = 0; i < 6; i++) if (fabs((double)Ar[i * 6 + i]) > (double)dmax_r) dmax_r = (real)fabs((double)Ar[i * 6 + i]);
+        memset(Lr, 0, sizeof Lr);
+        int ok_r = 1;
+        for (int j = 0; j < 6 && ok_r; j++) {
+            real d = Ar[j * 6 + j];
+            for (int m = 0; m < j; m++) d -= Lr[j * 6 + m] * Lr[j * 6 + m];
+            if (!(d > dmax_r * (real)6 * REAL_EPS)) { ok_r = 0; break; }
+            Lr[j * 6 + j] = SQRT_R(d);
+            for (int i = j + 1; i < 6; i++) {
+                real t = Ar[i * 6 + j];
+                for (int m = 0; m < j; m++) t -= Lr[i * 6 + m] * Lr[j * 6 + m];
+                Lr[i * 6 + j] = t / Lr[j * 6 + j];
+            }
+        }
+        if (ok_r) {
+            for (int i = 0; i < 6; i++) {
+                real t = (real)sys[21 + i];
+                for (int m = 0; m < i; m++) t -= Lr[i * 6 + m] * yr[m];
+                yr[i] = t / Lr[i * 6 + i];
+            }
+            for (int i = 5; i >= 0; i--) {
+                real t = yr[i];
+                for (int m = i + 1; m < 6; m++) t -= Lr[m * 6 + i] * xr[m];
+                xr[i] = t / Lr[i * 6 + i];
+            }
+            for (int i = 0; i < 6; i++) x[i] = (double)xr[i];
+            if (rank_out) *rank_out = 6;
+            return ORC_OK;
+        }
+        /* rank deficient: the default build's minimal-norm branch below */
+    }
+#endif
     double A[36], L[36];
     int k = 0;
     for (int a = 0; a < 6; a++)
@@ -810,6 +1034,22 @@ int FN(orc_solve_4dof)(const double *sys, double *x, int *rank_out)
 void FN(orc_delta_T)(const double *x, double *T)
 {
     mat4_identity(T);
+#ifdef ORC_ACCUM_T
+    /* Eigen::AngleAxis<T>(x.head(3).norm(), x.head(3).normalized()).toRotationMatrix(), in T */
+    {
+        const real x0 = (real)x[0], x1 = (real)x[1], x2 = (real)x[2];
+        const real th = SQRT_R((x0 * x0 + x1 * x1) + x2 * x2);
+        if (th > (real)0 && isfinite(th)) {
+            const real ux = x0 / th, uy = x1 / th, uz = x2 / th;
+            const real c = COS_R(th), sn = SIN_R(th), Cc = (real)1 - c;
+            T[0] = (double)(real)(c + ux * ux * Cc);       T[1] = (double)(real)(ux * uy * Cc - uz * sn); T[2] = (double)(real)(ux * uz * Cc + uy * sn);
+            T[4] = (double)(real)(uy * ux * Cc + uz * sn); T[5] = (double)(real)(c + uy * uy * Cc);       T[6] = (double)(real)(uy * uz * Cc - ux * sn);
+            T[8] = (double)(real)(uz * ux * Cc - uy * sn); T[9] = (double)(real)(uz * uy * Cc + ux * sn); T[10] = (double)(real)(c + uz * uz * Cc);
+        }
+        T[3] = (double)(real)x[3]; T[7] = (double)(real)x[4]; T[11] = (double)(real)x[5];
+        return;
+    }
+#endif
     const double th = sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
     if (th > 0.0 && isfinite(th)) {
         const double ux = x[0] / th, uy = x[1] / th, uz = x[2] / th;
@@ -1185,7 +1425,7 @@ int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *r
     mat4_identity(T_ref_mean);
     T_ref_mean[3] = M->mean[0]; T_ref_mean[7] = M->mean[1]; T_ref_mean[11] = M->mean[2];
     mat4_rigid_inverse(T_ref_mean, T_ref_mean_inv);
-    mat4_mul(T_ref_mean_inv, T_init, T_pre);
+    mat4_mul_chain(T_ref_mean_inv, T_init, T_pre);
 
     const int K = prm->knn > 1 ? prm->knn : 1;
     const size_t np = (size_t)n * K;
@@ -1229,7 +1469,7 @@ int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *r
             FN(orc_delta_T)(x, dT);
         }
         memcpy(T_prev, T_iter, sizeof T_iter);
-        mat4_mul(dT, T_iter, T_iter);
+        mat4_mul_chain(dT, T_iter, T_iter);
         res->overlap = sys[27] / ((double)n * K);
         res->residual = sys[29];
         res->trim_limit = (double)limit;
@@ -1254,8 +1494,8 @@ int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *r
         if (prm->minimizer == 1) memset(res->cov, 0, sizeof res->cov);
         else FN(covariance_k)(step, n, K, ref, ref_nrm, ids, w, dT, prm->sensor_std_dev, res->cov);
         double t1[16];
-        mat4_mul(T_iter, T_pre, t1);
-        mat4_mul(T_ref_mean, t1, T_out);
+        mat4_mul_chain(T_iter, T_pre, t1);
+        mat4_mul_chain(T_ref_mean, t1, T_out);
     } else mat4_identity(T_out);
     if (last_ids) memcpy(last_ids, ids, sizeof(int) * np);
     if (last_d2) memcpy(last_d2, d2, sizeof(real) * np);

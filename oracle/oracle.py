@@ -17,11 +17,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
-def build(force: bool = False) -> str:
+VARIANTS = ("accum_t", "tie_high", "fma", "all3")
+
+
+def build(force: bool = False, variant: str = "") -> str:
+    """variant: "" = the oracle; "accum_t" / "tie_high" / "fma" / "all3" = the sensitivity builds of icp_oracle.c's header
+    (one unverifiable assumption flipped each; used by tests/test_sensitivity.py and tools/sensitivity_envelope.py only)."""
     src = os.path.join(_HERE, "icp_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
-    return _LIB_PATH
+    name = "liboracle.so" if not variant else f"liboracle_{variant}.so"
+    path = os.path.join(_HERE, name)
+    if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, name])
+    return path
 
 
 class Result(C.Structure):
@@ -56,8 +63,10 @@ DEFAULT_CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0
 class Oracle:
     """dtype = np.float32 (PointMatcher<float>) or np.float64 (PointMatcher<double>)."""
 
-    def __init__(self, dtype=np.float32):
-        self.lib = C.CDLL(build())
+    def __init__(self, dtype=np.float32, variant=""):
+        assert variant == "" or variant in VARIANTS, variant
+        self.variant = variant
+        self.lib = C.CDLL(build(variant=variant))
         self.dtype = np.dtype(dtype)
         self.sfx = "_f32" if self.dtype == np.float32 else "_f64"
         self.real = C.c_float if self.dtype == np.float32 else C.c_double
@@ -124,6 +133,26 @@ class Oracle:
         self._f("orc_knn_brute_k")(self._p(q), C.c_int(q.shape[0]), self._p(m), C.c_int(m.shape[0]), C.c_int(k),
                                    self.real(max_dist), self._p(ids), self._p(d2))
         return ids, d2
+
+    def filter_chain(self, filters, features):
+        """the input filters that only drop points (icp_oracle.c: orc_filter_chain): filters = [(type, p0, p1, ...)] with the type
+        numbers of include/pgicp.h, features (n, frows); returns the kept input indices"""
+        f = self._a(features)
+        types = np.array([int(s[0]) for s in filters], dtype=np.int32)
+        params = np.zeros((max(1, len(filters)), 8), dtype=np.float64)
+        for k, s in enumerate(filters):
+            params[k, :len(s) - 1] = s[1:]
+        idx = np.empty(max(1, f.shape[0]), dtype=np.int32)
+        n_out = C.c_int(0)
+        st = self._f("orc_filter_chain")(C.c_int(len(filters)), self._p(types), self._p(params), self._p(f), C.c_int(f.shape[1]),
+                                         C.c_int(f.shape[0]), self._p(idx), C.byref(n_out))
+        assert st == 0, st
+        return idx[:n_out.value].copy()
+
+    def fixstep_next(self, step, start_step, end_step, step_mult):
+        f = self.lib.orc_fixstep_next
+        f.restype = C.c_double
+        return f(C.c_double(step), C.c_double(start_step), C.c_double(end_step), C.c_double(step_mult))
 
     def normal_weights(self, rd_nrm, ref_nrm, ids, max_angle, w=None):
         """[EXT] SurfaceNormalOutlierFilter{maxAngle}: multiplies its weights into w (ones by default); ids (n,) or (n,k)"""
@@ -255,7 +284,7 @@ class Oracle:
                                           C.byref(rs), self._p(ids), self._p(d2))
         return dict(status=st, overlap=ov.value, residual=rs.value, ids=ids, d2=d2)
 
-    def icp(self, reading, ref_xyz, ref_nrm, T_init, trace=False, reading_nrm=None, **kw):
+    def icp(self, reading, ref_xyz, ref_nrm, T_init, trace=False, reading_nrm=None, want_last=True, **kw):
         """reading_nrm: the reading's `normals` descriptor (only the SurfaceNormalOutlierFilter looks at it); with knn > 1
         last_ids / last_d2 are (n, knn)"""
         reading, ref_xyz, ref_nrm = self._a(reading), self._a(ref_xyz), self._a(ref_nrm)
@@ -291,16 +320,25 @@ class Oracle:
     def map_free(self, m):
         self._f("orc_map_free")(m[0])
 
-    def icp_map(self, m, reading, T_init, **kw):
+    def icp_map(self, m, reading, T_init, want_last=False, **kw):
+        """want_last: also return the last iteration's correspondences (last_ids, last_d2)"""
         reading = self._a(reading)
         prm = self.params(**kw)
         T_init = np.ascontiguousarray(T_init, dtype=np.float64)
         T_out = np.zeros((4, 4))
         res = Result()
+        k = max(1, int(prm.knn))
+        shape = (reading.shape[0],) if k == 1 else (reading.shape[0], k)
+        ids = np.empty(shape, dtype=np.int32) if want_last else None
+        d2 = np.empty(shape, dtype=self.dtype) if want_last else None
         st = self._f("orc_icp_map")(C.byref(prm), m[0], self._p(reading), C.c_int(reading.shape[0]), self._p(T_init),
-                                    self._p(T_out), C.byref(res), None, C.c_int(0), None, None)
-        return dict(status=st, T=T_out, iterations=res.iterations, converged=bool(res.converged),
-                    max_iter_reached=bool(res.max_iter_reached), overlap=res.overlap, residual=res.residual)
+                                    self._p(T_out), C.byref(res), None, C.c_int(0),
+                                    self._p(ids) if want_last else None, self._p(d2) if want_last else None)
+        out = dict(status=st, T=T_out, iterations=res.iterations, converged=bool(res.converged),
+                   max_iter_reached=bool(res.max_iter_reached), overlap=res.overlap, residual=res.residual)
+        if want_last:
+            out.update(last_ids=ids, last_d2=d2)
+        return out
 
     # -- checker (type independent) ---------------------------------------
     def checker(self, max_iters, min_rot, min_trans, smooth):

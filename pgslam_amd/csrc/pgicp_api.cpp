@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,19 +27,34 @@ using namespace pgicp;
 
 namespace {
 
+// ---- allocation accounting (pgicp_debug_alloc_stats): hipMalloc / hipFree / hipHostMalloc are the calls of this library whose
+// cost depends on the HOST (1 ms on some boxes, 45 ms on others; hipFree waits for the whole device) -- counted and timed, so
+// that a slow pass of a caller can be told apart from a slow GPU
+struct AllocStats { std::atomic<long long> n[4], ns[4]; };
+AllocStats g_alloc;
+struct AllocTimer {
+    int k; std::chrono::steady_clock::time_point t0;
+    explicit AllocTimer(int kind) : k(kind), t0(std::chrono::steady_clock::now()) {}
+    ~AllocTimer() { g_alloc.n[k]++; g_alloc.ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+inline hipError_t t_malloc(void **p, size_t bytes) { AllocTimer t(0); return hipMalloc(p, bytes); }
+inline hipError_t t_free(void *p) { AllocTimer t(1); return hipFree(p); }
+inline hipError_t t_host_malloc(void **p, size_t bytes, unsigned flags) { AllocTimer t(2); return hipHostMalloc(p, bytes, flags); }
+inline hipError_t t_host_free(void *p) { AllocTimer t(3); return hipHostFree(p); }
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        if (p) { hipError_t e = t_free(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&p, want);
+        hipError_t e = t_malloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)t_free(p); p = nullptr; cap = 0; }
     template <typename U> U *as() const { return (U *)p; }
 };
 
@@ -46,7 +62,7 @@ struct DevBuf {
 struct SharedBlock {
     char *p = nullptr;
     size_t bytes = 0;
-    ~SharedBlock() { if (p) (void)hipFree(p); }
+    ~SharedBlock() { if (p) (void)t_free(p); }
 };
 
 template <typename T>
@@ -127,6 +143,18 @@ struct pgicp_ctx {
     // problems, none at 128 or 384 -- so the records travel through pinned memory in both directions
     char *h_up = nullptr, *h_down = nullptr;
     size_t h_up_cap = 0, h_down_cap = 0;
+    // Bounce buffer (pinned): host memory the CALLER owns never reaches hipMemcpy*.  The runtime pins a pageable range of more
+    // than ~128 KB on the fly (a userptr buffer object); when the caller later frees that memory (munmap, or a trimmed heap)
+    // the MMU notifier makes the kernel driver EVICT every queue of the process for 25-40 ms.  Measured in round 5 (NOTES_r05,
+    // profiles/r05_stall_diagnosis.txt): 10-100 such pauses in the first second of a process -- until glibc's dynamic mmap
+    // threshold stops handing out mmap()ed chunks of a cloud's size -- made slam_100k's ICP phase 0.6 s on one box and 3.0 s on
+    // another.  h2d() / d2h() below: memcpy through this buffer; copy-outs are completed by stream_sync().
+    struct Bounce {
+        char *p = nullptr;
+        size_t cap = 0, off = 0;
+        struct Out { void *dst; const char *src; size_t bytes; };
+        std::vector<Out> outs;
+    } bounce;
     int *h_flag = nullptr;          // coherent pinned pair {problems done, stamp} the last kernel of an iteration writes
     int flag_stamp = 0;             // iterations enqueued so far == the value the last one's k_compact_active will store
     int *stamp_dev = nullptr;       // the same count on the device (k_compact_active advances it)
@@ -236,9 +264,19 @@ void prof_collect_locked(pgicp_ctx *c)
 {
     if (c->prof_events.empty()) return;
     (void)hipStreamSynchronize(c->stream);
+    // diagnostics (PGICP_STALL_LOG=<ms>): scopes and gaps between consecutive scopes of this context longer than that
+    static const double stall_ms = std::getenv("PGICP_STALL_LOG") ? std::atof(std::getenv("PGICP_STALL_LOG")) : 0.0;
+    const ProfEvent *prev = nullptr;
     for (auto &e : c->prof_events) {
         float ms = 0.f;
+        if (stall_ms > 0.0 && prev) {
+            float gap = 0.f;
+            if (hipEventElapsedTime(&gap, prev->b, e.a) == hipSuccess && gap > stall_ms)
+                std::fprintf(stderr, "pgicp stall: %.2f ms between scope %d and scope %d (context %p)\n", gap, prev->kid, e.kid, (void *)c);
+        }
+        prev = &e;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            if (stall_ms > 0.0 && ms > stall_ms) std::fprintf(stderr, "pgicp stall: scope %d took %.2f ms (context %p)\n", e.kid, ms, (void *)c);
             for (int kid : {e.kid, e.kid2}) {
                 if (kid < 0) continue;
                 c->prof_launches[kid] += 1;
@@ -248,9 +286,8 @@ void prof_collect_locked(pgicp_ctx *c)
                 c->prof_map_points[kid] += e.map_points;
             }
         }
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
     }
+    for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     c->prof_events.clear();
 }
 void prof_collect(pgicp_ctx *c)
@@ -327,6 +364,62 @@ void upload_consumed(pgicp_ctx *c, int mask)
         if (mask & (1 << s)) { (void)hipEventRecord(c->up[s].consumed, c->stream); c->up[s].has_consumer = true; }
 }
 
+// ---- transfers between the device and host memory the caller owns (see pgicp_ctx::Bounce) ----
+constexpr size_t kDirectCopyBytes = 64 << 10;        // below this the runtime stages the copy itself (it pins from ~128 KB on)
+static void bounce_drain(pgicp_ctx *c)               // the stream is idle: finish the copy-outs, the whole buffer is free again
+{
+    for (auto &o : c->bounce.outs) std::memcpy(o.dst, o.src, o.bytes);
+    c->bounce.outs.clear();
+    c->bounce.off = 0;
+}
+static hipError_t stream_sync(pgicp_ctx *c)
+{
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    bounce_drain(c);
+    return e;
+}
+static int bounce_take(pgicp_ctx *c, size_t bytes, char **out)
+{
+    pgicp_ctx::Bounce &B = c->bounce;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (B.off + need > B.cap) {
+        HIPC(c, stream_sync(c));                     // wrap around: what is in flight lands first
+        if (need > B.cap) {
+            if (B.p) (void)t_host_free(B.p);
+            B.p = nullptr; B.cap = 0;
+            const size_t want = need + need / 4 + (1u << 20);
+            HIPC(c, t_host_malloc((void **)&B.p, want, hipHostMallocDefault));
+            B.cap = want;
+        }
+    }
+    *out = B.p + B.off;
+    B.off += need;
+    return PGICP_OK;
+}
+// host -> device on the context's stream; `src` may be reused as soon as the call returns
+static int h2d(pgicp_ctx *c, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return PGICP_OK;
+    if (bytes < kDirectCopyBytes) { HIPC(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream)); return PGICP_OK; }
+    char *b = nullptr;
+    { const int st = bounce_take(c, bytes, &b); if (st) return st; }
+    std::memcpy(b, src_host, bytes);
+    HIPC(c, hipMemcpyAsync(dst_dev, b, bytes, hipMemcpyHostToDevice, c->stream));
+    return PGICP_OK;
+}
+// device -> host on the context's stream; `dst` holds the data after the next stream_sync(c)
+static int d2h(pgicp_ctx *c, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0) return PGICP_OK;
+    if (bytes < kDirectCopyBytes) { HIPC(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream)); return PGICP_OK; }
+    char *b = nullptr;
+    { const int st = bounce_take(c, bytes, &b); if (st) return st; }
+    HIPC(c, hipMemcpyAsync(b, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    c->bounce.outs.push_back({dst_host, b, bytes});
+    return PGICP_OK;
+}
+#define XFER(ctx, call) do { const int st_ = (call); if (st_) return st_; } while (0)
+
 // Every entry point that may be handed a device pointer of pgicp_upload_* declares one of these: to_device() makes the
 // compute stream wait for the upload (on the device) and notes the set; when the call returns -- its kernels queued, most
 // calls synchronised -- the set is marked consumed, so that the next upload into it waits for them.
@@ -348,7 +441,7 @@ int to_device(pgicp_ctx *c, const T *p, int stride, int n, int mem, DevBuf &stag
         return PGICP_OK;
     }
     const size_t bytes = sizeof(T) * ((size_t)(n - 1) * stride + 3);
-    HIPC(c, hipMemcpyAsync((char *)stage.p + stage_off_bytes, p, bytes, hipMemcpyHostToDevice, c->stream));
+    XFER(c, h2d(c, (char *)stage.p + stage_off_bytes, p, bytes));
     *out = (const T *)((char *)stage.p + stage_off_bytes);
     return PGICP_OK;
 }
@@ -356,10 +449,10 @@ int to_device(pgicp_ctx *c, const T *p, int stride, int n, int mem, DevBuf &stag
 static int pinned_ensure(pgicp_ctx *c, char **buf, size_t *cap, size_t bytes)
 {
     if (bytes <= *cap) return PGICP_OK;
-    HIPC(c, hipStreamSynchronize(c->stream));                 // a transfer out of / into the old buffer may still be queued
-    if (*buf) (void)hipHostFree(*buf);
+    HIPC(c, stream_sync(c));                 // a transfer out of / into the old buffer may still be queued
+    if (*buf) (void)t_host_free(*buf);
     *buf = nullptr; *cap = 0;
-    HIPC(c, hipHostMalloc((void **)buf, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+    HIPC(c, t_host_malloc((void **)buf, bytes + bytes / 4 + 4096, hipHostMallocDefault));
     *cap = bytes + bytes / 4 + 4096;
     return PGICP_OK;
 }
@@ -377,7 +470,7 @@ int sync_maps_table(pgicp_ctx *c)
     const int n = (int)S.maps.size();
     if (n == 0) return PGICP_OK;
     if (n > S.d_maps_cap) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_sync(c));
         HIPC(c, S.d_maps.ensure(sizeof(MapDev<T>) * (size_t)(n + 16)));
         S.d_maps_cap = n + 16;
     }
@@ -396,8 +489,8 @@ int sync_maps_table(pgicp_ctx *c)
         h[i].first = m.first;
         h[i].nsx = (m.g.nx + 7) >> 3; h[i].nsy = (m.g.ny + 7) >> 3; h[i].nsz = (m.g.nz + 7) >> 3;
     }
-    HIPC(c, hipMemcpyAsync(S.d_maps.p, h.data(), sizeof(MapDev<T>) * n, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));   // h goes out of scope
+    XFER(c, h2d(c, S.d_maps.p, h.data(), sizeof(MapDev<T>) * n));
+    HIPC(c, stream_sync(c));   // h goes out of scope
     return PGICP_OK;
 }
 
@@ -451,9 +544,9 @@ int block_alloc(pgicp_ctx *c, size_t bytes, char **out, size_t *got)
         }
     }
     const size_t padded = bytes + bytes / 8;
-    if (hipMalloc((void **)out, padded) == hipSuccess) { *got = padded; return PGICP_OK; }
+    if (t_malloc((void **)out, padded) == hipSuccess) { *got = padded; return PGICP_OK; }
     (void)hipGetLastError();
-    HIPC(c, hipMalloc((void **)out, bytes));
+    HIPC(c, t_malloc((void **)out, bytes));
     *got = bytes;
     return PGICP_OK;
 }
@@ -477,7 +570,7 @@ void block_release(pgicp_ctx *c, char *p, size_t bytes)
             return;
         }
     }
-    (void)hipFree(p);
+    (void)t_free(p);
 }
 
 // Work on the context stream that uses the map is ordered before whatever reuses the block (block_release records an
@@ -550,14 +643,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     }
     HIPC(c, c->stats.ensure(sizeof(unsigned long long) * 9 * (size_t)n));
     HIPC(c, c->bdesc.ensure(sizeof(BuildDesc<T>) * (size_t)n));
-    HIPC(c, hipMemcpyAsync(c->stats.p, h_stats.data(), sizeof(unsigned long long) * 9 * n, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
+    XFER(c, h2d(c, c->stats.p, h_stats.data(), sizeof(unsigned long long) * 9 * n));
+    XFER(c, h2d(c, c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n));
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, max_m, n);
         launch_centroid_bbox_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, max_m, c->stats.as<unsigned long long>());
     }
-    HIPC(c, hipMemcpyAsync(h_stats.data(), c->stats.p, sizeof(unsigned long long) * 9 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    XFER(c, d2h(c, h_stats.data(), c->stats.p, sizeof(unsigned long long) * 9 * n));
+    HIPC(c, stream_sync(c));
 
     // ---- phase 2: grids; every cloud gets its slice of ONE allocation and ONE set of build launches ----
     std::vector<MapHost<T>> Ms(n);
@@ -679,14 +772,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         M.sc_ext = g_ext + 6 * d.sbase;
         M.occ = g_occ + d.obase;
     }
-    HIPC(c, hipMemcpyAsync(c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n, hipMemcpyHostToDevice, c->stream));
+    XFER(c, h2d(c, c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n));
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
         launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_b, tot_s, max_m, max_cells, max_bins, max_nsc, max_blocks, kx == 4 ? 1 : 0, c->tmp_a.as<int>(),
                                    c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), c->tmp_w.as<unsigned long long>(), c->tmp_p.as<V4>(), c->tmp_n.as<V4>(), g_pts, g_nrm,
                                    g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o, g_ext);
     }
-    HIPC(c, hipStreamSynchronize(c->stream));          // `descs` (host) feeds an async copy
+    HIPC(c, stream_sync(c));          // `descs` (host) feeds an async copy
     HIPC(c, hipGetLastError());
     // ---- phase 3: register ----
     for (int k = 0; k < n; k++) {
@@ -838,11 +931,11 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     { const int pst = pinned_ensure(c, &c->h_up, &c->h_up_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
     std::memcpy(c->h_up, hp.data(), sizeof(ProblemDev) * (size_t)P);
     HIPC(c, hipMemcpyAsync(c->probs.p, c->h_up, sizeof(ProblemDev) * P, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipMemcpyAsync(c->src.p, hs.data(), sizeof(SrcDesc) * P, hipMemcpyHostToDevice, c->stream));
+    XFER(c, h2d(c, c->src.p, hs.data(), sizeof(SrcDesc) * P));
     std::vector<int> &ident = c->h_ident;
     ident.resize(P);
     std::iota(ident.begin(), ident.end(), 0);
-    HIPC(c, hipMemcpyAsync(c->active.p, ident.data(), sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
+    XFER(c, h2d(c, c->active.p, ident.data(), sizeof(int) * P));
     HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
     c->counters_clean = 1;
     c->seg_clean = 0;               // a new batch: its first matcher launch clears the segmented counters itself
@@ -862,7 +955,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
     // (no synchronisation here: hp is the caller's, hs / ident are context members, and every caller ends with
     // a stream synchronisation before it returns -- a wait at this point idles the GPU for ~25 us per scan)
     if (const char *e = std::getenv("PGICP_TRACE_ORIG")) {     // diagnostics build: narrate one query of problem 0
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_sync(c));
         std::vector<int> ord(hp[0].n);
         (void)hipMemcpy(ord.data(), c->order.as<int>(), sizeof(int) * ord.size(), hipMemcpyDeviceToHost);
         const int want = std::atoi(e);
@@ -937,7 +1030,7 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
             static const bool each_pass = std::getenv("PGICP_PHASE_EACH_PASS") != nullptr;     // diagnostics builds only
             if (each_pass) {
                 unsigned long long ph[48];
-                (void)hipStreamSynchronize(c->stream);
+                (void)stream_sync(c);
                 if (knn_phase_read(ph, 1) == 0)
                     std::fprintf(stderr, "    pass (seeded %d): wave-per-query kernel entries=%llu, longest wave %llu, longest entry %llu cycles; per entry: walk %.0f\n",
                                  use_seed, ph[46], ph[44], ph[45], (double)ph[36] / (double)std::max<unsigned long long>(1ULL, ph[46]));
@@ -1040,7 +1133,7 @@ static int wait_iteration_flag(pgicp_ctx *c)
             std::this_thread::yield();
         }
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) { fail(c, PGICP_ERR_HIP, "pgicp: stream synchronisation failed"); return -1; }
+    if (stream_sync(c) != hipSuccess) { fail(c, PGICP_ERR_HIP, "pgicp: stream synchronisation failed"); return -1; }
     if (__atomic_load_n(&c->h_flag[1], __ATOMIC_ACQUIRE) != want) {
         // a launch failed somewhere: the device's stamp and the host's are out of step.  Take the device's, so that the
         // context's NEXT call can work again instead of timing out for ever.
@@ -1114,7 +1207,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     std::vector<double> cs((size_t)P * kCovTerms);
     { const int pst = pinned_ensure(c, &c->h_down, &c->h_down_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
     HIPC(c, hipMemcpyAsync(c->h_down, c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(cs.data(), c->sums.p, sizeof(double) * cs.size(), hipMemcpyDeviceToHost, c->stream));
+    XFER(c, d2h(c, cs.data(), c->sums.p, sizeof(double) * cs.size()));
     std::vector<double> rsys;
     if (residual || res_ratio || res_status) {
         // The residual check of the result: one more pass of the chain WITHOUT a solve, with the final transform (it is in
@@ -1122,16 +1215,16 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         // iteration's correspondences, which the final increment (below the convergence thresholds) hardly moves: as a
         // separate, unseeded chain it cost a fifth of a loop-closure batch.  Seeds are candidates only: the matches are exact.
         launch_reopen(c->stream, c->probs.as<ProblemDev>(), P);
-        HIPC(c, hipMemcpyAsync(c->active.p, c->h_ident.data(), sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
+        XFER(c, h2d(c, c->active.p, c->h_ident.data(), sizeof(int) * P));
         c->prof_next_m = total_m;
         one_iteration<T>(c, L, ch, false, L.total, P, 1);
         HIPC(c, c->sums2.ensure(sizeof(double) * (size_t)P * kSys));
         launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(L.max_pairs()), kSys, c->probs.as<ProblemDev>(), 0,
                             c->sums2.as<double>(), P);
         rsys.resize((size_t)P * kSys);
-        HIPC(c, hipMemcpyAsync(rsys.data(), c->sums2.p, sizeof(double) * rsys.size(), hipMemcpyDeviceToHost, c->stream));
+        XFER(c, d2h(c, rsys.data(), c->sums2.p, sizeof(double) * rsys.size()));
     }
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     std::memcpy(hp.data(), c->h_down, sizeof(ProblemDev) * (size_t)P);
     for (int p = 0; p < P && !rsys.empty(); p++) {
@@ -1206,7 +1299,7 @@ int icp_pair(pgicp_ctx *c, const T *reading, int rd_stride, int n, const T *ref_
     pr.map_id = id; pr.reading = reading; pr.stride = rd_stride; pr.n = n; pr.mem = mem;
     std::memcpy(pr.T_init, T_init, sizeof pr.T_init);
     st = align_batch<T>(c, 1, &pr, T_out, stats);
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_sync(c);
     if (MapHost<T> *mh = get_map<T>(c, id)) free_map(c, *mh);
     return st;
 }
@@ -1274,10 +1367,14 @@ int match(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, int mem
     HIPC(c, c->tmp_b.ensure(sizeof(T) * np));
     launch_unpermute<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), c->order.as<int>(),
                         S.slot.template as<int>(), S.d2.template as<T>(), n, L.knn, c->tmp_a.as<int>(), c->tmp_b.as<T>());
-    const hipMemcpyKind k = mem == PGICP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * np, k, c->stream));
-    HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * np, k, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    if (mem == PGICP_DEVICE) {
+        HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * np, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * np, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        XFER(c, d2h(c, ids, c->tmp_a.p, sizeof(int) * np));
+        XFER(c, d2h(c, dist2, c->tmp_b.p, sizeof(T) * np));
+    }
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     return PGICP_OK;
 }
@@ -1310,10 +1407,10 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
     launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(L.max_pairs()), kSys, c->probs.as<ProblemDev>(), 0,
                         c->sums.as<double>(), P);
     std::vector<double> sys((size_t)P * kSys);
-    HIPC(c, hipMemcpyAsync(sys.data(), c->sums.p, sizeof(double) * sys.size(), hipMemcpyDeviceToHost, c->stream));
+    XFER(c, d2h(c, sys.data(), c->sums.p, sizeof(double) * sys.size()));
     { const int pst = pinned_ensure(c, &c->h_down, &c->h_down_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
     HIPC(c, hipMemcpyAsync(c->h_down, c->probs.p, sizeof(ProblemDev) * P, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     std::memcpy(hp.data(), c->h_down, sizeof(ProblemDev) * (size_t)P);
     int worst = PGICP_OK;
@@ -1352,7 +1449,7 @@ int outlier_weights(pgicp_ctx *c, const T *dist2, int n, int mem, T *weights, T 
     if (mem == PGICP_HOST) {
         HIPC(c, c->tmp_a.ensure(sizeof(T) * (size_t)n));
         HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)n));
-        HIPC(c, hipMemcpyAsync(c->tmp_a.p, dist2, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        XFER(c, h2d(c, c->tmp_a.p, dist2, sizeof(T) * (size_t)n));
         d_d2 = c->tmp_a.as<T>();
         d_w = weights ? c->tmp_b.as<T>() : nullptr;
     }
@@ -1362,10 +1459,10 @@ int outlier_weights(pgicp_ctx *c, const T *dist2, int n, int mem, T *weights, T 
         launch_trim_raw<T>(c->stream, d_d2, n, (T)c->prm.trim_ratio, (T)c->prm.quantile_scale, c->small.as<T>(), d_w);
     }
     T h[2];
-    HIPC(c, hipMemcpyAsync(h, c->small.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    XFER(c, d2h(c, h, c->small.p, sizeof h));
     if (mem == PGICP_HOST && weights)
-        HIPC(c, hipMemcpyAsync(weights, d_w, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+        XFER(c, d2h(c, weights, d_w, sizeof(T) * (size_t)n));
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     if (limit) *limit = h[0];
     if (n_finite) *n_finite = (int)h[1];
@@ -1393,8 +1490,8 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         if (st) return st;
         HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)n * K));
         HIPC(c, c->tmp_b.ensure(sizeof(T) * (size_t)n * K));
-        HIPC(c, hipMemcpyAsync(c->tmp_a.p, ids, sizeof(int) * (size_t)n * K, hipMemcpyHostToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(c->tmp_b.p, w, sizeof(T) * (size_t)n * K, hipMemcpyHostToDevice, c->stream));
+        XFER(c, h2d(c, c->tmp_a.p, ids, sizeof(int) * (size_t)n * K));
+        XFER(c, h2d(c, c->tmp_b.p, w, sizeof(T) * (size_t)n * K));
         d_ids = c->tmp_a.as<int>();
         d_w = c->tmp_b.as<T>();
     }
@@ -1411,8 +1508,8 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
                               M->mean, c->partials.as<double>(), c->sums.as<double>(), c->prm.error_minimizer);
     }
     double sys[kSys];
-    HIPC(c, hipMemcpyAsync(sys, c->sums.p, sizeof sys, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    XFER(c, d2h(c, sys, c->sums.p, sizeof sys));
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     if (sys_out) std::memcpy(sys_out, sys, sizeof sys);
     if (!(sys[28] > 0.0)) return fail(c, PGICP_ERR_NO_MATCH, "no point to minimize (ConvergenceError)");
@@ -1450,7 +1547,7 @@ int transform(pgicp_ctx *c, const double *T16, const T *in, int in_stride, T *ou
     if (mem == PGICP_DEVICE) {
         use.touch(in);
         launch_transform<T>(c->stream, in, in_stride, out, out_stride, n, T16, rotate_only);
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_sync(c));
         return PGICP_OK;
     }
     const size_t bi = staged_bytes(sizeof(T), in_stride, n), bo = staged_bytes(sizeof(T), out_stride, n);
@@ -1462,8 +1559,8 @@ int transform(pgicp_ctx *c, const double *T16, const T *in, int in_stride, T *ou
         int st0 = to_device<T>(c, in, in_stride, n, mem, S.staging, 0, &d_io);
         if (st0) return st0;
         launch_transform<T>(c->stream, d_io, in_stride, const_cast<T *>(d_io), out_stride, n, T16, rotate_only);
-        HIPC(c, hipMemcpyAsync(out, d_io, sizeof(T) * ((size_t)(n - 1) * out_stride + 3), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        XFER(c, d2h(c, out, d_io, sizeof(T) * ((size_t)(n - 1) * out_stride + 3)));
+        HIPC(c, stream_sync(c));
         HIPC(c, hipGetLastError());
         return PGICP_OK;
     }
@@ -1472,10 +1569,10 @@ int transform(pgicp_ctx *c, const double *T16, const T *in, int in_stride, T *ou
     int st = to_device<T>(c, in, in_stride, n, mem, S.staging, 0, &d_in);
     if (st) return st;
     // keep the caller's other rows (e.g. the homogeneous 1) when out is strided
-    HIPC(c, hipMemcpyAsync(S.stage_aux.p, out, sizeof(T) * ((size_t)(n - 1) * out_stride + 3), hipMemcpyHostToDevice, c->stream));
+    XFER(c, h2d(c, S.stage_aux.p, out, sizeof(T) * ((size_t)(n - 1) * out_stride + 3)));
     launch_transform<T>(c->stream, d_in, in_stride, S.stage_aux.template as<T>(), out_stride, n, T16, rotate_only);
-    HIPC(c, hipMemcpyAsync(out, S.stage_aux.p, sizeof(T) * ((size_t)(n - 1) * out_stride + 3), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    XFER(c, d2h(c, out, S.stage_aux.p, sizeof(T) * ((size_t)(n - 1) * out_stride + 3)));
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     return PGICP_OK;
 }
@@ -1504,8 +1601,8 @@ int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const 
         HIPC(c, S.stage_aux.ensure(((ob + 255) & ~(size_t)255) + onb + 256));
         d_ox = S.stage_aux.template as<T>();
         d_on = out_nrm ? (T *)((char *)S.stage_aux.p + ((ob + 255) & ~(size_t)255)) : nullptr;
-        HIPC(c, hipMemcpyAsync(d_ox, out_xyz, ob, hipMemcpyHostToDevice, c->stream));
-        if (out_nrm) HIPC(c, hipMemcpyAsync(d_on, out_nrm, onb, hipMemcpyHostToDevice, c->stream));
+        XFER(c, h2d(c, d_ox, out_xyz, ob));
+        if (out_nrm) XFER(c, h2d(c, d_on, out_nrm, onb));
     }
     size_t soff = 0;
     long long off = 0;
@@ -1528,10 +1625,10 @@ int build_local_map(pgicp_ctx *c, int n_kf, const T *const *xyz, const T *const 
         off += counts[k];
     }
     if (mem == PGICP_HOST) {
-        HIPC(c, hipMemcpyAsync(out_xyz, d_ox, ob, hipMemcpyDeviceToHost, c->stream));
-        if (out_nrm) HIPC(c, hipMemcpyAsync(out_nrm, d_on, onb, hipMemcpyDeviceToHost, c->stream));
+        XFER(c, d2h(c, out_xyz, d_ox, ob));
+        if (out_nrm) XFER(c, d2h(c, out_nrm, d_on, onb));
     }
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     return PGICP_OK;
 }
@@ -1559,7 +1656,7 @@ int surface_normals(pgicp_ctx *c, const T *xyz, int stride, int n, int mem, int 
         d_eig = out_eig ? (T *)(base + up(b_nrm)) : nullptr;
         d_ids = out_ids ? (int32_t *)(base + up(b_nrm) + up(b_eig)) : nullptr;
         d_d2 = out_d2 ? (T *)(base + up(b_nrm) + up(b_eig) + up(b_ids)) : nullptr;
-        if (out_stride > 3) HIPC(c, hipMemcpyAsync(d_nrm, out_nrm, b_nrm, hipMemcpyHostToDevice, c->stream));   // keep the caller's padding
+        if (out_stride > 3) XFER(c, h2d(c, d_nrm, out_nrm, b_nrm));   // keep the caller's padding
     }
     {
         ProfScope ps(c, PGICP_PROF_NORMALS, n);
@@ -1568,12 +1665,12 @@ int surface_normals(pgicp_ctx *c, const T *xyz, int stride, int n, int mem, int 
             return fail(c, PGICP_ERR_ARG, "pgicp_surface_normals: knn > 32");
     }
     if (mem == PGICP_HOST) {
-        HIPC(c, hipMemcpyAsync(out_nrm, d_nrm, b_nrm, hipMemcpyDeviceToHost, c->stream));
-        if (out_eig) HIPC(c, hipMemcpyAsync(out_eig, d_eig, b_eig, hipMemcpyDeviceToHost, c->stream));
-        if (out_ids) HIPC(c, hipMemcpyAsync(out_ids, d_ids, b_ids, hipMemcpyDeviceToHost, c->stream));
-        if (out_d2) HIPC(c, hipMemcpyAsync(out_d2, d_d2, b_d2, hipMemcpyDeviceToHost, c->stream));
+        XFER(c, d2h(c, out_nrm, d_nrm, b_nrm));
+        if (out_eig) XFER(c, d2h(c, out_eig, d_eig, b_eig));
+        if (out_ids) XFER(c, d2h(c, out_ids, d_ids, b_ids));
+        if (out_d2) XFER(c, d2h(c, out_d2, d_d2, b_d2));
     }
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     if (MapHost<T> *mh = get_map<T>(c, id)) free_map(c, *mh);
     return PGICP_OK;
@@ -1590,10 +1687,22 @@ int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int
     int types[PGICP_MAX_FILTERS];
     double params[8 * PGICP_MAX_FILTERS];
     for (int k = 0; k < nf; k++) {
-        if (f[k].type < PGICP_FILTER_IDENTITY || f[k].type > PGICP_FILTER_RANDOM_SAMPLING) return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: unknown filter type");
-        if (f[k].type == PGICP_FILTER_FIX_STEP && !(f[k].p[0] >= 1.0)) return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: FixStep needs step >= 1");
+        if (f[k].type < PGICP_FILTER_IDENTITY || f[k].type > PGICP_FILTER_MAX_POINT_COUNT) return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: unknown filter type");
+        if (f[k].type == PGICP_FILTER_FIX_STEP && !(f[k].p[0] >= 1.0 && f[k].p[0] <= 2147483647.0))
+            return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: FixStep needs 1 <= step <= INT_MAX");
+        if ((f[k].type == PGICP_FILTER_MAX_DIST || f[k].type == PGICP_FILTER_MIN_DIST) &&
+            !(f[k].p[1] == 0.0 || f[k].p[1] == 1.0 || f[k].p[1] == 2.0 || f[k].p[1] == 3.0))
+            return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: Min/MaxDist p[1] must be dim + 1 in {0 (radius), 1, 2, 3}");
+        if (f[k].type == PGICP_FILTER_RANDOM_SAMPLING && !(f[k].p[0] >= 0.0 && f[k].p[0] <= 1.0))
+            return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: RandomSampling needs 0 <= prob <= 1");
+        if ((f[k].type == PGICP_FILTER_RANDOM_SAMPLING || f[k].type == PGICP_FILTER_MAX_POINT_COUNT) &&
+            !(f[k].p[1] >= 0.0 && f[k].p[1] < 9007199254740992.0 && f[k].p[1] == std::floor(f[k].p[1])))
+            return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: the sampler's seed must be an integer in [0, 2^53)");
+        if (f[k].type == PGICP_FILTER_MAX_POINT_COUNT && !(f[k].p[0] >= 1.0 && f[k].p[0] <= 2147483647.0))
+            return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: MaxPointCount needs 1 <= maxCount <= INT_MAX");
         types[k] = f[k].type;
         std::memcpy(params + 8 * k, f[k].p, sizeof f[k].p);
+        if (f[k].type == PGICP_FILTER_MAX_POINT_COUNT) params[8 * k + 2] = sizeof(T) == 4 ? 1.0 : 0.0;   // prob = T(maxCount) / T(N)
     }
     HIPC(c, hipSetDevice(c->device));
     pgicp_ctx::FilterSet &S = c->fset[c->fset_next];
@@ -1614,14 +1723,14 @@ int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int
     HIPC(c, S.bsum.ensure(sizeof(int) * ((size_t)n / kScanChunkHost + 4)));
     const bool want_idx = kept_idx || ident;
     if (want_idx) HIPC(c, S.idx.ensure(sizeof(int) * (size_t)n));
-    HIPC(c, hipMemcpyAsync(S.in_f.p, feat, bf, hipMemcpyHostToDevice, c->stream));
-    if (dev_desc) HIPC(c, hipMemcpyAsync(S.in_d.p, desc, bd, hipMemcpyHostToDevice, c->stream));
+    XFER(c, h2d(c, S.in_f.p, feat, bf));
+    if (dev_desc) XFER(c, h2d(c, S.in_d.p, desc, bd));
     launch_filter_cloud<T>(c->stream, S.in_f.as<T>(), frows, frows, dev_desc ? S.in_d.as<T>() : nullptr, drows, n, nf, types, params,
                            ident ? nullptr : T16, rot0, rot1, S.keep.as<int>(), S.pos.as<int>(), S.bsum.as<int>(), S.out_f.as<T>(),
                            dev_desc ? S.out_d.as<T>() : nullptr, want_idx ? S.idx.as<int>() : nullptr);
     int kept = 0;
-    HIPC(c, hipMemcpyAsync(&kept, S.pos.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    XFER(c, d2h(c, &kept, S.pos.as<int>() + n, sizeof(int)));
+    HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     *n_out = kept;
     if (ident) {
@@ -1630,7 +1739,7 @@ int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int
         if (kept < n || kept_idx) {
             int *dst = kept_idx;
             if (!dst) { hidx.resize((size_t)std::max(kept, 1)); dst = hidx.data(); }
-            if (kept > 0) HIPC(c, hipMemcpy(dst, S.idx.p, sizeof(int) * (size_t)kept, hipMemcpyDeviceToHost));
+            if (kept > 0) { XFER(c, d2h(c, dst, S.idx.p, sizeof(int) * (size_t)kept)); HIPC(c, stream_sync(c)); }
             idx = dst;
         }
         if (kept == n) {
@@ -1644,10 +1753,10 @@ int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int
             }
         }
     } else if (kept > 0) {
-        HIPC(c, hipMemcpyAsync(out_feat, S.out_f.p, sizeof(T) * (size_t)frows * kept, hipMemcpyDeviceToHost, c->stream));
-        if (desc) HIPC(c, hipMemcpyAsync(out_desc, S.out_d.p, sizeof(T) * (size_t)drows * kept, hipMemcpyDeviceToHost, c->stream));
-        if (kept_idx) HIPC(c, hipMemcpyAsync(kept_idx, S.idx.p, sizeof(int) * (size_t)kept, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        XFER(c, d2h(c, out_feat, S.out_f.p, sizeof(T) * (size_t)frows * kept));
+        if (desc) XFER(c, d2h(c, out_desc, S.out_d.p, sizeof(T) * (size_t)drows * kept));
+        if (kept_idx) XFER(c, d2h(c, kept_idx, S.idx.p, sizeof(int) * (size_t)kept));
+        HIPC(c, stream_sync(c));
     }
     if (dev_feat) *dev_feat = S.out_f.as<T>();
     return PGICP_OK;
@@ -1682,9 +1791,9 @@ int debug_last_matches(pgicp_ctx *c, int problem, int32_t *ids, T *dist2)
     // `order` holds positions in the batch-wide sorted arrays: point the kernel at this problem's slice
     launch_unpermute<T>(c->stream, S.d_maps.template as<MapDev<T>>(), D.map, c->order.as<int>() + D.off,
                         S.slot.template as<int>() + D.off * D.knn, S.d2.template as<T>() + D.off * D.knn, D.n, D.knn, c->tmp_a.as<int>(), c->tmp_b.as<T>());
-    HIPC(c, hipMemcpyAsync(ids, c->tmp_a.p, sizeof(int) * np, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(dist2, c->tmp_b.p, sizeof(T) * np, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    XFER(c, d2h(c, ids, c->tmp_a.p, sizeof(int) * np));
+    XFER(c, d2h(c, dist2, c->tmp_b.p, sizeof(T) * np));
+    HIPC(c, stream_sync(c));
     return PGICP_OK;
 }
 
@@ -1729,14 +1838,14 @@ int upload(pgicp_ctx *c, int n, const T *const *host, const int *stride, const i
     if (U.pending) HIPC(c, hipEventSynchronize(U.uploaded));
     if (total > U.dev.cap) {
         // growing means freeing (hipFree waits for the device): nothing may still read the old block
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_sync(c));
         HIPC(c, hipStreamSynchronize(c->copy_stream));
         HIPC(c, U.dev.ensure(total));
     }
     if (mem == PGICP_HOST && total > U.pin_cap) {
-        if (U.pin) HIPC(c, hipHostFree(U.pin));
+        if (U.pin) HIPC(c, t_host_free(U.pin));
         U.pin = nullptr; U.pin_cap = 0;
-        HIPC(c, hipHostMalloc(&U.pin, total + total / 4, hipHostMallocDefault));
+        HIPC(c, t_host_malloc(&U.pin, total + total / 4, hipHostMallocDefault));
         U.pin_cap = total + total / 4;
     }
     size_t off = 0;
@@ -1848,7 +1957,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+              t_host_malloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) == hipSuccess;
     for (int s = 0; ok && s < 2; s++)
         ok = hipEventCreateWithFlags(&c->up[s].uploaded, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->up[s].consumed, hipEventDisableTiming) == hipSuccess;
@@ -1859,17 +1968,17 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     }
     // the polled iteration flag wants fine-grained (coherent) pinned memory; plain pinned memory also works with the
     // stream wait the poll falls back to, so a runtime that refuses the flags is not fatal
-    if (hipHostMalloc((void **)&c->h_flag, 64 * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    if (t_host_malloc((void **)&c->h_flag, 64 * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         (void)hipGetLastError();
         c->poll_us = 0;
-        if (hipHostMalloc((void **)&c->h_flag, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        if (t_host_malloc((void **)&c->h_flag, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
             c->h_flag = nullptr;
             pgicp_ctx_destroy(c);               // (streams, events, pinned memory and the device pool's context count)
             return PGICP_ERR_HIP;
         }
     }
     c->h_flag[0] = 0; c->h_flag[1] = 0;
-    if (hipMalloc((void **)&c->stamp_dev, 256) != hipSuccess || hipMemset(c->stamp_dev, 0, 256) != hipSuccess) {
+    if (t_malloc((void **)&c->stamp_dev, 256) != hipSuccess || hipMemset(c->stamp_dev, 0, 256) != hipSuccess) {
         pgicp_ctx_destroy(c);
         return PGICP_ERR_HIP;
     }
@@ -1884,7 +1993,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)stream_sync(c);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     prof_collect(c);
     {
@@ -1898,7 +2007,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     }
     for (int s = 0; s < 2; s++) {
         c->up[s].dev.release();
-        if (c->up[s].pin) (void)hipHostFree(c->up[s].pin);
+        if (c->up[s].pin) (void)t_host_free(c->up[s].pin);
         if (c->up[s].uploaded) (void)hipEventDestroy(c->up[s].uploaded);
         if (c->up[s].consumed) (void)hipEventDestroy(c->up[s].consumed);
     }
@@ -1909,7 +2018,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
         DevicePool &dp = pool_of(c->device);
         std::lock_guard<std::mutex> lock(dp.m);
         if (--dp.contexts <= 0) {                      // the device's last context: give the pooled blocks back
-            for (auto &kv : dp.blocks) { if (kv.second.released) (void)hipEventDestroy(kv.second.released); (void)hipFree(kv.second.p); }
+            for (auto &kv : dp.blocks) { if (kv.second.released) (void)hipEventDestroy(kv.second.released); (void)t_free(kv.second.p); }
             dp.blocks.clear();
             dp.bytes = 0;
             dp.contexts = 0;
@@ -1921,16 +2030,17 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->f32.nrm_pre, &c->f32.nrm_sorted, &c->f64.nrm_pre, &c->f64.nrm_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
                       &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->sel_tables, &c->queue, &c->f32.none_r, &c->f64.none_r})
         b->release();
-    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    if (c->h_up) (void)hipHostFree(c->h_up);
-    if (c->h_down) (void)hipHostFree(c->h_down);
-    if (c->h_flag) (void)hipHostFree(c->h_flag);
+    if (c->h_pinned) (void)t_host_free(c->h_pinned);
+    if (c->h_up) (void)t_host_free(c->h_up);
+    if (c->h_down) (void)t_host_free(c->h_down);
+    if (c->h_flag) (void)t_host_free(c->h_flag);
+    if (c->bounce.p) (void)t_host_free(c->bounce.p);
     if (std::getenv("PGICP_GRAPH_DEBUG"))
         std::fprintf(stderr, "pgicp context %p: %lld iteration graphs captured, %lld replayed, %d failures\n", (void *)c, c->graph_captures, c->graph_launches, c->graph_failures);
     for (auto &fs : c->fset)
         for (DevBuf *b : {&fs.in_f, &fs.in_d, &fs.keep, &fs.pos, &fs.bsum, &fs.out_f, &fs.out_d, &fs.idx}) b->release();
     for (auto &g : c->iter_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (c->stamp_dev) (void)hipFree(c->stamp_dev);
+    if (c->stamp_dev) (void)t_free(c->stamp_dev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1947,13 +2057,13 @@ int pgicp_host_alloc(pgicp_ctx *c, size_t bytes, void **out)
 {
     if (!c || !out || bytes == 0) return fail(c, PGICP_ERR_ARG, "pgicp_host_alloc: bad argument");
     HIPC(c, hipSetDevice(c->device));
-    HIPC(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    HIPC(c, t_host_malloc(out, bytes, hipHostMallocDefault));
     return PGICP_OK;
 }
 int pgicp_host_free(pgicp_ctx *c, void *p)
 {
     if (!c) return PGICP_ERR_ARG;
-    if (p) HIPC(c, hipHostFree(p));
+    if (p) HIPC(c, t_host_free(p));
     return PGICP_OK;
 }
 
@@ -1961,16 +2071,16 @@ int pgicp_device_alloc(pgicp_ctx *c, size_t bytes, void **out)
 {
     if (!c || !out || bytes == 0) return fail(c, PGICP_ERR_ARG, "pgicp_device_alloc: bad argument");
     HIPC(c, hipSetDevice(c->device));
-    if (hipMalloc(out, bytes) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(c, PGICP_ERR_HIP, "pgicp_device_alloc: out of device memory"); }
+    if (t_malloc(out, bytes) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(c, PGICP_ERR_HIP, "pgicp_device_alloc: out of device memory"); }
     return PGICP_OK;
 }
 int pgicp_device_free(pgicp_ctx *c, void *p)
 {
     // (the context may be NULL: an owner that outlives its context -- a keyframe freed at process exit -- still frees)
     if (!p) return PGICP_OK;
-    if (!c) return hipFree(p) == hipSuccess ? PGICP_OK : PGICP_ERR_HIP;
+    if (!c) return t_free(p) == hipSuccess ? PGICP_OK : PGICP_ERR_HIP;
     HIPC(c, hipSetDevice(c->device));
-    HIPC(c, hipFree(p));
+    HIPC(c, t_free(p));
     return PGICP_OK;
 }
 int pgicp_device_copy(pgicp_ctx *c, void *dst, const void *src, size_t bytes, int kind)
@@ -1980,8 +2090,10 @@ int pgicp_device_copy(pgicp_ctx *c, void *dst, const void *src, size_t bytes, in
     if (!bytes) return PGICP_OK;
     HIPC(c, hipSetDevice(c->device));
     const hipMemcpyKind k = kind == PGICP_COPY_TO_DEVICE ? hipMemcpyHostToDevice : kind == PGICP_COPY_FROM_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    HIPC(c, hipMemcpyAsync(dst, src, bytes, k, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    if (kind == PGICP_COPY_TO_DEVICE) XFER(c, h2d(c, dst, src, bytes));
+    else if (kind == PGICP_COPY_FROM_DEVICE) XFER(c, d2h(c, dst, src, bytes));
+    else HIPC(c, hipMemcpyAsync(dst, src, bytes, k, c->stream));
+    HIPC(c, stream_sync(c));
     return PGICP_OK;
 }
 
@@ -2007,7 +2119,7 @@ int pgicp_ctx_device(const pgicp_ctx *c, int *device) { if (!c || !device) retur
 int pgicp_ctx_synchronize(pgicp_ctx *c)
 {
     if (!c) return PGICP_ERR_ARG;
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_sync(c));
     return PGICP_OK;
 }
 
@@ -2230,6 +2342,13 @@ int pgicp_check_icp_result(const pgicp_stats *icp, double residual_error, double
     if (icp->overlap < overlap_threshold) return 0;            // LoopCloser.hpp:331
     if (residual_error > residual_error_threshold) return 0;   // LoopCloser.hpp:335
     return 1;
+}
+
+int pgicp_debug_alloc_stats(long long out[8])
+{
+    if (!out) return PGICP_ERR_ARG;
+    for (int k = 0; k < 4; k++) { out[2 * k] = g_alloc.n[k].load(); out[2 * k + 1] = g_alloc.ns[k].load(); }
+    return PGICP_OK;
 }
 
 int pgicp_debug_counters(pgicp_ctx *c, int out[4])

@@ -124,16 +124,42 @@ void yaml_and_matrix()
         bool differs = b3.getNbPoints() != b1.getNbPoints();
         for (int j = 0; !differs && j < (int)b1.getNbPoints(); j++) differs = b1.features(0, j) != b3.features(0, j);
         CHECK(differs);
-        std::istringstream vs("- FixStepSamplingDataPointsFilter:\n    startStep: 4\n    endStep: 2\n");
+        // a varying step ([EXT] FixStepSampling.cpp: step *= stepMult after every cloud, clamped at endStep; init() starts over)
+        std::istringstream vs("- FixStepSamplingDataPointsFilter:\n    startStep: 8\n    endStep: 2\n    stepMult: 0.5\n");
+        PointMatcher<float>::DataPointsFilters v(vs);
+        const int want[5] = {13, 25, 50, 50, 50};                              // steps 8, 4, 2, 2, 2 over 100 points
+        for (int k = 0; k < 5; k++) { auto c = cloud_of(100); v.apply(c); CHECK((int)c.getNbPoints() == want[k]); }
+        v.init();
+        { auto c = cloud_of(100); v.apply(c); CHECK(c.getNbPoints() == 13 && c.features(0, 1) == 8.f); }
+        std::istringstream bad_step("- FixStepSamplingDataPointsFilter:\n    startStep: 0\n");
         threw = false;
-        try { PointMatcher<float>::DataPointsFilters v(vs); } catch (const std::runtime_error &) { threw = true; }
-        CHECK(threw);                                                          // a varying step is not restated
+        try { PointMatcher<float>::DataPointsFilters w(bad_step); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
+        // MaxPointCount: nothing happens up to maxCount points; beyond, about maxCount survive (the seeded sampler, prob = maxCount / N)
+        std::istringstream ms("- MaxPointCountDataPointsFilter:\n    maxCount: 1000\n");
+        PointMatcher<float>::DataPointsFilters mc(ms);
+        auto few = cloud_of(1000), many = cloud_of(8000);
+        mc.apply(few); mc.apply(many);
+        CHECK(few.getNbPoints() == 1000 && many.getNbPoints() > 850 && many.getNbPoints() < 1150);
+        // Min / MaxDist along one axis ([EXT] MaxDist.cpp: features(dim, i) < maxDist) and by radius (the norm in T, strict)
+        std::istringstream ds("- MaxDistDataPointsFilter:\n    maxDist: 5\n    dim: 0\n- MinDistDataPointsFilter:\n    minDist: 2\n    dim: 0\n");
+        PointMatcher<float>::DataPointsFilters dl(ds);
+        auto line = cloud_of(10);
+        dl.apply(line);
+        CHECK(line.getNbPoints() == 2 && line.features(0, 0) == 3.f && line.features(0, 1) == 4.f);
+        const float tri[6] = {3.f, 4.f, 0.f, 3.f, 4.f, 0.01f};              // |(3,4,0)| = 5 exactly: strict comparisons drop it both ways
+        std::istringstream rs("- MaxDistDataPointsFilter:\n    maxDist: 5\n"), rs2("- MinDistDataPointsFilter:\n    minDist: 5\n");
+        PointMatcher<float>::DataPointsFilters rmax(rs), rmin(rs2);
+        auto t1 = PointMatcher<float>::DataPoints::fromXYZ(tri, 2, nullptr), t2 = PointMatcher<float>::DataPoints::fromXYZ(tri, 2, nullptr);
+        rmax.apply(t1); rmin.apply(t2);
+        CHECK(t1.getNbPoints() == 0 && t2.getNbPoints() == 1 && t2.features(2, 0) == 0.01f);
     }
     // an epsilon > 0 (libnabo's allowance for an approximate search, common in libpointmatcher's example configurations) is
     // accepted: the exact search meets it
     { std::istringstream ok("- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: 3.16\n"); PointMatcher<float>::DataPointsFilters g(ok); CHECK(g.size() == 1); }
     // anything outside the supported set is refused at load time, never ignored
-    for (const char *txt : {"- MaxPointCountDataPointsFilter:\n    maxCount: 100\n",
+    for (const char *txt : {"- MaxDensityDataPointsFilter:\n    maxDensity: 100\n",
+                            "- MaxDistDataPointsFilter:\n    maxDist: 5\n    dim: 3\n",
                             "- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: -1\n",
                             "- SurfaceNormalDataPointsFilter:\n    knn: 64\n"}) {
         std::istringstream bad(txt);

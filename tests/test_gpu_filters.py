@@ -1,7 +1,7 @@
 """The localizer's input stage on the device (pgicp_filter_cloud): input_filters_.apply + the sensor transform
-(/root/reference/src/pgslam/Localizer.hpp:103-106) in one pass.  The kept points must be those the host filters of
-include/pgslam_amd/pointmatcher.hpp keep (restated here in numpy, the same arithmetic), index for index; the moved
-coordinates those of pgicp_transform; and the device copy must serve as an ICP reading."""
+(/root/reference/src/pgslam/Localizer.hpp:103-106) in one pass.  The kept points must be those the oracle's restatement of
+libpointmatcher's filters keeps (oracle/icp_oracle.c: orc_filter_chain, citing upstream's DataPointsFilters/*.cpp), index for
+index; the moved coordinates those of the oracle's RigidTransformation; and the device copy must serve as an ICP reading."""
 import numpy as np
 import pytest
 
@@ -10,43 +10,8 @@ from pgslam_amd import icp, synth
 pytestmark = pytest.mark.gpu
 
 
-def splitmix(z):
-    z = (z + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-    return z ^ (z >> 31)
-
-
-def host_filters(filters, f):
-    """the filters of pointmatcher.hpp, one after the other, on the (n, frows) features; returns the kept input indices"""
-    idx = np.arange(f.shape[0])
-    for spec in filters:
-        t, p = spec[0], spec[1:]
-        x = f[idx]
-        if t in (icp.FILTER_MAX_DIST, icp.FILTER_MIN_DIST):
-            lim = float(f.dtype.type(p[0]))
-            r2 = (x[:, 0].astype(np.float64) ** 2 + x[:, 1].astype(np.float64) ** 2) + x[:, 2].astype(np.float64) ** 2
-            keep = (r2 < lim * lim) == (t == icp.FILTER_MAX_DIST)
-        elif t == icp.FILTER_BOUNDING_BOX:
-            lo, hi = np.asarray(p[0:3], dtype=f.dtype), np.asarray(p[3:6], dtype=f.dtype)
-            inside = np.all((lo < x[:, :3]) & (x[:, :3] < hi), axis=1)
-            keep = inside != bool(p[6])
-        elif t == icp.FILTER_REMOVE_NAN:
-            keep = ~np.any(np.isnan(x), axis=1)
-        elif t == icp.FILTER_FIX_STEP:
-            keep = np.arange(len(idx)) % int(p[0]) == 0
-        elif t == icp.FILTER_RANDOM_SAMPLING:
-            seed = int(p[1])
-            u = np.array([(splitmix((seed * 0x100000001B3 + j) & 0xFFFFFFFFFFFFFFFF) >> 11) / 9007199254740992.0 for j in range(len(idx))])
-            keep = u < float(f.dtype.type(p[0]))
-        else:
-            keep = np.ones(len(idx), dtype=bool)
-        idx = idx[keep]
-    return idx
-
-
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_filter_chain_keeps_what_the_host_filters_keep(ctx, oracle32, oracle64, dtype):
+def test_filter_chain_keeps_what_the_oracle_keeps(ctx, oracle32, oracle64, dtype):
     o = oracle32 if dtype == np.float32 else oracle64
     w = synth.make_two_scans(6000, rings=16)
     xyz, nrm = w["ref_xyz"].astype(dtype), w["ref_nrm"].astype(dtype)
@@ -63,11 +28,16 @@ def test_filter_chain_keeps_what_the_host_filters_keep(ctx, oracle32, oracle64, 
         [(icp.FILTER_BOUNDING_BOX, -2.0, -1.5, -3.0, 2.0, 1.5, 3.0, 1.0), (icp.FILTER_FIX_STEP, 3)],
         [(icp.FILTER_FIX_STEP, 2), (icp.FILTER_RANDOM_SAMPLING, 0.6, 7), (icp.FILTER_MAX_DIST, 30.0), (icp.FILTER_FIX_STEP, 5)],
         [(icp.FILTER_REMOVE_NAN,), (icp.FILTER_RANDOM_SAMPLING, 0.25, 123456789), (icp.FILTER_BOUNDING_BOX, -50, -50, -50, 50, 50, 50, 0.0)],
+        # along one axis (dim = p[1] - 1), and a NaN in front of the distance filters: it fails both comparisons
+        [(icp.FILTER_MAX_DIST, 12.0, 1), (icp.FILTER_MIN_DIST, -3.0, 2), (icp.FILTER_MIN_DIST, 0.2, 3)],
+        [(icp.FILTER_MIN_DIST, 2.0)],
+        [(icp.FILTER_MAX_DIST, -40.0)],                                       # |maxDist|, as upstream takes it
+        [(icp.FILTER_MAX_POINT_COUNT, 1500, 11), (icp.FILTER_FIX_STEP, 2), (icp.FILTER_MAX_POINT_COUNT, 100000, 3)],
     ]
     for filters in chains:
         for Tm in (None, T):
             of, od, idx, dev = ctx.filter_cloud(filters, f, d, T=Tm, rotate_rows=(0, 3))
-            want = host_filters(filters, f)
+            want = o.filter_chain(filters, f)
             assert np.array_equal(idx, want), filters
             assert len(of) == len(want) and dev.n == len(want)
             if Tm is None:
@@ -79,6 +49,43 @@ def test_filter_chain_keeps_what_the_host_filters_keep(ctx, oracle32, oracle64, 
                 assert np.array_equal(od[:, 0:3], o.transform(Tm, d[want][:, 0:3], rotate_only=True))    # normals rotate
                 assert np.array_equal(od[:, 3:6], o.transform(Tm, d[want][:, 3:6], rotate_only=True))
                 assert np.array_equal(od[:, 6], d[want][:, 6])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_distance_filters_at_their_limits(ctx, oracle32, oracle64, dtype):
+    """points whose norm lands exactly on, one ulp below and one ulp above the limit: the device computes the norm as upstream
+    does -- sqrt((x x + y y) + z z) in T, correctly rounded -- and compares strictly"""
+    o = oracle32 if dtype == np.float32 else oracle64
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=(20000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    lim = dtype(7.25)
+    pts = (d * float(lim)).astype(dtype)                                       # norms within a few ulps of the limit, both sides
+    pts[:4] = np.array([[3, 4, 0], [0, 5, 0], [5, 0, 0], [0, 3, 4]], dtype=dtype) * dtype(1.45)      # exactly 7.25
+    f = np.concatenate([pts, np.ones((len(pts), 1), dtype=dtype)], axis=1)
+    nrm = np.sqrt((pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1]) + pts[:, 2] * pts[:, 2])
+    assert (nrm == lim).sum() >= 4 and (nrm < lim).sum() > 1000 and (nrm > lim).sum() > 1000
+    for filters in ([(icp.FILTER_MAX_DIST, float(lim))], [(icp.FILTER_MIN_DIST, float(lim))]):
+        _, _, idx, _ = ctx.filter_cloud(filters, f, None)
+        want = o.filter_chain(filters, f)
+        assert np.array_equal(idx, want)
+        keep = nrm < lim if filters[0][0] == icp.FILTER_MAX_DIST else nrm > lim
+        assert np.array_equal(want, np.nonzero(keep)[0])                       # and numpy's own sqrt agrees with both
+
+
+def test_fixstep_with_a_changing_step(oracle32):
+    """[EXT] FixStepSampling.cpp: step *= stepMult after every cloud, clamped at endStep (the caller's state across calls)"""
+    steps, s = [], 8.0
+    for _ in range(5):
+        steps.append(int(s))
+        s = oracle32.fixstep_next(s, 8.0, 2.0, 0.5)
+    assert steps == [8, 4, 2, 2, 2]
+    s = 3.0
+    seq = []
+    for _ in range(4):
+        seq.append(int(s))
+        s = oracle32.fixstep_next(s, 3.0, 10.0, 1.5)
+    assert seq == [3, 4, 6, 10]
 
 
 def test_filtered_cloud_is_an_icp_reading_without_a_second_upload(ctx, oracle32):

@@ -466,3 +466,56 @@ def test_bound_checker_scripted(oracle32):
     c = oracle32.checker(1, 0.0, 0.0, 3)
     oracle32.checker_set_bound(c, 0.3, 0.5)
     assert oracle32.checker_check(c, T) == 4
+
+
+# ---- input filters that only drop points (orc_filter_chain: [EXT] DataPointsFilters/*.cpp as cited in icp_oracle.c) ----
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_filter_chain_against_numpy(oracle32, oracle64, dtype):
+    o = oracle32 if dtype == np.float32 else oracle64
+    rng = np.random.default_rng(11)
+    f = np.concatenate([rng.normal(size=(5000, 3)) * 10, np.ones((5000, 1))], axis=1).astype(dtype)
+    f[7, 2] = np.nan
+    f[9, 3] = np.nan
+    x = f[:, :3]
+    nrm = np.sqrt((x[:, 0] * x[:, 0] + x[:, 1] * x[:, 1]) + x[:, 2] * x[:, 2])           # in dtype, as Eigen's .norm()
+    lim = dtype(12.5)
+    assert np.array_equal(o.filter_chain([(1, 12.5)], f), np.nonzero(nrm < lim)[0])          # MaxDist, radius; NaN fails
+    assert np.array_equal(o.filter_chain([(2, 12.5)], f), np.nonzero(nrm > lim)[0])          # MinDist: strictly above
+    assert np.array_equal(o.filter_chain([(1, -12.5)], f), np.nonzero(nrm < lim)[0])         # |maxDist|
+    assert np.array_equal(o.filter_chain([(1, 3.0, 2)], f), np.nonzero(x[:, 1] < dtype(3.0))[0])   # dim = 1
+    assert np.array_equal(o.filter_chain([(2, -1.0, 3)], f), np.nonzero(x[:, 2] > dtype(-1.0))[0])  # dim = 2 (NaN at 7 dropped)
+    inside = np.all((x > dtype(-5)) & (x < dtype(6)), axis=1)
+    assert np.array_equal(o.filter_chain([(3, -5, -5, -5, 6, 6, 6, 1)], f), np.nonzero(~inside)[0])
+    assert np.array_equal(o.filter_chain([(3, -5, -5, -5, 6, 6, 6, 0)], f), np.nonzero(inside)[0])
+    assert np.array_equal(o.filter_chain([(4,)], f), np.array([i for i in range(5000) if i not in (7, 9)]))
+    assert np.array_equal(o.filter_chain([(5, 7)], f), np.arange(0, 5000, 7))
+    # a chain: every filter sees what the one before it kept (FixStep counts positions in THAT cloud)
+    a = np.nonzero(nrm < lim)[0]
+    assert np.array_equal(o.filter_chain([(1, 12.5), (5, 3)], f), a[::3])
+    # samplers: reproducible per seed, about prob of the points; MaxPointCount does nothing up to maxCount
+    r1, r2, r3 = o.filter_chain([(6, 0.3, 5)], f), o.filter_chain([(6, 0.3, 5)], f), o.filter_chain([(6, 0.3, 6)], f)
+    assert np.array_equal(r1, r2) and not np.array_equal(r1, r3) and 1300 < len(r1) < 1700
+    assert len(o.filter_chain([(7, 5000, 1)], f)) == 5000 and 800 < len(o.filter_chain([(7, 1000, 1)], f)) < 1200
+
+
+def test_filter_limits_are_strict(oracle32):
+    """|(3, 4, 0)| = 5 exactly: MaxDist 5 and MinDist 5 both drop it; the bounding box drops points ON its faces from the inside"""
+    o = oracle32
+    f = np.array([[3, 4, 0, 1], [3, 4, 0.01, 1], [3, 3.99, 0, 1], [1, 1, 1, 1], [2, 0, 0, 1]], dtype=np.float32)
+    assert list(o.filter_chain([(1, 5.0)], f)) == [2, 3, 4]
+    assert list(o.filter_chain([(2, 5.0)], f)) == [1]
+    assert list(o.filter_chain([(3, 0, 0, 0, 2, 2, 2, 0)], f)) == [3]         # (2, 0, 0) lies on two faces: not inside
+
+
+def test_fixstep_step_evolution(oracle32):
+    o = oracle32
+    steps, s = [], 8.0
+    for _ in range(5):
+        steps.append(int(s))
+        s = o.fixstep_next(s, 8.0, 2.0, 0.5)
+    assert steps == [8, 4, 2, 2, 2]
+    seq, s = [], 3.0
+    for _ in range(4):
+        seq.append(int(s))
+        s = o.fixstep_next(s, 3.0, 10.0, 1.5)
+    assert seq == [3, 4, 6, 10]

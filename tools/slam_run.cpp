@@ -165,7 +165,13 @@ static int run_mt(FILE *f, int S, int N)
     return 0;
 }
 
-struct StResult { double slam_s = 0, icp_first_s = 0, icp_p50_s = 0, icp_p99_s = 0, icp_max_s = 0; int icp_max_scan = 0; std::string json; };
+struct StResult {
+    double slam_s = 0, icp_first_s = 0, icp_p50_s = 0, icp_p99_s = 0, icp_max_s = 0;
+    int icp_max_scan = 0;
+    long long alloc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pgicp_debug_alloc_stats of this pass: calls / ns of hipMalloc, hipFree, hipHostMalloc, hipHostFree
+    std::string slowest;                                // JSON list: the five slowest ICP calls (scan, seconds, iterations, map rebuilt by the scan before)
+    std::string json;
+};
 
 // one pass of the single-thread flavour over the sequence: a fresh facade (graph, chains, contexts), every scan through AddData
 static int run_st(const char *seq_path, int limit, const char *rec_path, int rec_n, StResult &out)
@@ -193,6 +199,11 @@ static int run_st(const char *seq_path, int limit, const char *rec_path, int rec
     std::vector<double> err_track;
     double t_icp_loop = 0.0, t_io = 0.0;
     double icp_s_before = 0.0;
+    std::vector<int> icp_scan_iters, icp_scan_after_rebuild;
+    int rebuilds_before = 0;
+    bool rebuilt_last_scan = false;
+    long long alloc0[8];
+    (void)pgicp_debug_alloc_stats(alloc0);
     std::vector<double> icp_scan_s;                 // the ICP call of every scan (localizer phase 1), to tell a cold start from a slow box
     long long icp_iterations = 0;
     int not_converged = 0;
@@ -216,6 +227,10 @@ static int run_st(const char *seq_path, int limit, const char *rec_path, int rec
             const double so_far = slam.localizer().phase_seconds()[1];
             icp_scan_s.push_back(so_far - icp_s_before);
             icp_s_before = so_far;
+            icp_scan_iters.push_back(s > 0 ? slam.localizer().icp().lastStats.iterations : 0);
+            icp_scan_after_rebuild.push_back(rebuilt_last_scan ? 1 : 0);
+            rebuilt_last_scan = slam.localizer().rebuilds() != rebuilds_before;
+            rebuilds_before = slam.localizer().rebuilds();
         }
         last_cloud_points = cloud->getNbPoints();
         truth.push_back(from_rows(Tt.data()));
@@ -253,6 +268,23 @@ static int run_st(const char *seq_path, int limit, const char *rec_path, int rec
     long long kp_l = 0, kp_u = 0, kp_p = 0, kp_m = 0;
     double kp_ms = 0;
     (void)pgicp_profile_process(PGICP_PROF_KNN_GRID, &kp_l, &kp_ms, &kp_u, &kp_p, &kp_m);
+    {
+        long long a1[8];
+        (void)pgicp_debug_alloc_stats(a1);
+        for (int k = 0; k < 8; k++) out.alloc[k] = a1[k] - alloc0[k];
+        std::vector<int> order(icp_scan_s.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return icp_scan_s[(size_t)a] > icp_scan_s[(size_t)b]; });
+        out.slowest = "[";
+        for (size_t k = 0; k < std::min<size_t>(5, order.size()); k++) {
+            char b[160];
+            const size_t i = (size_t)order[k];
+            std::snprintf(b, sizeof b, "%s{\"scan\": %zu, \"s\": %.6f, \"iterations\": %d, \"map_rebuilt_by_previous_scan\": %d}", k ? ", " : "", i, icp_scan_s[i],
+                          icp_scan_iters[i], icp_scan_after_rebuild[i]);
+            out.slowest += b;
+        }
+        out.slowest += "]";
+    }
     std::vector<double> sorted_icp(icp_scan_s.begin() + std::min<size_t>(1, icp_scan_s.size()), icp_scan_s.end());   // (scan 0 makes the first keyframe: no ICP)
     if (sorted_icp.empty()) sorted_icp.push_back(0.0);
     out.icp_first_s = sorted_icp[0];
@@ -326,10 +358,19 @@ int main(int argc, char **argv)
     for (int p = 0; p < passes; p++) { char b[64]; std::snprintf(b, sizeof b, "%s%.6f", p ? ", " : "", res[(size_t)p].slam_s); passes_json += b; }
     passes_json += "]";
     const StResult &r = res.back();
+    auto alloc_json = [](const StResult &q) {
+        char b[256];
+        std::snprintf(b, sizeof b, "{\"hipMalloc\": [%lld, %.4f], \"hipFree\": [%lld, %.4f], \"hipHostMalloc\": [%lld, %.4f], \"hipHostFree\": [%lld, %.4f]}",
+                      q.alloc[0], q.alloc[1] * 1e-9, q.alloc[2], q.alloc[3] * 1e-9, q.alloc[4], q.alloc[5] * 1e-9, q.alloc[6], q.alloc[7] * 1e-9);
+        return std::string(b);
+    };
     std::printf("%s, \"passes\": %d, \"pass_slam_s\": %s, \"slam_s_last_pass\": %.6f, \"slam_s_median_timed\": %.6f, "
                 "\"icp_call_s\": {\"first\": %.6f, \"p50\": %.6f, \"p99\": %.6f, \"max\": %.6f, \"max_at_scan\": %d, "
-                "\"first_of_pass0\": %.6f, \"max_of_pass0\": %.6f}}\n",
+                "\"first_of_pass0\": %.6f, \"max_of_pass0\": %.6f}, "
+                "\"alloc_calls_and_seconds_last_pass\": %s, \"alloc_calls_and_seconds_pass0\": %s, \"slowest_icp_calls_last_pass\": %s, "
+                "\"slowest_icp_calls_pass0\": %s}\n",
                 r.json.c_str(), passes, passes_json.c_str(), r.slam_s, median, r.icp_first_s, r.icp_p50_s, r.icp_p99_s, r.icp_max_s,
-                r.icp_max_scan, res[0].icp_first_s, res[0].icp_max_s);
+                r.icp_max_scan, res[0].icp_first_s, res[0].icp_max_s, alloc_json(r).c_str(), alloc_json(res[0]).c_str(), r.slowest.c_str(),
+                res[0].slowest.c_str());
     return 0;
 }
