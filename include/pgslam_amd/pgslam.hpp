@@ -237,6 +237,8 @@ public:
         temp_icp.referenceDataPointsFilters.init();
         temp_icp.referenceDataPointsFilters.apply(reference);
         temp_icp.matcher->init(reference);
+        // a SurfaceNormalOutlierFilter compares descriptors of both clouds: the stage-by-stage chain below needs the reference
+        if (temp_icp.hasNormalFilter()) prepared_reference_ = std::move(reference); else prepared_reference_ = DP();
     }
     //! the same for a candidate map that is in device memory already (assembled there from resident keyframe clouds): no
     //! upload; only when the chain's reference filters change nothing (false: the caller takes the host flow)
@@ -247,7 +249,7 @@ public:
             std::istringstream iss(icp_config_buffer_);
             temp_icp_->loadFromYaml(iss);
         }
-        if (!temp_icp_->referenceDataPointsFilters.allIdentity()) return false;
+        if (!temp_icp_->referenceDataPointsFilters.allIdentity() || temp_icp_->hasNormalFilter()) return false;
         temp_icp_->matcher->initDevice(candidate_map_in_world_frame, 0);
         return true;
     }
@@ -273,6 +275,16 @@ public:
         // are pure functions of the cloud here: pointmatcher.hpp alignOnMap)
         temp_icp.readingStepDataPointsFilters.init();
         temp_icp.readingStepDataPointsFilters.apply(reading);
+        if (temp_icp.hasNormalFilter() && reading.normalsPtr() != nullptr && prepared_reference_.normalsPtr() != nullptr) {
+            // the fused device pass knows no descriptor filter: stage by stage, exactly as Localizer.hpp:323-347 spells it --
+            // move the reading, findClosests, outlierFilters.compute (the normal filter on the host), weightedPointUsedRatio
+            const DP moved = rigid_transformation_->compute(reading, T_world_robot);
+            const typename PM::Matches matches = temp_icp.matcher->findClosests(moved);
+            const typename PM::OutlierWeights w = temp_icp.outlierFilters.compute(moved, prepared_reference_, matches);
+            double sum = 0;
+            for (int j = 0; j < w.cols(); j++) for (int i = 0; i < w.rows(); i++) sum += (double)w(i, j);
+            return (T)(sum / ((double)w.rows() * (double)w.cols()));
+        }
         double Tm[16], ratio = 0, residual = 0;
         pgslam_amd::to_row_major16(T_world_robot, Tm);
         temp_icp.pushParams();
@@ -306,6 +318,7 @@ private:
     ICPSequence icp_sequence_;
     std::string icp_config_buffer_;
     std::unique_ptr<typename PM::ICP> temp_icp_;    // ComputeOverlapOf's temporary (kept: see there)
+    DP prepared_reference_;                         // the probe's filtered reference, kept only for a chain with a descriptor filter
     Matrix T_refkf_robot_, T_world_robot_, last_input_T_world_robot_, T_world_refkf_;
     T overlap_threshold_, minimal_overlap_;
     bool has_map_;
@@ -489,6 +502,15 @@ public:
         }
         typename PM::ICP &temp_icp = *temp_icp_;
         temp_icp.matcher->init(candidate_cloud);
+        if (temp_icp.hasNormalFilter() && input_cloud.normalsPtr() != nullptr && candidate_cloud.normalsPtr() != nullptr) {
+            // with a descriptor filter in the chain: LoopCloser.hpp:352-362 stage by stage (transformations.apply, findClosests,
+            // outlierFilters.compute -- the normal filter on the host --, getResidualError)
+            DP reading(input_cloud);
+            temp_icp.transformations.apply(reading, T_refkf_kf);
+            const typename PM::Matches matches = temp_icp.matcher->findClosests(reading);
+            const typename PM::OutlierWeights w = temp_icp.outlierFilters.compute(reading, candidate_cloud, matches);
+            return temp_icp.errorMinimizer->getResidualError(reading, candidate_cloud, w, matches);
+        }
         double Tm[16], ratio = 0, residual = 0;
         pgslam_amd::to_row_major16(T_refkf_kf, Tm);
         temp_icp.pushParams();
@@ -559,11 +581,20 @@ public:
         }
         // every candidate's reference is indexed in one call (ICP::operator() builds it inside, LoopCloser.hpp:98)
         PM::check(ctx, pgslam_amd::Abi<T>::map_create_batch(ctx, P, xyz.data(), xs.data(), nrm.data(), ns.data(), ms.data(), 1, maps.data()));
+        // a SurfaceNormalOutlierFilter acts when the readings carry normals (without them its weights are ones):
+        // all of the batch's readings or none -- one device chain per call
+        int with_nrm = 0;
+        if (chain_.hasNormalFilter()) for (int k = 0; k < P; k++) with_nrm += reading_of(k).normalsPtr() != nullptr ? 1 : 0;
+        if (with_nrm != 0 && with_nrm != P)
+            throw std::runtime_error("LoopClosureBatch: a SurfaceNormalOutlierFilter is configured and only some readings carry normals");
+        chain_.pushParams(with_nrm == P && P > 0 && chain_.hasNormalFilter());
         for (int k = 0; k < P; k++) {
             const Candidate &c = queue_[mine[k]];
             const DP &rd = reading_of(k);
+            std::memset(&pr[k], 0, sizeof pr[k]);
             pr[k].map_id = maps[k]; pr[k].reading = rd.xyzPtr(); pr[k].stride = rd.xyzStride();
             pr[k].n = (int)rd.getNbPoints(); pr[k].mem = PGICP_HOST;
+            if (with_nrm == P && chain_.hasNormalFilter()) { pr[k].normals = rd.normalsPtr(); pr[k].nstride = rd.normalsStride(); }
             pgslam_amd::to_row_major16(c.T_init, pr[k].T_init);
         }
         std::vector<double> Tout((size_t)16 * P);

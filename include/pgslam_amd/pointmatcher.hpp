@@ -78,6 +78,7 @@ struct DeviceCloud {
     T *xyz = nullptr, *nrm = nullptr;
     int n = 0, xs = 3, ns = 3;
     size_t cap_x = 0, cap_n = 0;                    // elements allocated
+    bool has_nrm = false;                           // the CURRENT contents carry normals (a reused buffer may hold an older cloud's)
     DeviceCloud() {}
     DeviceCloud(const DeviceCloud &) = delete;
     DeviceCloud &operator=(const DeviceCloud &) = delete;
@@ -86,7 +87,7 @@ struct DeviceCloud {
     {
         if (xyz) pgicp_device_free(nullptr, xyz);
         if (nrm) pgicp_device_free(nullptr, nrm);
-        xyz = nrm = nullptr; n = 0; cap_x = cap_n = 0;
+        xyz = nrm = nullptr; n = 0; cap_x = cap_n = 0; has_nrm = false;
     }
     static void fail(pgicp_ctx *c, int st, const char *what)
     {
@@ -108,9 +109,9 @@ struct DeviceCloud {
             fail(c, pgicp_device_alloc(c, sizeof(T) * (need_n + need_n / 8), (void **)&nrm), "DeviceCloud: device allocation");
             cap_n = need_n + need_n / 8;
         }
-        n = count; xs = xstride; ns = nstride;
+        n = count; xs = xstride; ns = nstride; has_nrm = normals;
     }
-    bool hasNormals() const { return nrm != nullptr && cap_n >= (size_t)n * ns && n > 0; }
+    bool hasNormals() const { return has_nrm && nrm != nullptr && cap_n >= (size_t)n * ns && n > 0; }
     //! host -> device, strides kept as they are on the host (`x` holds (count - 1) * xstride + 3 elements at least)
     void upload(pgicp_ctx *c, const T *x, int xstride, const T *nr, int nstride, int count)
     {
@@ -869,6 +870,12 @@ struct PointMatcher {
         {
             double ratio, res;
             if (!chain->matcher || chain->matcher->mapId < 0) throw std::runtime_error("getResidualError: matcher->init() was not called");
+            // pgicp_error_stats reads n x knn ids and weights with the CONTEXT's knn: push the chain's parameters and refuse
+            // matches made under another knn (an out-of-bounds host read otherwise -- ADVICE round 4)
+            chain->pushParams();
+            const int K = chain->matcher->knn < 1 ? 1 : chain->matcher->knn, n = (int)filteredReading.getNbPoints();
+            if (m.ids.rows() != K || w.rows() != K || m.ids.cols() != n || w.cols() != n)
+                throw std::runtime_error("getResidualError: matches / weights are not knn x N of this chain's matcher");
             check(chain->ctx, A::stats(chain->ctx, chain->matcher->mapId, filteredReading.xyzPtr(), filteredReading.xyzStride(),
                                        (int)filteredReading.getNbPoints(), m.ids.data(), w.data(), &ratio, &res, nullptr));
             return (T)res;
@@ -1104,10 +1111,14 @@ struct PointMatcher {
         };
         //! a device copy of a cloud may stand for the cloud itself in operator(): the chain's reading filters change nothing
         //! and no outlier filter looks at the reading's descriptors
+        bool hasNormalFilter() const
+        {
+            for (auto &f : outlierFilters) if (std::dynamic_pointer_cast<SurfaceNormalOutlierFilter>(f)) return true;
+            return false;
+        }
         bool deviceReadingEquivalent() const
         {
-            for (auto &f : outlierFilters) if (std::dynamic_pointer_cast<SurfaceNormalOutlierFilter>(f)) return false;
-            return readingDataPointsFilters.allIdentity() && readingStepDataPointsFilters.allIdentity();
+            return !hasNormalFilter() && readingDataPointsFilters.allIdentity() && readingStepDataPointsFilters.allIdentity();
         }
         DeviceReading uploadReading(const DataPoints &readingIn)
         {
@@ -1123,6 +1134,10 @@ struct PointMatcher {
     protected:
         TransformationParameters alignOnMap(const DeviceReading &r, const TransformationParameters &T_init)
         {
+            // a device reading is coordinates only: a chain whose SurfaceNormalOutlierFilter compares the READING's normals must be
+            // given the host cloud (refused, never run without the filter -- ADVICE round 4)
+            if (hasNormalFilter() && r.filtered && r.filtered->normalsPtr() != nullptr)
+                throw std::logic_error("ICP: a SurfaceNormalOutlierFilter needs the reading's normals; pass the host cloud, not a device reading");
             prefilteredReadingPtsCount = r.filtered->getNbPoints();
             double Ti[16], To[16];
             pgslam_amd::to_row_major16(T_init, Ti);

@@ -719,6 +719,9 @@ public:
     //! host seconds spent in: [0] input filters + sensor transform, [1] the ICP call, [2] everything after it
     //! (neighbour composition, overlap probe, keyframe insertion, local-map rebuilds)
     const double *phase_seconds() const { return phase_s_; }
+    //! inside [2]: [0] neighbour-composition search, [1] overlap probe, [2] local-map rebuilds, [3] keyframe insertion (the
+    //! single-thread flavour closes loops and optimises inside it)
+    const double *after_icp_seconds() const { return sub_s_; }
     void ProcessData(const Matrix &input_T_world_robot, const Matrix &input_T_robot_sensor, DPPtr cloud)
     {
         using clk = std::chrono::steady_clock;
@@ -800,7 +803,10 @@ public:
         if (!slot) return;
         slot->cloud = cloud.get();
         const auto direct = PreProcess(input_T_robot_sensor, cloud);
-        slot->reading = direct ? direct : icp_sequence_.uploadReading(*cloud);
+        // (a chain that looks at the reading's descriptors -- SurfaceNormalOutlierFilter -- or filters the reading takes the host
+        // cloud in ProcessData: nothing is uploaded ahead for it, the slot only remembers that the cloud is pre-processed)
+        if (direct) slot->reading = direct;
+        else if (icp_sequence_.deviceReadingEquivalent()) slot->reading = icp_sequence_.uploadReading(*cloud);
         prefetches_++;
     }
     size_t prefetches() const { return prefetches_; }
@@ -938,7 +944,13 @@ private:
         std::vector<size_t> next = comp_, neigh;
         const bool enough = overlap >= overlap_threshold_;
         bool took_neighbor = false;
-        if (FindNeighborComposition(neigh) && IsBetterOverlap(overlap, OverlapWith(neigh), overlap_threshold_)) { next = neigh; took_neighbor = true; }
+        bool have_neigh;
+        { SubTimer t(sub_s_[0]); have_neigh = FindNeighborComposition(neigh); }
+        if (have_neigh) {
+            T ov;
+            { SubTimer t(sub_s_[1]); ov = OverlapWith(neigh); }
+            if (IsBetterOverlap(overlap, ov, overlap_threshold_)) { next = neigh; took_neighbor = true; }
+        }
         if (!took_neighbor) {
             if (enough) {
                 size_t best = 0;
@@ -946,7 +958,8 @@ private:
                 for (size_t i = 1; i < comp_.size(); i++) { const double d = PoseDistance(g[comp_[i]].optimized_T_world_kf, T_world_robot_); if (d < bd) { bd = d; best = i; } }
                 if (best != comp_.size() - 1) std::swap(next[best], next[next.size() - 1]);
             } else {
-                const size_t v = map_manager_->AddNewKeyframe(comp_.back(), T_world_robot_, T_refkf_robot_, icp_sequence_.errorMinimizer->getCovariance(), input_cloud_);
+                size_t v;
+                { SubTimer t(sub_s_[3]); v = map_manager_->AddNewKeyframe(comp_.back(), T_world_robot_, T_refkf_robot_, icp_sequence_.errorMinimizer->getCovariance(), input_cloud_); }
                 // the loop closer may have optimised the graph inside AddNewKeyframe: comp_ poses are re-read below
                 next = comp_;
                 next.push_back(v);
@@ -957,7 +970,7 @@ private:
         if (!(same_set && next.back() == comp_.back())) {
             const size_t old_ref = comp_.back();
             comp_ = next;
-            Rebuild();
+            { SubTimer t(sub_s_[2]); Rebuild(); }
             if (comp_.back() != old_ref) T_refkf_robot_ = g[comp_.back()].optimized_T_world_kf.inverse() * T_world_robot_;
         }
     }
@@ -976,6 +989,12 @@ private:
     T overlap_threshold_ = T(0.8);
     int rebuilds_ = 0;
     double phase_s_[3] = {0, 0, 0};
+    double sub_s_[4] = {0, 0, 0, 0};
+    struct SubTimer {
+        double &acc; std::chrono::steady_clock::time_point t0;
+        explicit SubTimer(double &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+        ~SubTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    };
 };
 
 template <typename T>
