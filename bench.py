@@ -656,6 +656,17 @@ def main_slam(args, collect=False):
         t = torch.tensor([slam_s], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         slam_s = float(t.item())
+    # the multi-thread flavour (pgslam::PoseGraphSlamMT: input stage, localizer, loop closer and optimiser on their own threads) on
+    # the same sequence, free running -- reported next to the single-thread figure, never `value`
+    mt = None
+    if rank == 0 and not distributed:
+        try:
+            o_mt = subprocess.run([exe, seq, "--filters", args.slam_filters, "--mt"], env=env, capture_output=True, text=True, check=True)
+            d_mt = json.loads(o_mt.stdout.strip().splitlines()[-1])
+            mt = {k: d_mt.get(k) for k in ("scans_per_s", "wall_s", "keyframes", "loops_closed", "loop_batches", "largest_loop_batch", "loop_batches_on_device",
+                                           "tracking_error_last_m", "localizer_thread_s")}
+        except Exception as e:                      # reported, not hidden
+            mt = dict(error=f"{type(e).__name__}: {e}")
     # one more pass that records ICP calls, replayed through the CPU oracle: parity evidence + the CPU figure
     cpu = None
     replay = None
@@ -695,7 +706,7 @@ def main_slam(args, collect=False):
                                    f"(BASELINE.json configs[3]), host clouds through pgslam::PoseGraphSlam<float> (C++ facade), input filters: "
                                    f"{res.get('input_filters')}",
                        "parallelism": f"{world} independent replica(s), one process per GPU"},
-            "slam": res, "replay_vs_oracle": replay, "cpu_baseline": cpu, "roofline": slam_roofline(res_prof, args.slam_points)})
+            "slam": res, "slam_mt": mt, "replay_vs_oracle": replay, "cpu_baseline": cpu, "roofline": slam_roofline(res_prof, args.slam_points)})
     if collect:
         return out
     if out is not None:
@@ -1060,13 +1071,13 @@ def compact_leg(d, wall_s):
             "set_map_ms", "median_translation_error_m",
             "mean_iterations", "converged_fraction", "final_position_error_m", "host_input", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
             "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size",
-            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "shard_proxy", "replay_vs_oracle", "scans_per_s_each_pass", "scans_per_s_median_pass", "selection_guess_misses_per_scan")
+            "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "shard_proxy", "slam_mt", "replay_vs_oracle", "scans_per_s_each_pass", "scans_per_s_median_pass", "selection_guess_misses_per_scan")
     out = {k: d[k] for k in keep if k in d}
     if "slam" in d:
         out["slam"] = {k: d["slam"].get(k) for k in ("scans", "points_per_scan", "keyframes", "loops_closed", "loop_candidates_tried",
                                                      "map_rebuilds", "mean_icp_iterations", "tracking_error_rms_m", "localizer_host_s",
                                                      "input_filters", "device_input_stages", "device_readings_used", "device_map_rebuilds", "points_after_filters_last_scan",
-                                                     "passes", "pass_slam_s", "slam_s_median_timed", "icp_call_s")}
+                                                     "passes", "pass_slam_s", "slam_s_median_timed", "icp_call_s", "loop_candidates_assembled_on_device", "keyframes_resident")}
     r = out.get("roofline")
     if r:
         out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches",

@@ -14,6 +14,7 @@
 #pragma once
 #include <chrono>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <sstream>
 #include <string>
@@ -113,14 +114,22 @@ typename Types<T>::DP BuildLocalMapCloud(const std::vector<typename Types<T>::Ke
 }
 
 //! the keyframe's cloud goes to device memory once (points and normals, host strides kept)
+//! `ctx`: a context of the device the copy is to live on (the chain that will assemble maps from it); the buffers are plain
+//! device memory, usable by every context of that device
 template <typename T>
-void EnsureKeyframeOnDevice(typename Types<T>::Keyframe &kf)
+void EnsureKeyframeOnDevice(typename Types<T>::Keyframe &kf, pgicp_ctx *ctx = nullptr)
 {
     if (kf.device_cloud) return;
     auto dc = std::make_shared<pgslam_amd::DeviceCloud<T>>();
     const auto &c = *kf.cloud_ptr;
-    dc->upload(pgslam_amd::default_context(), c.xyzPtr(), c.xyzStride(), c.descriptorExists("normals") ? c.normalsPtr() : nullptr, c.normalsStride(), (int)c.getNbPoints());
+    dc->upload(ctx ? ctx : pgslam_amd::default_context(), c.xyzPtr(), c.xyzStride(), c.descriptorExists("normals") ? c.normalsPtr() : nullptr, c.normalsStride(), (int)c.getNbPoints());
     kf.device_cloud = dc;
+}
+//! bytes a keyframe's device copy holds
+template <typename T>
+size_t DeviceKeyframeBytes(const typename Types<T>::Keyframe &kf)
+{
+    return kf.device_cloud ? sizeof(T) * (kf.device_cloud->cap_x + kf.device_cloud->cap_n) : 0;
 }
 
 //! BuildLocalMapCloud over keyframes whose clouds are resident (EnsureKeyframeOnDevice), INTO device memory: the same
@@ -483,6 +492,40 @@ public:
         r.accepted = CheckIcpResult(r);
         return r;
     }
+    //! The same for a candidate whose clouds are in device memory already (keyframe clouds resident, the candidate map
+    //! assembled from them there): ICP::operator() and ComputeResidualError on device memory -- the same index builds, the same
+    //! chain, no cloud crosses PCIe (LoopCloser.hpp:282-296 assembles the candidate map, :98 aligns, :343-365 checks).  Only for a
+    //! chain whose data-point filters change nothing and that looks at no reading descriptor; `host_reference` makes the host copy
+    //! of the candidate map if an observer (onAlign) asks for it.
+    bool DeviceCandidateEquivalent() const
+    {
+        return icp_.referenceDataPointsFilters.allIdentity() && icp_.deviceReadingEquivalent();
+    }
+    Result ProcessCandidateOnDevice(const DPPtr &input_cloud, const pgslam_amd::DeviceCloud<T> &input_dev, const pgslam_amd::DeviceCloud<T> &candidate_dev,
+                                    const Matrix &input_T_refkf_kf, std::function<DP()> host_reference)
+    {
+        Result r;
+        typename PM::ICPChainBase::DeviceReading rd;
+        rd.dev = input_dev.xyz; rd.filtered = input_cloud;
+        r.T_refkf_kf = icp_.computeOnDevice(rd, candidate_dev, input_T_refkf_kf, host_reference);
+        r.max_iterations_reached = icp_.getMaxNumIterationsReached();
+        r.overlap = icp_.errorMinimizer->getOverlap();
+        r.cov = icp_.errorMinimizer->getCovariance();
+        // ComputeResidualError (LoopCloser.hpp:343-365): a second index on the RAW candidate cloud, the reading moved by the result
+        if (!temp_icp_) {
+            temp_icp_.reset(new typename PM::ICP());
+            std::istringstream iss(icp_config_buffer_);
+            temp_icp_->loadFromYaml(iss);
+        }
+        temp_icp_->matcher->initDevice(candidate_dev, 0);
+        double Tm[16], ratio = 0, residual = 0;
+        pgslam_amd::to_row_major16(r.T_refkf_kf, Tm);
+        temp_icp_->pushParams();
+        PM::check(temp_icp_->ctx, pgslam_amd::Abi<T>::partial_dev(temp_icp_->ctx, temp_icp_->matcher->mapId, input_dev.xyz, input_dev.xs, input_dev.n, Tm, &ratio, &residual));
+        r.residual = (T)residual;
+        r.accepted = CheckIcpResult(r);
+        return r;
+    }
     //! LoopCloser.hpp:308-340
     bool CheckIcpResult(const Result &r) const
     {
@@ -533,7 +576,16 @@ template <typename T>
 class LoopClosureBatch {
 public:
     IMPORT_PGSLAM_TYPES(T)
-    struct Candidate { long long from_id, to_id; DPPtr reading, reference; Matrix T_init; };
+    //! reading_dev / reference_dev (optional): the same clouds in device memory (keyframe clouds resident, the candidate map
+    //! assembled there) -- used, and nothing uploaded, when every candidate of a batch has both and the chain's data-point
+    //! filters change nothing; `reference` may then be null (reference_points says how many points the device copy holds)
+    struct Candidate {
+        long long from_id, to_id; DPPtr reading, reference; Matrix T_init;
+        std::shared_ptr<pgslam_amd::DeviceCloud<T>> reading_dev, reference_dev;
+    };
+    pgicp_ctx *Context() { return chain_.ctx; }
+    bool DeviceCandidateEquivalent() const { return chain_.referenceDataPointsFilters.allIdentity() && chain_.deviceReadingEquivalent(); }
+    size_t device_batches() const { return device_batches_; }
     void SetIcpConfigFromString(const std::string &yaml) { std::istringstream iss(yaml); chain_.loadFromYaml(iss); yaml_ = yaml; }
     void Add(const Candidate &c) { queue_.push_back(c); }
     void Clear() { queue_.clear(); }
@@ -542,7 +594,7 @@ public:
     std::vector<int> Shard(int world_size, int rank) const
     {
         std::vector<int64_t> cost(queue_.size());
-        for (size_t i = 0; i < queue_.size(); i++) cost[i] = (int64_t)queue_[i].reading->getNbPoints() + (int64_t)queue_[i].reference->getNbPoints();
+        for (size_t i = 0; i < queue_.size(); i++) cost[i] = CostOf(queue_[i]);
         std::vector<int> idx(queue_.size());
         int n = 0;
         if (pgicp_shard_pairs((int)queue_.size(), cost.data(), world_size, rank, idx.data(), (int)idx.size(), &n) != PGICP_OK)
@@ -561,6 +613,9 @@ public:
         std::vector<pgicp_problem> pr(P);
         std::vector<int> maps(P, -1), xs(P), ns(P), ms(P);
         std::vector<const T *> xyz(P), nrm(P);
+        bool on_device = DeviceCandidateEquivalent();
+        for (int k = 0; k < P && on_device; k++) on_device = queue_[mine[k]].reading_dev && queue_[mine[k]].reference_dev && queue_[mine[k]].reference_dev->hasNormals();
+        if (on_device) return RunOnDevice(mine, overlap_threshold, residual_threshold);
         // the chain's data-point filters act on copies, as ICP::operator() applies them (LoopCloser.hpp:98 -> reference
         // filters, then reading filters); a chain without filters reads the candidates' clouds where they lie
         std::vector<DP> ref_f, rd_f;
@@ -627,7 +682,7 @@ public:
         int world = 1, rank = 0, slots = 0;
         if (pgicp_comm_info(comm, &world, &rank) != PGICP_OK) throw std::runtime_error("LoopClosureBatch::Gather: no communicator");
         std::vector<int64_t> cost(queue_.size());
-        for (size_t i = 0; i < queue_.size(); i++) cost[i] = (int64_t)queue_[i].reading->getNbPoints() + (int64_t)queue_[i].reference->getNbPoints();
+        for (size_t i = 0; i < queue_.size(); i++) cost[i] = CostOf(queue_[i]);
         if (pgicp_shard_slots((int)queue_.size(), cost.data(), world, &slots) != PGICP_OK) throw std::runtime_error("pgicp_shard_slots failed");
         std::vector<pgicp_edge> all(queue_.size());
         if (pgicp_allgather_edges(comm, local.data(), mine.data(), (int)local.size(), slots, (int)queue_.size(), all.data()) != PGICP_OK)
@@ -636,9 +691,58 @@ public:
     }
 
 private:
+    static int64_t CostOf(const Candidate &c)
+    {
+        return (int64_t)(c.reading ? c.reading->getNbPoints() : c.reading_dev ? (size_t)c.reading_dev->n : 0) +
+               (int64_t)(c.reference ? c.reference->getNbPoints() : c.reference_dev ? (size_t)c.reference_dev->n : 0);
+    }
+    //! Run for candidates that live in device memory: the same two calls (pgicp_map_create_batch, pgicp_align_residual_batch)
+    //! with mem = PGICP_DEVICE
+    std::vector<pgicp_edge> RunOnDevice(const std::vector<int> &mine, T overlap_threshold, T residual_threshold)
+    {
+        pgicp_ctx *ctx = chain_.ctx;
+        const int P = (int)mine.size();
+        std::vector<pgicp_edge> edges(P);
+        std::vector<pgicp_problem> pr(P);
+        std::vector<int> maps(P, -1), xs(P), ns(P), ms(P);
+        std::vector<const T *> xyz(P), nrm(P);
+        for (int k = 0; k < P; k++) {
+            const auto &ref = *queue_[mine[k]].reference_dev;
+            xyz[k] = ref.xyz; xs[k] = ref.xs; nrm[k] = ref.nrm; ns[k] = ref.ns; ms[k] = ref.n;
+        }
+        PM::check(ctx, sizeof(T) == 4 ? pgicp_map_create_batch_f32(ctx, P, (const float *const *)xyz.data(), xs.data(), (const float *const *)nrm.data(), ns.data(), ms.data(), PGICP_DEVICE, 1, maps.data())
+                                      : pgicp_map_create_batch_f64(ctx, P, (const double *const *)xyz.data(), xs.data(), (const double *const *)nrm.data(), ns.data(), ms.data(), PGICP_DEVICE, 1, maps.data()));
+        chain_.pushParams();
+        for (int k = 0; k < P; k++) {
+            const Candidate &c = queue_[mine[k]];
+            std::memset(&pr[k], 0, sizeof pr[k]);
+            pr[k].map_id = maps[k]; pr[k].reading = c.reading_dev->xyz; pr[k].stride = c.reading_dev->xs; pr[k].n = c.reading_dev->n; pr[k].mem = PGICP_DEVICE;
+            pgslam_amd::to_row_major16(c.T_init, pr[k].T_init);
+        }
+        std::vector<double> Tout((size_t)16 * P), residual(P, 1.0 / 0.0);
+        std::vector<pgicp_stats> st(P);
+        const int rc = sizeof(T) == 4 ? pgicp_align_residual_batch_f32(ctx, P, pr.data(), Tout.data(), st.data(), residual.data(), nullptr, nullptr)
+                                      : pgicp_align_residual_batch_f64(ctx, P, pr.data(), Tout.data(), st.data(), residual.data(), nullptr, nullptr);
+        for (int k = 0; k < P; k++) pgicp_map_destroy(ctx, maps[k]);
+        if (rc != PGICP_OK && rc != PGICP_ERR_NO_MATCH && rc != PGICP_ERR_NAN && rc != PGICP_ERR_BOUND) PM::check(ctx, rc);
+        for (int k = 0; k < P; k++) {
+            const Candidate &c = queue_[mine[k]];
+            pgicp_edge &e = edges[k];
+            std::memset(&e, 0, sizeof e);
+            e.from_id = c.from_id; e.to_id = c.to_id; e.status = st[k].status; e.iterations = st[k].iterations;
+            e.max_iter_reached = st[k].max_iter_reached; e.overlap = st[k].overlap;
+            std::memcpy(e.T_from_to, Tout.data() + 16 * k, sizeof e.T_from_to);
+            std::memcpy(e.cov, st[k].cov, sizeof e.cov);
+            e.residual = residual[k];
+            e.accepted = pgicp_check_icp_result(&st[k], residual[k], (double)overlap_threshold, (double)residual_threshold);
+        }
+        device_batches_++;
+        return edges;
+    }
     typename PM::ICP chain_;
     std::string yaml_;
     std::vector<Candidate> queue_;
+    size_t device_batches_ = 0;
 };
 
 }  // namespace pgslam

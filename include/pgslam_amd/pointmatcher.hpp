@@ -1205,6 +1205,24 @@ struct PointMatcher {
             struct Reset { const DataPoints *&p; ~Reset() { p = nullptr; } } reset{this->currentReference};
             return this->alignOnMap(readingIn, T_init);
         }
+        //! ICP::operator() for clouds that are in device memory already: mean-centring + index build of `reference` in place,
+        //! the loop on the device copy of the reading (`reading.filtered` = its host cloud: sizes, the observer's copy).  Only for
+        //! a chain whose filters change nothing (deviceReadingEquivalent, identity reference filters); `hostReference` makes the
+        //! host copy of the reference when an observer asks for it.
+        TransformationParameters computeOnDevice(const typename ICPChainBase::DeviceReading &reading, const pgslam_amd::DeviceCloud<T> &reference,
+                                                 const TransformationParameters &T_init, std::function<DataPoints()> hostReference)
+        {
+            if (!this->referenceDataPointsFilters.allIdentity() || !this->deviceReadingEquivalent())
+                throw std::logic_error("ICP::computeOnDevice: the chain filters its clouds or reads their descriptors");
+            if (!reference.hasNormals() && !(this->errorMinimizer && this->errorMinimizer->pointToPoint))
+                throw std::runtime_error("PointToPlaneErrorMinimizer: the reference has no 'normals' descriptor");
+            this->prefilteredReferencePtsCount = reference.n;
+            this->matcher->initDevice(reference, 1);
+            this->currentReference = nullptr;
+            this->lazyReference = hostReference;
+            struct Reset { std::function<DataPoints()> &f; const DataPoints *&p; ~Reset() { f = nullptr; p = nullptr; } } reset{this->lazyReference, this->currentReference};
+            return this->alignOnMap(reading, T_init);
+        }
     };
 
     struct ICPSequence : ICP {

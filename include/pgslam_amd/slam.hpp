@@ -23,6 +23,7 @@
 #include <chrono>
 #include <deque>
 #include <limits>
+#include <list>
 #include <mutex>
 #include <queue>
 #include <thread>
@@ -504,6 +505,29 @@ public:
     void UpdateKeyframeTransform(size_t v, const Matrix &updated, typename Types<T>::Time t) { graph_[v].optimized_T_world_kf = updated; graph_[v].update_time = t; version_++; }
     //! bumped whenever an optimisation rewrites keyframe poses: a localizer that has seen this version is up to date
     unsigned long long Version() const { return version_; }
+    //! Keyframe clouds in device memory (graph locked): the copy is made on first use, through a context of the device that
+    //! will read it, and the least recently used copies are dropped once the budget is exceeded -- a long drive does not fill
+    //! HBM with clouds of places left behind (the host cloud stays; a dropped copy is uploaded again when a composition names
+    //! the keyframe once more).  Budget: PGSLAM_DEVICE_KEYFRAMES_MB (default 8192); the `keep` newest uses are never dropped.
+    void EnsureKeyframeResident(size_t v, pgicp_ctx *ctx)
+    {
+        Keyframe &kf = graph_[v];
+        if (!kf.device_cloud) { EnsureKeyframeOnDevice<T>(kf, ctx); resident_bytes_ += DeviceKeyframeBytes<T>(kf); device_uploads_++; }
+        resident_lru_.remove(v);
+        resident_lru_.push_front(v);
+        static const size_t budget = (size_t)(std::getenv("PGSLAM_DEVICE_KEYFRAMES_MB") ? std::atof(std::getenv("PGSLAM_DEVICE_KEYFRAMES_MB")) : 8192.0) << 20;
+        while (resident_bytes_ > budget && resident_lru_.size() > 16) {
+            const size_t old = resident_lru_.back();
+            resident_lru_.pop_back();
+            resident_bytes_ -= std::min(resident_bytes_, DeviceKeyframeBytes<T>(graph_[old]));
+            graph_[old].device_cloud.reset();                  // (copies of the keyframe still in use keep theirs until they go)
+            device_evictions_++;
+        }
+    }
+    size_t resident_keyframes() const { return resident_lru_.size(); }
+    size_t resident_bytes() const { return resident_bytes_; }
+    size_t device_uploads() const { return device_uploads_; }
+    size_t device_evictions() const { return device_evictions_; }
     void NotifyKeyframeUpdate();
     void WriteGraphviz(const std::string &path)
     {
@@ -524,6 +548,8 @@ private:
     }
     PoseGraph<T> graph_;
     std::recursive_mutex graph_mutex_;
+    std::list<size_t> resident_lru_;                 // vertices with a device copy, most recently used first
+    size_t resident_bytes_ = 0, device_uploads_ = 0, device_evictions_ = 0;
     unsigned long long version_ = 0;
     size_t fixed_vertex_ = 0;
     std::weak_ptr<GraphLocalizer<T>> localizer_;
@@ -644,8 +670,17 @@ public:
         return false;
     }
     //! what ProcessVertex hands to the ICP: LoopCloser.hpp:86-95 (graph locked while it is put together, LoopCloserMT.hpp:72-76)
-    struct PreparedCandidate { size_t ref_v, input_v; DPPtr reading; DPPtr reference; Matrix guess; };
-    bool PrepareCandidate(size_t input_v, PreparedCandidate &out)
+    //! `reading_dev` / `reference_dev`: the same two clouds in device memory when the candidate was put together there (`device_ctx`
+    //! given and the keyframes resident): the candidate map is assembled in HBM from the resident keyframe clouds, as the
+    //! localizer's maps are -- `reference` (the host cloud) is then made only on demand (`host_reference`)
+    struct PreparedCandidate {
+        size_t ref_v, input_v; DPPtr reading; DPPtr reference; Matrix guess;
+        std::shared_ptr<pgslam_amd::DeviceCloud<T>> reading_dev, reference_dev;
+        std::function<DP()> host_reference;
+    };
+    void SetDeviceCandidates(bool on) { device_candidates_ = on; }
+    size_t device_candidates() const { return device_candidates_made_; }
+    bool PrepareCandidate(size_t input_v, PreparedCandidate &out, pgicp_ctx *device_ctx = nullptr)
     {
         auto lock = map_manager_->GetGraphLock();
         auto &g = map_manager_->GetGraph();
@@ -655,19 +690,33 @@ public:
         candidates_tried_++;
         // candidate local map: composition order, reference = back (LocalMap::UpdateToNewComposition)
         LocalMap<T> lm(capacity_);
-        for (size_t v : comp) lm.PushKeyframe(g[v]);
-        lm.BuildCloudFromData();
         out.ref_v = comp.back(); out.input_v = input_v;
         out.reading = g[input_v].cloud_ptr;
-        out.reference = std::make_shared<DP>(lm.Cloud());
         out.guess = g[out.ref_v].optimized_T_world_kf.inverse() * g[input_v].optimized_T_world_kf;           // LoopCloser.hpp:95
+        if (device_ctx && device_candidates_) {
+            for (size_t v : comp) { map_manager_->EnsureKeyframeResident(v, device_ctx); lm.PushKeyframe(g[v]); }
+            map_manager_->EnsureKeyframeResident(input_v, device_ctx);
+            const std::vector<Keyframe> order = lm.AssemblyOrder();
+            out.reference_dev = std::make_shared<pgslam_amd::DeviceCloud<T>>();
+            BuildLocalMapOnDevice<T>(device_ctx, order, *out.reference_dev);
+            out.reading_dev = g[input_v].device_cloud;
+            out.host_reference = [order]() { return BuildLocalMapCloud<T>(order); };
+            out.reference.reset();
+            device_candidates_made_++;
+            return true;
+        }
+        for (size_t v : comp) lm.PushKeyframe(g[v]);
+        lm.BuildCloudFromData();
+        out.reference = std::make_shared<DP>(lm.Cloud());
         return true;
     }
     void ProcessVertex(size_t input_v)
     {
         PreparedCandidate c;
-        if (!PrepareCandidate(input_v, c)) return;
-        auto r = closer().ProcessCandidate(*c.reading, *c.reference, c.guess);                                // :98 + CheckIcpResult
+        LoopCloser<T> &lc = closer();
+        if (!PrepareCandidate(input_v, c, lc.DeviceCandidateEquivalent() ? (pgicp_ctx *)lc.icp().ctx : nullptr)) return;
+        auto r = c.reference_dev ? lc.ProcessCandidateOnDevice(c.reading, *c.reading_dev, *c.reference_dev, c.guess, c.host_reference)
+                                 : lc.ProcessCandidate(*c.reading, *c.reference, c.guess);                     // :98 + CheckIcpResult
         if (r.accepted) {
             loops_closed_++;
             optimizer_->AddNewData(c.ref_v, input_v, r.T_refkf_kf, r.cov);                            // :104-108
@@ -692,6 +741,8 @@ protected:
     T overlap_threshold_ = T(0.8), residual_error_threshold_ = T(5000);       // :18-19
     size_t capacity_ = 3;                                                     // :20
     int loops_closed_ = 0, candidates_tried_ = 0;
+    bool device_candidates_ = std::getenv("PGSLAM_HOST_LOOP_CANDIDATES") == nullptr;     // candidate maps assembled in HBM (default)
+    size_t device_candidates_made_ = 0;
 };
 
 // ------------------------------------------------------------------ localizer on the graph
@@ -775,16 +826,34 @@ public:
         typename PM::ICPChainBase::DeviceReading direct;
         Prefetched *slot = FindPrefetched(cloud.get());
         if (slot && slot->preprocessed) return direct;
+        direct = PreProcessOn(icp_sequence_.ctx, input_T_robot_sensor, cloud);
+        if (slot) slot->preprocessed = true;
+        return direct;
+    }
+    //! The input stage of one cloud on a context of the caller's choosing (the MT flavour's pre-processing thread runs it on its
+    //! own, while this object's thread aligns the scan before): touches the cloud, the input filters and `rigid_` only.
+    typename PM::ICPChainBase::DeviceReading PreProcessOn(pgicp_ctx *ctx, const Matrix &input_T_robot_sensor, DPPtr cloud)
+    {
+        typename PM::ICPChainBase::DeviceReading direct;
         const T *dev = nullptr;
-        if (device_input_stage_ && PM::filterAndTransformOnDevice(icp_sequence_.ctx, input_filters_, *cloud, input_T_robot_sensor, &dev)) {
+        if (device_input_stage_ && PM::filterAndTransformOnDevice(ctx, input_filters_, *cloud, input_T_robot_sensor, &dev)) {
             device_input_stages_++;
             if (icp_sequence_.deviceReadingEquivalent()) { direct.dev = dev; direct.filtered = cloud; }
         } else {
             input_filters_.apply(*cloud);
             (*cloud) = rigid_->compute(*cloud, input_T_robot_sensor);
         }
-        if (slot) slot->preprocessed = true;
         return direct;
+    }
+    //! a cloud whose input stage has run elsewhere (PreProcessOn): ProcessData takes it as pre-processed, with `reading` as its
+    //! device copy (empty: the host cloud is aligned)
+    void AdoptPreprocessed(DPPtr cloud, const typename PM::ICPChainBase::DeviceReading &reading)
+    {
+        Prefetched *slot = FindPrefetched(cloud.get());
+        if (!slot) slot = FindPrefetched(nullptr);
+        if (!slot) { prefetched_[0] = Prefetched(); slot = &prefetched_[0]; }
+        slot->cloud = cloud.get(); slot->preprocessed = true; slot->reading = reading;
+        prefetches_++;
     }
     //! scans whose input filters + sensor transform ran as one device pass
     size_t device_input_stages() const { return device_input_stages_; }
@@ -852,7 +921,7 @@ protected:
         // in place -- no cloud crosses PCIe (the host flow uploads the keyframes, downloads the assembled map and uploads it
         // again: 24 MB per rebuild at 100 k-pt scans).  Same values bit for bit; the host copy is made when somebody asks.
         if (device_local_map_ && icp_sequence_.deviceMapEquivalent()) {
-            for (size_t v : comp_) { EnsureKeyframeOnDevice<T>(g[v]); lm.PushKeyframe(g[v]); }
+            for (size_t v : comp_) { map_manager_->EnsureKeyframeResident(v, icp_sequence_.ctx); lm.PushKeyframe(g[v]); }
             const std::vector<Keyframe> order = lm.AssemblyOrder();
             BuildLocalMapOnDevice<T>(icp_sequence_.ctx, order, map_assembly_);
             icp_sequence_.setMap(map_assembly_, [order]() { return BuildLocalMapCloud<T>(order); });
@@ -881,7 +950,7 @@ protected:
             LocalMap<T> lm(capacity_);
             bool prepared = false;
             if (device_local_map_) {                    // (as Rebuild: assembled and moved to the world frame in device memory)
-                for (size_t v : comp) { EnsureKeyframeOnDevice<T>(g[v]); lm.PushKeyframe(g[v]); }
+                for (size_t v : comp) { map_manager_->EnsureKeyframeResident(v, probe_->OverlapContext()); lm.PushKeyframe(g[v]); }
                 const Matrix T_world_ref = g[comp.back()].optimized_T_world_kf;
                 BuildLocalMapOnDevice<T>(probe_->OverlapContext(), lm.AssemblyOrder(), probe_assembly_, &T_world_ref);
                 prepared = probe_->PrepareOverlapReference(probe_assembly_);
@@ -1094,7 +1163,10 @@ public:
     }
     void Run() { stop_ = false; thread_ = std::thread(&OptimizerMT::Main, this); }
     void Stop() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (thread_.joinable()) thread_.join(); }
-    bool Idle() { std::lock_guard<std::mutex> l(m_); return queue_.empty() && !busy_; }
+    bool Idle() { std::lock_guard<std::mutex> l(m_); return (queue_.empty() || paused_) && !busy_; }
+    //! (for deterministic hosts: while paused the constraints queue up; Resume() lets one solve take them all)
+    void Pause() { std::lock_guard<std::mutex> l(m_); paused_ = true; }
+    void Resume() { { std::lock_guard<std::mutex> l(m_); paused_ = false; } cv_.notify_one(); }
 
 private:
     void Main()
@@ -1103,7 +1175,7 @@ private:
             std::vector<typename Base::InputData> batch;
             {
                 std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [this] { return !queue_.empty() || stop_; });
+                cv_.wait(l, [this] { return (!queue_.empty() && !paused_) || stop_; });
                 if (stop_) break;
                 batch.assign(queue_.begin(), queue_.end());          // all of it: one solve (OptimizerMT.hpp:59-65)
                 queue_.clear();
@@ -1118,7 +1190,7 @@ private:
     std::condition_variable cv_;
     std::deque<typename Base::InputData> queue_;
     std::thread thread_;
-    bool stop_ = false, busy_ = false;
+    bool stop_ = false, busy_ = false, paused_ = false;
     std::exception_ptr error_;
 public:
     std::exception_ptr TakeError() { std::lock_guard<std::mutex> l(m_); std::exception_ptr e = error_; error_ = nullptr; return e; }
@@ -1140,9 +1212,19 @@ public:
     }
     void Run() { stop_ = false; thread_ = std::thread(&LoopCloserMT::Main, this); }
     void Stop() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (thread_.joinable()) thread_.join(); }
-    bool Idle() { std::lock_guard<std::mutex> l(m_); return queue_.empty() && !busy_; }
+    bool Idle() { std::lock_guard<std::mutex> l(m_); return (queue_.empty() || paused_) && !busy_; }
     int batches() const { return batches_; }
     int largest_batch() const { return largest_batch_; }
+    //! While paused the worker leaves its queue alone (vertices keep arriving); Resume() lets it drain what has piled up as ONE
+    //! device batch.  SetMaxBatch(1) restores upstream's one vertex at a time (LoopCloserMT.hpp:49-62).  Both are for hosts
+    //! that want a deterministic batch (tests, benchmarks): the dispatcher's results do not depend on how the queue is cut.
+    void Pause() { std::lock_guard<std::mutex> l(m_); paused_ = true; }
+    void Resume() { { std::lock_guard<std::mutex> l(m_); paused_ = false; } cv_.notify_one(); }
+    void SetMaxBatch(size_t n) { std::lock_guard<std::mutex> l(m_); max_batch_ = n < 1 ? 1 : n; }
+    size_t queued() { std::lock_guard<std::mutex> l(m_); return queue_.size(); }
+    //! every edge the dispatcher has produced so far, accepted or not, in the order it was produced
+    std::vector<pgicp_edge> edges() { std::lock_guard<std::mutex> l(m_); return edges_; }
+    size_t device_batches() const { return device_batches_; }
 
 private:
     void Main()
@@ -1153,24 +1235,33 @@ private:
             std::vector<size_t> vs;
             {
                 std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [this] { return !queue_.empty() || stop_; });
+                cv_.wait(l, [this] { return (!queue_.empty() && !paused_) || stop_; });
                 if (stop_) break;
-                vs.assign(queue_.begin(), queue_.end());          // every waiting vertex: one device batch
-                queue_.clear();
+                const size_t take = std::min(queue_.size(), max_batch_);
+                vs.assign(queue_.begin(), queue_.begin() + (long)take);     // every waiting vertex (up to max_batch_): one device batch
+                queue_.erase(queue_.begin(), queue_.begin() + (long)take);
                 busy_ = true;
             }
             std::exception_ptr err;
             try {
             if (!configured) { batch.SetIcpConfigFromString(yaml_); configured = true; }
             std::vector<typename Base::PreparedCandidate> cands;
+            pgicp_ctx *dev_ctx = batch.DeviceCandidateEquivalent() ? batch.Context() : nullptr;
             for (size_t v : vs) {
                 typename Base::PreparedCandidate c;
-                if (this->PrepareCandidate(v, c)) cands.push_back(c);
+                if (this->PrepareCandidate(v, c, dev_ctx)) cands.push_back(c);
             }
             if (!cands.empty()) {
                 batch.Clear();
-                for (auto &c : cands) batch.Add({(long long)c.ref_v, (long long)c.input_v, c.reading, c.reference, c.guess});
+                for (auto &c : cands) {
+                    typename LoopClosureBatch<T>::Candidate bc;
+                    bc.from_id = (long long)c.ref_v; bc.to_id = (long long)c.input_v; bc.reading = c.reading; bc.reference = c.reference; bc.T_init = c.guess;
+                    bc.reading_dev = c.reading_dev; bc.reference_dev = c.reference_dev;
+                    batch.Add(bc);
+                }
                 const auto edges = batch.Run(batch.Shard(1, 0), this->overlap_threshold_, this->residual_error_threshold_);
+                device_batches_ = batch.device_batches();
+                { std::lock_guard<std::mutex> l(m_); edges_.insert(edges_.end(), edges.begin(), edges.end()); }
                 batches_++;
                 largest_batch_ = std::max(largest_batch_, (int)cands.size());
                 for (const pgicp_edge &e : edges)
@@ -1191,8 +1282,11 @@ private:
     std::condition_variable cv_;
     std::deque<size_t> queue_;
     std::thread thread_;
-    bool stop_ = false, busy_ = false;
+    bool stop_ = false, busy_ = false, paused_ = false;
+    size_t max_batch_ = (size_t)1 << 30;
     int batches_ = 0, largest_batch_ = 0;
+    size_t device_batches_ = 0;
+    std::vector<pgicp_edge> edges_;
     std::exception_ptr error_;
 public:
     std::exception_ptr TakeError() { std::lock_guard<std::mutex> l(m_); std::exception_ptr e = error_; error_ = nullptr; return e; }
@@ -1207,53 +1301,111 @@ public:
     ~LocalizerMT() override { Stop(); }
     void AddNewData(unsigned long long, const std::string &, const Matrix &T_world_robot, const Matrix &T_robot_sensor, DPPtr cloud) override
     {
-        { std::lock_guard<std::mutex> l(m_); queue_.push_back(std::make_tuple(T_world_robot, T_robot_sensor, cloud)); }
-        cv_.notify_one();
+        auto it = std::make_shared<Item>();
+        it->T_world_robot = T_world_robot; it->T_robot_sensor = T_robot_sensor; it->cloud = cloud;
+        { std::lock_guard<std::mutex> l(m_); queue_.push_back(it); }
+        cv_.notify_all();
     }
     //! MapManager::NotifyKeyframeUpdate lands here from the optimiser's thread: only the flag is set, the update itself
     //! happens on the localizer's own thread (LocalizerMT.hpp:123-136)
     void UpdateFromGraph() override
     {
         { std::lock_guard<std::mutex> l(m_); outdated_ = true; }
-        cv_.notify_one();
+        cv_.notify_all();
     }
-    void Run() { stop_ = false; thread_ = std::thread(&LocalizerMT::Main, this); }
-    void Stop() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (thread_.joinable()) thread_.join(); }
+    void Run()
+    {
+        stop_ = false;
+        thread_ = std::thread(&LocalizerMT::Main, this);
+        pre_thread_ = std::thread(&LocalizerMT::PreMain, this);
+    }
+    void Stop()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        if (thread_.joinable()) thread_.join();
+        if (pre_thread_.joinable()) pre_thread_.join();
+    }
     bool Idle() { std::lock_guard<std::mutex> l(m_); return queue_.empty() && !busy_ && !outdated_; }
     size_t processed() { std::lock_guard<std::mutex> l(m_); return processed_; }
+    //! seconds the localizer's thread has waited for a scan's input stage to finish on the pre-processing thread
+    double waited_for_input_stage() { std::lock_guard<std::mutex> l(m_); return wait_pre_s_; }
 
 private:
+    // A queued scan.  Its input stage -- the input filters and the sensor->robot transform, Localizer.hpp:103-106, on the
+    // device: upload, one pass, the filtered cloud back -- runs on the PRE-PROCESSING thread, on that thread's own context, while
+    // the localizer's thread aligns the scan before it: upstream's queue (LocalizerMT.hpp:27-40) already holds the scan by then.
+    // At most two scans ahead (their device copies live in the context's ring of result sets).  All pre-processing of this
+    // flavour happens there, in arrival order: the filters' own state (a FixStep filter's step) sees the scans in order.
+    struct Item {
+        Matrix T_world_robot, T_robot_sensor;
+        DPPtr cloud;
+        int state = 0;                                              // 0 queued, 1 being pre-processed, 2 pre-processed
+        typename PM::ICPChainBase::DeviceReading reading;
+        std::exception_ptr err;
+    };
+    void PreMain()
+    {
+        for (;;) {
+            std::shared_ptr<Item> it;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] {
+                    if (stop_) return true;
+                    // the scan being aligned is no longer in the queue: entries 0 and 1 are the two after it
+                    for (size_t i = 0; i < queue_.size() && i < 2; i++) if (queue_[i]->state == 0) { it = queue_[i]; return true; }
+                    return false;
+                });
+                if (stop_) break;
+                it->state = 1;
+            }
+            try { it->reading = this->PreProcessOn(pre_ctx_, it->T_robot_sensor, it->cloud); } catch (...) { it->err = std::current_exception(); }
+            { std::lock_guard<std::mutex> l(m_); it->state = 2; }
+            cv_.notify_all();
+        }
+    }
     void Main()
     {
         for (;;) {
-            bool outdated = false, have = false, have_next = false;
-            std::tuple<Matrix, Matrix, DPPtr> item, next;
+            bool outdated = false;
+            std::shared_ptr<Item> it;
             {
                 std::unique_lock<std::mutex> l(m_);
                 cv_.wait(l, [this] { return !queue_.empty() || stop_ || outdated_; });
                 if (stop_) break;
                 outdated = outdated_;
                 outdated_ = false;
-                if (!queue_.empty()) { item = queue_.front(); queue_.pop_front(); have = true; }
-                if (have && !queue_.empty()) { next = queue_.front(); have_next = true; }     // (stays queued)
+                if (!queue_.empty()) {
+                    const auto tw = std::chrono::steady_clock::now();
+                    cv_.wait(l, [this] { return queue_.front()->state == 2 || stop_; });      // (its input stage is done, or nearly)
+                    wait_pre_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+                    if (stop_) break;
+                    it = queue_.front();
+                    queue_.pop_front();
+                }
                 busy_ = true;
             }
+            cv_.notify_all();                                          // (the pre-processing thread may look one scan further)
             std::exception_ptr err;
             try {
                 if (outdated) this->UpdateFromGraphNow();             // (takes the graph lock)
-                // the scan after this one is already here: its transfer starts now and overlaps this scan's ICP
-                if (have_next) this->Prefetch(std::get<1>(next), std::get<2>(next));
-                if (have) this->ProcessData(std::get<0>(item), std::get<1>(item), std::get<2>(item));
+                if (it) {
+                    if (it->err) std::rethrow_exception(it->err);
+                    this->AdoptPreprocessed(it->cloud, it->reading);
+                    this->ProcessData(it->T_world_robot, it->T_robot_sensor, it->cloud);
+                }
             } catch (...) { err = std::current_exception(); }
-            { std::lock_guard<std::mutex> l(m_); busy_ = false; if (have) processed_++; if (err && !error_) error_ = err; }
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; if (it) processed_++; if (err && !error_) error_ = err; }
         }
     }
     std::mutex m_;
     std::condition_variable cv_;
-    std::deque<std::tuple<Matrix, Matrix, DPPtr>> queue_;
-    std::thread thread_;
+    std::deque<std::shared_ptr<Item>> queue_;
+    std::thread thread_, pre_thread_;
+    pgslam_amd::LazyContext pre_ctx_{0};
     bool stop_ = false, busy_ = false, outdated_ = false;
     size_t processed_ = 0;
+    double wait_pre_s_ = 0;
     std::exception_ptr error_;
 public:
     std::exception_ptr TakeError() { std::lock_guard<std::mutex> l(m_); std::exception_ptr e = error_; error_ = nullptr; return e; }

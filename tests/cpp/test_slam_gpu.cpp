@@ -81,8 +81,9 @@ void run_mt(const char *name)
         CHECK(slam.localizer().processed() == (size_t)S);
         // free running, the next scan is queued while the current one aligns: its cloud was uploaded ahead (pgicp_upload_*,
         // LocalizerMT.hpp:27-40) and the ICP ran on the device copy; in lock step there is never a next scan to prefetch
-        if (free_running) CHECK(slam.localizer().prefetches() > (size_t)S / 2);
-        else CHECK(slam.localizer().prefetches() == 0);
+        // every scan's input stage runs on the flavour's pre-processing thread (round 5), free running up to two scans ahead of
+        // the one being aligned (LocalizerMT.hpp:27-40: the queue holds them by then), in lock step just before its own ICP
+        CHECK(slam.localizer().prefetches() == (size_t)S);
         auto lock = slam.map_manager().GetGraphLock();
         auto &g = slam.map_manager().GetGraph();
         CHECK(g.NumVertices() == (size_t)S);
@@ -150,8 +151,8 @@ void run_mt_sensor_pose(const char *name)
     for (int s = 0; s < S; s++) slam.AddData((unsigned long long)s, "world", odom[s], T_robot_sensor, clouds[s]);
     slam.WaitIdle();
     CHECK(slam.localizer().processed() == (size_t)S);
-    CHECK(slam.localizer().prefetches() > (size_t)S / 2);
-    CHECK(slam.localizer().device_readings_used() >= slam.localizer().prefetches());     // every prefetched upload was the one aligned
+    CHECK(slam.localizer().prefetches() == (size_t)S);
+    CHECK(slam.localizer().device_readings_used() == (size_t)S - 1);                     // every ICP ran on the device copy its input stage left (scan 0 has no ICP)
     CHECK(slam.localizer().device_input_stages() == (size_t)S);                          // (the input stage of every scan ran on the device)
     for (int s = 0; s < S; s++) CHECK(clouds[s]->getNbPoints() == (n_raw + 1) / 2);      // filtered once, in place
     CHECK(pose_diff(slam.localizer().T_world_robot(), truth[S - 1]) < 3e-2);
@@ -185,6 +186,7 @@ void run_device_local_map(const char *name)
         // (threshold 0.8: some scans join the current map, some become keyframes, and the neighbour-composition probe runs)
         slam.localizer().SetOverlapThreshold(T(0.8));
         slam.localizer().SetDeviceLocalMap(on_device != 0);
+        slam.loop_closer().SetDeviceCandidates(on_device != 0);          // (the loop closer's candidate maps: assembled in HBM / through the host)
         slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
         slam.loop_closer().SetGeometricalDistanceThreshold(T(0.3));
         for (int s = 0; s < S; s++) {
@@ -200,8 +202,9 @@ void run_device_local_map(const char *name)
         if (!on_device) {
             for (size_t v = 0; v < g.NumVertices(); v++) host_kf.push_back(g[v].optimized_T_world_kf);
             host_loops = loops; host_rebuilds = slam.localizer().rebuilds(); host_map = map;
-            CHECK(slam.localizer().device_rebuilds() == 0);
+            CHECK(slam.localizer().device_rebuilds() == 0 && slam.loop_closer().device_candidates() == 0);
         } else {
+            CHECK(slam.loop_closer().device_candidates() == (size_t)slam.loop_closer().candidates_tried());
             CHECK(g.NumVertices() == host_kf.size() && loops == host_loops && slam.localizer().rebuilds() == host_rebuilds);
             for (size_t v = 0; v < g.NumVertices(); v++) CHECK(pose_diff(g[v].optimized_T_world_kf, host_kf[v]) == 0.0);
             CHECK(slam.localizer().device_rebuilds() == (size_t)host_rebuilds);
@@ -217,8 +220,71 @@ void run_device_local_map(const char *name)
     }
 }
 
+// The batched dispatcher INSIDE the facade (LoopCloserMT.hpp:26-34 queues vertices, :45-67 pops them one at a time; here the
+// worker drains its queue into one device batch): the loop closer is held back while the localizer makes fifteen keyframes, then
+// let go -- every waiting vertex becomes a candidate of ONE batch (LoopClosureBatch over device-resident clouds) -- against the same
+// drive with the dispatcher cut to one vertex per batch, upstream's way.  The optimiser is held back in both runs, so that both
+// see the same graph: the edges must be the same, bit for bit.
+template <typename T>
+void run_mt_batched_dispatcher(const char *name)
+{
+    IMPORT_PGSLAM_TYPES(T)
+    TransformationPtr rigid = PM::get().REG(Transformation).create("RigidTransformation");
+    const int S = 15;
+    std::vector<Matrix> truth, odom;
+    for (int s = 0; s < S; s++) {
+        const double a = 2 * M_PI * s / (S - 1);
+        truth.push_back(pose<T>(1.5 + 0.5 * std::cos(a), 1.5 + 0.5 * std::sin(a), 0.0, a * 0.2));
+    }
+    odom.push_back(truth[0]);
+    for (int s = 1; s < S; s++) odom.push_back(odom[s - 1] * (truth[s - 1].inverse() * truth[s]) * pose<T>(0.012, -0.009, 0.0, 0.005));
+    std::vector<pgicp_edge> edges[2];
+    int largest[2] = {0, 0}, batches[2] = {0, 0};
+    for (int one_at_a_time = 0; one_at_a_time < 2; one_at_a_time++) {
+        pgslam::PoseGraphSlamMT<T> slam;
+        slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+        slam.localizer().SetOverlapThreshold(T(0.9));
+        slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
+        slam.loop_closer().SetGeometricalDistanceThreshold(T(0.6));
+        slam.loop_closer().Pause();
+        slam.optimizer().Pause();
+        if (one_at_a_time) slam.loop_closer().SetMaxBatch(1);
+        slam.Run();
+        for (int s = 0; s < S; s++) {
+            auto cloud = std::make_shared<DP>(rigid->compute(make_corner<T>(2000, 70 + s, 0.004), truth[s].inverse()));
+            slam.AddData((unsigned long long)s, "world", odom[s], Matrix::Identity(4, 4), cloud);
+        }
+        slam.WaitIdle();                                                 // (a paused worker counts as resting)
+        CHECK(slam.localizer().processed() == (size_t)S && slam.loop_closer().queued() == (size_t)S - 1 && slam.loop_closer().batches() == 0);
+        slam.loop_closer().Resume();
+        while (slam.loop_closer().queued() > 0 || !slam.loop_closer().Idle()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        slam.RethrowWorkerError();
+        edges[one_at_a_time] = slam.loop_closer().edges();
+        largest[one_at_a_time] = slam.loop_closer().largest_batch();
+        batches[one_at_a_time] = slam.loop_closer().batches();
+        CHECK(slam.loop_closer().device_batches() == (size_t)batches[one_at_a_time]);      // candidates assembled and aligned in device memory
+        slam.optimizer().Resume();
+        slam.WaitIdle();
+        CHECK(slam.optimizer().runs() == (slam.loop_closer().loops_closed() > 0 ? 1 : 0)); // one solve drains every accepted edge (OptimizerMT.hpp:59-65)
+    }
+    CHECK(batches[0] == 1 && largest[0] >= 3);                            // the batch path closed the loops: several candidates in one device batch
+    CHECK(batches[1] == largest[0] && largest[1] == 1);
+    CHECK(edges[0].size() == edges[1].size() && !edges[0].empty());
+    int accepted = 0;
+    for (size_t k = 0; k < edges[0].size() && k < edges[1].size(); k++) {
+        const pgicp_edge &a = edges[0][k], &b = edges[1][k];
+        CHECK(a.from_id == b.from_id && a.to_id == b.to_id && a.accepted == b.accepted && a.iterations == b.iterations && a.status == b.status);
+        CHECK(std::memcmp(a.T_from_to, b.T_from_to, sizeof a.T_from_to) == 0 && a.residual == b.residual && a.overlap == b.overlap);
+        CHECK(std::memcmp(a.cov, b.cov, sizeof a.cov) == 0);
+        accepted += a.accepted;
+    }
+    CHECK(accepted >= 1);
+    std::printf("%s: ok  (%zu candidates as ONE device batch == the same %zu one at a time, bit for bit; %d accepted)\n", name, edges[0].size(), edges[1].size(), accepted);
+}
+
 int main()
 {
+    run_mt_batched_dispatcher<float>("batched dispatcher inside PoseGraphSlamMT<float>");
     run_device_local_map<float>("local maps from device-resident keyframes, PoseGraphSlam<float>");
     run_device_local_map<double>("local maps from device-resident keyframes, PoseGraphSlam<double>");
     run_mt_sensor_pose<float>("PoseGraphSlamMT<float>, sensor off the robot's origin + sampling input filter");

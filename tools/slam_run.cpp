@@ -156,12 +156,17 @@ static int run_mt(FILE *f, int S, int N)
                 "\"keyframes\": %zu, \"loop_edges\": %d, \"loop_candidates_tried\": %d, \"loops_closed\": %d, \"loop_batches\": %d, "
                 "\"largest_loop_batch\": %d, \"optimizer_runs\": %d, \"optimizer_iterations\": %d, \"optimizer_host_s\": %.6f, "
                 "\"map_rebuilds\": %d, \"tracking_error_last_m\": %.5f, \"keyframes_revisiting_within_3m_by_estimate\": %d, "
-                "\"clouds_uploaded_one_scan_ahead\": %zu}\n",
+                "\"clouds_uploaded_one_scan_ahead\": %zu, \"loop_batches_on_device\": %zu, \"loop_candidates_assembled_on_device\": %zu, "
+                "\"keyframes_resident\": %zu, \"keyframe_uploads\": %zu, \"keyframe_evictions\": %zu, "
+                "\"localizer_thread_s\": {\"waiting_for_input_stage\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f, \"overlap_probe\": %.4f, \"rebuilds\": %.4f, \"new_keyframes\": %.4f}}\n",
                 S, N, wall, wall, (S - 1) / wall, g.NumVertices(), loops, slam.loop_closer().candidates_tried(), slam.loop_closer().loops_closed(),
                 slam.loop_closer().batches(), slam.loop_closer().largest_batch(), slam.optimizer().runs(), slam.optimizer().total_iterations(),
                 slam.optimizer().total_seconds(), slam.localizer().rebuilds(), e_last,
                 count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4),
-                slam.localizer().prefetches());
+                slam.localizer().prefetches(), slam.loop_closer().device_batches(), slam.loop_closer().device_candidates(),
+                slam.map_manager().resident_keyframes(), slam.map_manager().device_uploads(), slam.map_manager().device_evictions(),
+                slam.localizer().waited_for_input_stage(), slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2],
+                slam.localizer().after_icp_seconds()[1], slam.localizer().after_icp_seconds()[2], slam.localizer().after_icp_seconds()[3]);
     return 0;
 }
 
@@ -303,6 +308,7 @@ static int run_st(const char *seq_path, int limit, const char *rec_path, int rec
                 "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d, "
                 "\"localizer_host_s\": {\"filters_and_sensor_transform\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f, \"after_icp_parts\": {\"neighbour_search\": %.4f, \"overlap_probe\": %.4f, \"rebuilds\": %.4f, \"new_keyframes_incl_loop_closing\": %.4f}}, "
                 "\"input_filters\": \"%s\", \"device_input_stages\": %zu, \"device_readings_used\": %zu, \"device_map_rebuilds\": %zu, \"points_after_filters_last_scan\": %u, "
+                "\"loop_candidates_assembled_on_device\": %zu, \"keyframes_resident\": %zu, \"keyframe_uploads\": %zu, \"keyframe_evictions\": %zu, "
                 "\"keyframes_revisiting_within_3m_by_truth\": %d, \"keyframes_revisiting_within_3m_by_estimate\": %d, "
                 "\"knn_profile\": {\"launches\": %lld, \"total_ms\": %.4f, \"reading_points\": %lld, \"problems\": %lld, \"map_points\": %lld}",
                 S, N, wall, t_icp_loop, t_io, (S - 1) / t_icp_loop, g.NumVertices(), loops, slam.loop_closer().candidates_tried(),
@@ -314,6 +320,7 @@ static int run_st(const char *seq_path, int limit, const char *rec_path, int rec
                 slam.localizer().after_icp_seconds()[0], slam.localizer().after_icp_seconds()[1], slam.localizer().after_icp_seconds()[2], slam.localizer().after_icp_seconds()[3],
                 g_filters == kSensorFilters ? "RemoveNaN, MaxDist 79.9, BoundingBox (vehicle)" : "Identity", slam.localizer().device_input_stages(),
                 slam.localizer().device_readings_used(), slam.localizer().device_rebuilds(), last_cloud_points,
+                slam.loop_closer().device_candidates(), slam.map_manager().resident_keyframes(), slam.map_manager().device_uploads(), slam.map_manager().device_evictions(),
                 count_revisits(std::min(g.NumVertices(), kf_scan.size()), [&](size_t v, int a) { return (double)truth[kf_scan[v]](a, 3); }, 3.0, 4),
                 count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4),
                 kp_l, kp_ms, kp_u, kp_p, kp_m);
