@@ -318,7 +318,29 @@ def main_loopclosure(args, collect=False):
         dist.broadcast_object_list(uid, src=0)
     comm = icp.Comm(ctx, world, rank, uid[0])
 
+    # --lc-contexts C > 1: the shard as C sub-batches on C contexts (C HIP streams, C host threads): one sub-batch's index build
+    # and nearly empty last iterations overlap another's full launches (pgicp contexts are fully concurrent, include/pgicp.h)
+    extra_ctx = [icp.Context(local_rank, **CHAIN, check_every=args.check_every) for _ in range(max(0, args.lc_contexts - 1))]
+
     def align_shard(idx):
+        if extra_ctx and len(idx) >= 2 * len(extra_ctx) + 2:
+            cs = [ctx] + extra_ctx
+            C_ = len(cs)
+            idx = list(idx)
+            parts = [None] * C_
+
+            def work(k):
+                sub = idx[k::C_]
+                parts[k] = lc.align_local(cs[k], [cands[i] for i in sub], cfg)
+            th = [threading.Thread(target=work, args=(k,)) for k in range(C_)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            out_ = np.zeros(len(idx), dtype=lc.EDGE_DTYPE)
+            for k in range(C_):
+                out_[k::C_] = parts[k]
+            return out_
         parts = [lc.align_local(ctx, [cands[i] for i in idx[k:k + args.pair_chunk]], cfg)
                  for k in range(0, len(idx), args.pair_chunk)]
         return np.concatenate(parts) if parts else np.zeros(0, dtype=lc.EDGE_DTYPE)
@@ -466,6 +488,8 @@ def main_loopclosure(args, collect=False):
             "speedup_vs_one_gpu": (args.steps * len(cands) / elapsed) / single if single else None})
     comm.close()
     ctx.close()
+    for c_ in extra_ctx:
+        c_.close()
     if collect:
         return out
     if out is not None:
@@ -1175,6 +1199,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=512)
     ap.add_argument("--pair-chunk", type=int, default=512,
                     help="pairs aligned per device batch (measured at 512 pairs on one GPU: 64 -> 4 260, 128 -> 4 820, 256 -> 5 180, 512 -> 5 440 pairs/s)")
+    ap.add_argument("--lc-contexts", type=int, default=1, help="loopclosure: sub-batches of a rank's shard aligned concurrently on this many contexts")
     ap.add_argument("--shard-proxy", action="store_true",
                     help="loopclosure at N = 1: also time every rank's LPT shard of a 2-, 4- and 8-rank job alone on this GPU and report "
                          "the predicted multi-GPU speed-up (`shard_proxy`; always on in the default line's loop_closure leg)")

@@ -114,6 +114,13 @@ struct ProblemDev {
     double qraw1;            // the same of the last FIRST selection of an iteration: the next first selection's guess.  (A first
                              // selection sees upper bounds where queries are still queued -- a scan that runs ahead of its map has
                              // thousands -- so its result sits well above the iteration's final one, iteration after iteration.)
+    // (round 5) hints from the context's PREVIOUS call of the same kind: the raw quantiles that call's problem of the same
+    // index found in its iterations 0..3 -- [0]: first selections, [1]: second selections; 0: none.  A stream of scans (SLAM, the
+    // streaming mapper) runs two or three iterations per scan: without them every selection of a scan is an "early" one (no
+    // guess in iteration 0, a band ten octaves wide after it).  A hint only shapes the band: a rank outside it falls back to the
+    // full select, the result is exact either way.  qrec: what THIS call found (read back by the host for the next call).
+    double qhint[2][4];
+    double qrec[2][4];
     double sys[kSys];        // final sums of the last iteration
     Checker chk;
 };

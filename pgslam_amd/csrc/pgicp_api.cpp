@@ -172,6 +172,13 @@ struct pgicp_ctx {
     int counters_clean = 0;         // the matcher's queue counters were zeroed by the last kernel of the previous iteration
     int seg_clean = 0;              // the matcher's SEGMENTED queue counters were zeroed by the previous iteration's first selection
     int poll_us = 400;              // how long the host polls h_flag before it blocks on the stream instead
+    // selection hints (ProblemDev::qhint): what the previous call of the same kind found, per problem index -- [0] pgicp_align*,
+    // [1] pgicp_partial_chain*; dropped when the chain changes.  sel_guess_first: the enqueued iteration's FIRST selection may take
+    // the band path although the matcher is unseeded (every problem carries a hint for it).
+    struct SelHint { double q[2][4]; };
+    std::vector<SelHint> sel_hints[2];
+    int sel_guess_first = 0;
+    int sel_hints_on = 1;           // PGICP_SEL_HINTS=0 turns them off (A/B)
     int fast_rings_seeded = 1, fast_rings_unseeded = 3;
     double cell_scale = 1.0;     // experiment knob PGICP_CELL_SCALE: the automatic grid cell times this
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
@@ -821,7 +828,7 @@ struct BatchLayout {
 // Prepare a batch: stage readings, fill + upload ProblemDev, run the prologue
 // transform.  `Tpre_of(p, out16)` provides each problem's pre-transform.
 template <typename T, typename F>
-int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLayout &L, std::vector<ProblemDev> &hp)
+int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLayout &L, std::vector<ProblemDev> &hp, int hint_kind = -1)
 {
     if (P > 65535) return fail(c, PGICP_ERR_ARG, "pgicp: at most 65535 problems per batch (the problem index is a launch-grid dimension)");
     State<T> &S = state<T>(c);
@@ -923,6 +930,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         std::memset(&D, 0, sizeof D);
         D.map = map_index<T>(c, pr[p].map_id); D.n = pr[p].n; D.off = off; D.knn = L.knn;
         off += pr[p].n;
+        if (hint_kind >= 0 && c->sel_hints_on && (int)c->sel_hints[hint_kind].size() == P) std::memcpy(D.qhint, c->sel_hints[hint_kind][(size_t)p].q, sizeof D.qhint);
         Tpre_of(p, D.Tpre);
         mat4_identity(D.T_iter); mat4_identity(D.T_prev); mat4_identity(D.dT);
         for (int i = 0; i < 12; i++) { D.Tcur[i] = D.T_iter[i]; D.Tcur_f[i] = (float)D.T_iter[i]; }
@@ -1012,7 +1020,8 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
         // (with the grid matcher this selection also clears the matcher's segmented queue counters for the next iteration)
         const bool grid = c->prm.matcher == PGICP_MATCHER_GRID;
         launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 0, active, c->sel_tables.as<int>(), c->qtmp.p,
-                              grid ? (int *)c->queue.p : nullptr, use_seed);      // (every selection but a run's first starts from the last one's result: ProblemDev::qraw)
+                              grid ? (int *)c->queue.p : nullptr, use_seed || c->sel_guess_first);      // (every selection but a run's first starts from the last one's result,
+                                                                                          // ProblemDev::qraw; a run's first from the previous call's, ::qhint, if there is one)
         c->seg_clean = grid ? 1 : 0;
     }
     if (c->prm.matcher == PGICP_MATCHER_GRID) {
@@ -1120,6 +1129,20 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
     if (with_solve) ++c->flag_stamp;
 }
 
+// every problem of the batch carries a hint for the first selection of its first pass
+static bool hints_cover_first(const std::vector<ProblemDev> &hp)
+{
+    for (const ProblemDev &D : hp) if (!(D.qhint[0][0] > 0.0)) return false;
+    return !hp.empty();
+}
+// what this call's selections found becomes the next call's hints (problem by problem; a call with another number of problems starts over)
+static void hints_store(pgicp_ctx *c, int kind, const std::vector<ProblemDev> &hp)
+{
+    std::vector<pgicp_ctx::SelHint> &H = c->sel_hints[kind];
+    H.resize(hp.size());
+    for (size_t p = 0; p < hp.size(); p++) std::memcpy(H[p].q, hp[p].qrec, sizeof H[p].q);
+}
+
 // number of finished problems after the iteration just enqueued (its k_compact_active carries c->flag_stamp)
 static int wait_iteration_flag(pgicp_ctx *c)
 {
@@ -1173,8 +1196,9 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         translation(mean, -1.0, Tm_inv);
         translation(mean, +1.0, Tref[p].data());
         mat4_mul(Tm_inv, pr[p].T_init, Tpre);
-    }, L, hp);
+    }, L, hp, 0);
     if (st) return st;
+    const bool hint_first = hints_cover_first(hp);
     long long total_m = 0;                       // (profile only) reference points over the batch's problems
     if (c->prof_on) for (int p = 0; p < P; p++) total_m += get_map<T>(c, pr[p].map_id)->m;
     const auto ht1 = std::chrono::steady_clock::now();
@@ -1186,7 +1210,9 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     for (int it = 0; it < prm.max_iters; it++) {
         const long long act_p = P - n_done;
         c->prof_next_m = total_m * act_p / P;
+        c->sel_guess_first = it == 0 && hint_first ? 1 : 0;
         one_iteration<T>(c, L, ch, true, L.total * act_p / P, act_p, it > 0 ? 1 : 0);
+        c->sel_guess_first = 0;
         if ((it + 1) % every == 0 || it + 1 == prm.max_iters) {
             // k_compact_active stores {problems done, stamp} straight into pinned host memory: polling it spares
             // the copy and the wake-up of a blocking wait (30-40 us of idle GPU per iteration of a single scan)
@@ -1227,6 +1253,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     std::memcpy(hp.data(), c->h_down, sizeof(ProblemDev) * (size_t)P);
+    hints_store(c, 0, hp);
     for (int p = 0; p < P && !rsys.empty(); p++) {
         const double *rs = rsys.data() + (size_t)p * kSys;
         const bool ok = hp[p].status == PGICP_ST_OK && rs[28] > 0.0;
@@ -1400,10 +1427,12 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
         double Tm_inv[16];
         translation(mean, -1.0, Tm_inv);
         mat4_mul(Tm_inv, pr[p].T_init, Tpre);
-    }, L, hp);
+    }, L, hp, 1);
     if (st) return st;
     const ChainDev<T> ch = make_chain<T>(c->prm);
+    c->sel_guess_first = hints_cover_first(hp) ? 1 : 0;
     one_iteration<T>(c, L, ch, false, L.total, P, 0);
+    c->sel_guess_first = 0;
     launch_sum_partials(c->stream, c->partials.as<double>(), reduce_blocks(L.max_pairs()), kSys, c->probs.as<ProblemDev>(), 0,
                         c->sums.as<double>(), P);
     std::vector<double> sys((size_t)P * kSys);
@@ -1413,6 +1442,7 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
     HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     std::memcpy(hp.data(), c->h_down, sizeof(ProblemDev) * (size_t)P);
+    hints_store(c, 1, hp);
     int worst = PGICP_OK;
     for (int p = 0; p < P; p++) {
         const double *s = sys.data() + (size_t)p * kSys;
@@ -1954,6 +1984,7 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     if (const char *e = std::getenv("PGICP_BIN_SHIFT_ADD")) c->bin_shift_add = std::atoi(e);
     if (const char *e = std::getenv("PGICP_MED_RINGS")) c->med_rings = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_POLL_US")) c->poll_us = std::atoi(e);
+    if (const char *e = std::getenv("PGICP_SEL_HINTS")) c->sel_hints_on = std::atoi(e);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
@@ -2145,6 +2176,13 @@ int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
         return fail(c, PGICP_ERR_ARG, "DifferentialTransformationChecker.smoothLength must be in [1,15]");
     if (p->matcher != PGICP_MATCHER_GRID && p->matcher != PGICP_MATCHER_BRUTE) return fail(c, PGICP_ERR_ARG, "unknown matcher");
     if (p->grid_cell < 0.0) return fail(c, PGICP_ERR_ARG, "grid_cell must be >= 0");
+    {   // another chain: its thresholds are not this one's (field by field: the struct has padding)
+        const pgicp_params &a = c->prm, &b = *p;
+        const bool same = a.knn == b.knn && a.max_dist == b.max_dist && a.trim_ratio == b.trim_ratio && a.outlier_max_dist == b.outlier_max_dist &&
+                          a.quantile_scale == b.quantile_scale && a.error_minimizer == b.error_minimizer && a.normal_max_angle == b.normal_max_angle &&
+                          a.matcher == b.matcher && a.grid_cell == b.grid_cell;
+        if (!same) { c->sel_hints[0].clear(); c->sel_hints[1].clear(); }
+    }
     c->prm = *p;
     if (c->prm.check_every < 1) c->prm.check_every = 1;
     return PGICP_OK;
