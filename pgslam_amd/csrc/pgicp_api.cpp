@@ -179,7 +179,7 @@ struct pgicp_ctx {
     std::vector<SelHint> sel_hints[2];
     int sel_guess_first = 0;
     int sel_hints_on = 1;           // PGICP_SEL_HINTS=0 turns them off (A/B)
-    int fast_rings_seeded = 1, fast_rings_unseeded = 3;
+    int fast_rings_seeded = 0, fast_rings_unseeded = 0;      // 0: by the maps' cell size (BatchLayout::rings_*); PGICP_FAST_RINGS_* set them
     double cell_scale = 1.0;     // experiment knob PGICP_CELL_SCALE: the automatic grid cell times this
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
@@ -822,6 +822,11 @@ struct BatchLayout {
     long long total = 0;
     int knn = 1;                // pairs per reading point (ChainDev::knn)
     bool normals = false;       // the readings' normals travel with them (a SurfaceNormalOutlierFilter is in the chain)
+    double max_h = 0.0;         // largest cell edge among the batch's maps
+    // Rings of cells the fast matcher walks beyond the 27-cell block before it queues a query: 3 unseeded / 1 seeded on the 9 cm
+    // cells of a 1 M-pt map (measured, rounds 3 and 4); the 28 cm cells of a 100 k-pt keyframe map -- loop closing -- are
+    // cheaper to walk than to queue: 5 / 2 there (round 5, tools/r5_lc_knobs.sh: +3...6 %).  The environment knobs override.
+    int rings_unseeded = 3, rings_seeded = 1;
     int max_pairs() const { return (int)std::min<long long>((long long)max_n * knn, 0x7FFFFFFFLL); }
 };
 
@@ -847,11 +852,14 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp: unknown map id " + std::to_string(pr[p].map_id));
         L.max_n = std::max(L.max_n, pr[p].n);
+        L.max_h = std::max(L.max_h, (double)M->g.h);
         dens = std::max(dens, (double)pr[p].n / (double)M->m);
         L.total += pr[p].n;
         if (pr[p].mem == PGICP_HOST) stage_total += staged_bytes(sizeof(T), pr[p].stride, pr[p].n) +
                                                     (L.normals ? staged_bytes(sizeof(T), pr[p].nstride, pr[p].n) : 0);
     }
+    L.rings_unseeded = c->fast_rings_unseeded > 0 ? c->fast_rings_unseeded : (L.max_h >= 0.18 ? 5 : 3);
+    L.rings_seeded = c->fast_rings_seeded > 0 ? c->fast_rings_seeded : (L.max_h >= 0.18 ? 2 : 1);
     if ((long long)L.max_n * L.knn > 0x7FFFFFF0LL || L.total * L.knn > 0x7FFFFFF0LL)
         return fail(c, PGICP_ERR_ARG, "pgicp: points x knn exceeds 2^31: split the batch");
     // Bins of the reading sort are blocks of map cells.  The rank pass costs O(bin population) per
@@ -1011,7 +1019,7 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
         if (!use_seed && c->prm.matcher == PGICP_MATCHER_GRID) ps.also(PGICP_PROF_KNN_GRID_UNSEEDED);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
-                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? c->fast_rings_seeded : c->fast_rings_unseeded, active, S.none_r.template as<T>(),
+                      c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? L.rings_seeded : L.rings_unseeded, active, S.none_r.template as<T>(),
                       L.P, c->queue.p, c->seg_clean ? 0 : 1);
         c->counters_clean = 0;
     }
@@ -1084,8 +1092,8 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         // FNV-1a over the argument values: shapes, switches, chain parameters, and every buffer the launches name
         unsigned long long key = 1469598103934665603ULL;
         auto mix = [&key](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ULL; } };
-        const int shape[11] = {(int)sizeof(T), L.P, (int)act_probs, L.max_n, use_seed, with_solve ? 1 : 0, c->med_rings, c->fast_rings_seeded,
-                               c->fast_rings_unseeded, c->prm.matcher, c->seg_clean};
+        const int shape[11] = {(int)sizeof(T), L.P, (int)act_probs, L.max_n, use_seed, with_solve ? 1 : 0, c->med_rings, L.rings_seeded,
+                               L.rings_unseeded, c->prm.matcher, c->seg_clean};
         mix(shape, sizeof shape);
         mix(&ch, sizeof ch);
         const void *bufs[] = {c->probs.p, S.d_maps.p, S.rd_sorted.p, S.slot.p, S.d2.p, S.none_r.p, c->small.p, c->slow_list.p, c->slow_lb.p,
@@ -1368,7 +1376,7 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                      c->slow_ring.as<int>(), c->fast_rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p, 1);
+                      c->slow_ring.as<int>(), L.rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p, 1);
         c->seg_clean = 0;
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
