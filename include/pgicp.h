@@ -56,6 +56,9 @@ extern "C" {
 #define PGICP_MINIMIZER_POINT_TO_PLANE 0   /* PointToPlane(WithCov)ErrorMinimizer */
 #define PGICP_MINIMIZER_POINT_TO_POINT 1   /* PointToPointErrorMinimizer (no covariance: the base class's zeros) */
 #define PGICP_MINIMIZER_POINT_TO_PLANE_4DOF 2   /* PointToPlaneErrorMinimizer{force4DOF: 1}: rotation about z and translation only */
+#define PGICP_MINIMIZER_POINT_TO_POINT_WITH_COV 3   /* (ABI 5) PointToPointWithCovErrorMinimizer{sensorStdDev}: the point-to-point solve with the
+                                                     * covariance estimate pgslam hands to its optimiser (Localizer.hpp:238, LoopCloser.hpp:108);
+                                                     * the estimate reads the reference's `normals`: the map must have them */
 #define PGICP_MAX_KNN 16
 
 typedef struct pgicp_ctx pgicp_ctx;
@@ -85,7 +88,7 @@ typedef struct pgicp_params {
                               * dist <= quantile_scale * getDistsQuantile(trim_ratio) (squared distances).  TrimmedDist is
                               * (trim_ratio, 1); MedianDist is (0.5, factor).  Default 1 */
     /* (ABI 4) the other modules the chain's slots may hold */
-    int error_minimizer;     /* PGICP_MINIMIZER_POINT_TO_PLANE | _POINT_TO_POINT | _POINT_TO_PLANE_4DOF */
+    int error_minimizer;     /* PGICP_MINIMIZER_POINT_TO_PLANE | _POINT_TO_POINT | _POINT_TO_PLANE_4DOF | _POINT_TO_POINT_WITH_COV */
     double bound_max_rot;    /* BoundTransformationChecker.maxRotationNorm (rad): 0 or +inf = not in the chain.  The ICP fails with */
     double bound_max_trans;  /* PGICP_ERR_BOUND when the accumulated correction exceeds either (.maxTranslationNorm) */
     double normal_max_angle; /* SurfaceNormalOutlierFilter.maxAngle (rad): a pair whose reading and reference normals differ by more

@@ -1011,6 +1011,10 @@ struct PointMatcher {
                 const auto &m = y.sections.at("errorMinimizer")[0];
                 if (m.name == "PointToPlaneWithCovErrorMinimizer") errorMinimizer->withCov = true;
                 else if (m.name == "PointToPointErrorMinimizer") errorMinimizer->pointToPoint = true;
+                // [EXT] PointToPointWithCovErrorMinimizer{sensorStdDev}: the point-to-point solve + the covariance estimate (the
+                // body of PointToPlaneWithCov's, read from the reference's normals) -- what a point-to-point pgslam configuration
+                // needs, its optimiser refuses the base class's zero covariance (Optimizer.hpp:94,109)
+                else if (m.name == "PointToPointWithCovErrorMinimizer") { errorMinimizer->pointToPoint = true; errorMinimizer->withCov = true; }
                 else if (m.name != "PointToPlaneErrorMinimizer") throw std::runtime_error("loadFromYaml: unsupported error minimizer " + m.name);
                 for (auto &kv : m.params) {
                     if (kv.first == "sensorStdDev") errorMinimizer->sensorStdDev = (T)to_double(kv.second, "sensorStdDev");
@@ -1063,7 +1067,7 @@ struct PointMatcher {
             }
             if (errorMinimizer) {
                 p.sensor_std_dev = (double)errorMinimizer->sensorStdDev;
-                p.error_minimizer = errorMinimizer->pointToPoint ? PGICP_MINIMIZER_POINT_TO_POINT
+                p.error_minimizer = errorMinimizer->pointToPoint ? (errorMinimizer->withCov ? PGICP_MINIMIZER_POINT_TO_POINT_WITH_COV : PGICP_MINIMIZER_POINT_TO_POINT)
                                     : errorMinimizer->force4DOF ? PGICP_MINIMIZER_POINT_TO_PLANE_4DOF : PGICP_MINIMIZER_POINT_TO_PLANE;
             }
             for (auto &f : outlierFilters)
@@ -1198,7 +1202,7 @@ struct PointMatcher {
             this->referenceDataPointsFilters.init();
             this->referenceDataPointsFilters.apply(reference);
             this->prefilteredReferencePtsCount = reference.getNbPoints();
-            if (!reference.descriptorExists("normals") && !(this->errorMinimizer && this->errorMinimizer->pointToPoint))
+            if (!reference.descriptorExists("normals") && !(this->errorMinimizer && this->errorMinimizer->pointToPoint && !this->errorMinimizer->withCov))
                 throw std::runtime_error("PointToPlaneErrorMinimizer: the reference has no 'normals' descriptor");
             this->matcher->initImpl(reference, 1);
             this->currentReference = &reference;
@@ -1214,7 +1218,7 @@ struct PointMatcher {
         {
             if (!this->referenceDataPointsFilters.allIdentity() || !this->deviceReadingEquivalent())
                 throw std::logic_error("ICP::computeOnDevice: the chain filters its clouds or reads their descriptors");
-            if (!reference.hasNormals() && !(this->errorMinimizer && this->errorMinimizer->pointToPoint))
+            if (!reference.hasNormals() && !(this->errorMinimizer && this->errorMinimizer->pointToPoint && !this->errorMinimizer->withCov))
                 throw std::runtime_error("PointToPlaneErrorMinimizer: the reference has no 'normals' descriptor");
             this->prefilteredReferencePtsCount = reference.n;
             this->matcher->initDevice(reference, 1);
@@ -1236,7 +1240,7 @@ struct PointMatcher {
         bool setMap(const pgslam_amd::DeviceCloud<T> &deviceCloud, std::function<DataPoints()> hostCopy)
         {
             if (!deviceMapEquivalent()) throw std::logic_error("ICPSequence::setMap(DeviceCloud): the chain has reference filters");
-            if (!deviceCloud.hasNormals() && !(this->errorMinimizer && this->errorMinimizer->pointToPoint))
+            if (!deviceCloud.hasNormals() && !(this->errorMinimizer && this->errorMinimizer->pointToPoint && !this->errorMinimizer->withCov))
                 throw std::runtime_error("PointToPlaneErrorMinimizer: the map has no 'normals' descriptor");
             mapPointCloud = DataPoints();
             this->prefilteredReferencePtsCount = deviceCloud.n;
@@ -1253,7 +1257,7 @@ struct PointMatcher {
             this->referenceDataPointsFilters.init();
             this->referenceDataPointsFilters.apply(mapPointCloud);
             this->prefilteredReferencePtsCount = mapPointCloud.getNbPoints();
-            if (!mapPointCloud.descriptorExists("normals") && !(this->errorMinimizer && this->errorMinimizer->pointToPoint))
+            if (!mapPointCloud.descriptorExists("normals") && !(this->errorMinimizer && this->errorMinimizer->pointToPoint && !this->errorMinimizer->withCov))
                 throw std::runtime_error("PointToPlaneErrorMinimizer: the map has no 'normals' descriptor");
             this->matcher->initImpl(mapPointCloud, 1);
             this->currentReference = &mapPointCloud;

@@ -126,7 +126,9 @@ typedef struct {
     int knn;                /* [A.3] KDTreeMatcher.knn: neighbours per reading point (<= 1: one).  Matches are knn x N; every
                              * later stage sees knn * N pairs */
     int minimizer;          /* 0: PointToPlane(WithCov)ErrorMinimizer [A.6]; 1: PointToPointErrorMinimizer (Kabsch / SVD);
-                             * 2: PointToPlane with force4DOF (orc_solve_4dof) */
+                             * 2: PointToPlane with force4DOF (orc_solve_4dof); 3: PointToPointWithCovErrorMinimizer -- the solve of 1 and
+                             * [EXT] ErrorMinimizers/PointToPointWithCov.cpp's estimateCovariance, which is PointToPlaneWithCov's body: the
+                             * same Censi sums over the kept pairs, read from the reference's `normals` (A.8) */
     double bound_max_rot;   /* [A.9] BoundTransformationChecker.maxRotationNorm (rad); <= 0 or inf: not in the chain */
     double bound_max_trans; /* [A.9] BoundTransformationChecker.maxTranslationNorm; <= 0 or inf: not in the chain */
     real normal_max_angle;  /* [A.4] SurfaceNormalOutlierFilter.maxAngle (rad); <= 0: not in the chain */
@@ -1356,7 +1358,7 @@ int FN(orc_partial_chain)(const FN(orc_params) *prm, const real *reading, int n,
     if (st == ORC_OK) FN(orc_maxdist_weights)(d2, n * K, prm->outlier_max_dist, w);
     if (st == ORC_OK) {
         double sys[30];
-        st = prm->minimizer == 1 ? FN(orc_p2point_system)(p, n, K, ref_xyz, ids, w, sys)
+        st = (prm->minimizer == 1 || prm->minimizer == 3) ? FN(orc_p2point_system)(p, n, K, ref_xyz, ids, w, sys)
                                  : FN(p2plane_system_k)(p, n, K, ref_xyz, ref_nrm, ids, w, sys);
         if (overlap) *overlap = sys[27] / ((double)n * K);
         if (residual) *residual = sys[29];
@@ -1456,7 +1458,7 @@ int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *r
         if (status != ORC_OK) break;
         FN(orc_maxdist_weights)(d2, n * K, prm->outlier_max_dist, w);
         if (use_nrm) FN(orc_normal_weights)(step_n, ref_nrm, ids, n, K, prm->normal_max_angle, w);
-        if (prm->minimizer == 1) {
+        if (prm->minimizer == 1 || prm->minimizer == 3) {
             status = FN(orc_p2point_system)(step, n, K, ref, ids, w, sys);
             if (status != ORC_OK) break;
             FN(orc_solve_p2point)(sys, dT);

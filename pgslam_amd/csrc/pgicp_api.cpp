@@ -313,6 +313,11 @@ ProfScope::~ProfScope()
     if (c->prof_events.size() >= 4096) prof_collect_locked(c);
 }
 
+static inline bool is_p2point(int m) { return m == PGICP_MINIMIZER_POINT_TO_POINT || m == PGICP_MINIMIZER_POINT_TO_POINT_WITH_COV; }
+// the chain reads the reference's normals: every minimiser but the plain point-to-point one (its WithCov form estimates the
+// covariance from them), and a SurfaceNormalOutlierFilter
+static inline bool needs_ref_normals(const pgicp_params &p) { return p.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT || p.normal_max_angle > 0.0; }
+
 template <typename T>
 ChainDev<T> make_chain(const pgicp_params &p)
 {
@@ -331,7 +336,7 @@ ChainDev<T> make_chain(const pgicp_params &p)
     ch.min_trans = p.min_diff_trans;
     ch.rank_rel_tol = 6.0 * (double)std::numeric_limits<T>::epsilon();
     ch.knn = std::max(1, p.knn);
-    ch.minimizer = p.error_minimizer == PGICP_MINIMIZER_POINT_TO_POINT ? 1 : 0;
+    ch.minimizer = is_p2point(p.error_minimizer) ? 1 : 0;
     ch.force4dof = p.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE_4DOF ? 1 : 0;
     ch.bound_rot = (p.bound_max_rot > 0.0 && std::isfinite(p.bound_max_rot)) ? p.bound_max_rot : 0.0;
     ch.bound_trans = (p.bound_max_trans > 0.0 && std::isfinite(p.bound_max_trans)) ? p.bound_max_trans : 0.0;
@@ -1192,7 +1197,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     for (int p = 0; p < P; p++) {
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_align: unknown map id");
-        if (!M->has_nrm && (prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT || prm.normal_max_angle > 0.0))
+        if (!M->has_nrm && needs_ref_normals(prm))
             return fail(c, PGICP_ERR_ARG, "pgicp_align: reference has no normals descriptor");
     }
     static const bool host_timing = std::getenv("PGICP_HOST_TIMING") != nullptr;      // diagnostics
@@ -1231,7 +1236,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
         }
     }
     const auto ht2 = std::chrono::steady_clock::now();
-    const bool with_cov = prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT;      // (PointToPoint: the base class's zeros)
+    const bool with_cov = prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT;      // (PointToPoint: the base class's zeros; its WithCov form: the same Censi estimate)
     if (with_cov) {
         ProfScope ps(c, PGICP_PROF_COV, L.total, P);
         launch_cov<T>(c->stream, c->probs.as<ProblemDev>(), S.d_maps.template as<MapDev<T>>(), S.rd_sorted.template as<T>(),
@@ -1424,7 +1429,7 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
     for (int p = 0; p < P; p++) {
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp_partial_chain: unknown map id");
-        if (!M->has_nrm && (c->prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT || c->prm.normal_max_angle > 0.0))
+        if (!M->has_nrm && needs_ref_normals(c->prm))
             return fail(c, PGICP_ERR_ARG, "pgicp: reference has no normals descriptor");
     }
     BatchLayout L;
@@ -1515,7 +1520,7 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     if (!c || !reading || !ids || !w || n <= 0 || stride < 3) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: bad argument");
     HIPC(c, hipSetDevice(c->device));
     MapHost<T> *M = get_map<T>(c, map_id);
-    if (!M || (!M->has_nrm && c->prm.error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT)) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: unknown map or no normals");
+    if (!M || (!M->has_nrm && !is_p2point(c->prm.error_minimizer))) return fail(c, PGICP_ERR_ARG, "pgicp_error_stats: unknown map or no normals");
     State<T> &S = state<T>(c);
     const int K = std::max(1, c->prm.knn);                   // ids / w: knn entries per reading point
     const T *d_rd = reading, *d_w = w;
@@ -1543,7 +1548,7 @@ int error_stats(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, n);
         launch_error_stats<T>(c->stream, S.d_maps.template as<MapDev<T>>(), map_index<T>(c, map_id), M->slot_of, d_rd, stride, d_ids, d_w, n, K,
-                              M->mean, c->partials.as<double>(), c->sums.as<double>(), c->prm.error_minimizer);
+                              M->mean, c->partials.as<double>(), c->sums.as<double>(), is_p2point(c->prm.error_minimizer) ? 1 : 0);
     }
     double sys[kSys];
     XFER(c, d2h(c, sys, c->sums.p, sizeof sys));
@@ -2167,7 +2172,7 @@ int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
     if (!c || !p) return PGICP_ERR_ARG;
     if (p->knn < 1 || p->knn > PGICP_MAX_KNN) return fail(c, PGICP_ERR_ARG, "KDTreeMatcher.knn must be in [1, " + std::to_string(PGICP_MAX_KNN) + "]");
     if (p->error_minimizer != PGICP_MINIMIZER_POINT_TO_PLANE && p->error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT &&
-        p->error_minimizer != PGICP_MINIMIZER_POINT_TO_PLANE_4DOF)
+        p->error_minimizer != PGICP_MINIMIZER_POINT_TO_PLANE_4DOF && p->error_minimizer != PGICP_MINIMIZER_POINT_TO_POINT_WITH_COV)
         return fail(c, PGICP_ERR_ARG, "unknown error minimizer");
     if (p->bound_max_rot < 0.0 || p->bound_max_rot != p->bound_max_rot || p->bound_max_trans < 0.0 || p->bound_max_trans != p->bound_max_trans)
         return fail(c, PGICP_ERR_ARG, "BoundTransformationChecker limits must be >= 0");

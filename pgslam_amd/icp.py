@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGICP_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libpgicp.so")
 
 OK, ERR_NO_MATCH, ERR_NAN, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_RIGID, ERR_BOUND = range(8)
-MINIMIZER_POINT_TO_PLANE, MINIMIZER_POINT_TO_POINT, MINIMIZER_POINT_TO_PLANE_4DOF = 0, 1, 2
+MINIMIZER_POINT_TO_PLANE, MINIMIZER_POINT_TO_POINT, MINIMIZER_POINT_TO_PLANE_4DOF, MINIMIZER_POINT_TO_POINT_WITH_COV = 0, 1, 2, 3
 HOST, DEVICE, HOST_PINNED = 0, 1, 2
 MATCHER_GRID, MATCHER_BRUTE = 0, 1
 PROF_NAMES = ["knn_grid", "knn_brute", "trim_select", "p2plane_reduce", "solve_update", "pretransform",

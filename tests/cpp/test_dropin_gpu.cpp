@@ -224,6 +224,15 @@ void run(const char *name)
         { std::istringstream iss(chain("", "", "PointToPointErrorMinimizer", "")); p2p.loadFromYaml(iss); }
         CHECK(pose_diff(p2p(reading, map, guess), P) < 3e-2);
         CHECK(p2p.errorMinimizer->getCovariance()(0, 0) == T(0));          // the base class's covariance: zeros
+        // PointToPointWithCovErrorMinimizer: the same alignment, and the covariance pgslam's optimiser needs (positive diagonal)
+        ICP p2pc;
+        { std::istringstream iss(chain("", "", "PointToPointWithCovErrorMinimizer:\n    sensorStdDev: 0.01", "")); p2pc.loadFromYaml(iss); }
+        {
+            const typename PM::TransformationParameters Ta = p2p(reading, map, guess), Tb = p2pc(reading, map, guess);
+            CHECK(pose_diff(Ta, Tb) == 0.0);
+            const typename PM::Matrix cov = p2pc.errorMinimizer->getCovariance();
+            for (int a = 0; a < 6; a++) CHECK(cov(a, a) > T(0));
+        }
 
         // PointToPlaneErrorMinimizer{force4DOF: 1}: the correction is a rotation about z and a translation -- the z axis of the
         // result is the z axis of the guess, whatever the scene asks for

@@ -148,7 +148,8 @@ def np_icp_ex(reading, ref, nrm, T_init, chain, reading_nrm=None):
     BoundTransformationChecker (angle and translation of the accumulated correction; exceeding either is an error),
     PointToPlaneErrorMinimizer{force4DOF} (the increment is a rotation about z and a translation: a 4 x 4 system)."""
     K = int(chain.get("knn", 1))
-    p2point = int(chain.get("error_minimizer", 0)) == 1
+    p2point = int(chain.get("error_minimizer", 0)) in (1, 3)       # (3: PointToPointWithCov -- the same solve, the Censi covariance kept)
+    p2p_cov = int(chain.get("error_minimizer", 0)) == 3
     force4dof = int(chain.get("error_minimizer", 0)) == 2          # PointToPlaneErrorMinimizer{force4DOF}: [rz tx ty tz] only
     max_angle = float(chain.get("normal_max_angle", 0.0))
     b_rot, b_tr = float(chain.get("bound_max_rot", 0.0)), float(chain.get("bound_max_trans", 0.0))
@@ -227,7 +228,7 @@ def np_icp_ex(reading, ref, nrm, T_init, chain, reading_nrm=None):
                 break
         if stop:
             mean = ref.mean(axis=0)
-            out["cov"] = np.zeros((6, 6)) if p2point else censi_cov(pk - mean, qk - mean, nk, dT, chain["sensor_std_dev"])
+            out["cov"] = np.zeros((6, 6)) if (p2point and not p2p_cov) else censi_cov(pk - mean, qk - mean, nk, dT, chain["sensor_std_dev"])
             break
     out["T"] = T_iter @ T if out["status"] == 0 else np.eye(4)
     out["iterations"] = it
@@ -252,7 +253,8 @@ def main_variants():
     fix = dict(map_xyz=w.map_xyz, map_nrm=w.map_nrm, reading=rd, reading_nrm=rn, T_init=T0, T_truth=Tt)
     variants = dict(knn3=dict(CHAIN, knn=3), p2point=dict(CHAIN, error_minimizer=1), p2point_knn2=dict(CHAIN, error_minimizer=1, knn=2),
                     normals=dict(CHAIN, normal_max_angle=0.5), bound_ok=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=1.0),
-                    bound_hit=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(CHAIN, error_minimizer=2))
+                    bound_hit=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(CHAIN, error_minimizer=2),
+                    p2point_cov=dict(CHAIN, error_minimizer=3))
     for name, ch in variants.items():
         r = np_icp_ex(rd, w.map_xyz, w.map_nrm, T0, ch, reading_nrm=rn if "normal_max_angle" in ch else None)
         for k in ("T", "iterations", "converged", "status", "overlap", "residual", "trim_limit", "n_kept", "n_finite"):

@@ -19,7 +19,8 @@ RESET = dict(knn=1, error_minimizer=0, bound_max_rot=0.0, bound_max_trans=0.0, n
              quantile_scale=1.0)
 VARIANTS = dict(knn3=dict(knn=3), p2point=dict(error_minimizer=1), p2point_knn2=dict(error_minimizer=1, knn=2),
                 normals=dict(normal_max_angle=0.5), bound_ok=dict(bound_max_rot=0.2, bound_max_trans=1.0),
-                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(error_minimizer=2))
+                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(error_minimizer=2),
+                p2point_cov=dict(error_minimizer=3))
 
 
 def pose_error(Ta, Tb):
@@ -80,7 +81,9 @@ def test_chain_variant_against_oracle_and_golden(ctx, oracle32, oracle64, gold, 
         assert st["residual"] == pytest.approx(r["residual"], rel=1e-6)
         if chain.get("error_minimizer", 0) == 1:
             assert not np.any(st["cov"])                      # PointToPoint: the base class's getCovariance
-        else:
+        else:                                                 # (PointToPointWithCov: the point-to-point result with the Censi estimate)
+            if chain.get("error_minimizer", 0) == 3:
+                assert np.any(st["cov"]) and np.allclose(st["cov"], st["cov"].T, rtol=1e-9, atol=1e-18)
             np.testing.assert_allclose(st["cov"], r["cov"], rtol=1e-5, atol=1e-14)
         # ... and the independent float64 chain
         gt, gr = pose_error(z[f"{name}_T"], T)

@@ -329,7 +329,8 @@ def test_median_dist_outlier_filter_restatement(oracle32, oracle64):
 # (np_icp_ex: scipy k-d tree, numpy.linalg.svd / solve), never against the oracle itself
 VARIANTS = dict(knn3=dict(knn=3), p2point=dict(error_minimizer=1), p2point_knn2=dict(error_minimizer=1, knn=2),
                 normals=dict(normal_max_angle=0.5), bound_ok=dict(bound_max_rot=0.2, bound_max_trans=1.0),
-                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(error_minimizer=2))
+                bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(error_minimizer=2),
+                p2point_cov=dict(error_minimizer=3))
 
 
 @pytest.mark.parametrize("name", sorted(VARIANTS))
