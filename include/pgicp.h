@@ -147,6 +147,10 @@ typedef struct pgicp_edge {
 int pgicp_abi_version(void);
 int pgicp_device_count(void);
 int pgicp_ctx_create(int device, pgicp_ctx **out);
+/* (ABI 5) the same with a stream of the device's highest priority (high_priority != 0): the context's launches are scheduled ahead of
+ * what other contexts have queued -- for a short, latency-critical stage that runs next to a long one (the MT flavour's input stage,
+ * LocalizerMT.hpp:27-40, next to the localizer's ICP) */
+int pgicp_ctx_create_priority(int device, int high_priority, pgicp_ctx **out);
 void pgicp_ctx_destroy(pgicp_ctx *ctx);
 const char *pgicp_last_error(const pgicp_ctx *ctx);
 /* The HIP stream (hipStream_t) every kernel of this context is launched on. */

@@ -51,8 +51,9 @@ inline pgicp_ctx *default_context(int device = 0)
 //! reference's tests/instantiation.cpp constructs them) touches no GPU until it is asked to compute something.
 struct LazyContext {
     int device = 0;
+    int high_priority = 0;                      // pgicp_ctx_create_priority: a stream of the device's highest priority
     mutable pgicp_ctx *p = nullptr;
-    explicit LazyContext(int d = 0) : device(d) {}
+    explicit LazyContext(int d = 0, int prio = 0) : device(d), high_priority(prio) {}
     LazyContext(const LazyContext &) = delete;
     LazyContext &operator=(const LazyContext &) = delete;
     ~LazyContext() { destroy(); }
@@ -60,7 +61,7 @@ struct LazyContext {
     pgicp_ctx *get() const
     {
         if (!p) {
-            const int st = pgicp_ctx_create(device, &p);
+            const int st = high_priority ? pgicp_ctx_create_priority(device, 1, &p) : pgicp_ctx_create(device, &p);
             if (st != PGICP_OK) { p = nullptr; throw std::runtime_error(std::string("pgslam_amd: cannot create a device context: ") + pgicp_status_string(st)); }
         }
         return p;

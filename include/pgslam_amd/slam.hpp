@@ -1330,6 +1330,8 @@ public:
     size_t processed() { std::lock_guard<std::mutex> l(m_); return processed_; }
     //! seconds the localizer's thread has waited for a scan's input stage to finish on the pre-processing thread
     double waited_for_input_stage() { std::lock_guard<std::mutex> l(m_); return wait_pre_s_; }
+    //! seconds the pre-processing thread has spent inside input stages
+    double input_stage_seconds() { std::lock_guard<std::mutex> l(m_); return pre_busy_s_; }
 
 private:
     // A queued scan.  Its input stage -- the input filters and the sensor->robot transform, Localizer.hpp:103-106, on the
@@ -1359,8 +1361,9 @@ private:
                 if (stop_) break;
                 it->state = 1;
             }
+            const auto tp = std::chrono::steady_clock::now();
             try { it->reading = this->PreProcessOn(pre_ctx_, it->T_robot_sensor, it->cloud); } catch (...) { it->err = std::current_exception(); }
-            { std::lock_guard<std::mutex> l(m_); it->state = 2; }
+            { std::lock_guard<std::mutex> l(m_); it->state = 2; pre_busy_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count(); }
             cv_.notify_all();
         }
     }
@@ -1402,10 +1405,10 @@ private:
     std::condition_variable cv_;
     std::deque<std::shared_ptr<Item>> queue_;
     std::thread thread_, pre_thread_;
-    pgslam_amd::LazyContext pre_ctx_{0};
+    pgslam_amd::LazyContext pre_ctx_{0, std::getenv("PGSLAM_PRE_STAGE_NORMAL_PRIORITY") ? 0 : 1};     // (its short launches go ahead of the ICP's queued ones)
     bool stop_ = false, busy_ = false, outdated_ = false;
     size_t processed_ = 0;
-    double wait_pre_s_ = 0;
+    double wait_pre_s_ = 0, pre_busy_s_ = 0;
     std::exception_ptr error_;
 public:
     std::exception_ptr TakeError() { std::lock_guard<std::mutex> l(m_); std::exception_ptr e = error_; error_ = nullptr; return e; }

@@ -1980,7 +1980,10 @@ void pgicp_default_params(pgicp_params *p)
     p->normal_max_angle = 0.0;
 }
 
-int pgicp_ctx_create(int device, pgicp_ctx **out)
+static int ctx_create_impl(int device, int high_priority, pgicp_ctx **out);
+int pgicp_ctx_create(int device, pgicp_ctx **out) { return ctx_create_impl(device, 0, out); }
+int pgicp_ctx_create_priority(int device, int high_priority, pgicp_ctx **out) { return ctx_create_impl(device, high_priority, out); }
+static int ctx_create_impl(int device, int high_priority, pgicp_ctx **out)
 {
     if (!out) return PGICP_ERR_ARG;
     *out = nullptr;
@@ -1999,7 +2002,11 @@ int pgicp_ctx_create(int device, pgicp_ctx **out)
     if (const char *e = std::getenv("PGICP_POLL_US")) c->poll_us = std::atoi(e);
     if (const char *e = std::getenv("PGICP_SEL_HINTS")) c->sel_hints_on = std::atoi(e);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_UNSEEDED")) c->fast_rings_unseeded = std::max(1, std::atoi(e));
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+    // a high-priority context: its (short) launches are scheduled ahead of the other contexts' queued work -- the MT facade's
+    // input stage next to the localizer's ICP
+    int prio_least = 0, prio_greatest = 0;
+    if (high_priority) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    bool ok = (high_priority ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
               t_host_malloc((void **)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault) == hipSuccess;
     for (int s = 0; ok && s < 2; s++)

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_partial_chain_batch_f32",
     "pgicp_partial_chain_batch_f64", "pgicp_transform_f32", "pgicp_transform_f64",
     "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_surface_normals_f32", "pgicp_surface_normals_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
-    "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters", "pgicp_debug_alloc_stats",
+    "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters", "pgicp_debug_alloc_stats", "pgicp_ctx_create_priority",
     "pgicp_debug_last_matches_f32", "pgicp_debug_last_matches_f64",
     "pgicp_status_string", "pgicp_upload_f32", "pgicp_upload_f64", "pgicp_host_alloc", "pgicp_host_free",
     "pgicp_ctx_device", "pgicp_comm_unique_id", "pgicp_comm_create", "pgicp_comm_destroy", "pgicp_comm_info",

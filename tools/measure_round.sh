@@ -8,6 +8,7 @@ mkdir -p $OUT
 python3 bench.py --prepare-only > /dev/null 2>&1
 python3 bench.py --workload stream --prepare-only > /dev/null 2>&1
 python3 bench.py --workload slam --prepare-only > /dev/null 2>&1
+python3 bench.py --workload slam --slam-scans 600 --slam-points 100000 --slam-filters sensor --prepare-only > /dev/null 2>&1
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_n1.json     # (the driver's command line)
 python3 bench.py --workload loopclosure --pairs 512 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_loopclosure.json
 python3 bench.py --workload stream --streams 1 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_stream_1.json
@@ -17,6 +18,8 @@ python3 bench.py --workload slam --steps 1 --warmup 0 2>/dev/null | tail -1 > $O
 python3 bench.py --workload slam --slam-scans 600 --slam-points 100000 --slam-filters sensor --slam-record 8 --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_slam100k.json
 python3 bench.py --workload f64 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_f64.json
 ./tools/slam_run /tmp/pgslam_amd_seq_4500_10000_0.8.bin --mt > $OUT/slam_mt.json 2>/dev/null
+./tools/slam_run /tmp/pgslam_amd_seq_600_100000_0.8.bin --filters sensor --mt > $OUT/slam100k_mt.json 2>/dev/null
+python3 bench.py --workload loopclosure --pairs 512 --steps 3 --warmup 1 --no-cpu-baseline --shard-proxy 2>/dev/null | tail -1 > $OUT/bench_loopclosure_shard_proxy.json
 python3 tools/bench_normals.py 2>/dev/null | grep -v amdgpu > $OUT/bench_normals.json
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
@@ -26,13 +29,18 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/t
 # the copy / compute overlap of the host-input pipeline: kernels and memory copies on one time line
 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$OUT/trace_host -o t -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-fixed30 --no-cpu-baseline --no-profile --no-workloads > $REPO/$OUT/trace_host.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace_stream -o t -- python3 $REPO/bench.py --workload stream --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host-input > $REPO/$OUT/trace_stream.log 2>&1
+# the facade at sensor size: two passes of the 600-scan drive (the program itself after `--`)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/trace_slam100k -o t -- $REPO/tools/slam_run /tmp/pgslam_amd_seq_600_100000_0.8.bin --filters sensor --passes 2 > $REPO/$OUT/trace_slam100k.log 2>&1
 cd $REPO
 python3 tools/trace_summary.py $OUT/trace > $OUT/trace_summary.txt 2>&1
 python3 tools/trace_summary.py $OUT/trace_lc > $OUT/trace_lc_summary.txt 2>&1
 python3 tools/overlap_summary.py $OUT/trace_host > $OUT/host_input_overlap.txt 2>&1
 python3 tools/trace_summary.py $OUT/trace_stream > $OUT/trace_stream_summary.txt 2>&1
 python3 tools/timeline.py $OUT/trace_stream > $OUT/stream_timeline_last_scan.txt 2>&1
-rm -rf $OUT/trace/*.db $OUT/trace_lc/*.db $OUT/trace_host/*.db $OUT/trace_stream/*.db 2>/dev/null
+python3 tools/trace_summary.py $OUT/trace_slam100k > $OUT/trace_slam100k_summary.txt 2>&1
+rm -rf $OUT/trace/*.db $OUT/trace_lc/*.db $OUT/trace_host/*.db $OUT/trace_stream/*.db $OUT/trace_slam100k/*.db 2>/dev/null
+# (the raw per-dispatch traces are tens of MB: only the summaries and the per-kernel statistics travel back)
+find $OUT -name '*_kernel_trace.csv' -delete; find $OUT -name '*_memory_copy_trace.csv' -delete; find $OUT -name '*_agent_info.csv' -delete
 # counters: every --pmc pass its own run (tools/r4_pmc.sh) -> knn_traffic*.json, knn_pmc.json
 bash tools/r4_pmc.sh measure/pmc > $OUT/pmc.log 2>&1
 for f in $OUT/bench_*.json $OUT/slam_mt.json; do echo "$f: $(cut -c1-300 $f)"; done

@@ -17,6 +17,9 @@ cp $M/trace_summary.txt $P/${R}_trace_summary.txt
 cp $M/slam_mt.json $P/${R}_slam_run_mt.json
 cp $M/bench_slam100k.json $P/${R}_bench_slam100k.json
 cp $M/bench_f64.json $P/${R}_bench_f64.json
+cp $M/slam100k_mt.json $P/${R}_slam100k_run_mt.json 2>/dev/null
+cp $M/bench_loopclosure_shard_proxy.json $P/${R}_bench_loopclosure_shard_proxy.json 2>/dev/null
+cp $M/trace_slam100k_summary.txt $P/${R}_slam100k_trace_summary.txt 2>/dev/null
 cp $M/trace_stream_summary.txt $P/${R}_stream_kernel_totals.txt
 cp $M/stream_timeline_last_scan.txt $P/${R}_stream_timeline_last_scan.txt
 for f in knn_traffic knn_pmc knn_traffic_loopclosure knn_traffic_stream knn_traffic_f64 knn_traffic_slam; do cp $M/pmc/$f.json $P/$f.json; done

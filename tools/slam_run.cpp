@@ -158,14 +158,14 @@ static int run_mt(FILE *f, int S, int N)
                 "\"map_rebuilds\": %d, \"tracking_error_last_m\": %.5f, \"keyframes_revisiting_within_3m_by_estimate\": %d, "
                 "\"clouds_uploaded_one_scan_ahead\": %zu, \"loop_batches_on_device\": %zu, \"loop_candidates_assembled_on_device\": %zu, "
                 "\"keyframes_resident\": %zu, \"keyframe_uploads\": %zu, \"keyframe_evictions\": %zu, "
-                "\"localizer_thread_s\": {\"waiting_for_input_stage\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f, \"overlap_probe\": %.4f, \"rebuilds\": %.4f, \"new_keyframes\": %.4f}}\n",
+                "\"input_stage_thread_s\": %.4f, \"localizer_thread_s\": {\"waiting_for_input_stage\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f, \"overlap_probe\": %.4f, \"rebuilds\": %.4f, \"new_keyframes\": %.4f}}\n",
                 S, N, wall, wall, (S - 1) / wall, g.NumVertices(), loops, slam.loop_closer().candidates_tried(), slam.loop_closer().loops_closed(),
                 slam.loop_closer().batches(), slam.loop_closer().largest_batch(), slam.optimizer().runs(), slam.optimizer().total_iterations(),
                 slam.optimizer().total_seconds(), slam.localizer().rebuilds(), e_last,
                 count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4),
                 slam.localizer().prefetches(), slam.loop_closer().device_batches(), slam.loop_closer().device_candidates(),
                 slam.map_manager().resident_keyframes(), slam.map_manager().device_uploads(), slam.map_manager().device_evictions(),
-                slam.localizer().waited_for_input_stage(), slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2],
+                slam.localizer().input_stage_seconds(), slam.localizer().waited_for_input_stage(), slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2],
                 slam.localizer().after_icp_seconds()[1], slam.localizer().after_icp_seconds()[2], slam.localizer().after_icp_seconds()[3]);
     return 0;
 }
