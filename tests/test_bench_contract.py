@@ -43,6 +43,21 @@ def test_recorded_line_keeps_the_contract():
         assert w["value"] > 0 and "roofline" in w and 0.0 < w["roofline"]["frac"] < 1.0
     assert d["workloads"]["f64"]["value"] >= 0.45 * d["value"]           # the double path at about half the float rate (0.48-0.51 by run)
     assert len(d["workloads"]["stream"]["scans_per_s_each_pass"]) >= 3
+    if "legs" in d:                                                      # (round 5 on)
+        # the LAST key, compact: the driver keeps the tail of the line -- every leg's [value, roofline.frac] must be in it
+        assert list(d.keys())[-1] == "legs" and len(json.dumps(d["legs"])) < 700
+        for leg in ("headline", "f64", "stream", "slam", "slam_100k", "loop_closure"):
+            v = d["legs"][leg]
+            assert v[0] > 0 and 0.0 < v[1] < 1.0
+        assert d["legs"]["headline"][0] == pytest.approx(d["value"], rel=1e-3)
+        assert "bound_means" in r
+        # the one-GPU proxy of the 8-GPU target (north_star: >= 3.5x on batched loop closing)
+        sp = d["workloads"]["loop_closure"]["shard_proxy"]
+        assert d["legs"]["loop_closure_predicted_speedup_8"] == pytest.approx(sp["predicted_speedup"]["8"])
+        assert sp["predicted_speedup"]["8"] >= 3.5 and len(sp["per_world"]["8"]["shard_ms"]) == 8
+        assert sp["predicted_speedup"]["2"] < sp["predicted_speedup"]["4"] < sp["predicted_speedup"]["8"]
+        # the SLAM legs time passes AFTER a warm one, in one process
+        assert d["workloads"]["slam_100k"]["slam"]["passes"] >= 4 and len(d["workloads"]["slam_100k"]["slam"]["pass_slam_s"]) >= 4
 
 
 def test_metric_is_baselines():
