@@ -367,6 +367,18 @@ int pgicp_filter_cloud_f64(pgicp_ctx *ctx, int n_filters, const pgicp_filter *fi
                            const double *descriptors, int drows, int n, const double *T, int rotate_row0, int rotate_row1,
                            double *out_features, double *out_descriptors, int32_t *kept_idx, int *n_out, const double **dev_features);
 
+/* (ABI 5) pgicp_filter_cloud_dev: the same device pass for a caller that does the host side itself -- WITHOUT a transformation (a
+ * sensor at the robot's origin, or a caller that transforms later): the caller's arrays are not written.  n_out = points kept,
+ * dev_features = their device copy (an ICP reading, valid for the next three filter calls on the context), dropped_idx = the
+ * ASCENDING input indices of the points dropped, n_dropped of them -- when n_dropped > dropped_cap the list is incomplete and
+ * the caller takes pgicp_filter_cloud instead.  A range sensor's input filters drop a handful of a scan's points: the caller
+ * closes those gaps in its own arrays, on another thread while the ICP already runs on the device copy if it likes
+ * (pgslam::GraphLocalizer does). */
+int pgicp_filter_cloud_dev_f32(pgicp_ctx *ctx, int n_filters, const pgicp_filter *filters, const float *features, int frows, int n,
+                               int32_t *dropped_idx, int dropped_cap, int *n_dropped, int *n_out, const float **dev_features);
+int pgicp_filter_cloud_dev_f64(pgicp_ctx *ctx, int n_filters, const pgicp_filter *filters, const double *features, int frows, int n,
+                               int32_t *dropped_idx, int dropped_cap, int *n_dropped, int *n_out, const double **dev_features);
+
 /* ---- loop-closure dispatcher helpers (host logic, no GPU needed) -------
  * pgicp_shard_pairs: deterministic longest-processing-time split of n_pairs
  * candidate ICPs (cost[i] ~ N_i + M_i) over world_size ranks; writes the pair

@@ -311,8 +311,8 @@ public:
         double Tm[16], ratio = 0, residual = 0;
         pgslam_amd::to_row_major16(T_world_robot, Tm);
         temp_icp.pushParams();
-        PM::check(temp_icp.ctx, pgslam_amd::Abi<T>::partial_dev(temp_icp.ctx, temp_icp.matcher->mapId, reading.dev, reading.filtered->xyzStride(),
-                                                               (int)reading.filtered->getNbPoints(), Tm, &ratio, &residual));
+        PM::check(temp_icp.ctx, pgslam_amd::Abi<T>::partial_dev(temp_icp.ctx, temp_icp.matcher->mapId, reading.dev, reading.xyzStride(), reading.points(), Tm,
+                                                               &ratio, &residual));
         return (T)ratio;
     }
     const Matrix &T_refkf_robot() const { return T_refkf_robot_; }

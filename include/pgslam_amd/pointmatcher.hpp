@@ -688,6 +688,52 @@ struct PointMatcher {
         return true;
     }
 
+    //! closes the gaps of the dropped columns (ascending indices) in features and descriptors: what the filters' compactColumns
+    //! leaves, as a few block moves
+    static void compactByDropped(DataPoints &c, const std::vector<int32_t> &dropped)
+    {
+        const int n = (int)c.features.cols();
+        if (dropped.empty()) return;
+        const size_t fr = (size_t)c.features.rows(), dr = (size_t)c.descriptors.rows();
+        T *f = c.features.data(), *d = dr ? c.descriptors.data() : nullptr;
+        int dst = dropped[0];
+        for (size_t k = 0; k < dropped.size(); k++) {
+            const int from = dropped[k] + 1, to = k + 1 < dropped.size() ? dropped[k + 1] : n;      // the kept run [from, to)
+            if (to > from) {
+                std::memmove(f + (size_t)dst * fr, f + (size_t)from * fr, sizeof(T) * fr * (size_t)(to - from));
+                if (d) std::memmove(d + (size_t)dst * dr, d + (size_t)from * dr, sizeof(T) * dr * (size_t)(to - from));
+                dst += to - from;
+            }
+        }
+        c.features.conservativeResize(c.features.rows(), dst);
+        if (dr) c.descriptors.conservativeResize((int)dr, dst);
+    }
+    //! The device half of filterAndTransformOnDevice for a cloud that needs NO transformation (`Tm` the identity): the filters run
+    //! on the uploaded features, `dev` / `kept` describe the filtered device copy, `dropped` lists what the HOST cloud still holds
+    //! too much (ascending) -- the caller applies compactByDropped(cloud, dropped) when it suits it, e.g. on another thread while
+    //! the ICP runs on the device copy.  false: not applicable (a transformation, a filter without a device form, more than 4 096
+    //! points dropped): nothing was done, the caller takes filterAndTransformOnDevice.
+    static bool filterOnDeviceDeferred(pgicp_ctx *c, const DataPointsFilters &filters, const DataPoints &cloud, const TransformationParameters &Tm,
+                                       const T **dev, int *kept, std::vector<int32_t> &dropped)
+    {
+        std::vector<pgicp_filter> specs;
+        const int n = (int)cloud.getNbPoints();
+        if (n == 0 || cloud.features.rows() < 3 || !filters.deviceSpecs(specs)) return false;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (Tm(i, j) != (i == j ? T(1) : T(0))) return false;
+        dropped.resize(4096);
+        int nd = 0;
+        const int rc = sizeof(T) == 4
+            ? pgicp_filter_cloud_dev_f32(c, (int)specs.size(), specs.data(), (const float *)cloud.features.data(), (int)cloud.features.rows(), n, dropped.data(),
+                                         (int)dropped.size(), &nd, kept, (const float **)dev)
+            : pgicp_filter_cloud_dev_f64(c, (int)specs.size(), specs.data(), (const double *)cloud.features.data(), (int)cloud.features.rows(), n, dropped.data(),
+                                         (int)dropped.size(), &nd, kept, (const double **)dev);
+        check(c, rc);
+        if (nd > (int)dropped.size()) { dropped.clear(); return false; }       // (the filters' state has not moved: afterDevicePass was not called)
+        dropped.resize((size_t)nd);
+        for (auto &f : filters) f->afterDevicePass();
+        return true;
+    }
+
     struct ICPChainBase;
 
     // ------------------------------------------------------------------ Matcher
@@ -1112,6 +1158,11 @@ struct PointMatcher {
         struct DeviceReading {
             const T *dev = nullptr;
             std::shared_ptr<DataPoints> filtered;         // the host copy after the chain's reading filters (what was uploaded)
+            //! points and stride of the device copy when they are known without looking at `filtered` (-1: ask it) -- a host copy whose
+            //! gaps are still being closed on another thread must not be read (GraphLocalizer's deferred host compaction)
+            int n = -1, stride = -1;
+            int points() const { return n >= 0 ? n : (int)filtered->getNbPoints(); }
+            int xyzStride() const { return stride >= 0 ? stride : filtered->xyzStride(); }
             explicit operator bool() const { return dev != nullptr; }
         };
         //! a device copy of a cloud may stand for the cloud itself in operator(): the chain's reading filters change nothing
@@ -1143,13 +1194,13 @@ struct PointMatcher {
             // given the host cloud (refused, never run without the filter -- ADVICE round 4)
             if (hasNormalFilter() && r.filtered && r.filtered->normalsPtr() != nullptr)
                 throw std::logic_error("ICP: a SurfaceNormalOutlierFilter needs the reading's normals; pass the host cloud, not a device reading");
-            prefilteredReadingPtsCount = r.filtered->getNbPoints();
+            prefilteredReadingPtsCount = (unsigned)r.points();
             double Ti[16], To[16];
             pgslam_amd::to_row_major16(T_init, Ti);
             pgicp_stats st;
             pushParams();
             // (the call makes its stream wait, on the device, for the upload; the host does not)
-            const int rc = A::align_dev(ctx, matcher->mapId, r.dev, r.filtered->xyzStride(), (int)r.filtered->getNbPoints(), Ti, To, &st);
+            const int rc = A::align_dev(ctx, matcher->mapId, r.dev, r.xyzStride(), r.points(), Ti, To, &st);
             storeStats(st);
             check(ctx, rc);
             const TransformationParameters T_out = pgslam_amd::from_row_major16<T>(To);

@@ -745,6 +745,53 @@ protected:
     size_t device_candidates_made_ = 0;
 };
 
+//! one background job at a time on a thread of its own (made at first use): start(fn) ... wait()
+class HostWorker {
+public:
+    ~HostWorker()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        if (t_.joinable()) t_.join();
+    }
+    void start(std::function<void()> fn)
+    {
+        wait();
+        { std::lock_guard<std::mutex> l(m_); job_ = std::move(fn); busy_ = true; if (!t_.joinable()) t_ = std::thread(&HostWorker::Main, this); }
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return !busy_; });
+        if (err_) { std::exception_ptr e = err_; err_ = nullptr; std::rethrow_exception(e); }
+    }
+private:
+    void Main()
+    {
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return stop_ || (busy_ && job_); });
+                if (stop_) return;
+                fn = std::move(job_);
+                job_ = nullptr;
+            }
+            std::exception_ptr e;
+            try { fn(); } catch (...) { e = std::current_exception(); }
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; err_ = e; }
+            cv_.notify_all();
+        }
+    }
+    std::thread t_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, stop_ = false;
+    std::exception_ptr err_;
+};
+
 // ------------------------------------------------------------------ localizer on the graph
 template <typename T>
 class GraphLocalizer {
@@ -778,7 +825,15 @@ public:
         using clk = std::chrono::steady_clock;
         const auto t0 = clk::now();
         input_cloud_ = cloud;
-        typename PM::ICPChainBase::DeviceReading direct = PreProcess(input_T_robot_sensor, cloud);
+        // (single-thread flavour, sensor at the robot's origin: the input stage leaves the handful of dropped points in the HOST
+        // cloud for the moment -- the device copy is complete -- and their gaps are closed on the worker thread while the ICP runs)
+        Deferred defer;
+        typename PM::ICPChainBase::DeviceReading direct = PreProcess(input_T_robot_sensor, cloud, &defer);
+        struct Join { HostWorker &w; bool on; ~Join() { if (on) { try { w.wait(); } catch (...) {} } } } join{host_worker_, false};
+        if (defer.cloud) {
+            if (comp_.empty()) PM::compactByDropped(*defer.cloud, defer.dropped);      // (the first cloud becomes a keyframe at once)
+            else { host_worker_.start([defer]() { PM::compactByDropped(*defer.cloud, defer.dropped); }); join.on = true; deferred_compactions_++; }
+        }
         const auto t1 = clk::now();
         phase_s_[0] += std::chrono::duration<double>(t1 - t0).count();
         auto &g = map_manager_->GetGraph();
@@ -801,6 +856,7 @@ public:
         input_device_ = ahead && ahead.filtered.get() == cloud.get() ? ahead : typename PM::ICPChainBase::DeviceReading();
         if (ahead) { T_refkf_robot_ = icp_sequence_(ahead, T_refkf_robot_ * d); device_readings_used_++; }
         else T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);
+        if (join.on) { join.on = false; host_worker_.wait(); }       // the host cloud is whole again before anything below looks at it
         const auto t2 = clk::now();
         phase_s_[1] += std::chrono::duration<double>(t2 - t1).count();
         {
@@ -818,7 +874,10 @@ public:
     //! upload was prefetched has been through it already).
     //! Returns the device copy of the pre-processed cloud when the input stage ran on the device (pgicp_filter_cloud: filters
     //! and transform in one pass over the uploaded scan) and that copy can stand for the cloud in the ICP; empty otherwise.
-    typename PM::ICPChainBase::DeviceReading PreProcess(const Matrix &input_T_robot_sensor, DPPtr cloud)
+    //! what the host cloud still holds too much after a deferred device pass (PM::filterOnDeviceDeferred)
+    struct Deferred { DPPtr cloud; std::vector<int32_t> dropped; };
+    size_t deferred_compactions() const { return deferred_compactions_; }
+    typename PM::ICPChainBase::DeviceReading PreProcess(const Matrix &input_T_robot_sensor, DPPtr cloud, Deferred *defer = nullptr)
     {
         // per-cloud state: while scan k aligns, scan k + 1 has been through here already (Prefetch) -- one "last cloud"
         // memo would alternate between the two and send every prefetched cloud through the filters and the sensor
@@ -826,16 +885,26 @@ public:
         typename PM::ICPChainBase::DeviceReading direct;
         Prefetched *slot = FindPrefetched(cloud.get());
         if (slot && slot->preprocessed) return direct;
-        direct = PreProcessOn(icp_sequence_.ctx, input_T_robot_sensor, cloud);
+        direct = PreProcessOn(icp_sequence_.ctx, input_T_robot_sensor, cloud, defer);
         if (slot) slot->preprocessed = true;
         return direct;
     }
     //! The input stage of one cloud on a context of the caller's choosing (the MT flavour's pre-processing thread runs it on its
     //! own, while this object's thread aligns the scan before): touches the cloud, the input filters and `rigid_` only.
-    typename PM::ICPChainBase::DeviceReading PreProcessOn(pgicp_ctx *ctx, const Matrix &input_T_robot_sensor, DPPtr cloud)
+    typename PM::ICPChainBase::DeviceReading PreProcessOn(pgicp_ctx *ctx, const Matrix &input_T_robot_sensor, DPPtr cloud, Deferred *defer = nullptr)
     {
         typename PM::ICPChainBase::DeviceReading direct;
         const T *dev = nullptr;
+        // deferred form: only when the ICP will run on the device copy and nobody observes the host cloud during it
+        if (defer && device_input_stage_ && deferred_host_compaction_ && icp_sequence_.deviceReadingEquivalent() && !icp_sequence_.onAlign) {
+            int kept = 0;
+            if (PM::filterOnDeviceDeferred(ctx, input_filters_, *cloud, input_T_robot_sensor, &dev, &kept, defer->dropped)) {
+                device_input_stages_++;
+                direct.dev = dev; direct.filtered = cloud; direct.n = kept; direct.stride = cloud->xyzStride();
+                if (!defer->dropped.empty()) defer->cloud = cloud;
+                return direct;
+            }
+        }
         if (device_input_stage_ && PM::filterAndTransformOnDevice(ctx, input_filters_, *cloud, input_T_robot_sensor, &dev)) {
             device_input_stages_++;
             if (icp_sequence_.deviceReadingEquivalent()) { direct.dev = dev; direct.filtered = cloud; }
@@ -905,7 +974,9 @@ protected:
         for (auto &p : prefetched_) if (p.cloud == cloud) return &p;
         return nullptr;
     }
-    size_t prefetches_ = 0, device_readings_used_ = 0, device_input_stages_ = 0;
+    size_t prefetches_ = 0, device_readings_used_ = 0, device_input_stages_ = 0, deferred_compactions_ = 0;
+    bool deferred_host_compaction_ = std::getenv("PGSLAM_SYNC_HOST_COMPACTION") == nullptr;
+    HostWorker host_worker_;
     typename PM::ICPChainBase::DeviceReading input_device_;      // the current scan's device copy (while it is valid: this ProcessData)
     bool device_input_stage_ = std::getenv("PGSLAM_HOST_INPUT_STAGE") == nullptr;
     bool device_local_map_ = std::getenv("PGSLAM_HOST_LOCAL_MAP") == nullptr;      // keyframe clouds resident, maps assembled in HBM

@@ -69,7 +69,7 @@ void launch_trim_raw(hipStream_t st, const T *d2, int n, T ratio, T scale, T *li
 template <typename T>
 void launch_filter_cloud(hipStream_t st, const T *feat, int fstride, int frows, const T *desc, int drows, int n, int n_filters,
                          const int *types, const double *params, const double *T16, int rot0, int rot1, int *keep, int *pos,
-                         int *block_sums, T *out_feat, T *out_desc, int *kept_idx);
+                         int *block_sums, T *out_feat, T *out_desc, int *kept_idx, int *dropped = nullptr, int dropped_cap = 0);
 template <typename T>
 void launch_slot_of(hipStream_t st, const typename Vec4<T>::type *pts, int first, int m, int *slot_of);
 template <typename T>

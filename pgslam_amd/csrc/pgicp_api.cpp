@@ -133,7 +133,7 @@ struct pgicp_ctx {
     // pgicp_filter_cloud: four sets of device buffers used in turn (the filtered features of a call stay valid, as a device
     // reading, for the next three calls: a localizer that pre-processes scan k + 1 while scan k aligns, and now and then a
     // scan that was not pre-processed ahead, has three calls between making a reading and aligning it)
-    struct FilterSet { DevBuf in_f, in_d, keep, pos, bsum, out_f, out_d, idx; } fset[4];
+    struct FilterSet { DevBuf in_f, in_d, keep, pos, bsum, out_f, out_d, idx, drop; } fset[4];
     int fset_next = 0;
     int up_next = 0;
     int up_seen = 0;            // upload sets whose device pointers the running call was handed (see UploadUse)
@@ -1719,16 +1719,10 @@ int surface_normals(pgicp_ctx *c, const T *xyz, int stride, int n, int mem, int 
     return PGICP_OK;
 }
 
+// the filter list of pgicp_filter_cloud*, checked, as the launcher takes it
 template <typename T>
-int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int frows, const T *desc, int drows, int n, const double *T16,
-                 int rot0, int rot1, T *out_feat, T *out_desc, int32_t *kept_idx, int *n_out, const T **dev_feat)
+int filter_specs(pgicp_ctx *c, int nf, const pgicp_filter *f, int *types, double *params)
 {
-    if (!c || nf < 0 || nf > PGICP_MAX_FILTERS || (nf && !f) || !feat || frows < 3 || n <= 0 || (desc && drows <= 0) || !out_feat || !n_out ||
-        (desc && !out_desc) || (rot0 >= 0 && (!desc || rot0 + 3 > drows)) || (rot1 >= 0 && (!desc || rot1 + 3 > drows)))
-        return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: bad argument");
-    if (T16 && !is_rigid(T16)) return fail(c, PGICP_ERR_NOT_RIGID, "pgicp_filter_cloud: transformation is not rigid");
-    int types[PGICP_MAX_FILTERS];
-    double params[8 * PGICP_MAX_FILTERS];
     for (int k = 0; k < nf; k++) {
         if (f[k].type < PGICP_FILTER_IDENTITY || f[k].type > PGICP_FILTER_MAX_POINT_COUNT) return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: unknown filter type");
         if (f[k].type == PGICP_FILTER_FIX_STEP && !(f[k].p[0] >= 1.0 && f[k].p[0] <= 2147483647.0))
@@ -1747,6 +1741,20 @@ int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int
         std::memcpy(params + 8 * k, f[k].p, sizeof f[k].p);
         if (f[k].type == PGICP_FILTER_MAX_POINT_COUNT) params[8 * k + 2] = sizeof(T) == 4 ? 1.0 : 0.0;   // prob = T(maxCount) / T(N)
     }
+    return PGICP_OK;
+}
+
+template <typename T>
+int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int frows, const T *desc, int drows, int n, const double *T16,
+                 int rot0, int rot1, T *out_feat, T *out_desc, int32_t *kept_idx, int *n_out, const T **dev_feat)
+{
+    if (!c || nf < 0 || nf > PGICP_MAX_FILTERS || (nf && !f) || !feat || frows < 3 || n <= 0 || (desc && drows <= 0) || !out_feat || !n_out ||
+        (desc && !out_desc) || (rot0 >= 0 && (!desc || rot0 + 3 > drows)) || (rot1 >= 0 && (!desc || rot1 + 3 > drows)))
+        return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud: bad argument");
+    if (T16 && !is_rigid(T16)) return fail(c, PGICP_ERR_NOT_RIGID, "pgicp_filter_cloud: transformation is not rigid");
+    int types[PGICP_MAX_FILTERS];
+    double params[8 * PGICP_MAX_FILTERS];
+    { const int st = filter_specs<T>(c, nf, f, types, params); if (st) return st; }
     HIPC(c, hipSetDevice(c->device));
     pgicp_ctx::FilterSet &S = c->fset[c->fset_next];
     c->fset_next = (c->fset_next + 1) & 3;
@@ -1801,6 +1809,47 @@ int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int
         if (kept_idx) XFER(c, d2h(c, kept_idx, S.idx.p, sizeof(int) * (size_t)kept));
         HIPC(c, stream_sync(c));
     }
+    if (dev_feat) *dev_feat = S.out_f.as<T>();
+    return PGICP_OK;
+}
+
+// pgicp_filter_cloud_dev: the same device pass for a caller that keeps the host side to itself -- no transformation, the
+// caller's arrays are not written: the kept count, the device copy of the filtered features, and the ASCENDING indices of the
+// dropped points (a range sensor's input filters drop a handful of a scan's points: the caller closes those gaps in its own
+// arrays -- while the ICP already runs on the device copy, if it likes)
+template <typename T>
+int filter_cloud_dev(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int frows, int n, int32_t *dropped_idx, int dropped_cap,
+                     int *n_dropped, int *n_out, const T **dev_feat)
+{
+    if (!c || nf < 0 || nf > PGICP_MAX_FILTERS || (nf && !f) || !feat || frows < 3 || n <= 0 || !n_out || !n_dropped || dropped_cap < 0 ||
+        (dropped_cap && !dropped_idx))
+        return fail(c, PGICP_ERR_ARG, "pgicp_filter_cloud_dev: bad argument");
+    int types[PGICP_MAX_FILTERS];
+    double params[8 * PGICP_MAX_FILTERS];
+    { const int st = filter_specs<T>(c, nf, f, types, params); if (st) return st; }
+    HIPC(c, hipSetDevice(c->device));
+    pgicp_ctx::FilterSet &S = c->fset[c->fset_next];
+    c->fset_next = (c->fset_next + 1) & 3;
+    const size_t bf = sizeof(T) * (size_t)frows * n;
+    const int cap = std::min(dropped_cap, n);
+    HIPC(c, S.in_f.ensure(bf)); HIPC(c, S.out_f.ensure(bf));
+    HIPC(c, S.keep.ensure(sizeof(int) * ((size_t)n + 1))); HIPC(c, S.pos.ensure(sizeof(int) * ((size_t)n + 1)));
+    HIPC(c, S.bsum.ensure(sizeof(int) * ((size_t)n / kScanChunkHost + 4)));
+    HIPC(c, S.drop.ensure(sizeof(int) * (size_t)std::max(cap, 1)));
+    XFER(c, h2d(c, S.in_f.p, feat, bf));
+    launch_filter_cloud<T>(c->stream, S.in_f.as<T>(), frows, frows, nullptr, 0, n, nf, types, params, nullptr, -1, -1, S.keep.as<int>(), S.pos.as<int>(),
+                           S.bsum.as<int>(), S.out_f.as<T>(), nullptr, nullptr, cap ? S.drop.as<int>() : nullptr, cap);
+    // the kept count and the head of the dropped list in ONE round trip (a second one only when more than that were dropped)
+    int kept = 0;
+    const int head = std::min(cap, 256);
+    XFER(c, d2h(c, &kept, S.pos.as<int>() + n, sizeof(int)));
+    if (head) XFER(c, d2h(c, dropped_idx, S.drop.p, sizeof(int) * (size_t)head));
+    HIPC(c, stream_sync(c));
+    HIPC(c, hipGetLastError());
+    const int nd = n - kept;
+    if (nd > head && nd <= cap) { XFER(c, d2h(c, dropped_idx + head, S.drop.as<int>() + head, sizeof(int) * (size_t)(nd - head))); HIPC(c, stream_sync(c)); }
+    *n_out = kept;
+    *n_dropped = nd;                          // (more than dropped_cap: the list is incomplete -- the caller takes pgicp_filter_cloud)
     if (dev_feat) *dev_feat = S.out_f.as<T>();
     return PGICP_OK;
 }
@@ -2359,6 +2408,12 @@ int pgicp_filter_cloud_f32(pgicp_ctx *c, int nf, const pgicp_filter *f, const fl
 int pgicp_filter_cloud_f64(pgicp_ctx *c, int nf, const pgicp_filter *f, const double *feat, int frows, const double *desc, int drows, int n,
                            const double *T, int r0, int r1, double *of, double *od, int32_t *idx, int *n_out, const double **dev)
 { return filter_cloud<double>(c, nf, f, feat, frows, desc, drows, n, T, r0, r1, of, od, idx, n_out, dev); }
+int pgicp_filter_cloud_dev_f32(pgicp_ctx *c, int nf, const pgicp_filter *f, const float *feat, int frows, int n, int32_t *dropped, int cap, int *n_dropped,
+                               int *n_out, const float **dev)
+{ return filter_cloud_dev<float>(c, nf, f, feat, frows, n, dropped, cap, n_dropped, n_out, dev); }
+int pgicp_filter_cloud_dev_f64(pgicp_ctx *c, int nf, const pgicp_filter *f, const double *feat, int frows, int n, int32_t *dropped, int cap, int *n_dropped,
+                               int *n_out, const double **dev)
+{ return filter_cloud_dev<double>(c, nf, f, feat, frows, n, dropped, cap, n_dropped, n_out, dev); }
 
 int pgicp_shard_pairs(int n_pairs, const int64_t *cost, int world, int rank, int *out_idx, int cap, int *n_out)
 {

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "pgicp_partial_chain_f32", "pgicp_partial_chain_f64", "pgicp_partial_chain_batch_f32",
     "pgicp_partial_chain_batch_f64", "pgicp_transform_f32", "pgicp_transform_f64",
     "pgicp_build_local_map_f32", "pgicp_build_local_map_f64", "pgicp_surface_normals_f32", "pgicp_surface_normals_f64", "pgicp_shard_pairs", "pgicp_check_icp_result",
-    "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters", "pgicp_debug_alloc_stats", "pgicp_ctx_create_priority",
+    "pgicp_profile_enable", "pgicp_profile_reset", "pgicp_profile_get", "pgicp_debug_counters", "pgicp_debug_alloc_stats", "pgicp_ctx_create_priority", "pgicp_filter_cloud_dev_f32", "pgicp_filter_cloud_dev_f64",
     "pgicp_debug_last_matches_f32", "pgicp_debug_last_matches_f64",
     "pgicp_status_string", "pgicp_upload_f32", "pgicp_upload_f64", "pgicp_host_alloc", "pgicp_host_free",
     "pgicp_ctx_device", "pgicp_comm_unique_id", "pgicp_comm_create", "pgicp_comm_destroy", "pgicp_comm_info",
@@ -683,6 +683,24 @@ class Context:
         return of[:k], (od[:k] if od is not None else None), (idx[:k] if idx is not None else None), DevPtr(dev.value, frows, k, f.dtype)
 
     # ---- measurement --------------------------------------------------------
+    def filter_cloud_dev(self, filters, features, dropped_cap=4096):
+        """pgicp_filter_cloud_dev: the device pass alone (no transformation, the host arrays untouched): (kept count, DevPtr of the
+        filtered features, ascending indices of the dropped points -- None when more than dropped_cap were dropped)"""
+        f = np.ascontiguousarray(features)
+        assert f.ndim == 2 and f.dtype in (np.float32, np.float64)
+        n, frows = f.shape
+        specs = (Filter * max(1, len(filters)))()
+        for k, s_ in enumerate(filters):
+            specs[k].type = int(s_[0])
+            for j, v in enumerate(s_[1:]):
+                specs[k].p[j] = float(v)
+        dropped = np.empty(max(1, dropped_cap), dtype=np.int32)
+        nd, nout, dev = C.c_int(0), C.c_int(0), C.c_void_p(0)
+        fn = getattr(self.lib, "pgicp_filter_cloud_dev" + self._sfx(f.dtype))
+        self._check(fn(self.h, C.c_int(len(filters)), specs, C.c_void_p(f.ctypes.data), C.c_int(frows), C.c_int(n), C.c_void_p(dropped.ctypes.data),
+                       C.c_int(dropped_cap), C.byref(nd), C.byref(nout), C.byref(dev)))
+        return nout.value, DevPtr(dev.value, frows, nout.value, f.dtype), (dropped[:nd.value].copy() if nd.value <= dropped_cap else None)
+
     def profile_enable(self, on=True):
         self._check(self.lib.pgicp_profile_enable(self.h, C.c_int(int(on))))
 

@@ -108,6 +108,34 @@ def test_filtered_cloud_is_an_icp_reading_without_a_second_upload(ctx, oracle32)
     ctx.destroy_map(mid)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_device_only_pass_lists_the_dropped_points(ctx, oracle32, oracle64, dtype):
+    """pgicp_filter_cloud_dev: the caller's arrays stay as they are; the kept count, the ascending list of dropped indices (the
+    complement of what the oracle keeps) and a device copy that aligns like the compacted host cloud"""
+    o = oracle32 if dtype == np.float32 else oracle64
+    chain = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01, smooth_length=3, sensor_std_dev=0.01)
+    w = synth.make_scan_to_map(n_scan=6000, n_map=40_000, n_queries=1, n_map_poses=4, rings=16)
+    f = np.concatenate([w.scans_xyz[0], np.ones((len(w.scans_xyz[0]), 1), dtype=np.float32)], axis=1).astype(dtype)
+    f[11, 0] = np.nan
+    before = f.copy()
+    for filters in ([(icp.FILTER_REMOVE_NAN,), (icp.FILTER_MAX_DIST, 35.0), (icp.FILTER_BOUNDING_BOX, -1.2, -0.9, -2.0, 1.2, 0.9, 0.5, 1.0)],
+                    [(icp.FILTER_IDENTITY,)],
+                    [(icp.FILTER_FIX_STEP, 2)]):                                  # (half the cloud dropped: more than the list holds)
+        kept, dev, dropped = ctx.filter_cloud_dev(filters, f, dropped_cap=1024)
+        want = o.filter_chain(filters, f)
+        assert kept == len(want) and np.array_equal(f.view(np.uint8), before.view(np.uint8))
+        if len(f) - kept > 1024:
+            assert dropped is None
+            continue
+        assert np.array_equal(dropped, np.setdiff1d(np.arange(len(f)), want))
+        ctx.set_params(**chain)
+        mid = ctx.set_map(w.map_xyz.astype(dtype), w.map_nrm.astype(dtype), center=True, dtype=dtype)
+        Ta, sa = ctx.align(mid, dev, w.T_init[0], dtype=dtype)
+        Tb, sb = ctx.align(mid, np.ascontiguousarray(f[want][:, :3]), w.T_init[0], dtype=dtype)
+        assert np.array_equal(Ta, Tb) and sa["iterations"] == sb["iterations"] and sa["n_kept"] == sb["n_kept"]
+        ctx.destroy_map(mid)
+
+
 def test_local_map_from_device_resident_keyframes_equals_the_host_flow(ctx, oracle32):
     """Keyframe clouds kept in device memory of the caller's own (pgicp_device_alloc / _copy), the map assembled from them
     there (pgicp_build_local_map, mem = DEVICE) and indexed in place (pgicp_map_create, mem = DEVICE): the same cloud and the
