@@ -1384,11 +1384,16 @@ public:
         { std::lock_guard<std::mutex> l(m_); outdated_ = true; }
         cv_.notify_all();
     }
+    //! The input stage on a thread (and context) of its own, up to two scans ahead of the ICP: OFF by default since round 5's
+    //! measurement -- with the stage down to 0.15 ms (block moves, deferred host compaction on the localizer's worker) the hand-off
+    //! between the two threads costs the localizer's thread more waiting (0.2-0.35 ms per scan) than the stage itself;
+    //! PGSLAM_MT_INPUT_THREAD=1 (or SetInputThread(true) before Run) turns it on.
+    void SetInputThread(bool on) { pre_thread_on_ = on; }
     void Run()
     {
         stop_ = false;
         thread_ = std::thread(&LocalizerMT::Main, this);
-        pre_thread_ = std::thread(&LocalizerMT::PreMain, this);
+        if (pre_thread_on_) pre_thread_ = std::thread(&LocalizerMT::PreMain, this);
     }
     void Stop()
     {
@@ -1450,10 +1455,12 @@ private:
                 outdated = outdated_;
                 outdated_ = false;
                 if (!queue_.empty()) {
-                    const auto tw = std::chrono::steady_clock::now();
-                    cv_.wait(l, [this] { return queue_.front()->state == 2 || stop_; });      // (its input stage is done, or nearly)
-                    wait_pre_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-                    if (stop_) break;
+                    if (pre_thread_on_) {
+                        const auto tw = std::chrono::steady_clock::now();
+                        cv_.wait(l, [this] { return queue_.front()->state == 2 || stop_; });      // (its input stage is done, or nearly)
+                        wait_pre_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+                        if (stop_) break;
+                    }
                     it = queue_.front();
                     queue_.pop_front();
                 }
@@ -1465,8 +1472,9 @@ private:
                 if (outdated) this->UpdateFromGraphNow();             // (takes the graph lock)
                 if (it) {
                     if (it->err) std::rethrow_exception(it->err);
-                    this->AdoptPreprocessed(it->cloud, it->reading);
-                    this->ProcessData(it->T_world_robot, it->T_robot_sensor, it->cloud);
+                    if (pre_thread_on_) this->AdoptPreprocessed(it->cloud, it->reading);
+                    this->ProcessData(it->T_world_robot, it->T_robot_sensor, it->cloud);     // (without the input thread: the stage runs here, its
+                                                                                             // host compaction on the worker while the ICP runs)
                 }
             } catch (...) { err = std::current_exception(); }
             { std::lock_guard<std::mutex> l(m_); busy_ = false; if (it) processed_++; if (err && !error_) error_ = err; }
@@ -1478,6 +1486,7 @@ private:
     std::thread thread_, pre_thread_;
     pgslam_amd::LazyContext pre_ctx_{0, std::getenv("PGSLAM_PRE_STAGE_NORMAL_PRIORITY") ? 0 : 1};     // (its short launches go ahead of the ICP's queued ones)
     bool stop_ = false, busy_ = false, outdated_ = false;
+    bool pre_thread_on_ = std::getenv("PGSLAM_MT_INPUT_THREAD") != nullptr;
     size_t processed_ = 0;
     double wait_pre_s_ = 0, pre_busy_s_ = 0;
     std::exception_ptr error_;

@@ -1776,18 +1776,43 @@ int filter_cloud(pgicp_ctx *c, int nf, const pgicp_filter *f, const T *feat, int
     if (want_idx) HIPC(c, S.idx.ensure(sizeof(int) * (size_t)n));
     XFER(c, h2d(c, S.in_f.p, feat, bf));
     if (dev_desc) XFER(c, h2d(c, S.in_d.p, desc, bd));
+    // (without a transformation and without a caller's kept_idx the host side only has to close the gaps of the dropped points: a
+    // short ascending list of them comes back with the count -- the kept indices, 4 bytes a point, are fetched only when that
+    // list would not hold them)
+    constexpr int kDropCap = 4096, kDropHead = 256;
+    const bool want_drop = ident && !kept_idx;
+    if (want_drop) HIPC(c, S.drop.ensure(sizeof(int) * kDropCap));
     launch_filter_cloud<T>(c->stream, S.in_f.as<T>(), frows, frows, dev_desc ? S.in_d.as<T>() : nullptr, drows, n, nf, types, params,
                            ident ? nullptr : T16, rot0, rot1, S.keep.as<int>(), S.pos.as<int>(), S.bsum.as<int>(), S.out_f.as<T>(),
-                           dev_desc ? S.out_d.as<T>() : nullptr, want_idx ? S.idx.as<int>() : nullptr);
+                           dev_desc ? S.out_d.as<T>() : nullptr, want_idx ? S.idx.as<int>() : nullptr, want_drop ? S.drop.as<int>() : nullptr,
+                           want_drop ? std::min(kDropCap, n) : 0);
     int kept = 0;
+    int drop_list[kDropCap];
     XFER(c, d2h(c, &kept, S.pos.as<int>() + n, sizeof(int)));
+    if (want_drop) XFER(c, d2h(c, drop_list, S.drop.p, sizeof(int) * (size_t)std::min(kDropHead, n)));
     HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
     *n_out = kept;
-    if (ident) {
+    if (ident && want_drop && kept < n && n - kept <= std::min(kDropCap, n)) {
+        const int nd = n - kept;
+        if (nd > kDropHead) { XFER(c, d2h(c, drop_list + kDropHead, S.drop.as<int>() + kDropHead, sizeof(int) * (size_t)(nd - kDropHead))); HIPC(c, stream_sync(c)); }
+        // the kept runs between consecutive dropped points, moved as blocks (out may alias the input: towards the front only)
+        if (out_feat != feat) std::memcpy(out_feat, feat, sizeof(T) * (size_t)frows * (size_t)drop_list[0]);
+        if (desc && out_desc != desc) std::memcpy(out_desc, desc, sizeof(T) * (size_t)drows * (size_t)drop_list[0]);
+        int dst = drop_list[0];
+        for (int k = 0; k < nd; k++) {
+            const int from = drop_list[k] + 1, to = k + 1 < nd ? drop_list[k + 1] : n;
+            if (to > from) {
+                std::memmove(out_feat + (size_t)dst * frows, feat + (size_t)from * frows, sizeof(T) * (size_t)frows * (size_t)(to - from));
+                if (desc) std::memmove(out_desc + (size_t)dst * drows, desc + (size_t)from * drows, sizeof(T) * (size_t)drows * (size_t)(to - from));
+                dst += to - from;
+            }
+        }
+    } else if (ident) {
         std::vector<int> hidx;
         const int *idx = nullptr;
         if (kept < n || kept_idx) {
+            if (!want_idx) return fail(c, PGICP_ERR_HIP, "pgicp_filter_cloud: internal (kept indices not made)");
             int *dst = kept_idx;
             if (!dst) { hidx.resize((size_t)std::max(kept, 1)); dst = hidx.data(); }
             if (kept > 0) { XFER(c, d2h(c, dst, S.idx.p, sizeof(int) * (size_t)kept)); HIPC(c, stream_sync(c)); }

@@ -104,12 +104,14 @@ void run_mt(const char *name)
     }
     odom.push_back(truth[0]);
     for (int s = 1; s < S; s++) odom.push_back(odom[s - 1] * (truth[s - 1].inverse() * truth[s]) * pose<T>(0.012, -0.009, 0.0, 0.005));
-    for (int free_running = 0; free_running < 2; free_running++) {
+    for (int free_running = 0; free_running < 3; free_running++) {
         pgslam::PoseGraphSlamMT<T> slam;
         slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
         slam.localizer().SetOverlapThreshold(T(0.9));
         slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
         slam.loop_closer().SetGeometricalDistanceThreshold(T(0.3));
+        const bool input_thread = free_running == 2;                    // (third run: free running with the input stage on its own thread)
+        slam.localizer().SetInputThread(input_thread);
         slam.Run();
         for (int s = 0; s < S; s++) {
             auto cloud = std::make_shared<DP>(rigid->compute(make_corner<T>(2000, 70 + s, 0.004), truth[s].inverse()));
@@ -121,11 +123,9 @@ void run_mt(const char *name)
         }
         slam.WaitIdle();
         CHECK(slam.localizer().processed() == (size_t)S);
-        // free running, the next scan is queued while the current one aligns: its cloud was uploaded ahead (pgicp_upload_*,
-        // LocalizerMT.hpp:27-40) and the ICP ran on the device copy; in lock step there is never a next scan to prefetch
-        // every scan's input stage runs on the flavour's pre-processing thread (round 5), free running up to two scans ahead of
-        // the one being aligned (LocalizerMT.hpp:27-40: the queue holds them by then), in lock step just before its own ICP
-        CHECK(slam.localizer().prefetches() == (size_t)S);
+        // with the input thread every scan's input stage runs there, up to two scans ahead of the one being aligned
+        // (LocalizerMT.hpp:27-40: the queue holds them by then); without it (the default) on the localizer's own thread
+        CHECK(slam.localizer().prefetches() == (input_thread ? (size_t)S : 0));
         auto lock = slam.map_manager().GetGraphLock();
         auto &g = slam.map_manager().GetGraph();
         CHECK(g.NumVertices() == (size_t)S);
@@ -137,7 +137,7 @@ void run_mt(const char *name)
         CHECK(worst < (free_running ? 6e-2 : 3e-2));
         CHECK(pose_diff(slam.localizer().T_world_robot(), truth[S - 1]) < (free_running ? 6e-2 : 3e-2));
         std::printf("%s, %s: ok  (%zu keyframes, %d loop edges in %d device batch(es), largest %d; %d optimiser run(s); worst keyframe error %.2e)\n",
-                    name, free_running ? "free running" : "lock step", g.NumVertices(), loops, slam.loop_closer().batches(),
+                    name, free_running == 2 ? "free running, input thread" : free_running ? "free running" : "lock step", g.NumVertices(), loops, slam.loop_closer().batches(),
                     slam.loop_closer().largest_batch(), slam.optimizer().runs(), worst);
     }
 }
@@ -193,7 +193,7 @@ void run_mt_sensor_pose(const char *name)
     for (int s = 0; s < S; s++) slam.AddData((unsigned long long)s, "world", odom[s], T_robot_sensor, clouds[s]);
     slam.WaitIdle();
     CHECK(slam.localizer().processed() == (size_t)S);
-    CHECK(slam.localizer().prefetches() == (size_t)S);
+    CHECK(slam.localizer().prefetches() == 0);
     CHECK(slam.localizer().device_readings_used() == (size_t)S - 1);                     // every ICP ran on the device copy its input stage left (scan 0 has no ICP)
     CHECK(slam.localizer().device_input_stages() == (size_t)S);                          // (the input stage of every scan ran on the device)
     for (int s = 0; s < S; s++) CHECK(clouds[s]->getNbPoints() == (n_raw + 1) / 2);      // filtered once, in place
