@@ -515,8 +515,7 @@ public:
         if (!kf.device_cloud) { EnsureKeyframeOnDevice<T>(kf, ctx); resident_bytes_ += DeviceKeyframeBytes<T>(kf); device_uploads_++; }
         resident_lru_.remove(v);
         resident_lru_.push_front(v);
-        static const size_t budget = (size_t)(std::getenv("PGSLAM_DEVICE_KEYFRAMES_MB") ? std::atof(std::getenv("PGSLAM_DEVICE_KEYFRAMES_MB")) : 8192.0) << 20;
-        while (resident_bytes_ > budget && resident_lru_.size() > 16) {
+        while (resident_bytes_ > device_budget_ && resident_lru_.size() > 16) {
             const size_t old = resident_lru_.back();
             resident_lru_.pop_back();
             resident_bytes_ -= std::min(resident_bytes_, DeviceKeyframeBytes<T>(graph_[old]));
@@ -524,6 +523,7 @@ public:
             device_evictions_++;
         }
     }
+    void SetDeviceKeyframeBudgetMB(double mb) { device_budget_ = (size_t)(mb * 1048576.0); }
     size_t resident_keyframes() const { return resident_lru_.size(); }
     size_t resident_bytes() const { return resident_bytes_; }
     size_t device_uploads() const { return device_uploads_; }
@@ -550,6 +550,7 @@ private:
     std::recursive_mutex graph_mutex_;
     std::list<size_t> resident_lru_;                 // vertices with a device copy, most recently used first
     size_t resident_bytes_ = 0, device_uploads_ = 0, device_evictions_ = 0;
+    size_t device_budget_ = (size_t)((std::getenv("PGSLAM_DEVICE_KEYFRAMES_MB") ? std::atof(std::getenv("PGSLAM_DEVICE_KEYFRAMES_MB")) : 8192.0) * 1048576.0);
     unsigned long long version_ = 0;
     size_t fixed_vertex_ = 0;
     std::weak_ptr<GraphLocalizer<T>> localizer_;

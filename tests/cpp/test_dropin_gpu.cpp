@@ -120,6 +120,49 @@ void run(const char *name)
         CHECK(pose_diff(pgslam_amd::from_row_major16<T>(ef[0].T_from_to), r1.T_refkf_kf) == 0.0);
     }
 
+    {   // a chain WITH a SurfaceNormalOutlierFilter is never run without it: the batch carries the readings' normals and
+        // gives what the one-at-a-time loop closer gives; the residual / overlap probes run stage by stage; a device reading is refused
+        const std::string yaml = std::string("matcher:\n  KDTreeMatcher:\n    maxDist: 2.0\noutlierFilters:\n  - TrimmedDistOutlierFilter:\n      ratio: 0.85\n"
+                                             "  - SurfaceNormalOutlierFilter:\n      maxAngle: 0.6\nerrorMinimizer:\n  PointToPlaneWithCovErrorMinimizer:\n    sensorStdDev: 0.01\n"
+                                             "transformationCheckers:\n  - CounterTransformationChecker:\n      maxIterationCount: 30\n"
+                                             "  - DifferentialTransformationChecker:\n      minDiffRotErr: 0.001\n      minDiffTransErr: 0.01\n      smoothLength: 3\n");
+        // every seventh reading normal turned away: pairs the filter must drop
+        DP turned(reading);
+        const int rn = turned.getDescriptorStartingRow("normals");
+        for (int j = 0; j < (int)turned.getNbPoints(); j += 7) { const T a = turned.descriptors(rn, j); turned.descriptors(rn, j) = turned.descriptors(rn + 2, j); turned.descriptors(rn + 2, j) = -a; }
+        pgslam::LoopCloser<T> one, plain;
+        one.SetIcpConfigFromString(yaml);
+        plain.SetIcpConfigFromString(kIcpYaml);
+        const auto r1 = one.ProcessCandidate(turned, map, guess), r0 = plain.ProcessCandidate(turned, map, guess);
+        CHECK(r1.overlap < r0.overlap - T(0.05));                          // the filter acted in the ICP ...
+        CHECK(r1.residual < r0.residual);                                   // ... and in ComputeResidualError's chain (stage by stage)
+        pgslam::LoopClosureBatch<T> nb;
+        nb.SetIcpConfigFromString(yaml);
+        auto tp = std::make_shared<DP>(turned);
+        nb.Add({1, 2, tp, mp, guess});
+        nb.Add({3, 4, tp, mp, guess});
+        const auto en = nb.Run(nb.Shard(1, 0));
+        CHECK(en.size() == 2 && en[0].status == 0);
+        CHECK(pose_diff(pgslam_amd::from_row_major16<T>(en[0].T_from_to), r1.T_refkf_kf) == 0.0 && (T)en[0].overlap == r1.overlap);
+        CHECK(std::memcmp(en[0].T_from_to, en[1].T_from_to, sizeof en[0].T_from_to) == 0);
+        // the overlap probe of the localizer: the same chain, stage by stage
+        pgslam::Localizer<T> ln, lp;
+        ln.SetIcpConfigFromString(yaml);
+        lp.SetIcpConfigFromString(kIcpYaml);
+        const T on = ln.ComputeOverlapOf(turned, r1.T_refkf_kf, map), op = lp.ComputeOverlapOf(turned, r1.T_refkf_kf, map);
+        CHECK(on < op - T(0.05) && on > T(0.5));
+        // a device reading cannot carry normals: refused for this chain, never run without the filter
+        ICPSequence seqn;
+        { std::istringstream iss(yaml); seqn.loadFromYaml(iss); }
+        seqn.setMap(map);
+        CHECK(!seqn.deviceReadingEquivalent());
+        auto up = seqn.uploadReading(turned);
+        bool refused = false;
+        try { seqn(up, guess); } catch (const std::logic_error &) { refused = true; }
+        CHECK(refused);
+        CHECK(pose_diff(seqn(turned, guess), r1.T_refkf_kf) == 0.0);         // (the host cloud: with the filter, as ICP::operator() above)
+    }
+
     // --- LocalMap::BuildCloudFromData  (LocalMap.hpp:209-224)
     std::vector<Keyframe> kfs(2);
     kfs[0].id = 0; kfs[0].cloud_ptr = mp; kfs[0].optimized_T_world_kf = pose<T>(1, 0, 0, 0.1);

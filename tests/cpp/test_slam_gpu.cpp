@@ -262,6 +262,47 @@ void run_device_local_map(const char *name)
     }
 }
 
+// Keyframe clouds in device memory live under a budget (MapManager::EnsureKeyframeResident): with room for only a few of them the least
+// recently used copies are dropped and made again when a composition names the keyframe once more -- the same poses, keyframes and
+// loop edges as with every keyframe resident.
+template <typename T>
+void run_keyframe_residency(const char *name)
+{
+    IMPORT_PGSLAM_TYPES(T)
+    TransformationPtr rigid = PM::get().REG(Transformation).create("RigidTransformation");
+    const int S = 40;
+    std::vector<Matrix> truth, odom, ref_poses;
+    for (int s = 0; s < S; s++) {
+        const double a = 2 * M_PI * s / (S - 1);
+        truth.push_back(pose<T>(1.5 + 0.5 * std::cos(a), 1.5 + 0.5 * std::sin(a), 0.0, a * 0.2));
+    }
+    odom.push_back(truth[0]);
+    for (int s = 1; s < S; s++) odom.push_back(odom[s - 1] * (truth[s - 1].inverse() * truth[s]) * pose<T>(0.004, -0.003, 0.0, 0.002));
+    size_t loops_ref = 0;
+    for (int tight = 0; tight < 2; tight++) {
+        pgslam::PoseGraphSlam<T> slam;
+        if (tight) slam.map_manager().SetDeviceKeyframeBudgetMB(0.5);    // (a keyframe of this drive holds ~0.17 MB: the 16 most recently used stay)
+        slam.SetIcpConfigFromStrings("- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+        slam.localizer().SetOverlapThreshold(T(0.9));                    // every scan a keyframe
+        slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
+        slam.loop_closer().SetGeometricalDistanceThreshold(T(0.3));
+        for (int s = 0; s < S; s++) {
+            auto cloud = std::make_shared<DP>(rigid->compute(make_corner<T>(1500, 570 + s, 0.004), truth[s].inverse()));
+            slam.AddData((unsigned long long)s, "world", odom[s], Matrix::Identity(4, 4), cloud);
+            if (!tight) ref_poses.push_back(slam.localizer().T_world_robot());
+            else CHECK(pose_diff(slam.localizer().T_world_robot(), ref_poses[s]) == 0.0);
+        }
+        auto &mm = slam.map_manager();
+        if (!tight) { loops_ref = (size_t)slam.loop_closer().loops_closed(); CHECK(mm.device_evictions() == 0 && mm.resident_keyframes() == (size_t)S); }
+        else {
+            CHECK(mm.device_evictions() > 0 && mm.resident_keyframes() <= 17 && mm.device_uploads() > (size_t)S);
+            CHECK((size_t)slam.loop_closer().loops_closed() == loops_ref);
+            std::printf("%s: ok  (%d keyframes, %zu resident, %zu uploads, %zu evictions; poses and loops as with all of them resident)\n", name, S,
+                        mm.resident_keyframes(), mm.device_uploads(), mm.device_evictions());
+        }
+    }
+}
+
 // The batched dispatcher INSIDE the facade (LoopCloserMT.hpp:26-34 queues vertices, :45-67 pops them one at a time; here the
 // worker drains its queue into one device batch): the loop closer is held back while the localizer makes fifteen keyframes, then
 // let go -- every waiting vertex becomes a candidate of ONE batch (LoopClosureBatch over device-resident clouds) -- against the same
@@ -326,6 +367,7 @@ void run_mt_batched_dispatcher(const char *name)
 
 int main()
 {
+    run_keyframe_residency<float>("keyframe clouds under a device-memory budget, PoseGraphSlam<float>");
     run_deferred_compaction<float>("deferred host compaction, PoseGraphSlam<float>");
     run_deferred_compaction<double>("deferred host compaction, PoseGraphSlam<double>");
     run_mt_batched_dispatcher<float>("batched dispatcher inside PoseGraphSlamMT<float>");
