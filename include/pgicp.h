@@ -60,6 +60,16 @@ extern "C" {
                                                      * covariance estimate pgslam hands to its optimiser (Localizer.hpp:238, LoopCloser.hpp:108);
                                                      * the estimate reads the reference's `normals`: the map must have them */
 #define PGICP_MAX_KNN 16
+#define PGICP_ROBUST_NONE 0
+#define PGICP_ROBUST_CAUCHY 1
+#define PGICP_ROBUST_WELSCH 2
+#define PGICP_ROBUST_SC 3
+#define PGICP_ROBUST_GM 4
+#define PGICP_ROBUST_TUKEY 5
+#define PGICP_ROBUST_HUBER 6
+#define PGICP_ROBUST_L1 7
+#define PGICP_ROBUST_SCALE_NONE 0
+#define PGICP_ROBUST_SCALE_MAD 1
 
 typedef struct pgicp_ctx pgicp_ctx;
 
@@ -93,6 +103,14 @@ typedef struct pgicp_params {
     double bound_max_trans;  /* PGICP_ERR_BOUND when the accumulated correction exceeds either (.maxTranslationNorm) */
     double normal_max_angle; /* SurfaceNormalOutlierFilter.maxAngle (rad): a pair whose reading and reference normals differ by more
                               * gets weight 0 (the weights multiply in); needs pgicp_problem.normals; 0 = not in the chain */
+    /* (ABI 5) RobustOutlierFilter{robustFct, tuning, scaleEstimator, approximation} (distanceType point2point, nbIterationForScale 0):
+     * the chain's DISTANCE filter then -- no quantile filter beside it (trim_ratio must be 1, quantile_scale 1); MaxDist and
+     * SurfaceNormal filters may multiply in.  Every pair with a neighbour carries the weight f(dist / scale^2): nothing is trimmed,
+     * the matcher resolves every query exactly. */
+    int robust_fct;          /* PGICP_ROBUST_NONE (not in the chain) | _CAUCHY | _WELSCH | _SC | _GM | _TUKEY | _HUBER | _L1 */
+    double robust_tuning;    /* tuning (default 1) */
+    int robust_scale;        /* scaleEstimator: PGICP_ROBUST_SCALE_NONE | PGICP_ROBUST_SCALE_MAD (default: mad) */
+    double robust_approx;    /* approximation: pairs with dist / scale^2 >= approximation^2 get weight 0; 0 or +inf = none */
 } pgicp_params;
 
 /* What pgslam reads back after an ICP: errorMinimizer->getOverlap()

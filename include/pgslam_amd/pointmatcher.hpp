@@ -805,6 +805,42 @@ struct PointMatcher {
             return w;
         }
     };
+    //! [EXT] RobustOutlierFilter{robustFct, tuning, scaleEstimator, nbIterationForScale, distanceType, approximation}: an
+    //! M-estimator weight per pair from e2 = dist / scale^2 (OutlierFiltersImpl.cpp as restated in oracle/icp_oracle.c:
+    //! orc_robust_weights), scale = sqrt(median absolute deviation of the finite squared distances) or 1.  Supported as
+    //! upstream's defaults have it: distanceType point2point and nbIterationForScale 0 (the scale re-estimated at every
+    //! call); no TrimmedDist / MedianDist filter beside it, knn 1.  Inside an ICP run the device applies it
+    //! (pgicp_params.robust_*); this stage-level call is pgicp_outlier_weights under the same parameters.
+    struct RobustOutlierFilter : OutlierFilter {
+        ICPChainBase *chain; std::string robustFct, scaleEstimator; T tuning, approximation;
+        RobustOutlierFilter(ICPChainBase *c, const std::string &fct = "cauchy", T tun = T(1), const std::string &scale = "mad",
+                            T approx = std::numeric_limits<T>::infinity())
+            : chain(c), robustFct(fct), scaleEstimator(scale), tuning(tun), approximation(approx)
+        {
+            fctCode(); scaleCode();
+            if (!(tuning > T(0))) throw std::runtime_error("RobustOutlierFilter: tuning must be positive");
+        }
+        int fctCode() const
+        {
+            static const char *names[] = {"cauchy", "welsch", "sc", "gm", "tukey", "huber", "L1"};
+            for (int k = 0; k < 7; k++) if (robustFct == names[k]) return PGICP_ROBUST_CAUCHY + k;
+            throw std::runtime_error("RobustOutlierFilter: unknown robustFct " + robustFct + " (cauchy, welsch, sc, gm, tukey, huber, L1)");
+        }
+        int scaleCode() const
+        {
+            if (scaleEstimator == "mad") return PGICP_ROBUST_SCALE_MAD;
+            if (scaleEstimator == "none") return PGICP_ROBUST_SCALE_NONE;
+            throw std::runtime_error("RobustOutlierFilter: scaleEstimator " + scaleEstimator + " is not supported (mad, none)");
+        }
+        OutlierWeights compute(const DataPoints &, const DataPoints &, const Matches &input) override
+        {
+            OutlierWeights w(input.dists.rows(), input.dists.cols());
+            chain->pushParams();
+            T lim; int nf;
+            check(chain->ctx, A::weights(chain->ctx, input.dists.data(), (int)input.dists.size(), w.data(), &lim, &nf));
+            return w;
+        }
+    };
     //! [EXT] MaxDistOutlierFilter{maxDist}: weight 1 while the squared match distance is <= maxDist^2, else 0
     struct MaxDistOutlierFilter : OutlierFilter {
         T maxDist;
@@ -1045,11 +1081,27 @@ struct PointMatcher {
                         const T f = m.params.count("factor") ? (T)to_double(m.params.at("factor"), "factor") : T(3);
                         if (!(f > T(0))) throw std::runtime_error("MedianDistOutlierFilter: factor must be positive");
                         outlierFilters.push_back(std::make_shared<MedianDistOutlierFilter>(this, f));
+                    } else if (m.name == "RobustOutlierFilter" && n_trim++ == 0) {
+                        std::string fct = "cauchy", scale = "mad", dtype = "point2point";
+                        T tun = T(1), approx = std::numeric_limits<T>::infinity();
+                        int nbIter = 0;
+                        for (auto &kv : m.params) {
+                            if (kv.first == "robustFct") fct = kv.second;
+                            else if (kv.first == "scaleEstimator") scale = kv.second;
+                            else if (kv.first == "distanceType") dtype = kv.second;
+                            else if (kv.first == "tuning") tun = (T)to_double(kv.second, "tuning");
+                            else if (kv.first == "approximation") approx = (T)to_double(kv.second, "approximation");
+                            else if (kv.first == "nbIterationForScale") nbIter = (int)to_double(kv.second, "nbIterationForScale");
+                            else throw std::runtime_error("RobustOutlierFilter: unknown parameter " + kv.first);
+                        }
+                        if (dtype != "point2point") throw std::runtime_error("RobustOutlierFilter: distanceType " + dtype + " is not supported (point2point)");
+                        if (nbIter != 0) throw std::runtime_error("RobustOutlierFilter: nbIterationForScale must be 0 (the scale is estimated at every iteration)");
+                        outlierFilters.push_back(std::make_shared<RobustOutlierFilter>(this, fct, tun, scale, approx));
                     } else if (m.name == "MaxDistOutlierFilter" && n_max++ == 0)
                         outlierFilters.push_back(std::make_shared<MaxDistOutlierFilter>(m.params.count("maxDist") ? (T)to_double(m.params.at("maxDist"), "maxDist") : T(1)));
                     else
                         throw std::runtime_error("loadFromYaml: unsupported outlier filter chain at " + m.name +
-                                                 " (supported: one TrimmedDistOutlierFilter or MedianDistOutlierFilter, and / or one MaxDistOutlierFilter, "
+                                                 " (supported: one of TrimmedDistOutlierFilter, MedianDistOutlierFilter or RobustOutlierFilter, and / or one MaxDistOutlierFilter, "
                                                  "and / or one SurfaceNormalOutlierFilter)");
                 }
             } else outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
@@ -1111,6 +1163,11 @@ struct PointMatcher {
                 if (auto t = std::dynamic_pointer_cast<TrimmedDistOutlierFilter>(f)) { p.trim_ratio = (double)t->ratio; p.quantile_scale = 1.0; }
                 if (auto md = std::dynamic_pointer_cast<MedianDistOutlierFilter>(f)) { p.trim_ratio = 0.5; p.quantile_scale = (double)md->factor; }
                 if (auto m = std::dynamic_pointer_cast<MaxDistOutlierFilter>(f)) p.outlier_max_dist = (double)m->maxDist;
+                if (auto rb = std::dynamic_pointer_cast<RobustOutlierFilter>(f)) {
+                    if (p.robust_fct != PGICP_ROBUST_NONE) throw std::runtime_error("ICP chain: more than one RobustOutlierFilter");
+                    p.robust_fct = rb->fctCode(); p.robust_scale = rb->scaleCode(); p.robust_tuning = (double)rb->tuning;
+                    p.robust_approx = std::isfinite((double)rb->approximation) ? (double)rb->approximation : 0.0;
+                }
             }
             if (errorMinimizer) {
                 p.sensor_std_dev = (double)errorMinimizer->sensorStdDev;

@@ -87,11 +87,13 @@ typedef float real;
 #define SQRT_R(a) sqrt(a)
 #define COS_R(a) cos(a)
 #define SIN_R(a) sin(a)
+#define EXP_R(a) exp(a)
 #else
 #define FMA_R(a, b, c) fmaf((a), (b), (c))
 #define SQRT_R(a) sqrtf(a)
 #define COS_R(a) cosf(a)
 #define SIN_R(a) sinf(a)
+#define EXP_R(a) expf(a)
 #endif
 /* which index wins among candidates at exactly the same squared distance (see ORC_TIE_HIGH above) */
 #ifdef ORC_TIE_HIGH
@@ -132,6 +134,12 @@ typedef struct {
     double bound_max_rot;   /* [A.9] BoundTransformationChecker.maxRotationNorm (rad); <= 0 or inf: not in the chain */
     double bound_max_trans; /* [A.9] BoundTransformationChecker.maxTranslationNorm; <= 0 or inf: not in the chain */
     real normal_max_angle;  /* [A.4] SurfaceNormalOutlierFilter.maxAngle (rad); <= 0: not in the chain */
+    /* ---- round 5: [A.4] RobustOutlierFilter{robustFct, tuning, scaleEstimator, approximation} (distanceType point2point,
+     * nbIterationForScale 0); orc_robust_weights below ---- */
+    int robust_fct;         /* 0: not in the chain; 1 cauchy 2 welsch 3 sc 4 gm 5 tukey 6 huber 7 L1 */
+    real robust_tuning;     /* tuning */
+    int robust_scale;       /* scaleEstimator: 0 none, 1 mad */
+    real robust_approx;     /* approximation (a distance; its square cuts e2); <= 0 or +inf: none */
 } FN(orc_params);
 
 /* [A.4] the chain multiplies the weights of its outlier filters.  MaxDistOutlierFilter: weight 1 while the SQUARED
@@ -666,6 +674,63 @@ static int FN(orc_quantile_weights)(const real *d2, int n, real ratio, real scal
     if (scale > (real)0 && scale != (real)1) limit = scale * limit;
     for (int i = 0; i < n; i++) w[i] = (d2[i] <= limit) ? (real)1 : (real)0;
     if (limit_out) *limit_out = limit;
+    return ORC_OK;
+}
+
+/* --------------------------------------------------------------------------
+ * [A.4] RobustOutlierFilter ([EXT] OutlierFiltersImpl.cpp RobustOutlierFilter::robustFiltering, distanceType point2point,
+ * nbIterationForScale 0 = the scale is estimated at every call):
+ *   scale: scaleEstimator "mad": scale = sqrt(matches.getMedianAbsDeviation()), with [EXT] Matches::getMedianAbsDeviation =
+ *          median of |d - median(d)| over the finite (squared) distances, both medians the element at index size / 2 after
+ *          nth_element; "none": scale = 1
+ *   e2 = dists / (scale * scale)   (scale * scale in T: the square of the rounded root, not the deviation itself)
+ *   k = tuning, k2 = k * k:  cauchy 1 / (1 + e2 / k2) | welsch exp(-e2 / k2) | sc e2 >= k ? 4 k2 / (k + e2)^2 : 1 |
+ *          gm k2 / (k + e2)^2 | tukey e2 >= k2 ? 0 : (1 - e2 / k2)^2 | huber e2 >= k2 ? k / sqrt(e2) : 1 | L1 1 / sqrt(e2)
+ *   w = (w <= 1e-50) ? 1e-50 : w   -- the constant is a double compared with an array of T: in float it is 0, the clause a no-op
+ *   approximation != inf: w = e2 >= approximation^2 ? 0 : w
+ * An invalid match (distance +inf) comes out with weight 0 in every function (1e-50 in double: the pair is still dropped, its
+ * id is invalid).  Returns the squared scale through scale2_out.
+ * ------------------------------------------------------------------------ */
+int FN(orc_robust_weights)(const real *d2, int n, int fct, real tuning, int scale_est, real approx, real *w, real *scale2_out)
+{
+    real s2 = (real)1;
+    if (scale_est == 1) {
+        real *vals = (real *)malloc(sizeof(real) * (n > 0 ? n : 1));
+        int nf = 0;
+        for (int i = 0; i < n; i++) if (d2[i] != INFINITY) vals[nf++] = d2[i];
+        if (nf == 0) { free(vals); return ORC_ERR_NO_MATCH; }
+        qsort(vals, nf, sizeof(real), cmp_real);
+        const real med = vals[nf / 2];
+        for (int i = 0; i < nf; i++) vals[i] = vals[i] > med ? vals[i] - med : med - vals[i];      /* fabs(v - median) */
+        qsort(vals, nf, sizeof(real), cmp_real);
+        const real scale = SQRT_R(vals[nf / 2]);
+        free(vals);
+        s2 = scale * scale;
+    }
+    if (scale2_out) *scale2_out = s2;
+    const real k = tuning, k2 = k * k;
+    const int cut = approx > (real)0 && !isinf(approx);
+    const real a2 = approx * approx;
+    for (int i = 0; i < n; i++) {
+        const real e2 = d2[i] / s2;
+        real wi = (real)0;
+        switch (fct) {
+        case 1: wi = (real)1 / ((real)1 + e2 / k2); break;
+        case 2: wi = EXP_R(-(e2 / k2)); break;
+        case 3: { const real t = k + e2; wi = e2 >= k ? ((real)4 * k2) / (t * t) : (real)1; break; }
+        case 4: { const real t = k + e2; wi = k2 / (t * t); break; }
+        case 5: { const real t = (real)1 - e2 / k2; wi = e2 >= k2 ? (real)0 : t * t; break; }
+        case 6: wi = e2 >= k2 ? k / SQRT_R(e2) : (real)1; break;
+        case 7: wi = (real)1 / SQRT_R(e2); break;
+        default: free(NULL); return ORC_ERR_ARG;
+        }
+#ifdef ORC_DOUBLE
+        if (wi <= 1e-50) wi = 1e-50;
+#endif
+        if (cut && e2 >= a2) wi = (real)0;
+        if (d2[i] == INFINITY) wi = (real)0;                 /* (no neighbour: never an error element) */
+        w[i] = wi;
+    }
     return ORC_OK;
 }
 
@@ -1354,7 +1419,8 @@ int FN(orc_partial_chain)(const FN(orc_params) *prm, const real *reading, int n,
         if (t) FN(orc_kdtree_free)(t);
     }
     real limit; int nf;
-    int st = FN(orc_quantile_weights)(d2, n * K, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
+    int st = prm->robust_fct > 0 ? FN(orc_robust_weights)(d2, n * K, prm->robust_fct, prm->robust_tuning, prm->robust_scale, prm->robust_approx, w, &limit)
+                                 : FN(orc_quantile_weights)(d2, n * K, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
     if (st == ORC_OK) FN(orc_maxdist_weights)(d2, n * K, prm->outlier_max_dist, w);
     if (st == ORC_OK) {
         double sys[30];
@@ -1454,7 +1520,14 @@ int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *r
         if (use_nrm) FN(orc_transform)(T_iter, rd_n, step_n, n, 1);
         FN(match_k)(prm, tree, step, n, ref, m, K, ids, d2);
         real limit; int nf;
-        status = FN(orc_quantile_weights)(d2, n * K, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
+        if (prm->robust_fct > 0) {
+            /* the chain's distance filter is the robust one (no quantile filter beside it): every finite pair carries a weight */
+            real s2;
+            status = FN(orc_robust_weights)(d2, n * K, prm->robust_fct, prm->robust_tuning, prm->robust_scale, prm->robust_approx, w, &s2);
+            limit = INFINITY; nf = 0;
+            for (int i = 0; i < n * K; i++) nf += d2[i] != INFINITY;
+        } else
+            status = FN(orc_quantile_weights)(d2, n * K, prm->trim_ratio, prm->quantile_scale, w, &limit, &nf);
         if (status != ORC_OK) break;
         FN(orc_maxdist_weights)(d2, n * K, prm->outlier_max_dist, w);
         if (use_nrm) FN(orc_normal_weights)(step_n, ref_nrm, ids, n, K, prm->normal_max_angle, w);

@@ -45,7 +45,8 @@ def _params_type(real):
                     ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double),
                     ("use_kdtree", C.c_int), ("center_reference", C.c_int), ("outlier_max_dist", real),
                     ("quantile_scale", real), ("knn", C.c_int), ("minimizer", C.c_int), ("bound_max_rot", C.c_double),
-                    ("bound_max_trans", C.c_double), ("normal_max_angle", real)]
+                    ("bound_max_trans", C.c_double), ("normal_max_angle", real), ("robust_fct", C.c_int), ("robust_tuning", real),
+                    ("robust_scale", C.c_int), ("robust_approx", real)]
     return Params
 
 
@@ -90,7 +91,8 @@ class Oracle:
                            d["min_diff_trans"], d["smooth_length"], d["sensor_std_dev"],
                            int(use_kdtree), int(center_reference), d.get("outlier_max_dist", 0.0), d.get("quantile_scale", 1.0),
                            int(d.get("knn", 1)), int(d.get("error_minimizer", 0)), float(d.get("bound_max_rot", 0.0)),
-                           float(d.get("bound_max_trans", 0.0)), float(d.get("normal_max_angle", 0.0)))
+                           float(d.get("bound_max_trans", 0.0)), float(d.get("normal_max_angle", 0.0)), int(d.get("robust_fct", 0)),
+                           float(d.get("robust_tuning", 1.0)), int(d.get("robust_scale", 1)), float(d.get("robust_approx", 0.0)))
 
     # -- stages -----------------------------------------------------------
     def transform(self, T, pts, rotate_only=False):
@@ -153,6 +155,15 @@ class Oracle:
         f = self.lib.orc_fixstep_next
         f.restype = C.c_double
         return f(C.c_double(step), C.c_double(start_step), C.c_double(end_step), C.c_double(step_mult))
+
+    def robust_weights(self, d2, fct, tuning=1.0, scale=1, approx=0.0):
+        """[EXT] RobustOutlierFilter (orc_robust_weights): (weights, squared scale)"""
+        d2 = np.ascontiguousarray(d2, dtype=self.dtype)
+        w = np.empty_like(d2)
+        s2 = self.real(0)
+        st = self._f("orc_robust_weights")(self._p(d2), C.c_int(d2.size), C.c_int(fct), self.real(tuning), C.c_int(scale), self.real(approx), self._p(w), C.byref(s2))
+        assert st == 0, st
+        return w, np.dtype(self.dtype).type(s2.value)
 
     def normal_weights(self, rd_nrm, ref_nrm, ids, max_angle, w=None):
         """[EXT] SurfaceNormalOutlierFilter{maxAngle}: multiplies its weights into w (ones by default); ids (n,) or (n,k)"""

@@ -64,6 +64,16 @@ struct BuildDesc {
 };
 
 // Chain parameters as the kernels need them.
+// [EXT] RobustOutlierFilter (round 5): the weight of a pair is a function of its squared distance over the squared scale
+// (ProblemDev::robust_s2: the median absolute deviation's rounded root, squared -- or 1); fct 0: not in the chain
+template <typename T>
+struct RobustDev {
+    int fct;             // 1 cauchy 2 welsch 3 sc 4 gm 5 tukey 6 huber 7 L1
+    int mad;             // scaleEstimator: 1 mad, 0 none
+    int cut;             // approximation given: e2 >= a2 -> weight 0
+    T k, k2, a2;
+};
+
 template <typename T>
 struct ChainDev {
     T max_dist;          // may be +inf
@@ -82,6 +92,7 @@ struct ChainDev {
     double bound_rot, bound_trans;   // BoundTransformationChecker limits; <= 0: not in the chain
     T normal_cos;        // SurfaceNormalOutlierFilter: cos(maxAngle) evaluated in T on the host
     int use_normals;     // ... and whether it is in the chain
+    RobustDev<T> robust; // RobustOutlierFilter (the chain's distance filter then: no quantile filter beside it)
 };
 
 // One ICP problem of a batch.  Lives in device memory; written by the solve
@@ -121,6 +132,7 @@ struct ProblemDev {
     // full select, the result is exact either way.  qrec: what THIS call found (read back by the host for the next call).
     double qhint[2][4];
     double qrec[2][4];
+    double robust_s2;        // RobustOutlierFilter: this iteration's squared scale (k_robust_finish)
     double sys[kSys];        // final sums of the last iteration
     Checker chk;
 };

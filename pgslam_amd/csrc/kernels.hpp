@@ -64,6 +64,12 @@ void launch_cov(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, 
                 const T *d2, double *partials, double *out, int P, int max_n, const ChainDev<T> &ch);
 void launch_sum_partials(hipStream_t st, const double *partials, int max_blocks, int nt, const ProblemDev *probs,
                          int nb_uniform, double *out, int P);
+void launch_robust_open(hipStream_t st, ProblemDev *probs, const int *active, int n_active);
+template <typename T>
+void launch_robust_raw(hipStream_t st, const T *d2, int n, const RobustDev<T> &rb, T *dev, T *stat, T *w);
+template <typename T>
+void launch_robust_scale(hipStream_t st, ProblemDev *probs, const T *d2, T *dev, const ChainDev<T> &ch, int n_active, int max_pairs,
+                         const int *active, int *tables, void *keys);
 template <typename T>
 void launch_trim_raw(hipStream_t st, const T *d2, int n, T ratio, T scale, T *limit_nf, T *w);
 template <typename T>

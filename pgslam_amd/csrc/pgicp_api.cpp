@@ -134,6 +134,7 @@ struct pgicp_ctx {
     // reading, for the next three calls: a localizer that pre-processes scan k + 1 while scan k aligns, and now and then a
     // scan that was not pre-processed ahead, has three calls between making a reading and aligning it)
     struct FilterSet { DevBuf in_f, in_d, keep, pos, bsum, out_f, out_d, idx, drop; } fset[4];
+    DevBuf robust_dev;              // RobustOutlierFilter: the pairs' absolute deviations from the median (the second selection's input)
     int fset_next = 0;
     int up_next = 0;
     int up_seen = 0;            // upload sets whose device pointers the running call was handed (see UploadUse)
@@ -337,6 +338,10 @@ ChainDev<T> make_chain(const pgicp_params &p)
     ch.rank_rel_tol = 6.0 * (double)std::numeric_limits<T>::epsilon();
     ch.knn = std::max(1, p.knn);
     ch.minimizer = is_p2point(p.error_minimizer) ? 1 : 0;
+    ch.robust.fct = p.robust_fct; ch.robust.mad = p.robust_scale == PGICP_ROBUST_SCALE_MAD ? 1 : 0;
+    ch.robust.k = (T)p.robust_tuning; ch.robust.k2 = ch.robust.k * ch.robust.k;
+    ch.robust.cut = (p.robust_approx > 0.0 && std::isfinite(p.robust_approx)) ? 1 : 0;
+    { const T a = (T)p.robust_approx; ch.robust.a2 = a * a; }
     ch.force4dof = p.error_minimizer == PGICP_MINIMIZER_POINT_TO_PLANE_4DOF ? 1 : 0;
     ch.bound_rot = (p.bound_max_rot > 0.0 && std::isfinite(p.bound_max_rot)) ? p.bound_max_rot : 0.0;
     ch.bound_trans = (p.bound_max_trans > 0.0 && std::isfinite(p.bound_max_trans)) ? p.bound_max_trans : 0.0;
@@ -892,6 +897,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         HIPC(c, c->qrow.ensure(sizeof(int) * (size_t)L.total));
         // (the sort's words; afterwards the selection's key list: one key per PAIR)
         HIPC(c, c->qtmp.ensure(std::max(sizeof(unsigned long long) * (size_t)L.total, sizeof(T) * (size_t)L.total * L.knn)));
+        if (c->prm.robust_fct != PGICP_ROBUST_NONE) HIPC(c, c->robust_dev.ensure(sizeof(T) * (size_t)L.total * L.knn));
         HIPC(c, c->order.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
         HIPC(c, c->slow_lb.ensure(sizeof(T) * (size_t)L.total));
@@ -1033,10 +1039,13 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
         // (with the grid matcher this selection also clears the matcher's segmented queue counters for the next iteration)
         const bool grid = c->prm.matcher == PGICP_MATCHER_GRID;
         launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 0, active, c->sel_tables.as<int>(), c->qtmp.p,
-                              grid ? (int *)c->queue.p : nullptr, use_seed || c->sel_guess_first);      // (every selection but a run's first starts from the last one's result,
+                              grid ? (int *)c->queue.p : nullptr, ch.robust.fct != 0 ? 0 : (use_seed || c->sel_guess_first));      // (every selection but a run's first starts from the last one's result,
                                                                                           // ProblemDev::qraw; a run's first from the previous call's, ::qhint, if there is one)
         c->seg_clean = grid ? 1 : 0;
     }
+    const bool robust = ch.robust.fct != 0;
+    // RobustOutlierFilter: nothing is trimmed -- the threshold the lazy path resolves queued queries up to is +inf from here on
+    if (robust) launch_robust_open(c->stream, probs, active, nA);
     if (c->prm.matcher == PGICP_MATCHER_GRID) {
         // lazy resolution: only queued queries whose lower bound is within the threshold just
         // selected (an upper bound of the final one) are searched exactly; then the threshold
@@ -1059,7 +1068,12 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
             }
         }
         ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
-        launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 1, active, c->sel_tables.as<int>(), c->qtmp.p, nullptr, 1);
+        if (!robust) launch_trim_select<T>(c->stream, probs, S.d2.template as<T>(), ch, nA, L.max_n, 1, active, c->sel_tables.as<int>(), c->qtmp.p, nullptr, 1);
+    }
+    if (robust) {
+        // the scale of this iteration from the (now exact) distances: median, absolute deviations, their median
+        ProfScope ps(c, PGICP_PROF_TRIM, 0, 0);
+        launch_robust_scale<T>(c->stream, probs, S.d2.template as<T>(), c->robust_dev.as<T>(), ch, nA, L.max_n, active, c->sel_tables.as<int>(), c->qtmp.p);
     }
     {
         ProfScope ps(c, PGICP_PROF_REDUCE, act_units, act_probs);
@@ -1497,9 +1511,14 @@ int outlier_weights(pgicp_ctx *c, const T *dist2, int n, int mem, T *weights, T 
         d_w = weights ? c->tmp_b.as<T>() : nullptr;
     }
     HIPC(c, c->small.ensure(256));
+    // RobustOutlierFilter in the chain: its weights (the median and the median absolute deviation of the finite distances
+    // by the same block selection); `limit` comes back +inf -- the filter has none
+    const bool robust = c->prm.robust_fct != PGICP_ROBUST_NONE;
+    if (robust) HIPC(c, c->robust_dev.ensure(sizeof(T) * (size_t)n));
     {
         ProfScope ps(c, PGICP_PROF_TRIM, n);
-        launch_trim_raw<T>(c->stream, d_d2, n, (T)c->prm.trim_ratio, (T)c->prm.quantile_scale, c->small.as<T>(), d_w);
+        if (robust) launch_robust_raw<T>(c->stream, d_d2, n, make_chain<T>(c->prm).robust, c->robust_dev.as<T>(), c->small.as<T>(), d_w);
+        else launch_trim_raw<T>(c->stream, d_d2, n, (T)c->prm.trim_ratio, (T)c->prm.quantile_scale, c->small.as<T>(), d_w);
     }
     T h[2];
     XFER(c, d2h(c, h, c->small.p, sizeof h));
@@ -1507,7 +1526,7 @@ int outlier_weights(pgicp_ctx *c, const T *dist2, int n, int mem, T *weights, T 
         XFER(c, d2h(c, weights, d_w, sizeof(T) * (size_t)n));
     HIPC(c, stream_sync(c));
     HIPC(c, hipGetLastError());
-    if (limit) *limit = h[0];
+    if (limit) *limit = robust ? std::numeric_limits<T>::infinity() : h[0];
     if (n_finite) *n_finite = (int)h[1];
     if ((int)h[1] == 0) return fail(c, PGICP_ERR_NO_MATCH, "no outlier to filter (ConvergenceError)");
     return PGICP_OK;
@@ -2049,6 +2068,7 @@ void pgicp_default_params(pgicp_params *p)
     p->grid_cell = 0.0;
     p->check_every = 1;
     p->error_minimizer = PGICP_MINIMIZER_POINT_TO_PLANE;
+    p->robust_fct = PGICP_ROBUST_NONE; p->robust_tuning = 1.0; p->robust_scale = PGICP_ROBUST_SCALE_MAD; p->robust_approx = 0.0;
     p->bound_max_rot = 0.0;
     p->bound_max_trans = 0.0;
     p->normal_max_angle = 0.0;
@@ -2270,11 +2290,18 @@ int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
         return fail(c, PGICP_ERR_ARG, "DifferentialTransformationChecker.smoothLength must be in [1,15]");
     if (p->matcher != PGICP_MATCHER_GRID && p->matcher != PGICP_MATCHER_BRUTE) return fail(c, PGICP_ERR_ARG, "unknown matcher");
     if (p->grid_cell < 0.0) return fail(c, PGICP_ERR_ARG, "grid_cell must be >= 0");
+    if (p->robust_fct < PGICP_ROBUST_NONE || p->robust_fct > PGICP_ROBUST_L1 || (p->robust_scale != PGICP_ROBUST_SCALE_NONE && p->robust_scale != PGICP_ROBUST_SCALE_MAD) ||
+        (p->robust_fct != PGICP_ROBUST_NONE && !(p->robust_tuning > 0.0)) || p->robust_approx < 0.0 || p->robust_approx != p->robust_approx)
+        return fail(c, PGICP_ERR_ARG, "RobustOutlierFilter: unknown robustFct / scaleEstimator, or tuning <= 0, or approximation < 0");
+    if (p->robust_fct != PGICP_ROBUST_NONE && (p->trim_ratio != 1.0 || (p->quantile_scale != 1.0 && p->quantile_scale > 0.0)))
+        return fail(c, PGICP_ERR_ARG, "RobustOutlierFilter: no quantile filter (TrimmedDist / MedianDist) beside it (trim_ratio must be 1)");
+    if (p->robust_fct != PGICP_ROBUST_NONE && p->knn > 1)
+        return fail(c, PGICP_ERR_ARG, "RobustOutlierFilter: knn > 1 is not supported with it");
     {   // another chain: its thresholds are not this one's (field by field: the struct has padding)
         const pgicp_params &a = c->prm, &b = *p;
         const bool same = a.knn == b.knn && a.max_dist == b.max_dist && a.trim_ratio == b.trim_ratio && a.outlier_max_dist == b.outlier_max_dist &&
                           a.quantile_scale == b.quantile_scale && a.error_minimizer == b.error_minimizer && a.normal_max_angle == b.normal_max_angle &&
-                          a.matcher == b.matcher && a.grid_cell == b.grid_cell;
+                          a.matcher == b.matcher && a.grid_cell == b.grid_cell && a.robust_fct == b.robust_fct && a.robust_scale == b.robust_scale;
         if (!same) { c->sel_hints[0].clear(); c->sel_hints[1].clear(); }
     }
     c->prm = *p;

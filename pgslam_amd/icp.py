@@ -59,7 +59,8 @@ class Params(C.Structure):
                 ("smooth_length", C.c_int), ("sensor_std_dev", C.c_double), ("matcher", C.c_int),
                 ("grid_cell", C.c_double), ("check_every", C.c_int), ("outlier_max_dist", C.c_double),
                 ("quantile_scale", C.c_double), ("error_minimizer", C.c_int), ("bound_max_rot", C.c_double),
-                ("bound_max_trans", C.c_double), ("normal_max_angle", C.c_double)]
+                ("bound_max_trans", C.c_double), ("normal_max_angle", C.c_double), ("robust_fct", C.c_int), ("robust_tuning", C.c_double),
+                ("robust_scale", C.c_int), ("robust_approx", C.c_double)]
 
 
 class Stats(C.Structure):

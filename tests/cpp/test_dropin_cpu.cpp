@@ -209,6 +209,21 @@ int main()
         threw = false;
         try { icp.loadFromYaml(two); } catch (const std::runtime_error &) { threw = true; }
         CHECK(threw);
+        // RobustOutlierFilter takes the quantile filter's place; what the device chain does not implement is refused by name
+        std::istringstream rob("matcher:\n  KDTreeMatcher:\n    knn: 1\noutlierFilters:\n  - RobustOutlierFilter:\n      robustFct: huber\n      tuning: 2.0\n      approximation: 0.5\n");
+        icp.loadFromYaml(rob);
+        auto rb = std::dynamic_pointer_cast<PointMatcher<float>::RobustOutlierFilter>(icp.outlierFilters[0]);
+        CHECK(rb && rb->fctCode() == PGICP_ROBUST_HUBER && rb->scaleCode() == PGICP_ROBUST_SCALE_MAD && rb->tuning == 2.0f && rb->approximation == 0.5f);
+        for (const char *badp : {"      robustFct: lorentz\n", "      distanceType: point2plane\n", "      nbIterationForScale: 3\n", "      scaleEstimator: berg\n", "      tuning: 0\n"}) {
+            std::istringstream bad2(std::string("matcher:\n  KDTreeMatcher:\n    knn: 1\noutlierFilters:\n  - RobustOutlierFilter:\n") + badp);
+            threw = false;
+            try { icp.loadFromYaml(bad2); } catch (const std::runtime_error &) { threw = true; }
+            CHECK(threw);
+        }
+        std::istringstream rob2("matcher:\n  KDTreeMatcher:\n    knn: 1\noutlierFilters:\n  - RobustOutlierFilter:\n      robustFct: cauchy\n  - TrimmedDistOutlierFilter:\n      ratio: 0.8\n");
+        threw = false;
+        try { icp.loadFromYaml(rob2); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
     }
     std::puts("dropin cpu tests ok");
     return 0;

@@ -298,6 +298,39 @@ void run(const char *name)
         for (int j = 0; j < wn.cols(); j++) dropped += (wn(0, j) == T(0) && w(0, j) != T(0));
         CHECK(dropped >= 0);
 
+        // RobustOutlierFilter in the quantile filter's place: the run converges to the same pose; its stage-level weights are the
+        // M-estimator's of the squared distances over the MAD scale (here recomputed on the host, in T, bit for bit)
+        ICP rob;
+        {
+            std::istringstream iss(std::string("matcher:\n  KDTreeMatcher:\n    maxDist: 2.0\noutlierFilters:\n  - RobustOutlierFilter:\n      robustFct: cauchy\n      tuning: 1.5\n"
+                                               "errorMinimizer:\n  PointToPlaneWithCovErrorMinimizer\ntransformationCheckers:\n  - CounterTransformationChecker:\n      maxIterationCount: 30\n"
+                                               "  - DifferentialTransformationChecker:\n      minDiffRotErr: 0.001\n      minDiffTransErr: 0.01\n      smoothLength: 3\n"));
+            rob.loadFromYaml(iss);
+        }
+        CHECK(pose_diff(rob(reading, map, guess), P) < 1e-2);
+        CHECK(rob.errorMinimizer->getOverlap() > T(0) && rob.errorMinimizer->getOverlap() < T(1));     // the mean weight
+        CHECK(rob.errorMinimizer->getCovariance()(0, 0) > T(0));
+        {
+            const typename PM::OutlierWeights wr(rob.outlierFilters.compute(moved, reference, matches));
+            std::vector<T> v;
+            for (int j = 0; j < matches.dists.cols(); j++) if (std::isfinite((double)matches.dists(0, j))) v.push_back(matches.dists(0, j));
+            std::sort(v.begin(), v.end());
+            const T med = v[v.size() / 2];
+            for (auto &x : v) x = std::fabs(x - med);
+            std::sort(v.begin(), v.end());
+            const T sc = std::sqrt(v[v.size() / 2]), s2 = sc * sc, k2 = T(1.5) * T(1.5);
+            int same = 0;
+            for (int j = 0; j < wr.cols(); j++) {
+                const T e2 = matches.dists(0, j) / s2;
+                const T expect = std::isfinite((double)matches.dists(0, j)) ? T(1) / (T(1) + e2 / k2) : T(0);
+                same += (wr(0, j) == expect) || (sizeof(T) == 8 && expect <= T(1e-50) && wr(0, j) <= T(1e-50));
+            }
+            CHECK(same == (int)wr.cols());
+            typename PM::ErrorMinimizer::ErrorElements elr(moved, reference, wr, matches);
+            CHECK(elr.weightedPointUsedRatio > T(0) && elr.weightedPointUsedRatio < T(1));
+            CHECK(rob.errorMinimizer->getResidualError(moved, reference, wr, matches) >= 0);
+        }
+
         ICP bound;
         { std::istringstream iss(chain("", "", "PointToPlaneErrorMinimizer", "  - BoundTransformationChecker:\n      maxRotationNorm: 0.5\n      maxTranslationNorm: 0.02\n")); bound.loadFromYaml(iss); }
         bool bthrew = false;

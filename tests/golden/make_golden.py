@@ -103,6 +103,28 @@ def np_icp(reading, ref, nrm, T_init, chain):
         k = min(int(nf * chain["trim_ratio"]), nf - 1) if chain["trim_ratio"] < 1 else nf - 1
         limit = np.partition(vals, k)[k]
         keep = finite & (d2 <= limit)
+        wgt = np.ones_like(d2)
+        rf = int(chain.get("robust_fct", 0))
+        if rf:
+            # RobustOutlierFilter (the chain's distance filter then): scale from the median absolute deviation of the finite squared
+            # distances (elements at index size // 2), e2 = d2 / scale^2, the weight functions of the published source
+            s2 = 1.0
+            if int(chain.get("robust_scale", 1)) == 1:
+                med = np.partition(vals, nf // 2)[nf // 2]
+                dev = np.abs(vals - med)
+                s2 = float(np.partition(dev, nf // 2)[nf // 2])
+            kt = float(chain.get("robust_tuning", 1.0)); k2 = kt * kt
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                e2 = d2 / s2
+                wgt = {1: lambda: 1.0 / (1.0 + e2 / k2), 2: lambda: np.exp(-e2 / k2), 3: lambda: np.where(e2 >= kt, 4.0 * k2 / (kt + e2) ** 2, 1.0),
+                       4: lambda: k2 / (kt + e2) ** 2, 5: lambda: np.where(e2 >= k2, 0.0, (1.0 - e2 / k2) ** 2),
+                       6: lambda: np.where(e2 >= k2, kt / np.sqrt(e2), 1.0), 7: lambda: 1.0 / np.sqrt(e2)}[rf]()
+            ap = float(chain.get("robust_approx", 0.0))
+            if ap > 0 and np.isfinite(ap):
+                wgt = np.where(e2 >= ap * ap, 0.0, wgt)
+            wgt = np.where(finite, wgt, 0.0)
+            keep = finite & (wgt != 0)
+            limit = np.inf
         pk, qk, nk = p[keep], ref[idx[keep]], nrm[idx[keep]]
         e = np.sum(nk * (pk - qk), axis=1)
         J = np.column_stack([np.cross(pk, nk), nk])
@@ -177,6 +199,28 @@ def np_icp_ex(reading, ref, nrm, T_init, chain, reading_nrm=None):
         k = min(int(nf * chain["trim_ratio"]), nf - 1) if chain["trim_ratio"] < 1 else nf - 1
         limit = np.partition(vals, k)[k]
         keep = finite & (d2 <= limit)
+        wgt = np.ones_like(d2)
+        rf = int(chain.get("robust_fct", 0))
+        if rf:
+            # RobustOutlierFilter (the chain's distance filter then): scale from the median absolute deviation of the finite squared
+            # distances (elements at index size // 2), e2 = d2 / scale^2, the weight functions of the published source
+            s2 = 1.0
+            if int(chain.get("robust_scale", 1)) == 1:
+                med = np.partition(vals, nf // 2)[nf // 2]
+                dev = np.abs(vals - med)
+                s2 = float(np.partition(dev, nf // 2)[nf // 2])
+            kt = float(chain.get("robust_tuning", 1.0)); k2 = kt * kt
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                e2 = d2 / s2
+                wgt = {1: lambda: 1.0 / (1.0 + e2 / k2), 2: lambda: np.exp(-e2 / k2), 3: lambda: np.where(e2 >= kt, 4.0 * k2 / (kt + e2) ** 2, 1.0),
+                       4: lambda: k2 / (kt + e2) ** 2, 5: lambda: np.where(e2 >= k2, 0.0, (1.0 - e2 / k2) ** 2),
+                       6: lambda: np.where(e2 >= k2, kt / np.sqrt(e2), 1.0), 7: lambda: 1.0 / np.sqrt(e2)}[rf]()
+            ap = float(chain.get("robust_approx", 0.0))
+            if ap > 0 and np.isfinite(ap):
+                wgt = np.where(e2 >= ap * ap, 0.0, wgt)
+            wgt = np.where(finite, wgt, 0.0)
+            keep = finite & (wgt != 0)
+            limit = np.inf
         if rn is not None and max_angle > 0:
             a = rn @ Tc[:3, :3].T
             a = a / np.linalg.norm(a, axis=1, keepdims=True)
@@ -185,6 +229,7 @@ def np_icp_ex(reading, ref, nrm, T_init, chain, reading_nrm=None):
             keep &= np.einsum("ni,nki->nk", a, bq) >= math.cos(max_angle)
         ii, kk = np.nonzero(keep)
         pk, qk, nk = p[ii], ref[idx[ii, kk]], nrm[idx[ii, kk]]
+        wk = wgt[ii, kk]
         if p2point:
             mp, mq = pk.mean(0), qk.mean(0)
             M = (qk - mq).T @ (pk - mp)
@@ -198,16 +243,18 @@ def np_icp_ex(reading, ref, nrm, T_init, chain, reading_nrm=None):
         else:
             e = np.sum(nk * (pk - qk), axis=1)
             J = np.column_stack([np.cross(pk, nk), nk])
-            if force4dof:
+            if rf:
+                dT = rodrigues(np.linalg.solve(J.T @ (J * wk[:, None]), -J.T @ (wk * e)))
+            elif force4dof:
                 J4 = J[:, 2:]                                       # the z component of p x n, and n
                 x4 = np.linalg.solve(J4.T @ J4, -J4.T @ e)
                 dT = rodrigues(np.concatenate([[0.0, 0.0], x4]))
             else:
                 dT = rodrigues(np.linalg.solve(J.T @ J, -J.T @ e))
-            residual = float(np.sum(e * e))
+            residual = float(np.sum(wk * e * e))
         T_iter = dT @ T_iter
         it += 1
-        out.update(overlap=keep.sum() / (N * K), residual=residual, trim_limit=float(limit), n_kept=int(keep.sum()), n_finite=int(nf))
+        out.update(overlap=float(wk.sum()) / (N * K), residual=residual, trim_limit=float(limit), n_kept=int(keep.sum()), n_finite=int(nf))
         quats.append(quat_from_R(T_iter[:3, :3]))
         trans.append(T_iter[:3, 3].copy())
         stop = False
@@ -254,7 +301,10 @@ def main_variants():
     variants = dict(knn3=dict(CHAIN, knn=3), p2point=dict(CHAIN, error_minimizer=1), p2point_knn2=dict(CHAIN, error_minimizer=1, knn=2),
                     normals=dict(CHAIN, normal_max_angle=0.5), bound_ok=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=1.0),
                     bound_hit=dict(CHAIN, bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(CHAIN, error_minimizer=2),
-                    p2point_cov=dict(CHAIN, error_minimizer=3))
+                    p2point_cov=dict(CHAIN, error_minimizer=3),
+                    robust_cauchy=dict(CHAIN, trim_ratio=1.0, robust_fct=1, robust_tuning=1.0, robust_scale=1),
+                    robust_huber=dict(CHAIN, trim_ratio=1.0, robust_fct=6, robust_tuning=2.0, robust_scale=1),
+                    robust_tukey_none=dict(CHAIN, trim_ratio=1.0, robust_fct=5, robust_tuning=0.3, robust_scale=0, robust_approx=0.25))
     for name, ch in variants.items():
         r = np_icp_ex(rd, w.map_xyz, w.map_nrm, T0, ch, reading_nrm=rn if "normal_max_angle" in ch else None)
         for k in ("T", "iterations", "converged", "status", "overlap", "residual", "trim_limit", "n_kept", "n_finite"):

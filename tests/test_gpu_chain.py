@@ -16,11 +16,14 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01,
              smooth_length=3, sensor_std_dev=0.01)
 RESET = dict(knn=1, error_minimizer=0, bound_max_rot=0.0, bound_max_trans=0.0, normal_max_angle=0.0, outlier_max_dist=0.0,
-             quantile_scale=1.0)
+             quantile_scale=1.0, robust_fct=0, robust_tuning=1.0, robust_scale=1, robust_approx=0.0)
 VARIANTS = dict(knn3=dict(knn=3), p2point=dict(error_minimizer=1), p2point_knn2=dict(error_minimizer=1, knn=2),
                 normals=dict(normal_max_angle=0.5), bound_ok=dict(bound_max_rot=0.2, bound_max_trans=1.0),
                 bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(error_minimizer=2),
-                p2point_cov=dict(error_minimizer=3))
+                p2point_cov=dict(error_minimizer=3),
+                robust_cauchy=dict(trim_ratio=1.0, robust_fct=1, robust_tuning=1.0, robust_scale=1),
+                robust_huber=dict(trim_ratio=1.0, robust_fct=6, robust_tuning=2.0, robust_scale=1),
+                robust_tukey_none=dict(trim_ratio=1.0, robust_fct=5, robust_tuning=0.3, robust_scale=0, robust_approx=0.25))
 
 
 def pose_error(Ta, Tb):
@@ -162,3 +165,34 @@ def test_epsilon_above_zero_is_accepted_and_the_search_stays_exact(ctx, gold):
         ctx.set_params(epsilon=-0.5)
     ctx.set_params(epsilon=0.0)
     ctx.destroy_map(mid)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_robust_filter_stage_weights_bit_exact(ctx, oracle32, oracle64, dtype):
+    """RobustOutlierFilter::compute at stage level (pgicp_outlier_weights under robust_* parameters): all seven functions, with
+    the MAD scale and without, a cut-off, missing neighbours -- the weights bit for bit those of orc_robust_weights (welsch: to a few ulps, its exp() is a library function)."""
+    o = oracle32 if dtype == np.float32 else oracle64
+    rng = np.random.default_rng(77)
+    d2 = (rng.gamma(1.5, 0.02, size=5001) ** 2).astype(dtype)
+    d2[rng.integers(0, d2.size, 40)] = np.inf
+    bits = np.uint32 if dtype == np.float32 else np.uint64
+    for fct in range(1, 8):
+        for scale in (1, 0):
+            for approx in (0.0, 1.5):
+                tuning = 1.0 if scale else 0.02
+                ctx.set_params(**dict(CHAIN, **RESET))
+                ctx.set_params(**dict(CHAIN, trim_ratio=1.0, robust_fct=fct, robust_tuning=tuning, robust_scale=scale, robust_approx=approx))
+                w, limit, nf = ctx.outlier_weights(d2)
+                ow, _ = o.robust_weights(d2, fct, tuning, scale, approx)
+                assert nf == int(np.isfinite(d2).sum()) and np.isinf(limit)
+                if fct == 2:    # welsch: exp() is not correctly rounded in either library (the device's and glibc's differ in the last bits)
+                    np.testing.assert_allclose(w, ow, rtol=8 * np.finfo(dtype).eps, atol=np.finfo(dtype).tiny)
+                else:
+                    assert np.array_equal(w.view(bits), ow.view(bits)), (fct, scale, approx)
+                assert np.all(w[np.isinf(d2)] == 0)
+    with pytest.raises(icp.PgicpError):                         # a quantile filter beside it is refused
+        ctx.set_params(**dict(CHAIN, trim_ratio=0.8, robust_fct=1))
+    ctx.set_params(**dict(CHAIN, **RESET))
+    with pytest.raises(icp.PgicpError):
+        ctx.set_params(**dict(CHAIN, trim_ratio=1.0, robust_fct=1, knn=2))
+    ctx.set_params(**dict(CHAIN, **RESET))

@@ -330,7 +330,10 @@ def test_median_dist_outlier_filter_restatement(oracle32, oracle64):
 VARIANTS = dict(knn3=dict(knn=3), p2point=dict(error_minimizer=1), p2point_knn2=dict(error_minimizer=1, knn=2),
                 normals=dict(normal_max_angle=0.5), bound_ok=dict(bound_max_rot=0.2, bound_max_trans=1.0),
                 bound_hit=dict(bound_max_rot=0.2, bound_max_trans=0.05), force4dof=dict(error_minimizer=2),
-                p2point_cov=dict(error_minimizer=3))
+                p2point_cov=dict(error_minimizer=3),
+                robust_cauchy=dict(trim_ratio=1.0, robust_fct=1, robust_tuning=1.0, robust_scale=1),
+                robust_huber=dict(trim_ratio=1.0, robust_fct=6, robust_tuning=2.0, robust_scale=1),
+                robust_tukey_none=dict(trim_ratio=1.0, robust_fct=5, robust_tuning=0.3, robust_scale=0, robust_approx=0.25))
 
 
 @pytest.mark.parametrize("name", sorted(VARIANTS))
@@ -351,7 +354,8 @@ def test_oracle_matches_golden_chain_variants(oracle32, oracle64, name):
         assert r["n_finite"] == int(z[f"{name}_n_finite"])
         assert abs(r["n_kept"] - int(z[f"{name}_n_kept"])) <= 2
         assert r["overlap"] == pytest.approx(float(z[f"{name}_overlap"]), abs=1e-3)
-        assert r["trim_limit"] == pytest.approx(float(z[f"{name}_trim_limit"]), rel=1e-3)
+        if not name.startswith("robust"):                     # (a robust filter trims nothing: no threshold)
+            assert r["trim_limit"] == pytest.approx(float(z[f"{name}_trim_limit"]), rel=1e-3)
         assert r["residual"] == pytest.approx(float(z[f"{name}_residual"]), rel=1e-2)
         np.testing.assert_allclose(r["cov"], z[f"{name}_cov"], rtol=1e-3, atol=1e-12)
         if name == "force4dof":
@@ -520,3 +524,31 @@ def test_fixstep_step_evolution(oracle32):
         seq.append(int(s))
         s = o.fixstep_next(s, 3.0, 10.0, 1.5)
     assert seq == [3, 4, 6, 10]
+
+
+def test_robust_weights_against_numpy(oracle32, oracle64):
+    """[EXT] RobustOutlierFilter: the scale (median absolute deviation, elements at index size // 2, the square of the rounded
+    root) and the seven weight functions against a float64 numpy statement"""
+    rng = np.random.default_rng(17)
+    d2 = (rng.gamma(1.5, 0.02, size=4001)).astype(np.float64)
+    d2[::97] = np.inf
+    fin = d2[np.isfinite(d2)]
+    med = np.partition(fin, fin.size // 2)[fin.size // 2]
+    mad = np.partition(np.abs(fin - med), fin.size // 2)[fin.size // 2]
+    for o, dt, tol in ((oracle32, np.float32, 3e-6), (oracle64, np.float64, 1e-13)):
+        for scale in (0, 1):
+            s2 = mad if scale else 1.0
+            e2 = d2 / s2
+            for fct, k in ((1, 1.0), (2, 1.5), (3, 2.0), (4, 1.0), (5, 3.0), (6, 1.2), (7, 1.0)):
+                k2 = k * k
+                with np.errstate(all="ignore"):
+                    want = {1: 1 / (1 + e2 / k2), 2: np.exp(-e2 / k2), 3: np.where(e2 >= k, 4 * k2 / (k + e2) ** 2, 1.0), 4: k2 / (k + e2) ** 2,
+                            5: np.where(e2 >= k2, 0.0, (1 - e2 / k2) ** 2), 6: np.where(e2 >= k2, k / np.sqrt(e2), 1.0), 7: 1 / np.sqrt(e2)}[fct]
+                want = np.where(np.isfinite(d2), want, 0.0)
+                w, got_s2 = o.robust_weights(d2.astype(dt), fct, tuning=k, scale=scale)
+                assert float(got_s2) == pytest.approx(s2, rel=2e-6 if dt == np.float32 else 1e-14)
+                if dt == np.float64:
+                    want = np.where(np.isfinite(d2), np.maximum(want, 1e-50), 0.0)          # the double build's floor
+                np.testing.assert_allclose(w, want, rtol=20 * tol, atol=tol)
+    w, _ = oracle32.robust_weights(d2.astype(np.float32), 1, tuning=1.0, scale=0, approx=0.2)
+    assert np.all(w[d2 >= 0.04 + 1e-6] == 0) and np.all(w[d2 < 0.04 - 1e-6] > 0)
