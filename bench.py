@@ -685,10 +685,11 @@ def main_slam(args, collect=False):
     mt = None
     if rank == 0 and not distributed:
         try:
-            o_mt = subprocess.run([exe, seq, "--filters", args.slam_filters, "--mt"], env=env, capture_output=True, text=True, check=True)
+            # (as for the single-thread legs: passes inside one process, the first one the warm-up, the rate the median of the rest)
+            o_mt = subprocess.run([exe, seq, "--filters", args.slam_filters, "--mt", "--passes", str(max(1, args.slam_passes))], env=env, capture_output=True, text=True, check=True)
             d_mt = json.loads(o_mt.stdout.strip().splitlines()[-1])
             mt = {k: d_mt.get(k) for k in ("scans_per_s", "wall_s", "keyframes", "loops_closed", "loop_batches", "largest_loop_batch", "loop_batches_on_device",
-                                           "tracking_error_last_m", "localizer_thread_s")}
+                                           "tracking_error_last_m", "localizer_thread_s", "passes", "pass_wall_s")}
         except Exception as e:                      # reported, not hidden
             mt = dict(error=f"{type(e).__name__}: {e}")
     # one more pass that records ICP calls, replayed through the CPU oracle: parity evidence + the CPU figure

@@ -1385,10 +1385,11 @@ public:
         { std::lock_guard<std::mutex> l(m_); outdated_ = true; }
         cv_.notify_all();
     }
-    //! The input stage on a thread (and context) of its own, up to two scans ahead of the ICP: OFF by default since round 5's
-    //! measurement -- with the stage down to 0.15 ms (block moves, deferred host compaction on the localizer's worker) the hand-off
-    //! between the two threads costs the localizer's thread more waiting (0.2-0.35 ms per scan) than the stage itself;
-    //! PGSLAM_MT_INPUT_THREAD=1 (or SetInputThread(true) before Run) turns it on.
+    //! The input stage on a thread (and context) of its own, up to two scans ahead of the ICP: ON by default -- measured warm
+    //! (slam_run --mt --passes 4, 600 scans of 100 k points): 860-919 scans/s with it, 798-806 without, the localizer's thread
+    //! waiting 0.01 ms per scan for the hand-off.  (Round 5 first measured the opposite from single cold passes, where the
+    //! second context's first allocations and code-object loads land inside the timed run.)
+    //! PGSLAM_MT_INPUT_THREAD=0 (or SetInputThread(false) before Run) turns it off.
     void SetInputThread(bool on) { pre_thread_on_ = on; }
     void Run()
     {
@@ -1487,7 +1488,7 @@ private:
     std::thread thread_, pre_thread_;
     pgslam_amd::LazyContext pre_ctx_{0, std::getenv("PGSLAM_PRE_STAGE_NORMAL_PRIORITY") ? 0 : 1};     // (its short launches go ahead of the ICP's queued ones)
     bool stop_ = false, busy_ = false, outdated_ = false;
-    bool pre_thread_on_ = std::getenv("PGSLAM_MT_INPUT_THREAD") != nullptr;
+    bool pre_thread_on_ = !(std::getenv("PGSLAM_MT_INPUT_THREAD") && std::getenv("PGSLAM_MT_INPUT_THREAD")[0] == '0');
     size_t processed_ = 0;
     double wait_pre_s_ = 0, pre_busy_s_ = 0;
     std::exception_ptr error_;

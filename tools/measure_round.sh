@@ -17,8 +17,8 @@ python3 bench.py --workload stream --streams 16 --fleet --steps 2 --warmup 1 2>/
 python3 bench.py --workload slam --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_slam.json
 python3 bench.py --workload slam --slam-scans 600 --slam-points 100000 --slam-filters sensor --slam-record 8 --steps 1 --warmup 0 2>/dev/null | tail -1 > $OUT/bench_slam100k.json
 python3 bench.py --workload f64 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_f64.json
-./tools/slam_run /tmp/pgslam_amd_seq_4500_10000_0.8.bin --mt > $OUT/slam_mt.json 2>/dev/null
-./tools/slam_run /tmp/pgslam_amd_seq_600_100000_0.8.bin --filters sensor --mt > $OUT/slam100k_mt.json 2>/dev/null
+./tools/slam_run /tmp/pgslam_amd_seq_4500_10000_0.8.bin --mt --passes 3 > $OUT/slam_mt.json 2>/dev/null
+./tools/slam_run /tmp/pgslam_amd_seq_600_100000_0.8.bin --filters sensor --mt --passes 4 > $OUT/slam100k_mt.json 2>/dev/null
 python3 bench.py --workload loopclosure --pairs 512 --steps 3 --warmup 1 --no-cpu-baseline --shard-proxy 2>/dev/null | tail -1 > $OUT/bench_loopclosure_shard_proxy.json
 python3 tools/bench_normals.py 2>/dev/null | grep -v amdgpu > $OUT/bench_normals.json
 REPO=$PWD
