@@ -14,14 +14,20 @@ f = glob.glob('gpurun_out/lc_timeline/trace/**/*kernel_trace.csv', recursive=Tru
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last step: from the last k_mbin on
-last = max(i for i, r in enumerate(rows) if 'k_mbin' in r['Kernel_Name'])
+last = max(i for i, r in enumerate(rows) if 'k_centroid_bbox_b' in r['Kernel_Name'])
 t0 = int(rows[last]['Start_Timestamp'])
+prev_end = t0
+busy = 0
 for r in rows[last:]:
     n = r['Kernel_Name'].split('(')[0].split('<')[0].split('::')[-1]
-    if n.startswith('__amd'): continue
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    gap = (int(r['Start_Timestamp']) - prev_end) / 1e3
+    if gap > 30: print(f"          -- idle {gap:8.1f} us --")
+    prev_end = max(prev_end, int(r['End_Timestamp']))
+    busy += d
     if d < 20: continue
     print(f"{(int(r['Start_Timestamp'])-t0)/1e6:9.3f} ms  {n:24s} {d:9.1f} us  grid {r['Grid_Size_X']}x{r['Grid_Size_Y']} wg {r['Workgroup_Size_X']}")
+print(f"step: {(prev_end - t0)/1e6:.3f} ms from the first build kernel to the last kernel, kernels busy {busy/1e3:.3f} ms")
 P
 find $OUT -name '*.csv' -delete; rm -rf $OUT/trace
 cat $OUT/timeline.txt
