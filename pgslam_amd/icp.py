@@ -459,13 +459,15 @@ class Context:
                        _T16(T_init), T_out, C.byref(st)))
         return np.array(T_out[:]).reshape(4, 4), st.as_dict()
 
-    def align_residual_batch(self, map_ids, readings, T_inits, dtype=None, normals=None):
+    def align_residual_batch(self, map_ids, readings, T_inits, dtype=None, normals=None, raw_stats=False):
         """pgicp_align_residual_batch: the ICPs of a batch of loop-closure candidates and, fused, the residual check of every
         result (LoopCloser.hpp:98, 343-365).  Returns (T (P,4,4), stats, residual (P,), ratio (P,), status (P,)); never raises
         for a failed candidate (its residual is +inf)."""
-        return self.align_batch(map_ids, readings, T_inits, dtype=dtype, raise_on_error=False, normals=normals, _residual=True)
+        return self.align_batch(map_ids, readings, T_inits, dtype=dtype, raise_on_error=False, normals=normals, _residual=True, _raw_stats=raw_stats)
 
-    def align_batch(self, map_ids, readings, T_inits, dtype=None, raise_on_error=True, normals=None, _residual=False):
+    def align_batch(self, map_ids, readings, T_inits, dtype=None, raise_on_error=True, normals=None, _residual=False, _raw_stats=False):
+        """`_raw_stats`: the pgicp_stats records come back as ONE numpy record array (fields as in include/pgicp.h) instead of a
+        list of dicts -- a batch of 512 loop-closure candidates does not need 512 dictionaries to fill 512 edge records."""
         P = len(readings)
         if isinstance(map_ids, int):
             map_ids = [map_ids] * P
@@ -498,6 +500,8 @@ class Context:
             self._check(rc)
         elif rc not in (OK, ERR_NO_MATCH, ERR_NAN, ERR_BOUND):
             self._check(rc)
+        if _raw_stats:
+            return (T_out, sa, res, ratio, rst) if _residual else (T_out, sa)
         cov = sa["cov"].reshape(P, 6, 6)
         cols = [sa[k].tolist() for k in ("status", "iterations", "converged", "max_iter_reached", "overlap", "residual", "trim_limit",
                                           "n_kept", "n_finite")]
@@ -756,6 +760,22 @@ def shard_pairs(costs, world_size, rank):
     if st != OK:
         raise PgicpError(st, "pgicp_shard_pairs")
     return out[: cnt.value].copy()
+
+
+def check_icp_results(stats_records: np.ndarray, residual_error: np.ndarray, overlap_threshold=0.8, residual_error_threshold=5000.0) -> np.ndarray:
+    """LoopCloser::CheckIcpResult (LoopCloser.hpp:308-340) over a record array of pgicp_stats: pgicp_check_icp_result called on
+    every record in place (no per-candidate Python objects)."""
+    lib = load_library()
+    sa = np.ascontiguousarray(stats_records)
+    assert sa.dtype == _STATS_DTYPE
+    res = np.asarray(residual_error, dtype=np.float64)
+    out = np.empty(len(sa), dtype=np.int32)
+    base, step = sa.ctypes.data, sa.dtype.itemsize
+    fn = lib.pgicp_check_icp_result
+    ot, rt = C.c_double(overlap_threshold), C.c_double(residual_error_threshold)
+    for k in range(len(sa)):
+        out[k] = fn(C.c_void_p(base + k * step), C.c_double(res[k]), ot, rt)
+    return out
 
 
 def check_icp_result(stats: dict, residual_error, overlap_threshold=0.8, residual_error_threshold=5000.0) -> bool:

@@ -77,20 +77,17 @@ def align_local(ctx: icp.Context, cands, cfg: LoopClosureConfig):
     readings = [c.reading for c in cands]
     # ICP and residual check of the result in one device call (pgicp_align_residual_batch: the residual pass is seeded with
     # the last iteration's correspondences)
-    Ts, stats, residual, _, _ = ctx.align_residual_batch(map_ids, readings, [c.T_init for c in cands])
-    # the edge records column by column (512 per-candidate record assignments were a tenth of a step)
+    Ts, sa, residual, _, _ = ctx.align_residual_batch(map_ids, readings, [c.T_init for c in cands], raw_stats=True)
+    # the edge records column by column, straight from the pgicp_stats records (512 per-candidate dictionaries and record
+    # assignments were a tenth of a step)
     edges = np.zeros(len(cands), dtype=EDGE_DTYPE)
     edges["from_id"] = [c.from_id for c in cands]
     edges["to_id"] = [c.to_id for c in cands]
-    edges["status"] = [s["status"] for s in stats]
-    edges["iterations"] = [s["iterations"] for s in stats]
-    edges["max_iter_reached"] = [int(s["max_iter_reached"]) for s in stats]
-    edges["overlap"] = [s["overlap"] for s in stats]
+    for k in ("status", "iterations", "max_iter_reached", "overlap", "cov"):
+        edges[k] = sa[k]
     edges["residual"] = residual
     edges["T_from_to"] = np.asarray(Ts, dtype=np.float64).reshape(len(cands), 16)
-    edges["cov"] = np.stack([s["cov"] for s in stats]).reshape(len(cands), 36)
-    edges["accepted"] = [int(icp.check_icp_result(stats[k], float(residual[k]), cfg.overlap_threshold, cfg.residual_error_threshold))
-                         for k in range(len(cands))]
+    edges["accepted"] = icp.check_icp_results(sa, residual, cfg.overlap_threshold, cfg.residual_error_threshold)
     for m in map_ids:
         ctx.destroy_map(m)
     return edges

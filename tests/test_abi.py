@@ -70,6 +70,17 @@ def test_check_icp_result_follows_loop_closer():
     assert not icp.check_icp_result(ok, 5000.1)                                  # LoopCloser.hpp:335
     assert icp.check_icp_result(ok, 5000.0)
     assert not icp.check_icp_result(dict(ok, status=1), 1.0)
+    # the record-array form (what a batch of loop-closure candidates uses): the same function on every record
+    rng = np.random.default_rng(3)
+    sa = np.zeros(64, dtype=icp._STATS_DTYPE)
+    sa["status"] = rng.integers(0, 2, 64) * rng.integers(0, 2, 64)
+    sa["max_iter_reached"] = rng.integers(0, 2, 64)
+    sa["overlap"] = rng.uniform(0.6, 1.0, 64)
+    res = rng.uniform(0.0, 10000.0, 64)
+    got = icp.check_icp_results(sa, res, 0.8, 5000.0)
+    want = [icp.check_icp_result(dict(status=int(r["status"]), max_iter_reached=bool(r["max_iter_reached"]), overlap=float(r["overlap"])), float(x), 0.8, 5000.0)
+            for r, x in zip(sa, res)]
+    assert got.tolist() == [int(w) for w in want] and 0 < got.sum() < 64
 
 
 def test_numpy_views_of_the_batch_records_match_the_ctypes_structures():
