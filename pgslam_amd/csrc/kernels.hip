@@ -25,7 +25,10 @@
 #endif
 #ifndef PGICP_FAST_ATTR
 // (the double instantiation needs ~105 registers: 4 waves)
-#define PGICP_FAST_ATTR __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(sizeof(T) == 4 ? PGICP_FAST_WAVES : 4, sizeof(T) == 4 ? PGICP_FAST_WAVES : 4)))
+#ifndef PGICP_FAST_WAVES_D
+#define PGICP_FAST_WAVES_D 4
+#endif
+#define PGICP_FAST_ATTR __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(sizeof(T) == 4 ? PGICP_FAST_WAVES : PGICP_FAST_WAVES_D, sizeof(T) == 4 ? PGICP_FAST_WAVES : PGICP_FAST_WAVES_D)))
 #endif
 
 namespace pgicp {
