@@ -482,6 +482,27 @@ struct PointMatcher {
             }
         }
     };
+    //! [EXT] ShadowDataPointsFilter{eps} (DataPointsFilters/Shadow.cpp as restated in oracle/icp_oracle.c: orc_shadow_keep): keeps a
+    //! point while |normal.normalized() . position.normalized()| > sin(eps) -- drops surfaces seen at a grazing angle from the sensor's
+    //! origin.  Needs the normals descriptor; host side (it reads a descriptor the device input stage does not carry).
+    struct ShadowDataPointsFilter : DataPointsFilter {
+        T epsAngle, eps;
+        explicit ShadowDataPointsFilter(T e) : epsAngle(e), eps(std::sin(e)) {}
+        void inPlaceFilter(DataPoints &c) override
+        {
+            if (!c.descriptorExists("normals")) throw std::runtime_error("ShadowDataPointsFilter: cannot find normals in descriptors");
+            const int rn = c.getDescriptorStartingRow("normals");
+            auto normalized = [](T &x, T &y, T &z) { const T zz = (x * x + y * y) + z * z; if (zz > T(0)) { const T s = std::sqrt(zz); x = x / s; y = y / s; z = z / s; } };
+            compactColumns(c, [&](int j) {
+                T ax = c.descriptors(rn, j), ay = c.descriptors(rn + 1, j), az = c.descriptors(rn + 2, j);
+                T bx = c.features(0, j), by = c.features(1, j), bz = c.features(2, j);
+                normalized(ax, ay, az);
+                normalized(bx, by, bz);
+                const T d = (ax * bx + ay * by) + az * bz;
+                return (d < T(0) ? -d : d) > eps;
+            });
+        }
+    };
     //! [EXT] FixStepSamplingDataPointsFilter{startStep, endStep, stepMult} (DataPointsFilters/FixStepSampling.cpp): keeps points
     //! phase, phase + step, ...; after every cloud step *= stepMult, clamped at endStep in the direction of travel; init() goes back
     //! to startStep.  Upstream draws phase = rand() % step from the C library's global generator -- like RandomSampling there is
@@ -615,6 +636,10 @@ struct PointMatcher {
                 } else if (m.name == "OrientNormalsDataPointsFilter") {
                     this->push_back(std::make_shared<OrientNormalsDataPointsFilter>(
                         to_double(m.params.count("towardCenter") ? m.params.at("towardCenter") : std::string("1"), m.name) != 0.0));
+                } else if (m.name == "ShadowDataPointsFilter") {
+                    const double e = to_double(m.params.count("eps") ? m.params.at("eps") : std::string("0.1"), m.name);
+                    if (!(e >= 0.0 && e <= 3.14159265358979323846)) throw std::runtime_error(m.name + ": eps must be in [0, pi]");
+                    this->push_back(std::make_shared<ShadowDataPointsFilter>((T)e));
                 } else if (m.name == "FixStepSamplingDataPointsFilter") {
                     auto get = [&](const char *k, const char *def) { return to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
                     const double start = get("startStep", "10"), end = get("endStep", "10"), mult = get("stepMult", "1");
@@ -634,7 +659,7 @@ struct PointMatcher {
                 } else
                     throw std::runtime_error("DataPointsFilters: unsupported filter '" + m.name +
                                              "' (supported: Identity, MinDist, MaxDist, BoundingBox, RemoveNaN, SurfaceNormal, "
-                                             "ObservationDirection, OrientNormals, FixStepSampling, RandomSampling, MaxPointCount (seeded samplers, not rand()-parity))");
+                                             "ObservationDirection, OrientNormals, Shadow, FixStepSampling, RandomSampling, MaxPointCount (seeded samplers, not rand()-parity))");
             }
         }
         void init() { for (auto &f : *this) f->init(); }

@@ -291,6 +291,25 @@ void FN(orc_build_local_map)(int n_kf, const real *const *xyz, const real *const
  *          (SplitMix64 of seed p[1] and the point's index) -- same distribution, documented as NOT rand()-parity
  *   type 7 MaxPointCount {maxCount = p[0], seed = p[1]}: only when maxCount < N: the same draw with prob = T(maxCount) / T(N)
  * ------------------------------------------------------------------------ */
+/* [EXT] ShadowDataPointsFilter{eps} (DataPointsFilters/Shadow.cpp, as recalled): a point is KEPT when
+ *   | normals.col(i).normalized() . features.col(i).head(3).normalized() | > sin(eps)
+ * -- a surface seen at a grazing angle (the normal nearly perpendicular to the ray from the sensor's origin, where the cloud
+ * still is when the input filters run) is a "shadow" and goes.  normalized() = v / sqrt(v.v) when v.v > 0, v itself otherwise
+ * (Eigen); the dot product and the squared norms are summed in order, in T; sin() in T from the parameter read as T.
+ * keep[i] = 1 / 0.  Host side in the build (pointmatcher.hpp: ShadowDataPointsFilter): it needs the normals descriptor. */
+void FN(orc_shadow_keep)(const real *xyz, const real *nrm, int n, real eps_angle, int *keep)
+{
+    const real eps = SIN_R(eps_angle);
+    for (int i = 0; i < n; i++) {
+        real a[3] = {nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]}, b[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        const real za = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2], zb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+        if (za > (real)0) { const real sa = SQRT_R(za); a[0] = a[0] / sa; a[1] = a[1] / sa; a[2] = a[2] / sa; }
+        if (zb > (real)0) { const real sb = SQRT_R(zb); b[0] = b[0] / sb; b[1] = b[1] / sb; b[2] = b[2] / sb; }
+        const real d = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+        keep[i] = (d < (real)0 ? -d : d) > eps ? 1 : 0;
+    }
+}
+
 static uint64_t orc_splitmix(uint64_t z)
 {
     z += 0x9E3779B97F4A7C15ULL; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;

@@ -156,6 +156,13 @@ class Oracle:
         f.restype = C.c_double
         return f(C.c_double(step), C.c_double(start_step), C.c_double(end_step), C.c_double(step_mult))
 
+    def shadow_keep(self, xyz, nrm, eps_angle=0.1):
+        """[EXT] ShadowDataPointsFilter{eps} (orc_shadow_keep): boolean keep mask"""
+        xyz, nrm = self._a(xyz), self._a(nrm)
+        keep = np.zeros(len(xyz), dtype=np.int32)
+        self._f("orc_shadow_keep")(self._p(xyz), self._p(nrm), C.c_int(len(xyz)), self.real(eps_angle), keep.ctypes.data_as(C.c_void_p))
+        return keep.astype(bool)
+
     def robust_weights(self, d2, fct, tuning=1.0, scale=1, approx=0.0):
         """[EXT] RobustOutlierFilter (orc_robust_weights): (weights, squared scale)"""
         d2 = np.ascontiguousarray(d2, dtype=self.dtype)

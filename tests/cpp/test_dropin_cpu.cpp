@@ -106,6 +106,25 @@ void yaml_and_matrix()
         try { orient.apply(c2); } catch (const std::runtime_error &) { threw = true; }
         CHECK(threw);                                                          // no normals: refused like upstream
     }
+    {   // ShadowDataPointsFilter{eps}: a surface seen at a grazing angle goes -- |n^ . p^| > sin(eps) keeps
+        std::istringstream ss("- ShadowDataPointsFilter:\n    eps: 0.2\n");
+        PointMatcher<float>::DataPointsFilters sh(ss);
+        // points on the x axis; normals: along the ray (kept), perpendicular (dropped), 0.1 rad off perpendicular (dropped:
+        // sin 0.1 < sin 0.2), 0.3 rad off (kept), unnormalised and pointing away (kept: absolute value, normalised)
+        const float pts[] = {2, 0, 0,  2, 0, 0,  3, 0, 0,  3, 0, 0,  5, 0, 0};
+        auto c = PointMatcher<float>::DataPoints::fromXYZ(pts, 5);
+        PointMatcher<float>::Matrix nrm(3, 5);
+        const float nn[5][3] = {{1, 0, 0}, {0, 1, 0}, {std::sin(0.1f), std::cos(0.1f), 0}, {std::sin(0.3f), 0, std::cos(0.3f)}, {-7, 0, 1}};
+        for (int j = 0; j < 5; j++) for (int a = 0; a < 3; a++) nrm(a, j) = nn[j][a];
+        c.addDescriptor("normals", nrm);
+        sh.apply(c);
+        CHECK(c.getNbPoints() == 3 && c.features(0, 0) == 2.0f && c.features(0, 1) == 3.0f && c.features(0, 2) == 5.0f);
+        CHECK(c.descriptors(c.getDescriptorStartingRow("normals") + 2, 1) == std::cos(0.3f));     // descriptors travel with their points
+        auto bare = PointMatcher<float>::DataPoints::fromXYZ(pts, 5);
+        bool threw2 = false;
+        try { sh.apply(bare); } catch (const std::runtime_error &) { threw2 = true; }
+        CHECK(threw2);                                                         // no normals: refused like upstream
+    }
     {   // the sampling filters: FixStep keeps every step-th point; RandomSampling is seeded (reproducible, a different
         // sample per seed, about prob of the points) -- upstream draws from rand(): same distribution, no bit parity
         auto cloud_of = [&](int n) { std::vector<float> xyz(3 * n); for (int i = 0; i < n; i++) { xyz[3 * i] = (float)i; xyz[3 * i + 1] = 1.f; xyz[3 * i + 2] = 2.f; } return PointMatcher<float>::DataPoints::fromXYZ(xyz.data(), n, nullptr); };

@@ -552,3 +552,27 @@ def test_robust_weights_against_numpy(oracle32, oracle64):
                 np.testing.assert_allclose(w, want, rtol=20 * tol, atol=tol)
     w, _ = oracle32.robust_weights(d2.astype(np.float32), 1, tuning=1.0, scale=0, approx=0.2)
     assert np.all(w[d2 >= 0.04 + 1e-6] == 0) and np.all(w[d2 < 0.04 - 1e-6] > 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_shadow_filter_against_numpy(oracle32, oracle64, dtype):
+    """[EXT] ShadowDataPointsFilter{eps}: keep while |n^ . p^| > sin(eps), both vectors normalised (a zero vector stays zero) --
+    against an independent numpy statement; away from the threshold the masks are equal in either precision."""
+    o = oracle32 if dtype == np.float32 else oracle64
+    rng = np.random.default_rng(12)
+    xyz = rng.normal(0, 10, (4000, 3)).astype(dtype)
+    nrm = rng.normal(0, 1, (4000, 3)).astype(dtype)
+    nrm[::7] *= 5.0                     # unnormalised normals are normalised by the filter
+    nrm[5] = 0                          # a zero normal: dot 0, dropped
+    for eps in (0.0, 0.1, 0.7):
+        keep = o.shadow_keep(xyz, nrm, eps)
+        x64, n64 = xyz.astype(np.float64), nrm.astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            nh = np.where(np.linalg.norm(n64, axis=1, keepdims=True) > 0, n64 / np.linalg.norm(n64, axis=1, keepdims=True), n64)
+            ph = x64 / np.linalg.norm(x64, axis=1, keepdims=True)
+        v = np.abs(np.sum(nh * ph, axis=1))
+        sure = np.abs(v - np.sin(eps)) > 1e-5          # (a float32 dot product sits ~1e-7 from the double one)
+        assert np.array_equal(keep[sure], (v > np.sin(eps))[sure]) and sure.mean() > 0.999
+        assert not keep[5]
+    assert 0.05 < o.shadow_keep(xyz, nrm, 0.1).mean() < 0.99
+
