@@ -196,3 +196,34 @@ def test_robust_filter_stage_weights_bit_exact(ctx, oracle32, oracle64, dtype):
     with pytest.raises(icp.PgicpError):
         ctx.set_params(**dict(CHAIN, trim_ratio=1.0, robust_fct=1, knn=2))
     ctx.set_params(**dict(CHAIN, **RESET))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_robust_filter_in_a_batch_and_in_the_partial_chain(ctx, oracle32, oracle64, gold, dtype):
+    """RobustOutlierFilter with several problems in flight (two readings of different sizes against one map: each its own two
+    medians per iteration) and through the partial chain (ComputeOverlapWith / ComputeResidualError: the mean weight, the
+    weighted residual)."""
+    z = gold
+    o = oracle32 if dtype == np.float32 else oracle64
+    chain = dict(CHAIN, trim_ratio=1.0, robust_fct=1, robust_tuning=1.5, robust_scale=1)
+    ctx.set_params(**dict(CHAIN, **RESET))
+    ctx.set_params(**chain)
+    mx, mn = z["map_xyz"].astype(dtype), z["map_nrm"].astype(dtype)
+    mid = ctx.set_map(mx, mn, center=True, dtype=dtype)
+    T0 = [z["T_init"], z["T_init"] @ synth.se3(x=0.03, yaw=0.004), z["T_init"] @ synth.se3(y=-0.02, yaw=-0.003)]
+    rds = [z["reading"].astype(dtype), z["reading"][:2500].astype(dtype), z["reading"][700:].astype(dtype)]
+    Ts, sts = ctx.align_batch(mid, rds, T0, dtype=dtype)
+    for b in range(3):
+        r = o.icp(rds[b], mx, mn, T0[b], **chain)
+        dt, dr = pose_error(r["T"], Ts[b])
+        assert dt < 1e-5 and dr < 1e-5, (b, dt, dr)
+        assert sts[b]["iterations"] == r["iterations"] and sts[b]["n_finite"] == r["n_finite"] and sts[b]["n_kept"] == r["n_kept"]
+        assert sts[b]["overlap"] == pytest.approx(r["overlap"], rel=1e-6 if dtype == np.float32 else 1e-12)
+        assert 0.0 < sts[b]["overlap"] < 1.0 and np.isinf(sts[b]["trim_limit"])
+    ctx.destroy_map(mid)
+    rid = ctx.set_map(mx, mn, center=False, dtype=dtype)
+    ov, res = ctx.partial_chain(rid, rds[0], T=z["T_truth"], dtype=dtype)
+    po = o.partial_chain(rds[0], mx, mn, z["T_truth"], **chain)
+    assert ov == pytest.approx(po["overlap"], rel=1e-6 if dtype == np.float32 else 1e-12) and res == pytest.approx(po["residual"], rel=1e-6)
+    ctx.destroy_map(rid)
+    ctx.set_params(**dict(CHAIN, **RESET))
