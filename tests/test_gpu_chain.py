@@ -227,3 +227,30 @@ def test_robust_filter_in_a_batch_and_in_the_partial_chain(ctx, oracle32, oracle
     assert ov == pytest.approx(po["overlap"], rel=1e-6 if dtype == np.float32 else 1e-12) and res == pytest.approx(po["residual"], rel=1e-6)
     ctx.destroy_map(rid)
     ctx.set_params(**dict(CHAIN, **RESET))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_robust_filter_beside_the_other_filters(ctx, oracle32, oracle64, gold, dtype):
+    """A MaxDistOutlierFilter and a SurfaceNormalOutlierFilter beside the robust one: the weights multiply -- pairs beyond maxDist
+    and pairs whose normals disagree carry weight 0 whatever the M-estimator gives them; the medians are still over every
+    finite distance."""
+    z = gold
+    o = oracle32 if dtype == np.float32 else oracle64
+    mx, mn = z["map_xyz"].astype(dtype), z["map_nrm"].astype(dtype)
+    rd, rn = z["reading"].astype(dtype), z["reading_nrm"].astype(dtype)
+    for extra in (dict(outlier_max_dist=0.15), dict(normal_max_angle=0.5), dict(outlier_max_dist=0.3, normal_max_angle=0.8, error_minimizer=1)):
+        chain = dict(CHAIN, trim_ratio=1.0, robust_fct=6, robust_tuning=1.5, robust_scale=1, **extra)
+        ctx.set_params(**dict(CHAIN, **RESET))
+        ctx.set_params(**chain)
+        mid = ctx.set_map(mx, mn, center=True, dtype=dtype)
+        use_n = "normal_max_angle" in extra
+        T, st = ctx.align(mid, rd, z["T_init"], dtype=dtype, normals=rn if use_n else None)
+        r = o.icp(rd, mx, mn, z["T_init"], reading_nrm=rn if use_n else None, **chain)
+        ctx.destroy_map(mid)
+        dt, dr = pose_error(r["T"], T)
+        assert dt < 1e-5 and dr < 1e-5, (extra, dt, dr)
+        assert st["iterations"] == r["iterations"] and st["n_finite"] == r["n_finite"] and st["n_kept"] == r["n_kept"], extra
+        assert st["n_kept"] < st["n_finite"]                                 # the other filter did drop pairs
+        assert np.float32(st["trim_limit"]) == np.float32(r["trim_limit"])
+        assert st["overlap"] == pytest.approx(r["overlap"], rel=1e-6 if dtype == np.float32 else 1e-12)
+    ctx.set_params(**dict(CHAIN, **RESET))

@@ -48,9 +48,13 @@ def scene():
 t0 = time.time(); n = 0; nprob = 0; kinds = {}
 while time.time() - t0 < budget:
     chain = dict(CHAIN, max_dist=float(rng.choice([0.5, 1.0, 2.0, 2.0])), trim_ratio=float(rng.choice([0.7, 0.85, 0.85, 0.95])), quantile_scale=1.0,
-                 knn=int(rng.choice([1, 1, 2, 3, 4])), error_minimizer=int(rng.choice([0, 0, 1, 2])), bound_max_rot=0.0, bound_max_trans=0.0,
-                 normal_max_angle=0.0, outlier_max_dist=0.0)
+                 knn=int(rng.choice([1, 1, 2, 3, 4])), error_minimizer=int(rng.choice([0, 0, 1, 2, 3])), bound_max_rot=0.0, bound_max_trans=0.0,
+                 normal_max_angle=0.0, outlier_max_dist=0.0, robust_fct=0, robust_tuning=1.0, robust_scale=1, robust_approx=0.0)
     if rng.random() < 0.25: chain.update(trim_ratio=0.5, quantile_scale=float(rng.choice([0.6, 1.0, 3.0])))      # MedianDistOutlierFilter
+    if rng.random() < 0.2:                                                                                       # RobustOutlierFilter in the quantile filter's place
+        chain.update(trim_ratio=1.0, quantile_scale=1.0, knn=1, robust_fct=int(rng.integers(1, 8)), robust_scale=int(rng.integers(0, 2)),
+                     robust_approx=float(rng.choice([0.0, 0.0, 3.0])))
+        chain.update(robust_tuning=float(rng.choice([0.5, 1.0, 2.5])) if chain["robust_scale"] else float(rng.choice([0.05, 0.2, 0.5])))
     if rng.random() < 0.25: chain.update(outlier_max_dist=float(rng.choice([0.1, 0.3, 1.0])))
     if rng.random() < 0.35: chain.update(normal_max_angle=float(rng.choice([0.3, 0.8, 1.5])))
     b = rng.random()
@@ -75,9 +79,12 @@ while time.time() - t0 < budget:
         try:
             assert st[j]["status"] == o["status"]
             if o["status"] == 0:
-                assert st[j]["iterations"] == o["iterations"] and st[j]["n_finite"] == o["n_finite"] and st[j]["n_kept"] == o["n_kept"]
+                # (welsch: exp() is a library function on both sides -- a weight that underflows to zero in one and to a denormal in the
+                # other moves a pair of weight ~1e-45 between "kept" and "dropped")
+                slack = 8 if chain["robust_fct"] == 2 else 0
+                assert st[j]["iterations"] == o["iterations"] and st[j]["n_finite"] == o["n_finite"] and abs(st[j]["n_kept"] - o["n_kept"]) <= slack
                 if DT == np.float32: assert np.float32(st[j]["trim_limit"]) == np.float32(o["trim_limit"])
-                else: assert abs(st[j]["trim_limit"] - o["trim_limit"]) <= 1e-9 * o["trim_limit"]
+                else: assert st[j]["trim_limit"] == o["trim_limit"] or abs(st[j]["trim_limit"] - o["trim_limit"]) <= 1e-9 * o["trim_limit"]
                 dt, dr = pose_error(o["T"], Ts[j])
                 assert dt < 1e-5 and dr < 1e-5, (dt, dr)
         except AssertionError:
