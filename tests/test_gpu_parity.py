@@ -355,9 +355,16 @@ def test_loop_closure_batch_against_oracle(ctx, oracle32):
     assert len(lc.accepted_constraints(edges)) == int(edges["accepted"].sum())
 
 
-def test_fused_residual_pass_equals_the_separate_chain(ctx, oracle32):
+ROBUST = dict(trim_ratio=1.0, robust_fct=1, robust_tuning=2.0, robust_scale=1)
+NOT_ROBUST = dict(robust_fct=0)
+
+
+@pytest.mark.parametrize("extra", [NOT_ROBUST, ROBUST], ids=["trimmed", "robust"])
+def test_fused_residual_pass_equals_the_separate_chain(ctx, oracle32, extra):
     """pgicp_align_residual_batch: the ICPs are those of pgicp_align_batch, bit for bit; the residual pass -- seeded with the
-    last iteration's correspondences -- gives what the separate (unseeded) partial chain gives on the result."""
+    last iteration's correspondences -- gives what the separate (unseeded) partial chain gives on the result.  Also with a
+    RobustOutlierFilter in the chain (no threshold: every pair is resolved in the residual pass too)."""
+    CHAIN = dict(globals()["CHAIN"], **extra)
     ps = synth.make_pairs(6, n_pts=5000, n_keyframes=6, rings=16)
     ctx.set_params(**dict(CHAIN, matcher=icp.MATCHER_GRID))
     rds = [ps.reading_xyz[k] for k in range(6)]
@@ -376,11 +383,15 @@ def test_fused_residual_pass_equals_the_separate_chain(ctx, oracle32):
     r2, e2, s2 = ctx.partial_chain_batch([ids[k] for k in ok], [rds[k] for k in ok], [Ta[k] for k in ok])
     for j, k in enumerate(ok):
         assert rst[k] == 0 and s2[j] == 0
-        assert res[k] == pytest.approx(e2[j], rel=1e-4) and ratio[k] == pytest.approx(r2[j], rel=1e-9)
+        # (the fused pass moves the PRE-TRANSFORMED reading by the iteration transform, the separate chain the reading by the
+        # composed one: the last bits of a distance differ -- a count-based ratio does not see that, a mean robust weight does)
+        rtol = 1e-9 if not extra["robust_fct"] else 1e-5
+        assert res[k] == pytest.approx(e2[j], rel=1e-4) and ratio[k] == pytest.approx(r2[j], rel=rtol)
         po = oracle32.partial_chain(rds[k], ps.ref_xyz[k], ps.ref_nrm[k], Ta[k], **CHAIN)
-        assert res[k] == pytest.approx(po["residual"], rel=1e-3) and ratio[k] == pytest.approx(po["overlap"], rel=1e-9)
+        assert res[k] == pytest.approx(po["residual"], rel=1e-3) and ratio[k] == pytest.approx(po["overlap"], rel=rtol)
     for m in ids:
         ctx.destroy_map(m)
+    ctx.set_params(trim_ratio=globals()["CHAIN"]["trim_ratio"], robust_fct=0) if extra["robust_fct"] else None
 
 
 def test_batch_entry_points_equal_single_calls(ctx):
