@@ -392,11 +392,16 @@ class Context:
         return [DevPtr(out[k], bufs[k].stride, bufs[k].n, bufs[k].dtype, keep=bufs[k].keep) for k in range(n)]
 
     def set_params(self, **kw):
+        before = Params.from_buffer_copy(self.params)
         for k, v in kw.items():
             if not hasattr(self.params, k):
                 raise KeyError(k)
             setattr(self.params, k, v)
-        self._check(self.lib.pgicp_set_params(self.h, C.byref(self.params)))
+        try:
+            self._check(self.lib.pgicp_set_params(self.h, C.byref(self.params)))
+        except PgicpError:
+            self.params = before            # a refused setting leaves the context (and this mirror of it) as it was
+            raise
 
     @property
     def stream(self):

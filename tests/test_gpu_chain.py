@@ -192,6 +192,7 @@ def test_robust_filter_stage_weights_bit_exact(ctx, oracle32, oracle64, dtype):
                 assert np.all(w[np.isinf(d2)] == 0)
     with pytest.raises(icp.PgicpError):                         # a quantile filter beside it is refused
         ctx.set_params(**dict(CHAIN, trim_ratio=0.8, robust_fct=1))
+    assert ctx.params.trim_ratio == 1.0 and ctx.params.robust_fct == 7          # (a refused setting leaves the mirror as it was)
     ctx.set_params(**dict(CHAIN, **RESET))
     with pytest.raises(icp.PgicpError):
         ctx.set_params(**dict(CHAIN, trim_ratio=1.0, robust_fct=1, knn=2))
