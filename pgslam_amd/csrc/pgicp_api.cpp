@@ -1116,7 +1116,8 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         mix(shape, sizeof shape);
         mix(&ch, sizeof ch);
         const void *bufs[] = {c->probs.p, S.d_maps.p, S.rd_sorted.p, S.slot.p, S.d2.p, S.none_r.p, c->small.p, c->slow_list.p, c->slow_lb.p,
-                              c->slow_ring.p, c->slow2.p, c->active.p, c->queue.p, c->sel_tables.p, c->qtmp.p, c->partials.p, c->h_flag, c->stamp_dev};
+                              c->slow_ring.p, c->slow2.p, c->active.p, c->queue.p, c->sel_tables.p, c->qtmp.p, c->partials.p, c->h_flag, c->stamp_dev,
+                              c->robust_dev.p, L.normals ? S.nrm_sorted.p : nullptr};
         mix(bufs, sizeof bufs);
         pgicp_ctx::IterGraph *g = nullptr;
         for (auto &e : c->iter_graphs) if (e.exec && e.key == key) { g = &e; break; }

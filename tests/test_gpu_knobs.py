@@ -27,7 +27,7 @@ SETTINGS = [
 @pytest.mark.parametrize("setting", SETTINGS, ids=lambda s: ",".join(f"{k[6:]}={v}" for k, v in s.items()))
 def test_parity_holds_for_every_knob_setting(setting):
     env = dict(os.environ, **setting)
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_edge_cases.py", "tests/test_gpu_matcher_state.py", "tests/test_local_mapper.py",
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_edge_cases.py", "tests/test_gpu_matcher_state.py", "tests/test_local_mapper.py", "tests/test_gpu_chain.py",
                         "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
