@@ -37,6 +37,8 @@ struct MapDev {
     const int *sc_wit;                   // slot of a point in a nearest occupied super-cell (within kWitReach), else -1
     const float *sc_ext;                 // per super-cell: the box of its POINTS, (min x, y, z, max x, y, z) as offsets from the grid
                                          // origin, float, min > max when empty -- the slices of a street scene fill little of a 0.7 m cube
+    const float *ptsf;                   // double maps only (else null): the points again as (float x, y, z, index bits) records of 16 bytes, same
+                                         // order -- the fast matcher's prefilter reads these and the double record only of a candidate that may win
     const int *slot_of;                  // original index -> position in pts / nrm
     const int *near;                     // per 2x2x2 block of cells: a nearby occupied cell, -1 if none within kNearReach
     const unsigned *occ;                 // one bit per cell (cell id = bit index): occupied.  64x smaller than the tables, so it

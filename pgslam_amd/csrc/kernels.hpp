@@ -12,7 +12,7 @@ void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, l
                              int *cell_start, int *cell_start_f, int *bins_b, int *arrival, unsigned long long *words,
                              typename Vec4<T>::type *cpts, typename Vec4<T>::type *cnrm,
                              typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
-                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit, unsigned *occ, long long tot_o, float *sc_ext);
+                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit, unsigned *occ, long long tot_o, float *sc_ext, float *ptsf);
 template <typename T>
 void launch_query_sort(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, const MapDev<T> *maps, typename Vec4<T>::type *rd_pre, T *rd_sorted,
                        int *qkey, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int P,

@@ -84,6 +84,7 @@ struct MapHost {
     int *sc_wit = nullptr;
     float *sc_ext = nullptr;
     unsigned *occ = nullptr;
+    float *ptsf = nullptr;          // MapDev::ptsf (double maps)
     int first = 0;                  // MapDev::first
     // the one device allocation holding all of the above -- shared by the maps of one batched build and
     // returned to the pool (or freed) by whoever drops the last reference
@@ -494,7 +495,7 @@ int sync_maps_table(pgicp_ctx *c)
     std::vector<MapDev<T>> h(n);
     for (int i = 0; i < n; i++) {
         const MapHost<T> &m = S.maps[i];
-        h[i].pts = m.pts; h[i].nrm = m.nrm; h[i].cell_start = m.cell_start; h[i].g = m.g; h[i].m = m.used ? m.m : 0;
+        h[i].pts = m.pts; h[i].nrm = m.nrm; h[i].ptsf = m.ptsf; h[i].cell_start = m.cell_start; h[i].g = m.g; h[i].m = m.used ? m.m : 0;
         h[i].cell_start_f = m.cell_start_f; h[i].kx = m.kx;
         h[i].sc_count = m.sc_count;
         h[i].slot_of = m.slot_of;
@@ -760,9 +761,9 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? up(2 * sizeof(V4) * (size_t)tot_m) : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
                  b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c),
                  b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0, b_occ = up(sizeof(unsigned) * (size_t)tot_o),
-                 b_ext = up(sizeof(float) * 6 * (size_t)tot_s);
+                 b_ext = up(sizeof(float) * 6 * (size_t)tot_s), b_ptsf = sizeof(T) == 8 ? up(sizeof(float) * 4 * (size_t)tot_m + 64) : 0;
     auto blk = std::make_shared<SharedBlock>();
-    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext, &blk->p, &blk->bytes); if (ast) return ast; }
+    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext + b_ptsf, &blk->p, &blk->bytes); if (ast) return ast; }
     char *base = blk->p;
     V4 *g_pts = (V4 *)base, *g_nrm = any_nrm ? (V4 *)(base + b_pts) : nullptr;
     int *g_cs = (int *)(base + b_pts + b_nrm), *g_slot = (int *)(base + b_pts + b_nrm + b_cs),
@@ -772,6 +773,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         *g_csf = kx > 1 ? (int *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near) : g_cs;
     unsigned *g_occ = (unsigned *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf);
     float *g_ext = (float *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ);
+    float *g_ptsf = b_ptsf ? (float *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext) : nullptr;   // (16-byte records: blocks are 256-byte aligned)
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
         const BuildDesc<T> &d = descs[k];
@@ -788,13 +790,14 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         M.sc_wit = g_wit + d.sbase;
         M.sc_ext = g_ext + 6 * d.sbase;
         M.occ = g_occ + d.obase;
+        M.ptsf = g_ptsf;                             // (indexed by slot, like pts)
     }
     XFER(c, h2d(c, c->bdesc.p, descs.data(), sizeof(BuildDesc<T>) * n));
     {
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
         launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_b, tot_s, max_m, max_cells, max_bins, max_nsc, max_blocks, kx == 4 ? 1 : 0, c->tmp_a.as<int>(),
                                    c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), c->tmp_w.as<unsigned long long>(), c->tmp_p.as<V4>(), c->tmp_n.as<V4>(), g_pts, g_nrm,
-                                   g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o, g_ext);
+                                   g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o, g_ext, g_ptsf);
     }
     HIPC(c, stream_sync(c));          // `descs` (host) feeds an async copy
     HIPC(c, hipGetLastError());

@@ -296,3 +296,28 @@ def test_debug_counters_on_a_context_that_has_not_aligned_anything():
     out = c.debug_counters()
     assert list(out[:3]) == [0, 0, 0]
     c.close()
+
+
+@pytest.mark.parametrize("offset", [0.0, 3.0e3, 4.0e5])
+def test_double_clouds_far_from_the_origin_match_bit_for_bit(ctx, oracle64, offset):
+    """PointMatcher<double> with the clouds in a frame whose origin is kilometres away (a UTM-like frame, the map NOT centred): the
+    double fast matcher reads a float mirror of the map first (item_rounds_dp) -- at 400 km a float resolves 3 cm, so the
+    prefilter must widen its margin with the coordinates' magnitude and still hand every possible winner to the double
+    evaluation: ids and squared distances of every pair bit for bit the oracle's."""
+    s = synth.make_two_scans(6000, rings=16)
+    shift = np.array([offset, -0.7 * offset, 0.01 * offset])
+    ref = s["ref_xyz"].astype(np.float64) + shift
+    rd = s["reading_xyz"].astype(np.float64) + shift
+    T0 = np.eye(4)
+    T0[:3, 3] = [0.05, -0.03, 0.01]
+    # T0 acts about the origin: a small rotation there would throw the cloud kilometres away, so translation only
+    for max_dist in (2.0, 0.3):
+        ctx.set_params(**dict(CHAIN, max_dist=max_dist))
+        mid = ctx.set_map(ref, None, center=False, dtype=np.float64)
+        ids, d2 = ctx.match(mid, rd, T=T0, dtype=np.float64)
+        ctx.destroy_map(mid)
+        q = oracle64.transform(T0, rd)
+        oid, od2 = oracle64.knn_kdtree(q, ref, max_dist)
+        assert np.array_equal(ids, oid)
+        assert np.array_equal(d2.view(np.uint64), od2.view(np.uint64))
+    ctx.set_params(**CHAIN)
