@@ -321,3 +321,25 @@ def test_double_clouds_far_from_the_origin_match_bit_for_bit(ctx, oracle64, offs
         assert np.array_equal(ids, oid)
         assert np.array_equal(d2.view(np.uint64), od2.view(np.uint64))
     ctx.set_params(**CHAIN)
+
+
+def test_double_maps_of_one_batch_with_unbounded_max_dist(ctx, oracle64):
+    """maxDist = inf, double clouds, two maps indexed in one batch (their points share one array): a query starts without any bound, so
+    the float prefilter's first threshold is +inf -- it must still look only at its item's own records, not at the slots after them
+    (the next map's points)."""
+    a = synth.make_two_scans(3000, rings=16)
+    b = synth.make_two_scans(1200, rings=8)
+    refs = [a["ref_xyz"].astype(np.float64), b["ref_xyz"][:777].astype(np.float64) + np.array([0.3, -0.2, 0.1])]
+    rds = [a["reading_xyz"].astype(np.float64), b["reading_xyz"].astype(np.float64)]
+    ctx.set_params(**dict(CHAIN, max_dist=float("inf")))
+    ids = ctx.set_maps(refs, None, center=True, dtype=np.float64)
+    for k in range(2):
+        got_ids, got_d2 = ctx.match(ids[k], rds[k], T=a["T_init"], dtype=np.float64)
+        q = oracle64.transform(a["T_init"], rds[k])
+        oid, od2 = oracle64.knn_kdtree(q, refs[k], np.inf)
+        assert np.array_equal(got_ids, oid) and got_ids.max() < len(refs[k]) and got_ids.min() >= 0
+        # (the map is centred: a distance is computed from centred coordinates, the last bits may differ from the oracle's uncentred ones)
+        np.testing.assert_allclose(got_d2, od2, rtol=1e-9, atol=1e-18)
+    for m in ids:
+        ctx.destroy_map(m)
+    ctx.set_params(**CHAIN)
