@@ -42,16 +42,87 @@ CHAIN = dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, mi
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def emit(line: dict):
-    """The ONE JSON line, as the last thing on stdout: native libraries (RCCL prints a version banner when a communicator
-    is made) write through C stdio, whose buffer would otherwise be flushed after Python's at exit."""
+LINE_MAX = 6000             # the driver keeps ~8 KB of stdout: the final line stays well inside that
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config")
+LINE_FACTS = ("dry_run", "scans_total", "scans_converged", "mean_iterations", "median_translation_error_m", "set_map_ms", "pairs_ok",
+              "pairs_accepted", "rccl_ranks_seen", "comm_world_size", "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu",
+              "speedup_vs_cpu_baseline", "launched_by", "command_wall_s")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches",
+                 "active_problems_per_launch", "algorithmic_bytes_per_launch", "bound_measured", "traffic_measured_in_this_run",
+                 "valu_lane_ops_per_active_query_iteration", "frac_unseeded_launches", "frac_seeded_launches", "frac_shared_map")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "single_core_scans_per_s", "mean_iterations")
+
+
+def _short(v):
+    """Floats of the printed line at 6 significant digits (the full record keeps every bit)."""
+    if isinstance(v, float):
+        return float(f"{v:.6g}") if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _short(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_short(x) for x in v]
+    return v
+
+
+def compact_line(full: dict) -> dict:
+    """The line the driver parses: the contract's keys, `roofline` and `cpu_baseline` as flat objects of numbers and names (no
+    per-launch arrays, no prose beyond `sample`), a few scalar facts, `legs` LAST.  Everything else lives in the full record
+    (`bench_full.json`, see emit())."""
+    out = {k: full[k] for k in LINE_KEYS if k in full}
+    cfg = dict(out.get("config") or {})
+    cfg.pop("chain", None)                              # (the chain is BASELINE's: in the full record and in DESIGN.md)
+    out["config"] = cfg
+    r = full.get("roofline")
+    out["roofline"] = {k: r[k] for k in ROOFLINE_KEYS if k in r} if r else None
+    c = full.get("cpu_baseline")
+    out["cpu_baseline"] = {k: c[k] for k in CPU_KEYS if k in c} if c else None
+    for k in LINE_FACTS:
+        if full.get(k) is not None:
+            out[k] = full[k]
+    out["full_record"] = FULL_RECORD_NAME
+    out["legs"] = full.get("legs")
+    out = _short(out)
+    # a guard, not a plan: shed the optional facts (never the contract, roofline, cpu_baseline or legs) if a line ever grows
+    for k in reversed(LINE_FACTS):
+        if len(json.dumps(out)) < LINE_MAX:
+            break
+        out.pop(k, None)
+    if len(json.dumps(out)) >= LINE_MAX and out.get("cpu_baseline"):
+        out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:160]
+    return out
+
+
+FULL_RECORD_NAME = "bench_full.json"
+
+
+def write_full_record(full: dict):
+    """The whole record (every leg's long form, per-launch counters, per-step timings) as a FILE next to bench.py and, on a
+    gpurun box, under gpurun_out/ so that it travels back."""
+    text = json.dumps(full, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, FULL_RECORD_NAME), "w") as f:
+                    f.write(text + "\n")
+            except OSError:
+                pass
+
+
+def emit(full: dict):
+    """The ONE JSON line, as the last thing on stdout, short enough for the driver to keep whole (compact_line); the full
+    record goes to bench_full.json.  Native libraries (RCCL prints a version banner when a communicator is made) write
+    through C stdio, whose buffer would otherwise be flushed after Python's at exit."""
     import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
+    write_full_record(full)
+    line = json.dumps(compact_line(full), allow_nan=False)
+    assert len(line) < LINE_MAX, len(line)
     sys.stdout.flush()
-    print(json.dumps(line), flush=True)
+    print(line, flush=True)
 
 
 _DIST = {"on": False}
@@ -256,6 +327,16 @@ def cpu_baseline(w, sample_scans, n_threads, reps=3):
                 mean_iterations=iters, index_build_s=t_build)
 
 
+def check_all_ranks_reported(seen, comm_world, world):
+    """A multi-rank line is only a measurement if every rank's edges arrived through the communicator: the gathered records
+    name the rank that aligned them (`reserved[1]`), so a rank whose shard went missing -- or a communicator smaller than the
+    job -- ends the run with a non-zero exit code instead of a line (every rank holds the same gathered edges and fails alike)."""
+    if len(seen) != world or comm_world != world or list(seen) != list(range(world)):
+        print(f"bench.py: {world} rank(s) launched, communicator of {comm_world}, edges from ranks {list(seen)}: "
+              f"not a {world}-GPU measurement; no result line", file=sys.stderr)
+        sys.exit(3)
+
+
 def build_pairs(n_pts, n_keyframes=24, cache_dir="/tmp"):
     """Keyframe clouds for BASELINE configs[4] (cached; generated on host cores)."""
     from pgslam_amd import synth
@@ -279,10 +360,76 @@ def build_pairs(n_pts, n_keyframes=24, cache_dir="/tmp"):
     return xyz, nrm, poses
 
 
+def main_loopclosure_dry(args):
+    """HARNESS TEST ONLY (PGSLAM_BENCH_DRY_RANKS=1, tests/test_bench_ranks.py): the N > 1 skeleton of main_loopclosure on a box
+    without devices -- launch_ranks' processes, the LPT shard, pgicp_allgather_edges over the library's HOST transport, the
+    every-rank-reported check, rank 0 doing all pairs alone, the line's N > 1 keys -- with the device batch replaced by a
+    stand-in that computes nothing.  The line says so (`dry_run`, `data`) and its `value` measures nothing."""
+    import torch.distributed as dist
+    from pgslam_amd import icp, loop_closure as lc
+    world, rank, _ = ranks()
+    distributed = dist_begin("gloo", 0)
+    n = args.pairs
+    costs = [200_000 + 1_000 * (i % 7) for i in range(n)]
+    mine = lc.shard(costs, world, rank)
+    slots = icp.shard_slots(costs, world)
+    shm = "/dev/shm/pgslam_bench_dry_%s" % os.environ.get("MASTER_PORT", "0")
+    comm = icp.Comm.host(world, rank, shm, slots)
+    drop = os.environ.get("PGSLAM_BENCH_DRY_DROP_RANK")
+
+    def align_shard(idx):
+        e = np.zeros(len(idx), dtype=lc.EDGE_DTYPE)
+        e["from_id"], e["to_id"], e["iterations"], e["accepted"] = [1000 + i for i in idx], [2000 + i for i in idx], 5, 1
+        time.sleep(2e-4 * len(idx))
+        return e
+
+    def step():
+        local = align_shard(mine)
+        local["reserved"][:, 1] = rank + 1
+        if drop is not None and rank == int(drop):
+            return comm.allgather_edges(local[:0], np.zeros(0, np.int32), slots, n)
+        return comm.allgather_edges(local, np.asarray(mine, dtype=np.int32), slots, n)
+
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        edges = step()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    seen = sorted(set(int(v) - 1 for v in np.asarray(edges["reserved"])[:, 1] if v > 0))
+    comm_world, _ = comm.info()
+    check_all_ranks_reported(seen, comm_world, world)
+    single = None
+    if distributed:
+        if rank == 0:
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                align_shard(list(range(n)))
+            single = args.steps * n / (time.perf_counter() - t1)
+        dist.barrier()
+    comm.close()
+    if rank == 0:
+        value = args.steps * n / elapsed
+        emit({"metric": "DRY RUN of the loop-closure rank skeleton (no device, stand-in aligner): not a measurement", "value": value,
+              "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "none", "data": "dry run: nothing computed",
+              "config": {"workload": f"harness test, {n} stand-in pairs", "parallelism": f"{world} rank process(es), host transport"},
+              "dry_run": True, "roofline": None, "cpu_baseline": None,
+              "rccl_ranks_seen": len(seen), "comm_world_size": comm_world, "pairs_per_s_one_gpu_same_run": single,
+              "speedup_vs_one_gpu": value / single if single else None,
+              "launched_by": "bench.py itself (launch_ranks)" if os.environ.get("PGSLAM_BENCH_SELF_LAUNCHED") else "a launcher",
+              "legs": {"dry_run": True}})
+    dist_end()
+
+
 def main_loopclosure(args, collect=False):
     """BASELINE configs[4]: `--pairs` candidate pairs sharded over the ranks (strong scaling),
     every rank aligns its shard in device batches, one all-gather of the 512-byte edge records.
     At N > 1 rank 0 then aligns ALL pairs alone in the same run: `speedup_vs_one_gpu` is north_star's ratio."""
+    if os.environ.get("PGSLAM_BENCH_DRY_RANKS") == "1" and not collect:
+        return main_loopclosure_dry(args)
     import torch
     import torch.distributed as dist
     from pgslam_amd import icp, synth, loop_closure as lc
@@ -447,6 +594,7 @@ def main_loopclosure(args, collect=False):
                                "predicted_speedup(W) = T(all pairs) / (max_r T(shard) + world-1 all-gather latency); medians")
     seen = sorted(set(int(v) - 1 for v in np.asarray(edges["reserved"])[:, 1] if v > 0))
     comm_world, comm_rank = comm.info()
+    check_all_ranks_reported(seen, comm_world, world)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the oracle on a bounded sample of the same pairs: ICP::operator() (index build + loop) + the residual chain
@@ -611,7 +759,7 @@ def recorded_traffic(name, **match):
         return dict(traffic=None, traffic_source="profiles/%s.json is of another workload size" % name)
     return dict(traffic=tj.get("hbm_bytes_per_launch"), traffic_uncorrected=tj.get("hbm_bytes_per_launch_uncorrected"),
                 traffic_source="NOT measured in this run: profiles/%s.json, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                               "this command (tools/r4_pmc.sh); %s" % (name, tj.get("note", "")))
+                               "this command (tools/pmc_round.sh); %s" % (name, tj.get("note", "")))
 
 
 def slam_roofline(res, points=None):
@@ -1395,6 +1543,8 @@ def main():
                             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_uncorrected=traffic_raw,
                             traffic_source=traffic_src,
                             bound_measured=(pmc or {}).get("bound_measured", "valu"),
+                            traffic_measured_in_this_run=False,
+                            valu_lane_ops_per_active_query_iteration=(pmc or {}).get("valu_lane_ops_per_active_query_iteration"),
                             bound_measured_evidence=(pmc or {"note": "profiles/knn_pmc.json not found: see DESIGN.md section 4 (VALU 68-94 % busy)"}),
                             **split,
                             achieved_shared_map=achieved_shared, frac_shared_map=achieved_shared / HBM_PEAK_GBS,
@@ -1455,6 +1605,35 @@ def main():
         two_ctx = dict(scans_per_s=n2 / dt2, ms_per_step=dt2 * 1e3 / args.steps, over_one_context=(n2 / dt2) / (converged / elapsed),
                        note="the batch as two sub-batches of %d on two contexts (two HIP streams); same results" % (B // 2))
         c2[1].close()
+
+    # ---- companion figure: NO step repeats a problem.  The timed steps above align the same 128 (scan, guess) problems every step,
+    #      and the context keeps per-problem-index selection hints across calls (ProblemDev::qhint) -- a predictor no real stream
+    #      offers.  Here slot b of step s holds scan (b + s) mod 64 with a guess drawn from a seed no other step uses: hints
+    #      and scratch sizes come from a DIFFERENT problem, as in a live feed.  Never `value`.
+    rotated = None
+    if S == 1 and not args.no_fixed30 and not args.fixed_iters:
+        ctx.set_params(check_every=args.check_every)
+
+        def rot_problem(s_):
+            rd = [d_scans[(b + s_) % len(d_scans)] for b in range(B)]
+            ti = [w.T_truth[(b + s_) % len(d_scans)] @ synth.perturbation(77_000 + 1000 * rank + B * s_ + b) for b in range(B)]
+            return rd, ti
+        probs = [rot_problem(s_) for s_ in range(args.warmup + args.steps)]
+        for rd, ti in probs[:args.warmup]:
+            ctx.align_batch(map_id, rd, ti, raise_on_error=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nrot, irot = 0, []
+        for rd, ti in probs[args.warmup:]:
+            _, st_r = ctx.align_batch(map_id, rd, ti, raise_on_error=False)
+            nrot += sum(1 for s_ in st_r if s_["status"] == 0 and s_["converged"])
+            irot += [s_["iterations"] for s_ in st_r]
+        torch.cuda.synchronize()
+        dtr = time.perf_counter() - t0
+        rotated = dict(scans_per_s=nrot / dtr, ms_per_step=dtr * 1e3 / args.steps, scans_converged=nrot, scans_total=args.steps * B,
+                       mean_iterations=float(np.mean(irot)), over_repeated_batch=(nrot / dtr) / (converged / elapsed),
+                       how="slot b of step s = scan (b + s) mod %d with a fresh guess (seed 77000 + B s + b): no problem is seen twice, "
+                           "the cross-call selection hints come from a different problem" % len(d_scans))
 
     # ---- PCIe-inclusive companion figure: the caller owns HOST clouds (Localizer.hpp:103-126); step k+1's scans travel on
     #      the copy stream while step k aligns (pgicp_upload_f32), the compute stream waits for them on the device
@@ -1543,6 +1722,7 @@ def main():
             "fixed_30_iterations": fixed30,
             "two_contexts": two_ctx,
             "host_input": host_input,
+            "rotated_batch": rotated,
             "mean_iterations": iters_all / max(1, scans_all),
             "selection_guess_misses_per_step": sel_fallbacks / max(1, args.steps + args.warmup),
             "set_map_ms": t_setmap * 1e3,
@@ -1552,7 +1732,11 @@ def main():
             "cpu_baseline": cpu,
             "workloads": legs,
             "loop_closure": lc_leg,
+            # the N > 1 evidence of the loop-closure leg, where the driver's parser sees it
             "rccl_ranks_seen": (lc_leg or {}).get("rccl_ranks_seen"),
+            "comm_world_size": (lc_leg or {}).get("comm_world_size"),
+            "pairs_per_s_one_gpu_same_run": (lc_leg or {}).get("pairs_per_s_one_gpu_same_run"),
+            "speedup_vs_one_gpu": (lc_leg or {}).get("speedup_vs_one_gpu"),
             "launched_by": ("bench.py itself (launch_ranks)" if os.environ.get("PGSLAM_BENCH_SELF_LAUNCHED") else
                             ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process")),
             "command_wall_s": time.perf_counter() - t_cmd0,
@@ -1570,6 +1754,10 @@ def main():
         out["legs"] = {"unit": "[value, roofline.frac]; scans/s except loop_closure: pairs/s",
                        "headline": [round(value, 1), round(roofline["frac"], 4) if roofline else None],
                        "fixed30": [round(fixed30["scans_per_s"], 1), None] if fixed30 else None,
+                       # what the boundary's callers get (Localizer.hpp:103-126 hands HOST clouds; no live feed repeats a problem)
+                       "headline_host_pinned": [round(host_input["pinned_scans_per_s"], 1), None] if host_input else None,
+                       "headline_host_pageable": [round(host_input["pageable_scans_per_s"], 1), None] if host_input else None,
+                       "headline_rotated": [round(rotated["scans_per_s"], 1), None] if rotated else None,
                        "f64": vf(lg.get("f64")), "stream": vf(lg.get("stream")), "slam": vf(lg.get("slam")),
                        "slam_100k": vf(lg.get("slam_100k")), "loop_closure": vf(lg.get("loop_closure")),
                        "loop_closure_predicted_speedup_8": ((lg.get("loop_closure") or {}).get("shard_proxy") or {}).get("predicted_speedup", {}).get("8"),

@@ -710,6 +710,11 @@ private:
             const auto &ref = *queue_[mine[k]].reference_dev;
             xyz[k] = ref.xyz; xs[k] = ref.xs; nrm[k] = ref.nrm; ns[k] = ref.ns; ms[k] = ref.n;
         }
+        // whatever throws below (a partially failed map_create_batch, pushParams, PM::check): the maps made so far go back to the pool
+        struct MapGuard {
+            pgicp_ctx *ctx; std::vector<int> &ids;
+            ~MapGuard() { for (int &m : ids) if (m >= 0) { pgicp_map_destroy(ctx, m); m = -1; } }
+        } guard{ctx, maps};
         PM::check(ctx, sizeof(T) == 4 ? pgicp_map_create_batch_f32(ctx, P, (const float *const *)xyz.data(), xs.data(), (const float *const *)nrm.data(), ns.data(), ms.data(), PGICP_DEVICE, 1, maps.data())
                                       : pgicp_map_create_batch_f64(ctx, P, (const double *const *)xyz.data(), xs.data(), (const double *const *)nrm.data(), ns.data(), ms.data(), PGICP_DEVICE, 1, maps.data()));
         chain_.pushParams();
@@ -723,7 +728,6 @@ private:
         std::vector<pgicp_stats> st(P);
         const int rc = sizeof(T) == 4 ? pgicp_align_residual_batch_f32(ctx, P, pr.data(), Tout.data(), st.data(), residual.data(), nullptr, nullptr)
                                       : pgicp_align_residual_batch_f64(ctx, P, pr.data(), Tout.data(), st.data(), residual.data(), nullptr, nullptr);
-        for (int k = 0; k < P; k++) pgicp_map_destroy(ctx, maps[k]);
         if (rc != PGICP_OK && rc != PGICP_ERR_NO_MATCH && rc != PGICP_ERR_NAN && rc != PGICP_ERR_BOUND) PM::check(ctx, rc);
         for (int k = 0; k < P; k++) {
             const Candidate &c = queue_[mine[k]];

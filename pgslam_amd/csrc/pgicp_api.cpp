@@ -156,6 +156,7 @@ struct pgicp_ctx {
         size_t cap = 0, off = 0;
         struct Out { void *dst; const char *src; size_t bytes; };
         std::vector<Out> outs;
+        bool direct_out_pending = false;    // a small device -> host copy went straight to a caller's / a local buffer (see fail())
     } bounce;
     int *h_flag = nullptr;          // coherent pinned pair {problems done, stamp} the last kernel of an iteration writes
     int flag_stamp = 0;             // iterations enqueued so far == the value the last one's k_compact_active will store
@@ -226,9 +227,22 @@ MapHost<T> *get_map(pgicp_ctx *c, int id)
     return idx < 0 ? nullptr : &state<T>(c).maps[idx];
 }
 
+// Every failing exit of every entry point passes through here (directly, or through HIPC / XFER).  A device -> host copy may
+// still be queued at that point: a bounce copy-out whose destination is a local of the failing call or a caller's buffer
+// (pgicp_ctx::Bounce::outs), or a small direct hipMemcpyAsync into one.  Let the stream run dry so that nothing writes into
+// memory that goes out of scope with the return, and DROP the queued copy-outs -- the call has failed, its outputs are void --
+// so that no later stream_sync() (the next call's, bounce_take's wrap-around, pgicp_ctx_destroy) replays them.
 int fail(pgicp_ctx *c, int code, const std::string &msg)
 {
-    if (c) c->err = msg;
+    if (c) {
+        c->err = msg;
+        if (!c->bounce.outs.empty() || c->bounce.direct_out_pending) {
+            if (c->stream) (void)hipStreamSynchronize(c->stream);
+            c->bounce.outs.clear();
+            c->bounce.off = 0;
+            c->bounce.direct_out_pending = false;
+        }
+    }
     return code;
 }
 
@@ -389,6 +403,7 @@ static void bounce_drain(pgicp_ctx *c)               // the stream is idle: fini
     for (auto &o : c->bounce.outs) std::memcpy(o.dst, o.src, o.bytes);
     c->bounce.outs.clear();
     c->bounce.off = 0;
+    c->bounce.direct_out_pending = false;
 }
 static hipError_t stream_sync(pgicp_ctx *c)
 {
@@ -429,7 +444,11 @@ static int h2d(pgicp_ctx *c, void *dst_dev, const void *src_host, size_t bytes)
 static int d2h(pgicp_ctx *c, void *dst_host, const void *src_dev, size_t bytes)
 {
     if (bytes == 0) return PGICP_OK;
-    if (bytes < kDirectCopyBytes) { HIPC(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream)); return PGICP_OK; }
+    if (bytes < kDirectCopyBytes) {
+        c->bounce.direct_out_pending = true;
+        HIPC(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        return PGICP_OK;
+    }
     char *b = nullptr;
     { const int st = bounce_take(c, bytes, &b); if (st) return st; }
     HIPC(c, hipMemcpyAsync(b, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1114,8 +1133,10 @@ void one_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch, bo
         // FNV-1a over the argument values: shapes, switches, chain parameters, and every buffer the launches name
         unsigned long long key = 1469598103934665603ULL;
         auto mix = [&key](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ULL; } };
-        const int shape[11] = {(int)sizeof(T), L.P, (int)act_probs, L.max_n, use_seed, with_solve ? 1 : 0, c->med_rings, L.rings_seeded,
-                               L.rings_unseeded, c->prm.matcher, c->seg_clean};
+        // (sel_guess_first decides the `guess` argument of the iteration's first selection launch: the hinted and the
+        //  unhinted first iteration are different graphs)
+        const int shape[13] = {(int)sizeof(T), L.P, (int)act_probs, L.max_n, use_seed, with_solve ? 1 : 0, c->med_rings, L.rings_seeded,
+                               L.rings_unseeded, c->prm.matcher, c->seg_clean, c->sel_guess_first, c->sel_hints_on};
         mix(shape, sizeof shape);
         mix(&ch, sizeof ch);
         const void *bufs[] = {c->probs.p, S.d_maps.p, S.rd_sorted.p, S.slot.p, S.d2.p, S.none_r.p, c->small.p, c->slow_list.p, c->slow_lb.p,
@@ -2142,7 +2163,8 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)stream_sync(c);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->bounce.outs.clear();         // (every successful call has drained its own; whatever is left belongs to nobody)
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     prof_collect(c);
     {

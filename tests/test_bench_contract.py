@@ -1,17 +1,69 @@
-"""The bench line's contract, checked on the round's recorded line (profiles/rNN_bench_n1.json, written by `python bench.py --steps 20
---warmup 5` on the GPU box): the fields the driver reads, the roofline and cpu_baseline objects, and their arithmetic."""
-import glob, json, os
+"""The bench line's contract, checked on the round's recorded run (`python bench.py --steps 20 --warmup 5` on the GPU box):
+profiles/rNN_bench_n1.json is the LINE bench.py printed (round 6 on: the short form of bench.compact_line), and
+profiles/rNN_bench_n1_full.json the full record it wrote to bench_full.json (up to round 5 the line WAS the full record).
+Checked: the fields the driver reads, the roofline and cpu_baseline objects and their arithmetic, and that the printed line is
+short enough for the driver to keep whole (BENCH_r05.json: `parsed: null` -- the line had grown to 22.9 KB)."""
+import glob, json, os, sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def latest():
+    """(full record, BASELINE.json)"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_n1.json")))
     if not files:
         pytest.skip("no recorded bench line")
-    return json.load(open(files[-1])), json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    full = files[-1].replace("_bench_n1.json", "_bench_n1_full.json")
+    return json.load(open(full if os.path.exists(full) else files[-1])), json.load(open(os.path.join(ROOT, "BASELINE.json")))
+
+
+def strict_loads(text):
+    def refuse(name):
+        raise ValueError("not strict JSON: " + name)
+    return json.loads(text, parse_constant=refuse)
+
+
+def test_printed_line_is_short_strict_json_with_roofline_and_cpu_baseline():
+    """emit()'s own serialisation of the latest full record: < 6000 characters, strict JSON (no NaN / Infinity), the contract's keys,
+    flat `roofline` / `cpu_baseline` objects, `legs` last."""
+    import bench
+    full, _ = latest()
+    line = json.dumps(bench.compact_line(full), allow_nan=False)
+    assert len(line) < bench.LINE_MAX <= 6000, len(line)
+    d = strict_loads(line)
+    assert list(d)[-1] == "legs"
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r, c = d["roofline"], d["cpu_baseline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches", "active_problems_per_launch",
+              "algorithmic_bytes_per_launch", "bound_measured"):
+        assert k in r, k
+    assert all(not isinstance(v, (dict, list)) for v in r.values())          # no per-launch arrays, no nested evidence
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert d["legs"]["headline"][0] == pytest.approx(d["value"], rel=1e-3)
+    # a record that outgrows the line sheds optional facts, never the contract
+    fat = dict(full, launched_by="x" * 20000)
+    assert len(json.dumps(bench.compact_line(fat))) < bench.LINE_MAX
+
+
+def test_recorded_printed_line_is_the_short_form():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_n1.json")))
+    if not files or not os.path.exists(files[-1].replace("_bench_n1.json", "_bench_n1_full.json")):
+        pytest.skip("no round-6 record yet")
+    text = open(files[-1]).read().strip()
+    assert len(text) < 6000 and "\n" not in text
+    d = strict_loads(text)
+    assert list(d)[-1] == "legs" and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+    # what the boundary's callers get: host clouds (pinned / pageable), and a batch no step repeats
+    for leg in ("headline_host_pinned", "headline_host_pageable", "headline_rotated"):
+        assert d["legs"][leg][0] > 0, leg
+    assert d["legs"]["headline_rotated"][0] > 0.5 * d["value"]
 
 
 def test_recorded_line_keeps_the_contract():

@@ -343,3 +343,27 @@ def test_double_maps_of_one_batch_with_unbounded_max_dist(ctx, oracle64):
     for m in ids:
         ctx.destroy_map(m)
     ctx.set_params(**CHAIN)
+
+
+@pytest.mark.parametrize("away", [5.0e3, 2.0e5])
+def test_double_query_far_from_the_map_with_unbounded_max_dist(ctx, oracle64, away):
+    """A double reading kilometres from its map (a bad initial pose) with maxDist = inf: the fast matcher's walk is float arithmetic
+    (BK, k_match.inc), whose rounding at such offsets (2^-24 of 5 km is 0.3 mm per operation, of 200 km 12 mm) exceeds the grid's
+    fixed 2 % margin: bk_margin widens every test by the query's own offset, so no row or window holding the true neighbour is
+    pruned.  Part of the reading sits on the map (near queries), the rest far off: ids bit for bit the oracle's."""
+    s = synth.make_two_scans(5000, rings=16)
+    ref = s["ref_xyz"].astype(np.float64)
+    rd = s["reading_xyz"].astype(np.float64).copy()
+    rng = np.random.default_rng(12)
+    far = rng.random(len(rd)) < 0.5
+    rd[far] += np.array([away, 0.37 * away, -0.05 * away])
+    ctx.set_params(**dict(CHAIN, max_dist=float("inf")))
+    for center in (True, False):
+        mid = ctx.set_map(ref, None, center=center, dtype=np.float64)
+        ids, d2 = ctx.match(mid, rd, T=s["T_init"], dtype=np.float64)
+        ctx.destroy_map(mid)
+        q = oracle64.transform(s["T_init"], rd)
+        oid, od2 = oracle64.knn_kdtree(q, ref, np.inf)
+        assert np.array_equal(ids, oid), (center, int(np.sum(ids != oid)))
+        np.testing.assert_allclose(d2, od2, rtol=1e-9)
+    ctx.set_params(**CHAIN)

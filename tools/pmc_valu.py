@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What binds k_knn_grid, from rocprofv3 --pmc passes of the headline command (tools/r4_pmc.sh): per dispatch and over
+"""What binds k_knn_grid, from rocprofv3 --pmc passes of the headline command (tools/pmc_round.sh): per dispatch and over
 the step, VALU busy = 4 x SQ_INSTS_VALU / (1 024 SIMDs x cycles) (a wave64 VALU instruction holds a 16-lane SIMD for four
 cycles), texture-address busy = TA_TA_BUSY_sum / (256 CUs x cycles), with cycles = GRBM_GUI_ACTIVE / 8 (the counter sums
 over the XCDs).  Writes profiles/knn_pmc.json, which bench.py quotes in roofline.bound_measured_evidence.

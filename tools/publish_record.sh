@@ -2,23 +2,23 @@
 # copies the files of a tools/measure_round.sh run (gpurun_out/measure/) into profiles/ under this round's names:
 # tools/publish_record.sh r03
 R=${1:?round prefix, e.g. r03}; M=gpurun_out/measure; P=profiles
-cp $M/bench_n1.json $P/${R}_bench_n1.json
-cp $M/bench_loopclosure.json $P/${R}_bench_loopclosure.json
+cp $M/bench_n1.json $P/${R}_bench_n1.json; cp $M/bench_n1_full.json $P/${R}_bench_n1_full.json
+cp $M/bench_loopclosure_full.json $P/${R}_bench_loopclosure.json
 cp $M/bench_normals.json $P/${R}_bench_normals.json
-cp $M/bench_slam.json $P/${R}_bench_slam.json
-cp $M/bench_stream_1.json $P/${R}_bench_stream_1vehicle.json
-cp $M/bench_stream_4.json $P/${R}_bench_stream_4vehicles.json
-cp $M/bench_stream_fleet16.json $P/${R}_bench_stream_fleet16.json
+cp $M/bench_slam_full.json $P/${R}_bench_slam.json
+cp $M/bench_stream_1_full.json $P/${R}_bench_stream_1vehicle.json
+cp $M/bench_stream_4_full.json $P/${R}_bench_stream_4vehicles.json
+cp $M/bench_stream_fleet16_full.json $P/${R}_bench_stream_fleet16.json
 cp $M/host_input_overlap.txt $P/${R}_host_input_overlap.txt
 cp $M/trace_lc/t_kernel_stats.csv $P/${R}_loopclosure_kernel_stats.csv
 cp $M/trace_lc_summary.txt $P/${R}_loopclosure_trace_summary.txt
 cp $M/trace/t_kernel_stats.csv $P/${R}_rocprofv3_kernel_stats.csv
 cp $M/trace_summary.txt $P/${R}_trace_summary.txt
 cp $M/slam_mt.json $P/${R}_slam_run_mt.json
-cp $M/bench_slam100k.json $P/${R}_bench_slam100k.json
-cp $M/bench_f64.json $P/${R}_bench_f64.json
+cp $M/bench_slam100k_full.json $P/${R}_bench_slam100k.json
+cp $M/bench_f64_full.json $P/${R}_bench_f64.json
 cp $M/slam100k_mt.json $P/${R}_slam100k_run_mt.json 2>/dev/null
-cp $M/bench_loopclosure_shard_proxy.json $P/${R}_bench_loopclosure_shard_proxy.json 2>/dev/null
+cp $M/bench_loopclosure_shard_proxy_full.json $P/${R}_bench_loopclosure_shard_proxy.json 2>/dev/null
 cp $M/trace_slam100k_summary.txt $P/${R}_slam100k_trace_summary.txt 2>/dev/null
 cp $M/trace_stream_summary.txt $P/${R}_stream_kernel_totals.txt
 cp $M/stream_timeline_last_scan.txt $P/${R}_stream_timeline_last_scan.txt
