@@ -140,6 +140,10 @@ typedef struct {
     real robust_tuning;     /* tuning */
     int robust_scale;       /* scaleEstimator: 0 none, 1 mad */
     real robust_approx;     /* approximation (a distance; its square cuts e2); <= 0 or +inf: none */
+    /* ---- round 6: the order the pairs enter the reduction tree in (FN(tree_sum) below).  NULL: scan order.  Otherwise a
+     * permutation of the reading's points -- position j of the tree holds point pair_order[j] -- e.g. the one the HIP path
+     * sorts a reading by (pgicp_debug_reading_order): a sum does not depend on it mathematically, its last bits do ---- */
+    const int *pair_order;
 } FN(orc_params);
 
 /* [A.4] the chain multiplies the weights of its outlier filters.  MaxDistOutlierFilter: weight 1 while the SQUARED
@@ -754,15 +758,104 @@ int FN(orc_robust_weights)(const real *d2, int n, int fct, real tuning, int scal
 }
 
 /* --------------------------------------------------------------------------
+ * THE REDUCTION TREE ("RT-1") -- one agreed order and one agreed shape for every sum over pairs that
+ * feeds a result (normal equations, Kabsch sums, residual, Censi sums), stated here and walked by the HIP kernels
+ * (k_p2plane_reduce, k_cov_reduce, k_error_stats + block_reduce_store, sum_partials_256), so that a whole ICP -- T_out, cov,
+ * residual -- can be compared BIT FOR BIT instead of "to 1e-12": double addition is not associative, and until round 6 the
+ * oracle added in scan order in one chain while the device added in its own sorting order in a tree of its own.
+ *   T1  positions: pair position pos = j * K + k holds (point order[j], its k-th neighbour); order = identity (scan order)
+ *       unless the caller names another permutation of the points (orc_params.pair_order).
+ *   T2  blocks of 2048 positions; in block b "thread" t (0..255) adds the kept pairs at positions b*2048 + u*256 + t,
+ *       u = 0..7 in that order, each into its own accumulators, which start at +0.0.
+ *   T3  the 256 threads are four groups of 64 ("waves"); a group is folded by v[l] += v[l + o] for l < o, o = 32, 16, 8, 4,
+ *       2, 1 (the shuffle-down tree), the group's value is v[0].
+ *   T4  block value = (((+0.0 + g0) + g1) + g2) + g3.
+ *   T5  blocks -> problem: eight chains c = 0..7, chain c = ((+0.0 + B[c]) + B[c + 8]) + B[c + 16] ...; total =
+ *       (((+0.0 + chain0) + chain1) + ...) + chain7.
+ * What a pair adds is the callback's business (its own arithmetic, pair by pair, is the same on both sides already).
+ * This is NOT what libpointmatcher does (Eigen products over columns, in T: the ORC_ACCUM_T variant); double accumulation
+ * was the oracle's choice from round 1 and the envelope of round 5 says what it is worth.
+ * ------------------------------------------------------------------------ */
+#define ORC_RT_THREADS 256
+#define ORC_RT_PER_THREAD 8
+#define ORC_RT_SPAN (ORC_RT_THREADS * ORC_RT_PER_THREAD)
+#define ORC_RT_MAX_TERMS 48
+typedef void (*FN(pair_fn))(const void *ctx, size_t e, double *acc);      /* adds pair e (ORIGINAL numbering) if it is kept */
+static void FN(tree_sum)(size_t np, int K, int nt, const int *order, FN(pair_fn) f, const void *ctx, double *out)
+{
+    double (*thr)[ORC_RT_MAX_TERMS] = (double (*)[ORC_RT_MAX_TERMS])malloc(sizeof(double) * ORC_RT_MAX_TERMS * ORC_RT_THREADS);
+    const size_t nb = (np + ORC_RT_SPAN - 1) / ORC_RT_SPAN;
+    double chain[8][ORC_RT_MAX_TERMS];
+    for (int c = 0; c < 8; c++) for (int k = 0; k < nt; k++) chain[c][k] = 0.0;
+    for (size_t b = 0; b < nb; b++) {
+        for (int t = 0; t < ORC_RT_THREADS; t++) {                                  /* T2 */
+            for (int k = 0; k < nt; k++) thr[t][k] = 0.0;
+            for (int u = 0; u < ORC_RT_PER_THREAD; u++) {
+                const size_t pos = b * ORC_RT_SPAN + (size_t)u * ORC_RT_THREADS + t;
+                if (pos >= np) continue;
+                const size_t e = order ? (size_t)order[pos / K] * K + pos % K : pos;
+                f(ctx, e, thr[t]);
+            }
+        }
+        for (int k = 0; k < nt; k++) {
+            double blk = 0.0;
+            for (int g = 0; g < ORC_RT_THREADS / 64; g++) {                         /* T3 */
+                double v[64];
+                for (int l = 0; l < 64; l++) v[l] = thr[g * 64 + l][k];
+                for (int o = 32; o > 0; o >>= 1)
+                    for (int l = 0; l < o; l++) v[l] = v[l] + v[l + o];
+                blk += v[0];                                                        /* T4 */
+            }
+            chain[b & 7][k] += blk;                                                 /* T5: chain c takes blocks c, c + 8, ... in order */
+        }
+    }
+    for (int k = 0; k < nt; k++) {
+        double tot = 0.0;
+        for (int c = 0; c < 8; c++) tot += chain[c][k];
+        out[k] = tot;
+    }
+    free(thr);
+}
+
+/* --------------------------------------------------------------------------
  * [A.5]/[A.6]/[A.7] error elements -> point-to-plane normal equations
  *   sys[0..20]  upper triangle of A (row-major: 00 01 .. 05 11 12 .. 55)
  *   sys[21..26] b
  *   sys[27] sum w, sys[28] kept count, sys[29] residual sum w e^2
  * ------------------------------------------------------------------------ */
-/* knn = K neighbours per reading point: pair e = i * K + k is (reading point i, its k-th neighbour); the pairs are taken
- * k-major (all first neighbours, then all second ones), the order ErrorElements compacts them in [A.5] */
-static int FN(p2plane_system_k)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm,
-                                const int *ids, const real *w, double *sys)
+/* knn = K neighbours per reading point: pair e = i * K + k is (reading point i, its k-th neighbour).  The default build adds
+ * the pairs through the reduction tree above, in pair order e (point major: the Matches matrix's column order); the ORC_ACCUM_T
+ * variant keeps its own chain, k-major (all first neighbours, then all second ones), the order ErrorElements compacts them in
+ * [A.5] */
+typedef struct { const real *p, *ref_xyz, *ref_nrm, *w; const int *ids; int K; } FN(p2plane_ctx);
+static void FN(p2plane_pair)(const void *vc, size_t pe, double *sys)
+{
+    const FN(p2plane_ctx) *c = (const FN(p2plane_ctx) *)vc;
+    if (c->w[pe] == (real)0 || c->ids[pe] < 0) return;
+    const size_t i = pe / (size_t)c->K;
+    const int j = c->ids[pe];
+    const real *p = c->p, *ref_xyz = c->ref_xyz, *ref_nrm = c->ref_nrm;
+    const double wi = (double)c->w[pe];
+    const double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+    const double nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
+    const double dx = px - (double)ref_xyz[3 * j], dy = py - (double)ref_xyz[3 * j + 1],
+                 dz = pz - (double)ref_xyz[3 * j + 2];
+    const double e = (nx * dx + ny * dy) + nz * dz;
+    double J[6];
+    J[0] = py * nz - pz * ny;           /* c = p x n */
+    J[1] = pz * nx - px * nz;
+    J[2] = px * ny - py * nx;
+    J[3] = nx; J[4] = ny; J[5] = nz;
+    int k = 0;
+    for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) sys[k++] += wi * (J[a] * J[b]);
+    for (int a = 0; a < 6; a++) sys[21 + a] -= wi * (J[a] * e);
+    sys[27] += wi;
+    sys[28] += 1.0;
+    sys[29] += wi * (e * e);
+}
+static int FN(p2plane_system_ko)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm,
+                                 const int *ids, const real *w, const int *order, double *sys)
 {
     for (int i = 0; i < 30; i++) sys[i] = 0.0;
 #ifdef ORC_ACCUM_T
@@ -803,36 +896,27 @@ static int FN(p2plane_system_k)(const real *p, int n, int K, const real *ref_xyz
         return sys[28] > 0 ? ORC_OK : ORC_ERR_NO_MATCH;
     }
 #endif
-    for (int k = 0; k < K; k++)
-    for (int i = 0; i < n; i++) {
-        const size_t pe = (size_t)i * K + k;
-        if (w[pe] == (real)0 || ids[pe] < 0) continue;
-        const int j = ids[pe];
-        const double wi = (double)w[pe];
-        const double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
-        const double nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
-        const double dx = px - (double)ref_xyz[3 * j], dy = py - (double)ref_xyz[3 * j + 1],
-                     dz = pz - (double)ref_xyz[3 * j + 2];
-        const double e = (nx * dx + ny * dy) + nz * dz;
-        double J[6];
-        J[0] = py * nz - pz * ny;           /* c = p x n */
-        J[1] = pz * nx - px * nz;
-        J[2] = px * ny - py * nx;
-        J[3] = nx; J[4] = ny; J[5] = nz;
-        int k = 0;
-        for (int a = 0; a < 6; a++)
-            for (int b = a; b < 6; b++) sys[k++] += wi * (J[a] * J[b]);
-        for (int a = 0; a < 6; a++) sys[21 + a] -= wi * (J[a] * e);
-        sys[27] += wi;
-        sys[28] += 1.0;
-        sys[29] += wi * (e * e);
+    {
+        const FN(p2plane_ctx) c = {p, ref_xyz, ref_nrm, w, ids, K};
+        FN(tree_sum)((size_t)n * K, K, 30, order, FN(p2plane_pair), &c, sys);
     }
     return sys[28] > 0 ? ORC_OK : ORC_ERR_NO_MATCH;
+}
+__attribute__((unused)) static int FN(p2plane_system_k)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm,
+                                const int *ids, const real *w, double *sys)
+{
+    return FN(p2plane_system_ko)(p, n, K, ref_xyz, ref_nrm, ids, w, NULL, sys);
 }
 int FN(orc_p2plane_system)(const real *p, int n, const real *ref_xyz, const real *ref_nrm,
                            const int *ids, const real *w, double *sys)
 {
-    return FN(p2plane_system_k)(p, n, 1, ref_xyz, ref_nrm, ids, w, sys);
+    return FN(p2plane_system_ko)(p, n, 1, ref_xyz, ref_nrm, ids, w, NULL, sys);
+}
+/* the same with knn and the tree's order named (NULL: scan order) */
+int FN(orc_p2plane_system_o)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm,
+                             const int *ids, const real *w, const int *order, double *sys)
+{
+    return FN(p2plane_system_ko)(p, n, K > 1 ? K : 1, ref_xyz, ref_nrm, ids, w, order, sys);
 }
 
 /* --------------------------------------------------------------------------
@@ -883,24 +967,31 @@ void FN(orc_normal_weights)(const real *rd_nrm, const real *ref_nrm, const int *
  * of the norm of each delta").  getCovariance is the base class's: zeros.
  *   sys[0..2] sum w p   sys[3..5] sum w q   sys[6..14] sum w q_a p_b (row major)   sys[27] sum w  sys[28] kept  sys[29] residual
  * ------------------------------------------------------------------------ */
+typedef struct { const real *p, *ref_xyz, *w; const int *ids; int K; } FN(p2point_ctx);
+static void FN(p2point_pair)(const void *vc, size_t e, double *sys)
+{
+    const FN(p2point_ctx) *c = (const FN(p2point_ctx) *)vc;
+    if (c->w[e] == (real)0 || c->ids[e] < 0) return;
+    const real *pp = c->p + 3 * (e / (size_t)c->K), *qq = c->ref_xyz + 3 * (size_t)c->ids[e];
+    const double wi = (double)c->w[e];
+    for (int a = 0; a < 3; a++) { sys[a] += wi * (double)pp[a]; sys[3 + a] += wi * (double)qq[a]; }
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) sys[6 + 3 * a + b] += wi * ((double)qq[a] * (double)pp[b]);
+    const double dx = (double)(real)(pp[0] - qq[0]), dy = (double)(real)(pp[1] - qq[1]), dz = (double)(real)(pp[2] - qq[2]);
+    sys[27] += wi;
+    sys[28] += 1.0;
+    sys[29] += sqrt((dx * dx + dy * dy) + dz * dz);
+}
+int FN(orc_p2point_system_o)(const real *p, int n, int K, const real *ref_xyz, const int *ids, const real *w, const int *order, double *sys)
+{
+    if (K < 1) K = 1;
+    const FN(p2point_ctx) c = {p, ref_xyz, w, ids, K};
+    FN(tree_sum)((size_t)n * K, K, 30, order, FN(p2point_pair), &c, sys);      /* (slots 15..26 stay +0.0) */
+    return sys[28] > 0 ? ORC_OK : ORC_ERR_NO_MATCH;
+}
 int FN(orc_p2point_system)(const real *p, int n, int K, const real *ref_xyz, const int *ids, const real *w, double *sys)
 {
-    for (int i = 0; i < 30; i++) sys[i] = 0.0;
-    for (int k = 0; k < K; k++)
-    for (int i = 0; i < n; i++) {
-        const size_t e = (size_t)i * K + k;
-        if (w[e] == (real)0 || ids[e] < 0) continue;
-        const real *pp = p + 3 * i, *qq = ref_xyz + 3 * (size_t)ids[e];
-        const double wi = (double)w[e];
-        for (int a = 0; a < 3; a++) { sys[a] += wi * (double)pp[a]; sys[3 + a] += wi * (double)qq[a]; }
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) sys[6 + 3 * a + b] += wi * ((double)qq[a] * (double)pp[b]);
-        const double dx = (double)(real)(pp[0] - qq[0]), dy = (double)(real)(pp[1] - qq[1]), dz = (double)(real)(pp[2] - qq[2]);
-        sys[27] += wi;
-        sys[28] += 1.0;
-        sys[29] += sqrt((dx * dx + dy * dy) + dz * dz);
-    }
-    return sys[28] > 0 ? ORC_OK : ORC_ERR_NO_MATCH;
+    return FN(orc_p2point_system_o)(p, n, K, ref_xyz, ids, w, NULL, sys);
 }
 
 /* cyclic Jacobi eigen-decomposition of a symmetric 6x6 (double) */
@@ -1324,53 +1415,71 @@ int orc_checker_check(orc_checker *c, const double *T)
 
 /* [A.8] PointToPlaneWithCov: Censi closed form on the kept pairs of the last
  * iteration (p = reading moved by the previous T_iter), dT = last increment. */
-static void FN(covariance_k)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm, const int *ids,
-                             const real *w, const double *dT, double sensor_std_dev, double *cov);
+static void FN(covariance_ko)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm, const int *ids,
+                              const real *w, const double *dT, double sensor_std_dev, const int *order, double *cov);
 void FN(orc_covariance)(const real *p, int n, const real *ref_xyz, const real *ref_nrm, const int *ids,
                         const real *w, const double *dT, double sensor_std_dev, double *cov)
 {
-    FN(covariance_k)(p, n, 1, ref_xyz, ref_nrm, ids, w, dT, sensor_std_dev, cov);
+    FN(covariance_ko)(p, n, 1, ref_xyz, ref_nrm, ids, w, dT, sensor_std_dev, NULL, cov);
 }
-static void FN(covariance_k)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm, const int *ids,
-                             const real *w, const double *dT, double sensor_std_dev, double *cov)
+void FN(orc_covariance_o)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm, const int *ids,
+                          const real *w, const double *dT, double sensor_std_dev, const int *order, double *cov)
 {
-    double H[36], G[36];
-    memset(H, 0, sizeof H); memset(G, 0, sizeof G);
-    const double beta = -asin(dT[8]);
-    const double alpha = atan2(dT[9], dT[10]);
-    const double gamma = atan2(dT[4] / cos(beta), dT[0] / cos(beta));
-    const double t_x = dT[3], t_y = dT[7], t_z = dT[11];
-    for (int k = 0; k < K; k++)
-    for (int i = 0; i < n; i++) {
-        const size_t pe = (size_t)i * K + k;
-        if (w[pe] == (real)0 || ids[pe] < 0) continue;
-        const int j = ids[pe];
-        const double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
-        const double qx = ref_xyz[3 * j], qy = ref_xyz[3 * j + 1], qz = ref_xyz[3 * j + 2];
-        const double nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
-        const double rr = sqrt((px * px + py * py) + pz * pz);
-        const double rdx = px / rr, rdy = py / rr, rdz = pz / rr;
-        const double qr = sqrt((qx * qx + qy * qy) + qz * qz);
-        const double qdx = qx / qr, qdy = qy / qr, qdz = qz / qr;
-        const double n_alpha = nz * rdy - ny * rdz;
-        const double n_beta = nx * rdz - nz * rdx;
-        const double n_gamma = ny * rdx - nx * rdy;
-        double E = nx * (px - gamma * py + beta * pz + t_x - qx);
-        E += ny * (gamma * px + py - alpha * pz + t_y - qy);
-        E += nz * (-beta * px + alpha * py + pz + t_z - qz);
-        double Nr = nx * (rdx - gamma * rdy + beta * rdz);
-        Nr += ny * (gamma * rdx + rdy - alpha * rdz);
-        Nr += nz * (-beta * rdx + alpha * rdy + rdz);
-        const double Nq = -((nx * qdx + ny * qdy) + nz * qdz);
-        const double h[6] = {nx, ny, nz, rr * n_alpha, rr * n_beta, rr * n_gamma};
-        const double er = E + rr * Nr;
-        const double gr[6] = {nx * Nr, ny * Nr, nz * Nr, n_alpha * er, n_beta * er, n_gamma * er};
-        const double gq[6] = {nx * Nq, ny * Nq, nz * Nq, qr * n_alpha * Nq, qr * n_beta * Nq, qr * n_gamma * Nq};
+    FN(covariance_ko)(p, n, K > 1 ? K : 1, ref_xyz, ref_nrm, ids, w, dT, sensor_std_dev, order, cov);
+}
+/* one pair's terms: the upper triangles of H (21) and G (21) -- both are symmetric sums of symmetric terms, h[a] h[b] and
+ * gr[a] gr[b] + gq[a] gq[b] are the same doubles either way round -- added through the reduction tree (tree_sum) */
+typedef struct { const real *p, *ref_xyz, *ref_nrm, *w; const int *ids; int K; double alpha, beta, gamma, t_x, t_y, t_z; } FN(cov_ctx);
+static void FN(cov_pair)(const void *vc, size_t pe, double *acc)
+{
+    const FN(cov_ctx) *c = (const FN(cov_ctx) *)vc;
+    if (c->w[pe] == (real)0 || c->ids[pe] < 0) return;
+    const size_t i = pe / (size_t)c->K;
+    const int j = c->ids[pe];
+    const real *p = c->p, *ref_xyz = c->ref_xyz, *ref_nrm = c->ref_nrm;
+    const double alpha = c->alpha, beta = c->beta, gamma = c->gamma, t_x = c->t_x, t_y = c->t_y, t_z = c->t_z;
+    const double px = p[3 * i], py = p[3 * i + 1], pz = p[3 * i + 2];
+    const double qx = ref_xyz[3 * j], qy = ref_xyz[3 * j + 1], qz = ref_xyz[3 * j + 2];
+    const double nx = ref_nrm[3 * j], ny = ref_nrm[3 * j + 1], nz = ref_nrm[3 * j + 2];
+    const double rr = sqrt((px * px + py * py) + pz * pz);
+    const double rdx = px / rr, rdy = py / rr, rdz = pz / rr;
+    const double qr = sqrt((qx * qx + qy * qy) + qz * qz);
+    const double qdx = qx / qr, qdy = qy / qr, qdz = qz / qr;
+    const double n_alpha = nz * rdy - ny * rdz;
+    const double n_beta = nx * rdz - nz * rdx;
+    const double n_gamma = ny * rdx - nx * rdy;
+    double E = nx * (px - gamma * py + beta * pz + t_x - qx);
+    E += ny * (gamma * px + py - alpha * pz + t_y - qy);
+    E += nz * (-beta * px + alpha * py + pz + t_z - qz);
+    double Nr = nx * (rdx - gamma * rdy + beta * rdz);
+    Nr += ny * (gamma * rdx + rdy - alpha * rdz);
+    Nr += nz * (-beta * rdx + alpha * rdy + rdz);
+    const double Nq = -((nx * qdx + ny * qdy) + nz * qdz);
+    const double h[6] = {nx, ny, nz, rr * n_alpha, rr * n_beta, rr * n_gamma};
+    const double er = E + rr * Nr;
+    const double gr[6] = {nx * Nr, ny * Nr, nz * Nr, n_alpha * er, n_beta * er, n_gamma * er};
+    const double gq[6] = {nx * Nq, ny * Nq, nz * Nq, qr * n_alpha * Nq, qr * n_beta * Nq, qr * n_gamma * Nq};
+    int k = 0;
+    for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) {
+            acc[k] += h[a] * h[b];
+            acc[21 + k] += gr[a] * gr[b] + gq[a] * gq[b];
+            k++;
+        }
+}
+static void FN(covariance_ko)(const real *p, int n, int K, const real *ref_xyz, const real *ref_nrm, const int *ids,
+                              const real *w, const double *dT, double sensor_std_dev, const int *order, double *cov)
+{
+    double H[36], G[36], acc[42];
+    FN(cov_ctx) c = {p, ref_xyz, ref_nrm, w, ids, K, 0, 0, 0, dT[3], dT[7], dT[11]};
+    c.beta = -asin(dT[8]);
+    c.alpha = atan2(dT[9], dT[10]);
+    c.gamma = atan2(dT[4] / cos(c.beta), dT[0] / cos(c.beta));
+    FN(tree_sum)((size_t)n * K, K, 42, order, FN(cov_pair), &c, acc);
+    {
+        int k = 0;
         for (int a = 0; a < 6; a++)
-            for (int b = 0; b < 6; b++) {
-                H[a * 6 + b] += h[a] * h[b];
-                G[a * 6 + b] += gr[a] * gr[b] + gq[a] * gq[b];
-            }
+            for (int b = a; b < 6; b++) { H[a * 6 + b] = H[b * 6 + a] = acc[k]; G[a * 6 + b] = G[b * 6 + a] = acc[21 + k]; k++; }
     }
     /* inv(H) by Gauss-Jordan with partial pivoting */
     double M[6][12];
@@ -1443,8 +1552,8 @@ int FN(orc_partial_chain)(const FN(orc_params) *prm, const real *reading, int n,
     if (st == ORC_OK) FN(orc_maxdist_weights)(d2, n * K, prm->outlier_max_dist, w);
     if (st == ORC_OK) {
         double sys[30];
-        st = (prm->minimizer == 1 || prm->minimizer == 3) ? FN(orc_p2point_system)(p, n, K, ref_xyz, ids, w, sys)
-                                 : FN(p2plane_system_k)(p, n, K, ref_xyz, ref_nrm, ids, w, sys);
+        st = (prm->minimizer == 1 || prm->minimizer == 3) ? FN(orc_p2point_system_o)(p, n, K, ref_xyz, ids, w, prm->pair_order, sys)
+                                 : FN(p2plane_system_ko)(p, n, K, ref_xyz, ref_nrm, ids, w, prm->pair_order, sys);
         if (overlap) *overlap = sys[27] / ((double)n * K);
         if (residual) *residual = sys[29];
     }
@@ -1551,11 +1660,11 @@ int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *r
         FN(orc_maxdist_weights)(d2, n * K, prm->outlier_max_dist, w);
         if (use_nrm) FN(orc_normal_weights)(step_n, ref_nrm, ids, n, K, prm->normal_max_angle, w);
         if (prm->minimizer == 1 || prm->minimizer == 3) {
-            status = FN(orc_p2point_system)(step, n, K, ref, ids, w, sys);
+            status = FN(orc_p2point_system_o)(step, n, K, ref, ids, w, prm->pair_order, sys);
             if (status != ORC_OK) break;
             FN(orc_solve_p2point)(sys, dT);
         } else {
-            status = FN(p2plane_system_k)(step, n, K, ref, ref_nrm, ids, w, sys);
+            status = FN(p2plane_system_ko)(step, n, K, ref, ref_nrm, ids, w, prm->pair_order, sys);
             if (status != ORC_OK) break;
             double x[6]; int rank;
             if (prm->minimizer == 2) FN(orc_solve_4dof)(sys, x, &rank);
@@ -1586,7 +1695,7 @@ int FN(orc_icp_map_ex)(const FN(orc_params) *prm, const void *map, const real *r
         /* covariance on the last iteration's error elements (step = T_prev*rd); the point-to-point minimiser has the base
          * class's getCovariance: zeros */
         if (prm->minimizer == 1) memset(res->cov, 0, sizeof res->cov);
-        else FN(covariance_k)(step, n, K, ref, ref_nrm, ids, w, dT, prm->sensor_std_dev, res->cov);
+        else FN(covariance_ko)(step, n, K, ref, ref_nrm, ids, w, dT, prm->sensor_std_dev, prm->pair_order, res->cov);
         double t1[16];
         mat4_mul_chain(T_iter, T_pre, t1);
         mat4_mul_chain(T_ref_mean, t1, T_out);

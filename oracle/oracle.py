@@ -46,7 +46,7 @@ def _params_type(real):
                     ("use_kdtree", C.c_int), ("center_reference", C.c_int), ("outlier_max_dist", real),
                     ("quantile_scale", real), ("knn", C.c_int), ("minimizer", C.c_int), ("bound_max_rot", C.c_double),
                     ("bound_max_trans", C.c_double), ("normal_max_angle", real), ("robust_fct", C.c_int), ("robust_tuning", real),
-                    ("robust_scale", C.c_int), ("robust_approx", real)]
+                    ("robust_scale", C.c_int), ("robust_approx", real), ("pair_order", C.c_void_p)]
     return Params
 
 
@@ -87,12 +87,20 @@ class Oracle:
     def params(self, use_kdtree=True, center_reference=True, **kw):
         d = dict(DEFAULT_CHAIN)
         d.update(kw)
-        return self.Params(d["max_dist"], d["trim_ratio"], d["max_iters"], d["min_diff_rot"],
-                           d["min_diff_trans"], d["smooth_length"], d["sensor_std_dev"],
-                           int(use_kdtree), int(center_reference), d.get("outlier_max_dist", 0.0), d.get("quantile_scale", 1.0),
-                           int(d.get("knn", 1)), int(d.get("error_minimizer", 0)), float(d.get("bound_max_rot", 0.0)),
-                           float(d.get("bound_max_trans", 0.0)), float(d.get("normal_max_angle", 0.0)), int(d.get("robust_fct", 0)),
-                           float(d.get("robust_tuning", 1.0)), int(d.get("robust_scale", 1)), float(d.get("robust_approx", 0.0)))
+        # pair_order: the permutation of the reading's points the reduction tree takes the pairs in (icp_oracle.c "RT-1");
+        # None = scan order.  E.g. the HIP path's sorting order of the same reading (icp.Context.reading_order).
+        order = d.get("pair_order")
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.int32)
+        prm = self.Params(d["max_dist"], d["trim_ratio"], d["max_iters"], d["min_diff_rot"],
+                          d["min_diff_trans"], d["smooth_length"], d["sensor_std_dev"],
+                          int(use_kdtree), int(center_reference), d.get("outlier_max_dist", 0.0), d.get("quantile_scale", 1.0),
+                          int(d.get("knn", 1)), int(d.get("error_minimizer", 0)), float(d.get("bound_max_rot", 0.0)),
+                          float(d.get("bound_max_trans", 0.0)), float(d.get("normal_max_angle", 0.0)), int(d.get("robust_fct", 0)),
+                          float(d.get("robust_tuning", 1.0)), int(d.get("robust_scale", 1)), float(d.get("robust_approx", 0.0)),
+                          order.ctypes.data if order is not None else None)
+        prm._keep_order = order                       # (the structure only holds the address)
+        return prm
 
     # -- stages -----------------------------------------------------------
     def transform(self, T, pts, rotate_only=False):
@@ -182,14 +190,15 @@ class Oracle:
                                       self.real(max_angle), self._p(w))
         return w
 
-    def p2point_system(self, p, ref_xyz, ids, w):
+    def p2point_system(self, p, ref_xyz, ids, w, order=None):
         p, ref_xyz = self._a(p), self._a(ref_xyz)
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         w = np.ascontiguousarray(w, dtype=self.dtype)
         k = 1 if ids.ndim == 1 else ids.shape[1]
         sys_ = np.zeros(30, dtype=np.float64)
-        st = self._f("orc_p2point_system")(self._p(p), C.c_int(p.shape[0]), C.c_int(k), self._p(ref_xyz), self._p(ids), self._p(w),
-                                           self._p(sys_))
+        keep, po = self._order(order)
+        st = self._f("orc_p2point_system_o")(self._p(p), C.c_int(p.shape[0]), C.c_int(k), self._p(ref_xyz), self._p(ids), self._p(w),
+                                             po, self._p(sys_))
         return st, sys_
 
     def solve_p2point(self, sys_):
@@ -217,13 +226,23 @@ class Oracle:
         assert st == 0
         return w, np.dtype(self.dtype).type(limit.value), nf.value
 
-    def p2plane_system(self, p, ref_xyz, ref_nrm, ids, w):
+    @staticmethod
+    def _order(order):
+        """the reduction tree's order (icp_oracle.c "RT-1"): None = scan order, or a permutation of the points"""
+        if order is None:
+            return None, None
+        o = np.ascontiguousarray(order, dtype=np.int32)
+        return o, o.ctypes.data_as(C.c_void_p)
+
+    def p2plane_system(self, p, ref_xyz, ref_nrm, ids, w, order=None):
         p, ref_xyz, ref_nrm = self._a(p), self._a(ref_xyz), self._a(ref_nrm)
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         w = np.ascontiguousarray(w, dtype=self.dtype)
+        k = 1 if ids.ndim == 1 else ids.shape[1]
         sys_ = np.zeros(30, dtype=np.float64)
-        st = self._f("orc_p2plane_system")(self._p(p), C.c_int(p.shape[0]), self._p(ref_xyz), self._p(ref_nrm),
-                                           self._p(ids), self._p(w), self._p(sys_))
+        keep, po = self._order(order)
+        st = self._f("orc_p2plane_system_o")(self._p(p), C.c_int(p.shape[0]), C.c_int(k), self._p(ref_xyz), self._p(ref_nrm),
+                                             self._p(ids), self._p(w), po, self._p(sys_))
         return st, sys_
 
     def solve6(self, sys_):
@@ -239,14 +258,16 @@ class Oracle:
         self._f("orc_delta_T")(self._p(x), self._p(T))
         return T
 
-    def covariance(self, p, ref_xyz, ref_nrm, ids, w, dT, sensor_std_dev):
+    def covariance(self, p, ref_xyz, ref_nrm, ids, w, dT, sensor_std_dev, order=None):
         p, ref_xyz, ref_nrm = self._a(p), self._a(ref_xyz), self._a(ref_nrm)
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         w = np.ascontiguousarray(w, dtype=self.dtype)
         dT = np.ascontiguousarray(dT, dtype=np.float64)
+        k = 1 if ids.ndim == 1 else ids.shape[1]
         cov = np.zeros((6, 6))
-        self._f("orc_covariance")(self._p(p), C.c_int(p.shape[0]), self._p(ref_xyz), self._p(ref_nrm), self._p(ids),
-                                  self._p(w), self._p(dT), C.c_double(sensor_std_dev), self._p(cov))
+        keep, po = self._order(order)
+        self._f("orc_covariance_o")(self._p(p), C.c_int(p.shape[0]), C.c_int(k), self._p(ref_xyz), self._p(ref_nrm), self._p(ids),
+                                    self._p(w), self._p(dT), C.c_double(sensor_std_dev), po, self._p(cov))
         return cov
 
     def knn_k(self, ref, q, k, max_dist=np.inf):
