@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PGICP_ABI_VERSION 5
+#define PGICP_ABI_VERSION 6
 
 /* status codes (pgslam sees PM::ConvergenceError for 1, 2 and 7 through the C++ shim) */
 #define PGICP_OK 0
@@ -111,7 +111,20 @@ typedef struct pgicp_params {
     double robust_tuning;    /* tuning (default 1) */
     int robust_scale;        /* scaleEstimator: PGICP_ROBUST_SCALE_NONE | PGICP_ROBUST_SCALE_MAD (default: mad) */
     double robust_approx;    /* approximation: pairs with dist / scale^2 >= approximation^2 get weight 0; 0 or +inf = none */
+    /* (ABI 6) The order the pairs enter the reduction tree in.  Every sum over pairs that feeds a result -- the normal
+     * equations, the residual, the covariance sums -- is added in ONE stated tree (DESIGN.md section 2 "RT-1", restated in
+     * oracle/icp_oracle.c): blocks of 2048 pair positions, 256 accumulators a block, a shuffle-down fold, eight block chains.
+     * Double addition is not associative, so WHICH pair sits at which position decides the last bits of T, cov and residual:
+     *   PGICP_SUM_ORDER_SORTED  (default) positions follow the order the library sorts a reading in for its matcher (by map
+     *                           cell): the reduce kernels read everything coalesced.  The order of a call can be read back
+     *                           (pgicp_debug_reading_order); results are reproducible run to run, but a function of the map's grid.
+     *   PGICP_SUM_ORDER_SCAN    positions follow the caller's reading: results are a function of the inputs alone, bit for bit
+     *                           what a scan-order walk of the same tree gives on any implementation; the reduce kernels then
+     *                           gather (costs: DESIGN.md section 5). */
+    int sum_order;
 } pgicp_params;
+#define PGICP_SUM_ORDER_SORTED 0
+#define PGICP_SUM_ORDER_SCAN 1
 
 /* What pgslam reads back after an ICP: errorMinimizer->getOverlap()
  * (Localizer.hpp:278, LoopCloser.hpp:331), getCovariance() (Localizer.hpp:238,
@@ -470,6 +483,11 @@ int pgicp_debug_alloc_stats(long long out[8]);
  * upper bound and lies beyond the trim threshold).  Kept pairs carry exact ids and distances. */
 int pgicp_debug_last_matches_f32(pgicp_ctx *ctx, int problem, int32_t *ids, float *dist2);
 int pgicp_debug_last_matches_f64(pgicp_ctx *ctx, int problem, int32_t *ids, double *dist2);
+/* (ABI 6) Diagnostics: the permutation problem `problem` of the last align / partial-chain call sorted its reading by --
+ * order[j] = index (in the caller's reading) of the point at sorted position j; n entries.  With PGICP_SUM_ORDER_SORTED this
+ * is the order the pairs entered the reduction tree in: hand it to the oracle (orc_params.pair_order) and the whole ICP
+ * compares bit for bit (tests/test_gpu_bit_exact.py). */
+int pgicp_debug_reading_order(pgicp_ctx *ctx, int problem, int32_t *order);
 int pgicp_profile_enable(pgicp_ctx *ctx, int on);
 int pgicp_profile_reset(pgicp_ctx *ctx);
 int pgicp_profile_get(pgicp_ctx *ctx, int kernel_id, long long *launches, double *total_ms,

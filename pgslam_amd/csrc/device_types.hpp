@@ -95,6 +95,10 @@ struct ChainDev {
     T normal_cos;        // SurfaceNormalOutlierFilter: cos(maxAngle) evaluated in T on the host
     int use_normals;     // ... and whether it is in the chain
     RobustDev<T> robust; // RobustOutlierFilter (the chain's distance filter then: no quantile filter beside it)
+    // (ABI 6, per call rather than per chain) PGICP_SUM_ORDER_SCAN: sorted position of every reading point of the batch -- the
+    // inverse of the reading sort, indexed like the per-point arrays -- so that the reduce kernels can walk the pairs in the
+    // caller's order; null: they walk the sorted order
+    const int *scan_pos;
 };
 
 // One ICP problem of a batch.  Lives in device memory; written by the solve

@@ -53,6 +53,7 @@ template <typename T>
 int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m, int knn, T max_dist, T eps_rank, T *out_nrm,
                            int out_stride, T *out_eig, int *out_ids, T *out_d2);
 int reduce_blocks(int max_n);
+void launch_invert_order(hipStream_t st, const ProblemDev *probs, const int *order, int *scan_pos, int P, int max_n);
 template <typename T>
 void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const T *rd_nrm, const int *slot,
                    const T *d2, double *partials, int P, int max_n, const int *active, const ChainDev<T> &ch);

@@ -119,6 +119,7 @@ struct pgicp_ctx {
     State<float> f32;
     State<double> f64;
     DevBuf probs, src, partials, sums, sums2, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_w, tmp_p, tmp_n;
+    DevBuf scan_pos;                // PGICP_SUM_ORDER_SCAN: the inverse of `order` (sorted position of every reading point)
     DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active, sel_tables, queue;
     // host-input pipeline (pgicp_upload_*): a copy stream and two upload sets used alternately
     struct UploadSet {
@@ -362,6 +363,17 @@ ChainDev<T> make_chain(const pgicp_params &p)
     ch.bound_trans = (p.bound_max_trans > 0.0 && std::isfinite(p.bound_max_trans)) ? p.bound_max_trans : 0.0;
     ch.use_normals = p.normal_max_angle > 0.0 ? 1 : 0;
     ch.normal_cos = std::cos((T)p.normal_max_angle);          // in T, as the filter evaluates `cos(maxAngle)`
+    ch.scan_pos = nullptr;                                     // (set by chain_of: it names a buffer of the context)
+    return ch;
+}
+
+// the chain of a call that has sorted its readings (begin_batch): with PGICP_SUM_ORDER_SCAN the reduce kernels are handed the
+// inverse of that sort (pgicp_ctx::scan_pos, filled by begin_batch)
+template <typename T>
+ChainDev<T> chain_of(pgicp_ctx *c, const pgicp_params &p)
+{
+    ChainDev<T> ch = make_chain<T>(p);
+    ch.scan_pos = p.sum_order == PGICP_SUM_ORDER_SCAN ? c->scan_pos.as<int>() : nullptr;
     return ch;
 }
 
@@ -921,6 +933,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         HIPC(c, c->qtmp.ensure(std::max(sizeof(unsigned long long) * (size_t)L.total, sizeof(T) * (size_t)L.total * L.knn)));
         if (c->prm.robust_fct != PGICP_ROBUST_NONE) HIPC(c, c->robust_dev.ensure(sizeof(T) * (size_t)L.total * L.knn));
         HIPC(c, c->order.ensure(sizeof(int) * (size_t)L.total));
+        if (c->prm.sum_order == PGICP_SUM_ORDER_SCAN) HIPC(c, c->scan_pos.ensure(sizeof(int) * (size_t)L.total));
         HIPC(c, c->slow_list.ensure(sizeof(int2) * (size_t)L.total));
         HIPC(c, c->slow_lb.ensure(sizeof(T) * (size_t)L.total));
         HIPC(c, c->slow_ring.ensure(sizeof(int) * (size_t)L.total));
@@ -998,6 +1011,8 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
                              c->order.as<int>(), c->qcounts.as<int>(), c->qblock.as<int>(), c->qstart.as<int>(),
                              P, L.max_n, L.max_rows, L.bin_shift, L.normals ? S.nrm_pre.template as<typename Vec4<T>::type>() : nullptr,
                              L.normals ? S.nrm_sorted.template as<T>() : nullptr);
+        if (c->prm.sum_order == PGICP_SUM_ORDER_SCAN)
+            launch_invert_order(c->stream, c->probs.as<ProblemDev>(), c->order.as<int>(), c->scan_pos.as<int>(), P, L.max_n);
         upload_consumed(c, up_mask);                 // its first kernel is the only one that reads the readings where they lie
         c->up_seen = 0;
     }
@@ -1254,7 +1269,7 @@ int align_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *T_out, pgi
     long long total_m = 0;                       // (profile only) reference points over the batch's problems
     if (c->prof_on) for (int p = 0; p < P; p++) total_m += get_map<T>(c, pr[p].map_id)->m;
     const auto ht1 = std::chrono::steady_clock::now();
-    const ChainDev<T> ch = make_chain<T>(prm);
+    const ChainDev<T> ch = chain_of<T>(c, prm);
     const int every = std::max(1, prm.check_every);
     // active-problem accounting for the profile: exact when check_every == 1 and all
     // readings have the same size (the benchmark's case), an upper bound otherwise
@@ -1406,7 +1421,7 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
     }, L, hp);
     if (st) return st;
     State<T> &S = state<T>(c);
-    const ChainDev<T> ch = make_chain<T>(c->prm);
+    const ChainDev<T> ch = chain_of<T>(c, c->prm);
     const MapDev<T> *maps = S.d_maps.template as<MapDev<T>>();
     ProblemDev *probs = c->probs.as<ProblemDev>();
     if (L.knn > 1) {
@@ -1481,7 +1496,7 @@ int partial_chain_batch(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ra
         mat4_mul(Tm_inv, pr[p].T_init, Tpre);
     }, L, hp, 1);
     if (st) return st;
-    const ChainDev<T> ch = make_chain<T>(c->prm);
+    const ChainDev<T> ch = chain_of<T>(c, c->prm);
     c->sel_guess_first = hints_cover_first(hp) ? 1 : 0;
     one_iteration<T>(c, L, ch, false, L.total, P, 0);
     c->sel_guess_first = 0;
@@ -2094,6 +2109,7 @@ void pgicp_default_params(pgicp_params *p)
     p->check_every = 1;
     p->error_minimizer = PGICP_MINIMIZER_POINT_TO_PLANE;
     p->robust_fct = PGICP_ROBUST_NONE; p->robust_tuning = 1.0; p->robust_scale = PGICP_ROBUST_SCALE_MAD; p->robust_approx = 0.0;
+    p->sum_order = PGICP_SUM_ORDER_SORTED;
     p->bound_max_rot = 0.0;
     p->bound_max_trans = 0.0;
     p->normal_max_angle = 0.0;
@@ -2198,7 +2214,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
                       &c->probs, &c->src, &c->partials, &c->sums, &c->sums2, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e, &c->tmp_w, &c->tmp_p, &c->tmp_n,
-                      &c->f32.rd_sorted, &c->f64.rd_sorted, &c->f32.nrm_pre, &c->f32.nrm_sorted, &c->f64.nrm_pre, &c->f64.nrm_sorted, &c->qrow, &c->qtmp, &c->order, &c->qcounts, &c->qblock, &c->qstart,
+                      &c->f32.rd_sorted, &c->f64.rd_sorted, &c->f32.nrm_pre, &c->f32.nrm_sorted, &c->f64.nrm_pre, &c->f64.nrm_sorted, &c->qrow, &c->qtmp, &c->order, &c->scan_pos, &c->qcounts, &c->qblock, &c->qstart,
                       &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->sel_tables, &c->queue, &c->f32.none_r, &c->f64.none_r})
         b->release();
     if (c->h_pinned) (void)t_host_free(c->h_pinned);
@@ -2316,6 +2332,7 @@ int pgicp_set_params(pgicp_ctx *c, const pgicp_params *p)
         return fail(c, PGICP_ERR_ARG, "DifferentialTransformationChecker.smoothLength must be in [1,15]");
     if (p->matcher != PGICP_MATCHER_GRID && p->matcher != PGICP_MATCHER_BRUTE) return fail(c, PGICP_ERR_ARG, "unknown matcher");
     if (p->grid_cell < 0.0) return fail(c, PGICP_ERR_ARG, "grid_cell must be >= 0");
+    if (p->sum_order != PGICP_SUM_ORDER_SORTED && p->sum_order != PGICP_SUM_ORDER_SCAN) return fail(c, PGICP_ERR_ARG, "sum_order must be PGICP_SUM_ORDER_SORTED or PGICP_SUM_ORDER_SCAN");
     if (p->robust_fct < PGICP_ROBUST_NONE || p->robust_fct > PGICP_ROBUST_L1 || (p->robust_scale != PGICP_ROBUST_SCALE_NONE && p->robust_scale != PGICP_ROBUST_SCALE_MAD) ||
         (p->robust_fct != PGICP_ROBUST_NONE && !(p->robust_tuning > 0.0)) || p->robust_approx < 0.0 || p->robust_approx != p->robust_approx)
         return fail(c, PGICP_ERR_ARG, "RobustOutlierFilter: unknown robustFct / scaleEstimator, or tuning <= 0, or approximation < 0");
@@ -2588,6 +2605,17 @@ int pgicp_debug_counters(pgicp_ctx *c, int out[4])
 int pgicp_debug_dump_setup(long long total, int passes) { return knn_dump_setup(total, passes); }
 int pgicp_debug_dump_read(unsigned *cnt, float *d2, long long n) { return knn_dump_read(cnt, d2, n); }
 
+int pgicp_debug_reading_order(pgicp_ctx *c, int problem, int32_t *order)
+{
+    if (!c || problem < 0 || !order) return PGICP_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    ProblemDev D;
+    HIPC(c, hipMemcpy(&D, c->probs.as<ProblemDev>() + problem, sizeof D, hipMemcpyDeviceToHost));
+    if (D.n <= 0 || !c->order.p) return fail(c, PGICP_ERR_ARG, "pgicp_debug_reading_order: no reading was sorted for this problem");
+    XFER(c, d2h(c, order, c->order.as<int>() + D.off, sizeof(int) * (size_t)D.n));
+    HIPC(c, stream_sync(c));
+    return PGICP_OK;
+}
 int pgicp_debug_last_matches_f32(pgicp_ctx *c, int problem, int32_t *ids, float *dist2) { return debug_last_matches<float>(c, problem, ids, dist2); }
 int pgicp_debug_last_matches_f64(pgicp_ctx *c, int problem, int32_t *ids, double *dist2) { return debug_last_matches<double>(c, problem, ids, dist2); }
 

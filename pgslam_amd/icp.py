@@ -50,7 +50,9 @@ ABI_SYMBOLS = [
     "pgicp_status_string", "pgicp_upload_f32", "pgicp_upload_f64", "pgicp_host_alloc", "pgicp_host_free",
     "pgicp_ctx_device", "pgicp_comm_unique_id", "pgicp_comm_create", "pgicp_comm_destroy", "pgicp_comm_info",
     "pgicp_comm_last_error", "pgicp_shard_slots", "pgicp_allgather_edges", "pgicp_comm_create_host", "pgicp_profile_process",
+    "pgicp_debug_reading_order",
 ]
+SUM_ORDER_SORTED, SUM_ORDER_SCAN = 0, 1
 
 
 class Params(C.Structure):
@@ -60,7 +62,7 @@ class Params(C.Structure):
                 ("grid_cell", C.c_double), ("check_every", C.c_int), ("outlier_max_dist", C.c_double),
                 ("quantile_scale", C.c_double), ("error_minimizer", C.c_int), ("bound_max_rot", C.c_double),
                 ("bound_max_trans", C.c_double), ("normal_max_angle", C.c_double), ("robust_fct", C.c_int), ("robust_tuning", C.c_double),
-                ("robust_scale", C.c_int), ("robust_approx", C.c_double)]
+                ("robust_scale", C.c_int), ("robust_approx", C.c_double), ("sum_order", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -740,6 +742,13 @@ class Context:
         fn = getattr(self.lib, "pgicp_debug_last_matches" + self._sfx(dtype))
         self._check(fn(self.h, C.c_int(problem), C.c_void_p(ids.ctypes.data), C.c_void_p(d2.ctypes.data)))
         return ids, d2
+
+    def reading_order(self, n, problem=0):
+        """pgicp_debug_reading_order: order[j] = index, in the caller's reading, of the point the last call sorted to position j --
+        with sum_order = SUM_ORDER_SORTED the order the pairs entered the reduction tree in (hand it to the oracle as pair_order)."""
+        out = np.empty(n, dtype=np.int32)
+        self._check(self.lib.pgicp_debug_reading_order(self.h, C.c_int(problem), C.c_void_p(out.ctypes.data)))
+        return out
 
     def profile_reset(self):
         self._check(self.lib.pgicp_profile_reset(self.h))

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_sizes():
     lib = icp.load_library()
-    assert lib.pgicp_abi_version() == 5
+    assert lib.pgicp_abi_version() == 6
     assert ctypes.sizeof(icp.Edge) == 512
     p = icp.Params()
     lib.pgicp_default_params(ctypes.byref(p))
@@ -115,6 +115,6 @@ def test_header_is_plain_c99_and_its_records_are_the_bindings(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
     assert out.returncode == 0, out.stderr
     abi, knn, s_params, s_stats, s_problem, s_edge, s_filter = (int(v) for v in out.stdout.split())
-    assert abi == 5 and knn == 1
+    assert abi == 6 and knn == 1
     assert (s_params, s_stats, s_problem, s_edge, s_filter) == (C.sizeof(icp.Params), C.sizeof(icp.Stats), C.sizeof(icp.Problem), C.sizeof(icp.Edge),
                                                                 C.sizeof(icp.Filter))
