@@ -1313,6 +1313,9 @@ def main():
                          "pass this for a kernel trace that should hold only the metric's launches")
     ap.add_argument("--with-fixed30", action="store_true", help="(the default now; kept so that older command lines still parse)")
     ap.add_argument("--matcher", choices=["grid", "brute"], default="grid")
+    ap.add_argument("--sum-order", choices=["sorted", "scan"], default="sorted",
+                    help="pgicp_params.sum_order: the order the pairs enter the reduction tree in (sorted: the library's sorting order of "
+                         "the reading, all loads coalesced -- the default; scan: the caller's reading order, results a function of the inputs alone)")
     ap.add_argument("--grid-cell", type=float, default=0.0)
     ap.add_argument("--check-every", type=int, default=1,
                     help="the host looks at the device-side convergence flag every this many iterations (results do not depend on it; "
@@ -1398,6 +1401,8 @@ def main():
         w = build_workload(args.n_scan, args.n_map, args.queries)
 
     chain = dict(CHAIN)
+    if args.sum_order == "scan":
+        chain["sum_order"] = 1
     if args.fixed_iters:
         chain.update(min_diff_rot=0.0, min_diff_trans=0.0)
     S = max(1, args.streams)

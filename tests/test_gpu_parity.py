@@ -311,11 +311,20 @@ def test_full_size_icp_parity_and_properties(ctx, oracle32, full_size):
     om = oracle32.map_create(w.map_xyz, w.map_nrm)
     Ts, sts = ctx.align_batch(mid, w.scans_xyz[:4], w.T_init[:4])
     for b in range(4):
-        o = oracle32.icp_map(om, w.scans_xyz[b], w.T_init[b], **CHAIN)
+        # round 6: the pairs enter ONE reduction tree in ONE order on both sides (the device's sorting order, read back):
+        # T_out, cov, residual, overlap of a 100 k x 1 M ICP are the oracle's doubles, bit for bit
+        o = oracle32.icp_map(om, w.scans_xyz[b], w.T_init[b], pair_order=ctx.reading_order(len(w.scans_xyz[b]), problem=b), **CHAIN)
         dt, dr = pose_error(o["T"], Ts[b])
         assert dt < TOL_TRANS and dr < TOL_ROT, (b, dt, dr)
         assert sts[b]["iterations"] == o["iterations"] and sts[b]["converged"] == o["converged"]
-        assert sts[b]["overlap"] == pytest.approx(o["overlap"], rel=1e-12)
+        assert np.array_equal(Ts[b], o["T"]), (b, np.abs(Ts[b] - o["T"]).max())
+        assert np.array_equal(np.asarray(sts[b]["cov"]).reshape(6, 6), o["cov"]) and sts[b]["residual"] == o["residual"] and sts[b]["overlap"] == o["overlap"]
+    # ... and in scan order (sum_order = SCAN): a function of the inputs alone
+    ctx.set_params(sum_order=icp.SUM_ORDER_SCAN)
+    T_s, st_s = ctx.align(mid, w.scans_xyz[1], w.T_init[1])
+    o = oracle32.icp_map(om, w.scans_xyz[1], w.T_init[1], **CHAIN)
+    assert np.array_equal(T_s, o["T"]) and st_s["residual"] == o["residual"] and st_s["iterations"] == o["iterations"]
+    ctx.set_params(sum_order=icp.SUM_ORDER_SORTED)
     oracle32.map_free(om)
     # size-independent properties: (1) a converged result is a fixed point up to the stop criterion:
     # restarting from it stops after smoothLength iterations and moves less than minDiffTransErr /
