@@ -374,7 +374,8 @@ class Oracle:
                                     self._p(T_out), C.byref(res), None, C.c_int(0),
                                     self._p(ids) if want_last else None, self._p(d2) if want_last else None)
         out = dict(status=st, T=T_out, iterations=res.iterations, converged=bool(res.converged),
-                   max_iter_reached=bool(res.max_iter_reached), overlap=res.overlap, residual=res.residual)
+                   max_iter_reached=bool(res.max_iter_reached), overlap=res.overlap, residual=res.residual,
+                   trim_limit=res.trim_limit, n_kept=res.n_kept, n_finite=res.n_finite, cov=np.array(res.cov[:]).reshape(6, 6))
         if want_last:
             out.update(last_ids=ids, last_d2=d2)
         return out
