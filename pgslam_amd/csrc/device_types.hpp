@@ -29,8 +29,19 @@ struct MapDev {
     const typename Vec4<T>::type *pts;   // (x, y, z, bit-cast original index) cell-sorted, centred
     const typename Vec4<T>::type *nrm;   // the minimiser's records, same order: entry 2 s = the point again, 2 s + 1 = (nx, ny, nz, 0) -- one
                                          // 32-byte gather per pair instead of two 16-byte ones from two arrays; may be null
-    const int *cell_start;               // ncells + 1 exclusive prefix sums
-    const int *cell_start_f;             // the same prefix sums on cells kx times finer in x (== cell_start when kx == 1)
+    const int *cell_start;               // ncells + 1 exclusive prefix sums                       } the DENSE tables; both null when
+    const int *cell_start_f;             // the same prefix sums on cells kx times finer in x      } the map carries the succinct one
+                                         // (== cell_start when kx == 1)
+    // The SUCCINCT fine table (round 6; a map carries the dense tables or this one).  A range scan fills a fraction of a per
+    // cent of its fine cells (a 100 k-pt keyframe map: 2.8 M fine cells, 19 k of them occupied; the dense table is 11 MB a
+    // map -- seven times the points -- and 5.7 GB written per 512-pair loop-closure batch).  Per 64 fine cells one 16-byte word
+    // {occupancy mask (64 bits), rank = occupied fine cells of the BATCH before the group, 0}; per occupied fine cell the slot
+    // of its first point (`ostart`, ranks run over the maps of one batched build like the slots do; one sentinel entry).
+    //   start(f) = ostart[word[f >> 6].rank + popcount(word[f >> 6].mask & below(f & 63))]       (tab_fine, kernels.hip)
+    // Two dependent loads where the dense table has one -- but 20x fewer bytes, an empty range is recognised from the words
+    // alone, and the build writes 16 bytes where it wrote 256.
+    const uint4 *sw;                     // the words of this map (group g of its fine cells = sw[g]); null: dense tables
+    const int *ostart;                   // shared by the maps of one batched build (indexed by rank)
     int kx;                              // points of a cell are ordered by fine x cell, so fine ranges are contiguous too
     const int *sc_count;                 // occupancy flag per 8x8x8 super-cell
     const int *sc_dist;                  // Chebyshev distance (in super-cells, capped at kScReach + 1) to the nearest occupied one
@@ -61,6 +72,7 @@ struct BuildDesc {
     GridDesc<T> g;
     long long pbase, cbase, sbase, fbase;   // fbase: offset of this cloud's FINE cells (+1 sentinel) in the fine table
     long long obase;                        // offset (32-bit words) of this cloud's occupancy bits
+    long long wbase;                        // offset (16-byte words) of this cloud's succinct table (MapDev::sw)
     long long bbase;                        // offset of this cloud's BINS (512 fine cells each) in the build's counting sort
     int ncells, nsc, kx, ncells_f, nbins;
 };

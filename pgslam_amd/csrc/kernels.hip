@@ -125,6 +125,52 @@ __device__ __forceinline__ int load_tab(const int *p, int i)
     return as_global(p)[i];
 }
 
+// ---- the cell tables of a map, dense or succinct (MapDev::sw) ----------------------------------------------------------
+// occupied fine cells before cell k (0 .. 63) of a group, batch-wide: the word's rank + the mask bits below k
+__device__ __forceinline__ int succ_rank(const uint4 w, int k)
+{
+    const unsigned long long m = ((unsigned long long)w.y << 32) | w.x;
+    return (int)w.z + __popcll(m & ((1ULL << k) - 1ULL));
+}
+__device__ __forceinline__ uint4 load_word(const uint4 *sw, int g)
+{
+    typedef unsigned U4 __attribute__((ext_vector_type(4)));
+    const U4 r = as_global(reinterpret_cast<const U4 *>(sw))[g];
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+// slot of the first point whose fine cell is >= f  (f = 0 .. ncells_f, the sentinel included)
+template <bool SUCC, typename T>
+__device__ __forceinline__ int tab_fine(const MapDev<T> &M, int f)
+{
+    if constexpr (SUCC) return load_tab(M.ostart, succ_rank(load_word(M.sw, f >> 6), f & 63));
+    else return load_tab(M.cell_start_f, f);
+}
+// [a, b) = the points of fine cells [ia, ib): both table entries requested together; an EMPTY range costs the succinct
+// table no second round trip (equal ranks) and comes back as a = b = 0
+template <bool SUCC, typename T>
+__device__ __forceinline__ void tab_range(const MapDev<T> &M, int ia, int ib, int &a, int &b)
+{
+    if constexpr (SUCC) {
+        const uint4 wa = load_word(M.sw, ia >> 6), wb = load_word(M.sw, ib >> 6);
+        const int ra = succ_rank(wa, ia & 63), rb = succ_rank(wb, ib & 63);
+        a = 0; b = 0;
+        if (ra != rb) { a = load_tab(M.ostart, ra); b = load_tab(M.ostart, rb); }
+    } else { a = load_tab(M.cell_start_f, ia); b = load_tab(M.cell_start_f, ib); }
+}
+// the kernels that are not instantiated per table kind ask the map
+template <typename T> __device__ __forceinline__ int tab_fine_any(const MapDev<T> &M, int f) { return M.sw ? tab_fine<true, T>(M, f) : tab_fine<false, T>(M, f); }
+template <typename T> __device__ __forceinline__ void tab_range_any(const MapDev<T> &M, int ia, int ib, int &a, int &b)
+{
+    if (M.sw) tab_range<true, T>(M, ia, ib, a, b); else tab_range<false, T>(M, ia, ib, a, b);
+}
+// TK: 0 dense, 1 succinct (the kernel is instantiated per table kind), 2 ask the map
+template <int TK, typename T> __device__ __forceinline__ void tab_range_k(const MapDev<T> &M, int ia, int ib, int &a, int &b)
+{
+    if constexpr (TK == 2) tab_range_any<T>(M, ia, ib, a, b); else tab_range<TK == 1, T>(M, ia, ib, a, b);
+}
+// the points of SEARCH cell c (coarse: kx fine cells): [tab_coarse(c), tab_coarse(c + 1))
+template <typename T> __device__ __forceinline__ int tab_coarse_any(const MapDev<T> &M, int c) { return M.sw ? tab_fine<true, T>(M, c * M.kx) : load_tab(M.cell_start, c); }
+
 // The per-PAIR arrays (slot, d2, the selection's keys): knn entries per reading point, [point][neighbour]
 __device__ __forceinline__ int pairs_n(const ProblemDev &P) { return P.n * P.knn; }
 __device__ __forceinline__ long long pairs_off(const ProblemDev &P) { return P.off * P.knn; }

@@ -12,7 +12,8 @@ void launch_grid_build_batch(hipStream_t st, const BuildDesc<T> *descs, int n, l
                              int *cell_start, int *cell_start_f, int *bins_b, int *arrival, unsigned long long *words,
                              typename Vec4<T>::type *cpts, typename Vec4<T>::type *cnrm,
                              typename Vec4<T>::type *pts, typename Vec4<T>::type *nrm_out,
-                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit, unsigned *occ, long long tot_o, float *sc_ext, float *ptsf);
+                             int *slot_of, int *sc_count, int *near, int *sc_dist, int *sc_wit, unsigned *occ, long long tot_o, float *sc_ext, float *ptsf,
+                             uint4 *sw, int *ostart, int *flag_scratch, int *rank_scratch);
 template <typename T>
 void launch_query_sort(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, const MapDev<T> *maps, typename Vec4<T>::type *rd_pre, T *rd_sorted,
                        int *qkey, unsigned long long *qtmp, int *order, int *counts, int *block_sums, int *qstart, int P,
@@ -26,7 +27,8 @@ void launch_transform(hipStream_t st, const T *in, int in_stride, T *out, int ou
 template <typename T>
 void launch_knn(hipStream_t st, int matcher, const ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot,
                 T *d2, const ChainDev<T> &ch, int P, int max_n, int use_seed, int *slow_count, int2 *slow_list, T *slow_lb,
-                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf, int clear_queue_counters);
+                int *slow_ring, int fast_rings, const int *active, T *none_r, int n_problems, void *queue_buf, int clear_queue_counters,
+                int table_kinds);
 size_t knn_queue_bytes(int n_problems, int max_n, size_t elem);
 template <typename T>
 void launch_knn_med(hipStream_t st, ProblemDev *probs, const MapDev<T> *maps, const T *rd, int *slot, T *d2,

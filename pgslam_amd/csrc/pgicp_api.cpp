@@ -75,6 +75,8 @@ struct MapHost {
     typename Vec4<T>::type *nrm = nullptr;
     int *cell_start = nullptr;
     int *cell_start_f = nullptr;
+    uint4 *sw = nullptr;            // MapDev::sw / ostart: the succinct table (then cell_start / cell_start_f are null)
+    int *ostart = nullptr;
     int kx = 1;
     int *slot_of = nullptr;
     bool slot_of_made = false;      // (filled on first use: error_stats)
@@ -118,7 +120,7 @@ struct pgicp_ctx {
     pgicp_params prm{};
     State<float> f32;
     State<double> f64;
-    DevBuf probs, src, partials, sums, sums2, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_w, tmp_p, tmp_n;
+    DevBuf probs, src, partials, sums, sums2, small, stats, bdesc, tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f, tmp_r, tmp_w, tmp_p, tmp_n;
     DevBuf scan_pos;                // PGICP_SUM_ORDER_SCAN: the inverse of `order` (sorted position of every reading point)
     DevBuf qrow, qtmp, order, qcounts, qblock, qstart, qcursor, slow_list, slow_lb, slow_ring, slow2, active, sel_tables, queue;
     // host-input pipeline (pgicp_upload_*): a copy stream and two upload sets used alternately
@@ -186,6 +188,8 @@ struct pgicp_ctx {
     int fast_rings_seeded = 0, fast_rings_unseeded = 0;      // 0: by the maps' cell size (BatchLayout::rings_*); PGICP_FAST_RINGS_* set them
     double cell_scale = 1.0;     // experiment knob PGICP_CELL_SCALE: the automatic grid cell times this
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
+    int table_mode = 0;             // the cell tables a map is built with: 0 auto (PGICP_TABLE_AUTO_*, map_create_batch), 1 dense, 2 succinct
+                                    // (MapDev::sw); PGICP_TABLES=auto|dense|succinct
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
     int bin_shift_add = 0;          // experiment knob PGICP_BIN_SHIFT_ADD: coarser (+) or finer (-) bins of the reading sort
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
@@ -527,7 +531,7 @@ int sync_maps_table(pgicp_ctx *c)
     for (int i = 0; i < n; i++) {
         const MapHost<T> &m = S.maps[i];
         h[i].pts = m.pts; h[i].nrm = m.nrm; h[i].ptsf = m.ptsf; h[i].cell_start = m.cell_start; h[i].g = m.g; h[i].m = m.used ? m.m : 0;
-        h[i].cell_start_f = m.cell_start_f; h[i].kx = m.kx;
+        h[i].cell_start_f = m.cell_start_f; h[i].kx = m.kx; h[i].sw = m.sw; h[i].ostart = m.ostart;
         h[i].sc_count = m.sc_count;
         h[i].slot_of = m.slot_of;
         h[i].near = m.near;
@@ -703,7 +707,13 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
 
     // ---- phase 2: grids; every cloud gets its slice of ONE allocation and ONE set of build launches ----
     std::vector<MapHost<T>> Ms(n);
-    long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0, tot_o = 0, tot_b = 0;
+    long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0, tot_o = 0, tot_b = 0, tot_w = 0;
+    // The succinct table (MapDev::sw) for the maps of a BATCHED build -- the candidate maps of a loop-closure batch: hundreds of
+    // maps whose dense tables (11 MB each at 100 k points, seven times the points) neither fit a cache nor are cheap to write --
+    // the dense tables for a map built alone (the localizer's: one map, its tables 95 % L1 hits under spatially sorted queries,
+    // and a VALU-bound matcher that has no instructions to spare for ranks).  PGICP_TABLES overrides (measured both ways:
+    // profiles/r06_experiments/succinct_tables.txt).
+    const bool succ = c->table_mode == 2 || (c->table_mode == 0 && n > 1);
     int max_cells = 0, max_nsc = 0, max_bins = 0, max_blocks = 0;
     const int kx = std::max(1, std::min(8, c->grid_kx));
     bool any_nrm = false;
@@ -756,7 +766,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         for (int a = 0; a < 3; a++) d.mean[a] = M.mean[a];
         d.ncells = g.nx * g.ny * g.nz;
         d.nsc = ((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3);
-        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s; d.fbase = tot_f; d.obase = tot_o; d.bbase = tot_b;
+        d.pbase = tot_m; d.cbase = tot_c; d.sbase = tot_s; d.fbase = tot_f; d.obase = tot_o; d.bbase = tot_b; d.wbase = tot_w;
         d.kx = kx; d.ncells_f = d.ncells * kx;
         d.nbins = (d.ncells_f >> 9) + 1;                 // bins of the build's counting sort: 512 fine cells (kMapBinShift), sentinel included
         M.kx = kx;
@@ -767,6 +777,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         tot_f += ((long long)d.ncells_f + 1 + 3) & ~3LL;     // (every cloud's fine table starts on a 16-byte boundary: k_mfill stores four entries at a time)
         tot_o += (long long)(d.ncells >> 5) + 2;         // (a range test reads one word past the last cell's)
         tot_b += d.nbins;
+        tot_w += (long long)(d.ncells_f >> 6) + 2;       // (the sentinel cell's group, and one to spare)
         max_cells = std::max(max_cells, d.ncells);
         max_bins = std::max(max_bins, d.nbins);
         max_nsc = std::max(max_nsc, d.nsc);
@@ -783,18 +794,24 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     const size_t n_scratch = (size_t)std::max(tot_b + 2, tot_c);
     HIPC(c, c->tmp_a.ensure(sizeof(int) * (size_t)tot_m));                               // fine-cell keys: by point, then by slot
     HIPC(c, c->tmp_b.ensure(sizeof(int) * n_scratch));                                   // bin counts, then sweep scratch
-    HIPC(c, c->tmp_c.ensure(sizeof(int) * ((size_t)(tot_b + 1) / kScanChunkHost + 2)));  // the scan's block sums
+    HIPC(c, c->tmp_c.ensure(sizeof(int) * ((size_t)std::max(tot_b + 1, succ ? tot_m + 1 : 0LL) / kScanChunkHost + 2)));  // the scans' block sums
+    if (succ) {                                                                           // first-of-cell flags, and their ranks
+        HIPC(c, c->tmp_f.ensure(sizeof(int) * (size_t)(tot_m + 1)));
+        HIPC(c, c->tmp_r.ensure(sizeof(int) * (size_t)(tot_m + 1)));
+    }
     HIPC(c, c->tmp_d.ensure(sizeof(int) * n_scratch));                                   // bin starts, then sweep scratch
     HIPC(c, c->tmp_e.ensure(sizeof(int) * (size_t)tot_m));                               // arrival positions
     HIPC(c, c->tmp_w.ensure(sizeof(unsigned long long) * (size_t)tot_m));                // (fine cell, index) words of the cell sort
     HIPC(c, c->tmp_p.ensure(sizeof(V4) * 2 * (size_t)tot_m));                            // the records in cloud order: (point, normal) pairs
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? up(2 * sizeof(V4) * (size_t)tot_m) : 0, b_cs = up(sizeof(int) * (size_t)tot_c),
+    // (succinct: no dense tables -- b_cs keeps one entry so that the layout below stays one expression)
+    const size_t b_pts = up(sizeof(V4) * (size_t)tot_m), b_nrm = any_nrm ? up(2 * sizeof(V4) * (size_t)tot_m) : 0, b_cs = up(sizeof(int) * (size_t)(succ ? 1 : tot_c)),
                  b_slot = up(sizeof(int) * (size_t)tot_m), b_sc = up(sizeof(int) * (size_t)tot_s), b_near = up(sizeof(int) * (size_t)tot_c),
-                 b_csf = kx > 1 ? up(sizeof(int) * (size_t)tot_f) : 0, b_occ = up(sizeof(unsigned) * (size_t)tot_o),
-                 b_ext = up(sizeof(float) * 6 * (size_t)tot_s), b_ptsf = sizeof(T) == 8 ? up(sizeof(float) * 4 * (size_t)tot_m + 64) : 0;
+                 b_csf = (kx > 1 && !succ) ? up(sizeof(int) * (size_t)tot_f) : 0, b_occ = up(sizeof(unsigned) * (size_t)tot_o),
+                 b_ext = up(sizeof(float) * 6 * (size_t)tot_s), b_ptsf = sizeof(T) == 8 ? up(sizeof(float) * 4 * (size_t)tot_m + 64) : 0,
+                 b_sw = succ ? up(sizeof(uint4) * (size_t)tot_w) : 0, b_ost = succ ? up(sizeof(int) * (size_t)(tot_m + 2)) : 0;
     auto blk = std::make_shared<SharedBlock>();
-    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext + b_ptsf, &blk->p, &blk->bytes); if (ast) return ast; }
+    { const int ast = block_alloc(c, b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext + b_ptsf + b_sw + b_ost, &blk->p, &blk->bytes); if (ast) return ast; }
     char *base = blk->p;
     V4 *g_pts = (V4 *)base, *g_nrm = any_nrm ? (V4 *)(base + b_pts) : nullptr;
     int *g_cs = (int *)(base + b_pts + b_nrm), *g_slot = (int *)(base + b_pts + b_nrm + b_cs),
@@ -805,6 +822,8 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     unsigned *g_occ = (unsigned *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf);
     float *g_ext = (float *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ);
     float *g_ptsf = b_ptsf ? (float *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext) : nullptr;   // (16-byte records: blocks are 256-byte aligned)
+    uint4 *g_sw = succ ? (uint4 *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext + b_ptsf) : nullptr;
+    int *g_ost = succ ? (int *)(base + b_pts + b_nrm + b_cs + b_slot + 3 * b_sc + b_near + b_csf + b_occ + b_ext + b_ptsf + b_sw) : nullptr;
     for (int k = 0; k < n; k++) {
         MapHost<T> &M = Ms[k];
         const BuildDesc<T> &d = descs[k];
@@ -812,8 +831,10 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         M.pts = g_pts;                               // shared by the batch; this map's points start at slot `first`
         M.nrm = M.has_nrm ? g_nrm : nullptr;
         M.first = (int)d.pbase;
-        M.cell_start = g_cs + d.cbase;
-        M.cell_start_f = g_csf + d.fbase;
+        M.cell_start = succ ? nullptr : g_cs + d.cbase;
+        M.cell_start_f = succ ? nullptr : g_csf + d.fbase;
+        M.sw = succ ? g_sw + d.wbase : nullptr;
+        M.ostart = g_ost;
         M.slot_of = g_slot + d.pbase;
         M.sc_count = g_sc + d.sbase;
         M.near = g_near + d.cbase;
@@ -828,7 +849,7 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
         ProfScope ps(c, PGICP_PROF_GRID_BUILD, tot_m, n);
         launch_grid_build_batch<T>(c->stream, c->bdesc.as<BuildDesc<T>>(), n, tot_m, tot_b, tot_s, max_m, max_cells, max_bins, max_nsc, max_blocks, kx == 4 ? 1 : 0, c->tmp_a.as<int>(),
                                    c->tmp_b.as<int>(), c->tmp_c.as<int>(), g_cs, g_csf, c->tmp_d.as<int>(), c->tmp_e.as<int>(), c->tmp_w.as<unsigned long long>(), c->tmp_p.as<V4>(), c->tmp_n.as<V4>(), g_pts, g_nrm,
-                                   g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o, g_ext, g_ptsf);
+                                   g_slot, g_sc, g_near, g_scd, g_wit, g_occ, tot_o, g_ext, g_ptsf, g_sw, g_ost, succ ? c->tmp_f.as<int>() : nullptr, succ ? c->tmp_r.as<int>() : nullptr);
     }
     HIPC(c, stream_sync(c));          // `descs` (host) feeds an async copy
     HIPC(c, hipGetLastError());
@@ -866,6 +887,7 @@ struct BatchLayout {
     long long total = 0;
     int knn = 1;                // pairs per reading point (ChainDev::knn)
     bool normals = false;       // the readings' normals travel with them (a SurfaceNormalOutlierFilter is in the chain)
+    int table_kinds = 0;        // bit 0: some map of the batch carries the dense cell tables, bit 1: some map the succinct one (MapDev::sw)
     double max_h = 0.0;         // largest cell edge among the batch's maps
     // Rings of cells the fast matcher walks beyond the 27-cell block before it queues a query: 3 unseeded / 1 seeded on the 9 cm
     // cells of a 1 M-pt map (measured, rounds 3 and 4); the 28 cm cells of a 100 k-pt keyframe map -- loop closing -- are
@@ -881,7 +903,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
 {
     if (P > 65535) return fail(c, PGICP_ERR_ARG, "pgicp: at most 65535 problems per batch (the problem index is a launch-grid dimension)");
     State<T> &S = state<T>(c);
-    L.P = P; L.max_n = 0; L.max_rows = 1; L.total = 0;
+    L.P = P; L.max_n = 0; L.max_rows = 1; L.total = 0; L.table_kinds = 0;
     L.knn = std::max(1, c->prm.knn);
     L.normals = c->prm.normal_max_angle > 0.0;
     if (L.normals)
@@ -896,6 +918,7 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         MapHost<T> *M = get_map<T>(c, pr[p].map_id);
         if (!M) return fail(c, PGICP_ERR_ARG, "pgicp: unknown map id " + std::to_string(pr[p].map_id));
         L.max_n = std::max(L.max_n, pr[p].n);
+        L.table_kinds |= M->sw ? 2 : 1;
         L.max_h = std::max(L.max_h, (double)M->g.h);
         dens = std::max(dens, (double)pr[p].n / (double)M->m);
         L.total += pr[p].n;
@@ -1068,7 +1091,7 @@ void enqueue_iteration(pgicp_ctx *c, const BatchLayout &L, const ChainDev<T> &ch
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, nA, L.max_n, use_seed, c->small.as<int>() + 16, c->slow_list.as<int2>(),
                       c->slow_lb.as<T>(), c->slow_ring.as<int>(), use_seed ? L.rings_seeded : L.rings_unseeded, active, S.none_r.template as<T>(),
-                      L.P, c->queue.p, c->seg_clean ? 0 : 1);
+                      L.P, c->queue.p, c->seg_clean ? 0 : 1, L.table_kinds);
         c->counters_clean = 0;
     }
     {
@@ -1435,7 +1458,7 @@ int run_partial(pgicp_ctx *c, int map_id, const T *reading, int stride, int n, i
         ProfScope ps(c, c->prm.matcher == PGICP_MATCHER_BRUTE ? PGICP_PROF_KNN_BRUTE : PGICP_PROF_KNN_GRID, n);
         launch_knn<T>(c->stream, c->prm.matcher, probs, maps, S.rd_sorted.template as<T>(), S.slot.template as<int>(),
                       S.d2.template as<T>(), ch, 1, n, 0, c->small.as<int>() + 16, c->slow_list.as<int2>(), c->slow_lb.as<T>(),
-                      c->slow_ring.as<int>(), L.rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p, 1);
+                      c->slow_ring.as<int>(), L.rings_unseeded, c->active.as<int>(), S.none_r.template as<T>(), 1, c->queue.p, 1, L.table_kinds);
         c->seg_clean = 0;
         // public matcher output / partial chain: resolve every queued query exactly
         if (c->prm.matcher == PGICP_MATCHER_GRID)
@@ -2130,6 +2153,7 @@ static int ctx_create_impl(int device, int high_priority, pgicp_ctx **out)
     pgicp_default_params(&c->prm);
     if (const char *e = std::getenv("PGICP_FAST_RINGS_SEEDED")) c->fast_rings_seeded = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PGICP_KX")) c->grid_kx = std::atoi(e);
+    if (const char *e = std::getenv("PGICP_TABLES")) c->table_mode = !std::strcmp(e, "dense") ? 1 : !std::strcmp(e, "succinct") ? 2 : 0;
     if (const char *e = std::getenv("PGICP_CELL_SCALE")) { const double v = std::atof(e); if (v > 0.05 && v < 20.0) c->cell_scale = v; }
     if (const char *e = std::getenv("PGICP_NEAR_FRAC")) c->near_frac = std::atof(e);
     if (const char *e = std::getenv("PGICP_BIN_SHIFT_ADD")) c->bin_shift_add = std::atoi(e);
@@ -2213,7 +2237,7 @@ void pgicp_ctx_destroy(pgicp_ctx *c)
     }
     for (DevBuf *b : {&c->f32.d_maps, &c->f32.rd_pre, &c->f32.slot, &c->f32.d2, &c->f32.staging, &c->f32.stage_aux,
                       &c->f64.d_maps, &c->f64.rd_pre, &c->f64.slot, &c->f64.d2, &c->f64.staging, &c->f64.stage_aux,
-                      &c->probs, &c->src, &c->partials, &c->sums, &c->sums2, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e, &c->tmp_w, &c->tmp_p, &c->tmp_n,
+                      &c->probs, &c->src, &c->partials, &c->sums, &c->sums2, &c->small, &c->stats, &c->bdesc, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_d, &c->tmp_e, &c->tmp_f, &c->tmp_r, &c->tmp_w, &c->tmp_p, &c->tmp_n,
                       &c->f32.rd_sorted, &c->f64.rd_sorted, &c->f32.nrm_pre, &c->f32.nrm_sorted, &c->f64.nrm_pre, &c->f64.nrm_sorted, &c->qrow, &c->qtmp, &c->order, &c->scan_pos, &c->qcounts, &c->qblock, &c->qstart,
                       &c->qcursor, &c->slow_list, &c->slow_lb, &c->slow_ring, &c->slow2, &c->active, &c->sel_tables, &c->queue, &c->f32.none_r, &c->f64.none_r})
         b->release();
