@@ -188,8 +188,8 @@ struct pgicp_ctx {
     int fast_rings_seeded = 0, fast_rings_unseeded = 0;      // 0: by the maps' cell size (BatchLayout::rings_*); PGICP_FAST_RINGS_* set them
     double cell_scale = 1.0;     // experiment knob PGICP_CELL_SCALE: the automatic grid cell times this
     int grid_kx = 4;                // x refinement of the table the matcher narrows ranges with (MapDev::cell_start_f)
-    int table_mode = 0;             // the cell tables a map is built with: 0 auto (PGICP_TABLE_AUTO_*, map_create_batch), 1 dense, 2 succinct
-                                    // (MapDev::sw); PGICP_TABLES=auto|dense|succinct
+    int table_mode = 0;             // the cell tables a map is built with: 0 / 1 dense (the default), 2 succinct (MapDev::sw);
+                                    // PGICP_TABLES=dense|succinct, read when the context is made
     double near_frac = 0.2;         // MapDev::near looks this fraction of maxDist far (at most kNearReach cells)
     int bin_shift_add = 0;          // experiment knob PGICP_BIN_SHIFT_ADD: coarser (+) or finer (-) bins of the reading sort
     int med_rings = 4;              // rings a queued query may walk per lane before the wave-cooperative path takes it   // rings walked in the fast kernel before a query is queued
@@ -708,12 +708,12 @@ int map_create_batch(pgicp_ctx *c, int n, const MapSrc<T> *src, int mem, int cen
     // ---- phase 2: grids; every cloud gets its slice of ONE allocation and ONE set of build launches ----
     std::vector<MapHost<T>> Ms(n);
     long long tot_m = 0, tot_c = 0, tot_s = 0, tot_f = 0, tot_o = 0, tot_b = 0, tot_w = 0;
-    // The succinct table (MapDev::sw) for the maps of a BATCHED build -- the candidate maps of a loop-closure batch: hundreds of
-    // maps whose dense tables (11 MB each at 100 k points, seven times the points) neither fit a cache nor are cheap to write --
-    // the dense tables for a map built alone (the localizer's: one map, its tables 95 % L1 hits under spatially sorted queries,
-    // and a VALU-bound matcher that has no instructions to spare for ranks).  PGICP_TABLES overrides (measured both ways:
-    // profiles/r06_experiments/succinct_tables.txt).
-    const bool succ = c->table_mode == 2 || (c->table_mode == 0 && n > 1);
+    // The succinct table (MapDev::sw) is an OPTION (PGICP_TABLES=succinct), the dense tables the default for every map:
+    // measured in round 6 (profiles/r06_experiments/succinct_tables.txt) the succinct table makes a 100 k-pt map's tables 1.1 MB
+    // instead of 14 MB and the batched build 0.9 ms shorter per 512 maps, but the fast matcher pays a third dependent load and
+    // ~290 more instructions: +7 % per launch in loop closing (its traffic -13 %: the launches' bytes are results and points,
+    // not tables), -6 % headline, -5 % streaming.  It is what a map too sparse for dense tables would be built with.
+    const bool succ = c->table_mode == 2;
     int max_cells = 0, max_nsc = 0, max_bins = 0, max_blocks = 0;
     const int kx = std::max(1, std::min(8, c->grid_kx));
     bool any_nrm = false;

@@ -21,6 +21,9 @@ SETTINGS = [
     {"PGICP_SLOW_SQUARE_ROWS": "16", "PGICP_PRUNE_PCT": "0", "PGICP_FAST_LANES": "16", "PGICP_SLOW_BLOCKS": "64"},
     # ... and with every iteration replayed from a captured graph, the one-kernel selection for every size
     {"PGICP_GRAPH_MAX_P": "4096", "PGICP_SEL_SMALL_N": "100000000", "PGICP_FAST_LANES": "4"},
+    # round 6: every map with the succinct cell table (MapDev::sw: occupancy words + per-occupied-cell starts) instead of the dense ones
+    {"PGICP_TABLES": "succinct"},
+    {"PGICP_TABLES": "succinct", "PGICP_KX": "1", "PGICP_FAST_LANES": "16"},
 ]
 
 
@@ -28,6 +31,7 @@ SETTINGS = [
 def test_parity_holds_for_every_knob_setting(setting):
     env = dict(os.environ, **setting)
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_edge_cases.py", "tests/test_gpu_matcher_state.py", "tests/test_local_mapper.py", "tests/test_gpu_chain.py",
+                        "tests/test_gpu_bit_exact.py",
                         "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
