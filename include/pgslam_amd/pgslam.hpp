@@ -6,9 +6,9 @@
 //   pgslam::Types<T>            reference src/pgslam/types.h:13-61
 //   pgslam::BuildLocalMapCloud  LocalMap<T>::BuildCloudFromData   LocalMap.hpp:209-224
 //   pgslam::CloudInFrame        LocalMap<T>::CloudInWorldFrame    LocalMap.hpp:95-98
-//   pgslam::Localizer<T>        ProcessData / ComputeCurrentOverlap / ComputeOverlapWith
+//   pgslam::ScanLocalizer<T>    ProcessData / ComputeCurrentOverlap / ComputeOverlapWith
 //                               Localizer.hpp:91-135, 276-348
-//   pgslam::LoopCloser<T>       ProcessVertex core / CheckIcpResult / ComputeResidualError
+//   pgslam::PairLoopCloser<T>   ProcessVertex core / CheckIcpResult / ComputeResidualError
 //                               LoopCloser.hpp:83-110, 308-365
 //   pgslam::LoopClosureBatch<T> LoopCloserMT queue (LoopCloserMT.hpp:26-67) processed as a batch
 #pragma once
@@ -173,10 +173,10 @@ void BuildLocalMapOnDevice(pgicp_ctx *ctx, const std::vector<typename Types<T>::
 }
 
 template <typename T>
-class Localizer {
+class ScanLocalizer {
 public:
     IMPORT_PGSLAM_TYPES(T)
-    Localizer() : rigid_transformation_(PM::get().REG(Transformation).create("RigidTransformation")),
+    ScanLocalizer() : rigid_transformation_(PM::get().REG(Transformation).create("RigidTransformation")),
                   T_refkf_robot_(Matrix::Identity(4, 4)), T_world_robot_(Matrix::Identity(4, 4)),
                   last_input_T_world_robot_(Matrix::Identity(4, 4)), T_world_refkf_(Matrix::Identity(4, 4)),
                   overlap_threshold_(T(0.8)), minimal_overlap_(T(0.5)), has_map_(false) {}
@@ -231,7 +231,7 @@ public:
         return ComputeOverlapAgainstPrepared(reading_in, T_world_robot);
     }
     //! the reference half of ComputeOverlapOf (Localizer.hpp:313-317): reference filters + matcher->init.  A caller that
-    //! asks about the SAME candidate map scan after scan (GraphLocalizer's neighbour composition, unchanged while the
+    //! asks about the SAME candidate map scan after scan (Localizer's neighbour composition, unchanged while the
     //! graph is) prepares it once and calls ComputeOverlapAgainstPrepared per scan: same index, same result, without
     //! assembling, uploading and indexing the map every time.
     void PrepareOverlapReference(const DP &candidate_map_in_world_frame)
@@ -460,7 +460,7 @@ private:
 };
 
 template <typename T>
-class LoopCloser {
+class PairLoopCloser {
 public:
     IMPORT_PGSLAM_TYPES(T)
     struct Result {
@@ -470,7 +470,7 @@ public:
         T overlap, residual;
         bool max_iterations_reached;
     };
-    LoopCloser() : overlap_threshold_(T(0.8)), residual_error_threshold_(T(5000)) {}
+    PairLoopCloser() : overlap_threshold_(T(0.8)), residual_error_threshold_(T(5000)) {}
     void SetOverlapThreshold(T v) { overlap_threshold_ = v; }
     void SetResidualErrorThreshold(T v) { residual_error_threshold_ = v; }
     void SetIcpConfigFromString(const std::string &yaml)

@@ -1241,7 +1241,7 @@ struct PointMatcher {
             const T *dev = nullptr;
             std::shared_ptr<DataPoints> filtered;         // the host copy after the chain's reading filters (what was uploaded)
             //! points and stride of the device copy when they are known without looking at `filtered` (-1: ask it) -- a host copy whose
-            //! gaps are still being closed on another thread must not be read (GraphLocalizer's deferred host compaction)
+            //! gaps are still being closed on another thread must not be read (Localizer's deferred host compaction)
             int n = -1, stride = -1;
             int points() const { return n >= 0 ? n : (int)filtered->getNbPoints(); }
             int xyzStride() const { return stride >= 0 ? stride : filtered->xyzStride(); }

@@ -30,8 +30,20 @@
 #include <set>
 
 #include "pgslam.hpp"
+#include <iostream>
 
 namespace pgslam {
+
+//! a YAML file as text (the setters that take a path: Localizer.hpp:54-78, LoopCloser.hpp:58-74)
+inline std::string slurp_config_file(const std::string &p)
+{
+    std::ifstream ifs(p);
+    if (!ifs) throw std::runtime_error("[PoseGraphSlam] cannot open " + p);
+    std::stringstream ss;
+    ss << ifs.rdbuf();
+    return ss.str();
+}
+
 
 // ------------------------------------------------------------------ graph
 template <typename T>
@@ -473,8 +485,8 @@ private:
     }
 };
 
-template <typename T> class GraphLocalizer;
-template <typename T> class GraphLoopCloser;
+template <typename T> class Localizer;
+template <typename T> class LoopCloser;
 
 // ------------------------------------------------------------------ MapManager (MapManager.hpp)
 template <typename T>
@@ -487,8 +499,8 @@ public:
     //! recursive, because in that flavour the loop closer and the optimiser run nested inside the localizer's update.
     std::unique_lock<std::recursive_mutex> GetGraphLock() { return std::unique_lock<std::recursive_mutex>(graph_mutex_); }
     size_t GetFixedVertex() const { return fixed_vertex_; }
-    void SetLocalizer(std::shared_ptr<GraphLocalizer<T>> p) { localizer_ = p; }
-    void SetLoopCloser(std::shared_ptr<GraphLoopCloser<T>> p) { loop_closer_ = p; }
+    void SetLocalizer(std::shared_ptr<Localizer<T>> p) { localizer_ = p; }
+    void SetLoopCloser(std::shared_ptr<LoopCloser<T>> p) { loop_closer_ = p; }
     size_t AddFirstKeyframe(DPPtr cloud, const Matrix &T_world_kf)
     {
         const size_t v = graph_.AddVertex(MakeKeyframe(cloud, T_world_kf));
@@ -553,8 +565,8 @@ private:
     size_t device_budget_ = (size_t)((std::getenv("PGSLAM_DEVICE_KEYFRAMES_MB") ? std::atof(std::getenv("PGSLAM_DEVICE_KEYFRAMES_MB")) : 8192.0) * 1048576.0);
     unsigned long long version_ = 0;
     size_t fixed_vertex_ = 0;
-    std::weak_ptr<GraphLocalizer<T>> localizer_;
-    std::weak_ptr<GraphLoopCloser<T>> loop_closer_;
+    std::weak_ptr<Localizer<T>> localizer_;
+    std::weak_ptr<LoopCloser<T>> loop_closer_;
 };
 
 // ------------------------------------------------------------------ Optimizer (Optimizer.hpp)
@@ -632,17 +644,23 @@ protected:
 
 // ------------------------------------------------------------------ loop closer with its candidate search
 template <typename T>
-class GraphLoopCloser {
+class LoopCloser {
 public:
     IMPORT_PGSLAM_TYPES(T)
-    using Ptr = std::shared_ptr<GraphLoopCloser<T>>;
-    GraphLoopCloser(typename MapManager<T>::Ptr mm, typename Optimizer<T>::Ptr opt) : map_manager_(mm), optimizer_(opt) {}
+    using Ptr = std::shared_ptr<LoopCloser<T>>;
+    LoopCloser(typename MapManager<T>::Ptr mm, typename Optimizer<T>::Ptr opt) : map_manager_(mm), optimizer_(opt) {}
     void SetTopologicalDistanceThreshold(T v) { topo_dist_threshold_ = v; }
     void SetGeometricalDistanceThreshold(T v) { geom_dist_threshold_ = v; }
     void SetOverlapThreshold(T v) { overlap_threshold_ = v; if (closer_) closer_->SetOverlapThreshold(v); }
     void SetResidualErrorThreshold(T v) { residual_error_threshold_ = v; if (closer_) closer_->SetResidualErrorThreshold(v); }
-    void SetIcpConfigFromString(const std::string &yaml) { closer().SetIcpConfigFromString(yaml); }
-    virtual ~GraphLoopCloser() {}
+    virtual void SetIcpConfigFromString(const std::string &yaml) { closer().SetIcpConfigFromString(yaml); }
+    //! LoopCloser.hpp:58-74: the chain from a YAML FILE
+    void SetIcpConfig(const std::string &config_path) { SetIcpConfigFromString(slurp_config_file(config_path)); }
+    //! LoopCloser.hpp:53-56 -- the reference IGNORES its argument (`candidate_local_map_ = LocalMap(3)`): kept, so that a
+    //! configuration written against it gives the same candidates here.  SetCandidateLocalMapCapacity is the setter that means it.
+    void SetCandidateLocalMapMaxSize(size_t /*size*/) { capacity_ = 3; }
+    void SetCandidateLocalMapCapacity(size_t size) { capacity_ = size < 1 ? 1 : size; }
+    virtual ~LoopCloser() {}
     virtual void AddNewVertex(size_t v) { ProcessVertex(v); }
     int loops_closed() const { return loops_closed_; }
     int candidates_tried() const { return candidates_tried_; }
@@ -714,7 +732,7 @@ public:
     void ProcessVertex(size_t input_v)
     {
         PreparedCandidate c;
-        LoopCloser<T> &lc = closer();
+        PairLoopCloser<T> &lc = closer();
         if (!PrepareCandidate(input_v, c, lc.DeviceCandidateEquivalent() ? (pgicp_ctx *)lc.icp().ctx : nullptr)) return;
         auto r = c.reference_dev ? lc.ProcessCandidateOnDevice(c.reading, *c.reading_dev, *c.reference_dev, c.guess, c.host_reference)
                                  : lc.ProcessCandidate(*c.reading, *c.reference, c.guess);                     // :98 + CheckIcpResult
@@ -727,17 +745,17 @@ public:
 protected:
     typename MapManager<T>::Ptr map_manager_;
     //! the ICP object (and with it the device context) is created on first use: the graph searches need no GPU
-    LoopCloser<T> &closer()
+    PairLoopCloser<T> &closer()
     {
         if (!closer_) {
-            closer_.reset(new LoopCloser<T>());
+            closer_.reset(new PairLoopCloser<T>());
             closer_->SetOverlapThreshold(overlap_threshold_);
             closer_->SetResidualErrorThreshold(residual_error_threshold_);
         }
         return *closer_;
     }
     typename Optimizer<T>::Ptr optimizer_;
-    std::unique_ptr<LoopCloser<T>> closer_;
+    std::unique_ptr<PairLoopCloser<T>> closer_;
     T topo_dist_threshold_ = T(3), geom_dist_threshold_ = T(3);               // LoopCloser.hpp:16-17
     T overlap_threshold_ = T(0.8), residual_error_threshold_ = T(5000);       // :18-19
     size_t capacity_ = 3;                                                     // :20
@@ -795,22 +813,34 @@ private:
 
 // ------------------------------------------------------------------ localizer on the graph
 template <typename T>
-class GraphLocalizer {
+class Localizer {
 public:
     IMPORT_PGSLAM_TYPES(T)
-    using Ptr = std::shared_ptr<GraphLocalizer<T>>;
-    explicit GraphLocalizer(typename MapManager<T>::Ptr mm, size_t capacity = 3)
+    using Ptr = std::shared_ptr<Localizer<T>>;
+    explicit Localizer(typename MapManager<T>::Ptr mm, size_t capacity = 3)
         : map_manager_(mm), capacity_(capacity), rigid_(PM::get().REG(Transformation).create("RigidTransformation")),
           T_refkf_robot_(Matrix::Identity(4, 4)), T_world_robot_(Matrix::Identity(4, 4)), last_input_(Matrix::Identity(4, 4)) {}
     void SetOverlapThreshold(T v) { overlap_threshold_ = v; }
     void SetIcpConfigFromString(const std::string &yaml) { icp_yaml_ = yaml; probe_.reset(); probe_comp_.clear(); std::istringstream iss(yaml); icp_sequence_.loadFromYaml(iss); }
     void SetInputFiltersConfigFromString(const std::string &yaml) { std::istringstream iss(yaml); input_filters_ = DataPointsFilters(iss); }
+    //! Localizer.hpp:54-78: the chain / the input filters from a YAML FILE
+    void SetIcpConfig(const std::string &config_path) { SetIcpConfigFromString(slurp_config_file(config_path)); }
+    void SetInputFiltersConfig(const std::string &config_path) { SetInputFiltersConfigFromString(slurp_config_file(config_path)); }
+    //! Localizer.hpp:36-41: keyframes of the local map (and of the candidate compositions).  The reference replaces its LocalMap
+    //! object; here the current composition is cut down to its newest `size` keyframes and the map re-assembled on the next scan.
+    void SetLocalMapMaxSize(size_t size)
+    {
+        capacity_ = size < 1 ? 1 : size;
+        if (comp_.size() > capacity_) { comp_.erase(comp_.begin(), comp_.end() - (std::ptrdiff_t)capacity_); probe_.reset(); probe_comp_.clear(); if (!comp_.empty()) Rebuild(); }
+    }
+    //! Localizer.hpp:49-52
+    void SetMinimalOverlapThreshold(T v) { minimal_overlap_ = v; }
     const Matrix &T_world_robot() const { return T_world_robot_; }
     const std::vector<size_t> &composition() const { return comp_; }
     int rebuilds() const { return rebuilds_; }
     ICPSequence &icp() { return icp_sequence_; }
 
-    virtual ~GraphLocalizer() {}
+    virtual ~Localizer() {}
     virtual void AddNewData(unsigned long long, const std::string &, const Matrix &T_world_robot, const Matrix &T_robot_sensor, DPPtr cloud)
     {
         ProcessData(T_world_robot, T_robot_sensor, cloud);
@@ -1009,7 +1039,7 @@ protected:
     {
         auto &g = map_manager_->GetGraph();
         if (!probe_) {                                  // kept between calls: its ICP objects own device contexts
-            probe_.reset(new Localizer<T>());
+            probe_.reset(new ScanLocalizer<T>());
             probe_->SetIcpConfigFromString(icp_yaml_);
             probe_comp_.clear();
         }
@@ -1083,6 +1113,8 @@ private:
         auto &g = map_manager_->GetGraph();
         const T overlap = icp_sequence_.errorMinimizer->getOverlap();
         std::vector<size_t> next = comp_, neigh;
+        if (overlap < minimal_overlap_)                                     // Localizer.hpp:350-355: a warning, nothing else
+            std::cerr << "[Localizer] WARNING: overlap below minimal overlap! (" << overlap << " < " << minimal_overlap_ << ")\n";
         const bool enough = overlap >= overlap_threshold_;
         bool took_neighbor = false;
         bool have_neigh;
@@ -1121,13 +1153,14 @@ private:
     DataPointsFilters input_filters_;
     ICPSequence icp_sequence_;
     std::string icp_yaml_;
-    std::unique_ptr<Localizer<T>> probe_;            // runs ComputeOverlapWith for candidate compositions
+    std::unique_ptr<ScanLocalizer<T>> probe_;            // runs ComputeOverlapWith for candidate compositions
     std::vector<size_t> probe_comp_;                 // the composition whose world-frame map the probe holds indexed ...
     unsigned long long probe_version_ = 0;           // ... built at this version of the graph
     DPPtr input_cloud_;
     std::vector<size_t> comp_;                       // local map composition, reference keyframe last
     Matrix T_refkf_robot_, T_world_robot_, last_input_;
     T overlap_threshold_ = T(0.8);
+    T minimal_overlap_ = T(0.5);                     // Localizer.hpp:28
     int rebuilds_ = 0;
     double phase_s_[3] = {0, 0, 0};
     double sub_s_[4] = {0, 0, 0, 0};
@@ -1156,61 +1189,73 @@ void MapManager<T>::NotifyKeyframeUpdate()
 }
 
 // ------------------------------------------------------------------ facade (PoseGraphSlam.h:17-68, single-thread flavour)
-inline std::string slurp_config_file(const std::string &p)
-{
-    std::ifstream ifs(p);
-    if (!ifs) throw std::runtime_error("[PoseGraphSlam] cannot open " + p);
-    std::stringstream ss;
-    ss << ifs.rdbuf();
-    return ss.str();
-}
 
-template <typename T>
-class PoseGraphSlam {
+//! PoseGraphSlam.h:18-68: the base of both flavours, parametrised -- as upstream -- by the four worker class templates, so that
+//! code that derives from it or names its workers (`typename Slam::Localizer`, `localizer_ptr_`) compiles unchanged.
+template <typename T, template <typename> class MapManagerClass, template <typename> class LocalizerClass,
+          template <typename> class LoopCloserClass, template <typename> class OptimizerClass>
+class PoseGraphSlamBase {
 public:
+    using MapManager = MapManagerClass<T>;
+    using MapManagerPtr = typename MapManager::Ptr;
+    using Localizer = LocalizerClass<T>;
+    using LocalizerPtr = typename Localizer::Ptr;
+    using LoopCloser = LoopCloserClass<T>;
+    using LoopCloserPtr = typename LoopCloser::Ptr;
+    using Optimizer = OptimizerClass<T>;
+    using OptimizerPtr = typename Optimizer::Ptr;
     IMPORT_PGSLAM_TYPES(T)
-    PoseGraphSlam()
-        : map_manager_ptr_(std::make_shared<MapManager<T>>()), optimizer_ptr_(std::make_shared<Optimizer<T>>(map_manager_ptr_)),
-          loop_closer_ptr_(std::make_shared<GraphLoopCloser<T>>(map_manager_ptr_, optimizer_ptr_)),
-          localizer_ptr_(std::make_shared<GraphLocalizer<T>>(map_manager_ptr_))
+
+    PoseGraphSlamBase()
+        : map_manager_ptr_(std::make_shared<MapManager>()), optimizer_ptr_(std::make_shared<Optimizer>(map_manager_ptr_)),
+          loop_closer_ptr_(std::make_shared<LoopCloser>(map_manager_ptr_, optimizer_ptr_)),
+          localizer_ptr_(std::make_shared<Localizer>(map_manager_ptr_))
     {
         map_manager_ptr_->SetLocalizer(localizer_ptr_);
         map_manager_ptr_->SetLoopCloser(loop_closer_ptr_);
     }
     //! PoseGraphSlam.hpp:29-36: construct and configure from the three YAML files
-    PoseGraphSlam(const std::string &localizer_input_filters_config, const std::string &localizer_icp_config,
-                  const std::string &loop_closer_icp_config)
-        : PoseGraphSlam()
+    PoseGraphSlamBase(const std::string &localizer_input_filters_config, const std::string &localizer_icp_config,
+                      const std::string &loop_closer_icp_config)
+        : PoseGraphSlamBase()
     {
         SetIcpConfig(localizer_input_filters_config, localizer_icp_config, loop_closer_icp_config);
     }
-    //! the reference takes three file paths (PoseGraphSlam.hpp:38-48); the YAML texts are accepted as well
+    virtual ~PoseGraphSlamBase() {}
+    //! PoseGraphSlam.hpp:38-48: three file paths, handed to the workers' own setters
+    void SetIcpConfig(const std::string &input_filters_path, const std::string &localizer_icp_path, const std::string &loop_closer_icp_path)
+    {
+        localizer_ptr_->SetInputFiltersConfig(input_filters_path);
+        localizer_ptr_->SetIcpConfig(localizer_icp_path);
+        loop_closer_ptr_->SetIcpConfig(loop_closer_icp_path);
+    }
+    //! (an addition: the YAML texts themselves)
     void SetIcpConfigFromStrings(const std::string &input_filters_yaml, const std::string &localizer_icp_yaml, const std::string &loop_closer_icp_yaml)
     {
         localizer_ptr_->SetInputFiltersConfigFromString(input_filters_yaml);
         localizer_ptr_->SetIcpConfigFromString(localizer_icp_yaml);
         loop_closer_ptr_->SetIcpConfigFromString(loop_closer_icp_yaml);
     }
-    void SetIcpConfig(const std::string &input_filters_path, const std::string &localizer_icp_path, const std::string &loop_closer_icp_path)
-    {
-        SetIcpConfigFromStrings(slurp_config_file(input_filters_path), slurp_config_file(localizer_icp_path), slurp_config_file(loop_closer_icp_path));
-    }
     void AddData(unsigned long long timestamp, std::string world_frame_id, Matrix T_world_robot, Matrix T_robot_sensor, DPPtr cloud_ptr)
     {
         localizer_ptr_->AddNewData(timestamp, world_frame_id, T_world_robot, T_robot_sensor, cloud_ptr);
     }
-    void WriteGraphviz(const std::string &path) { map_manager_ptr_->WriteGraphviz(path); }
-    MapManager<T> &map_manager() { return *map_manager_ptr_; }
-    GraphLocalizer<T> &localizer() { return *localizer_ptr_; }
-    GraphLoopCloser<T> &loop_closer() { return *loop_closer_ptr_; }
-    Optimizer<T> &optimizer() { return *optimizer_ptr_; }
+    void WriteGraphviz(const std::string &path) { auto lock = map_manager_ptr_->GetGraphLock(); map_manager_ptr_->WriteGraphviz(path); }
+    MapManager &map_manager() { return *map_manager_ptr_; }
+    Localizer &localizer() { return *localizer_ptr_; }
+    LoopCloser &loop_closer() { return *loop_closer_ptr_; }
+    Optimizer &optimizer() { return *optimizer_ptr_; }
 
 protected:
-    typename MapManager<T>::Ptr map_manager_ptr_;
-    typename Optimizer<T>::Ptr optimizer_ptr_;
-    typename GraphLoopCloser<T>::Ptr loop_closer_ptr_;
-    typename GraphLocalizer<T>::Ptr localizer_ptr_;
+    MapManagerPtr map_manager_ptr_;
+    OptimizerPtr optimizer_ptr_;
+    LoopCloserPtr loop_closer_ptr_;
+    LocalizerPtr localizer_ptr_;
 };
+
+//! PoseGraphSlam.h:63-66: the single-thread flavour is an alias of the base
+template <typename T>
+using PoseGraphSlam = PoseGraphSlamBase<T, MapManager, Localizer, LoopCloser, Optimizer>;
 
 // ------------------------------------------------------------------ multi-thread flavour (PoseGraphSlamMT.hpp:21-26)
 // Three workers with input queues, as in the reference: the localizer (LocalizerMT.hpp:27-99), the loop closer
@@ -1219,13 +1264,13 @@ protected:
 // What differs, on purpose: the loop closer DRAINS its queue and runs all waiting candidates as ONE device batch
 // (pgslam::LoopClosureBatch; upstream pops one vertex at a time, LoopCloserMT.hpp:49-62), and the optimiser -- as
 // upstream -- drains its queue into one solve.  WaitIdle() is an addition for deterministic hosts (tests, benchmarks).
-template <typename T> class PoseGraphSlamMT;
 
 template <typename T>
 class OptimizerMT : public Optimizer<T> {
 public:
     IMPORT_PGSLAM_TYPES(T)
     using Base = Optimizer<T>;
+    using Ptr = std::shared_ptr<OptimizerMT<T>>;
     explicit OptimizerMT(typename MapManager<T>::Ptr mm) : Base(mm) {}
     ~OptimizerMT() override { Stop(); }
     void AddNewData(size_t from, size_t to, const Matrix &T_from_to, const Matrix &cov) override
@@ -1269,14 +1314,15 @@ public:
 };
 
 template <typename T>
-class LoopCloserMT : public GraphLoopCloser<T> {
+class LoopCloserMT : public LoopCloser<T> {
 public:
     IMPORT_PGSLAM_TYPES(T)
-    using Base = GraphLoopCloser<T>;
+    using Base = LoopCloser<T>;
+    using Ptr = std::shared_ptr<LoopCloserMT<T>>;
     LoopCloserMT(typename MapManager<T>::Ptr mm, typename Optimizer<T>::Ptr opt) : Base(mm, opt), optimizer_(opt) {}
     ~LoopCloserMT() override { Stop(); }
     //! (the batch dispatcher on the worker thread owns the ICP object; the base class's one-at-a-time closer is not made)
-    void SetIcpConfigFromString(const std::string &yaml) { yaml_ = yaml; }
+    void SetIcpConfigFromString(const std::string &yaml) override { yaml_ = yaml; }
     void AddNewVertex(size_t v) override
     {
         { std::lock_guard<std::mutex> l(m_); queue_.push_back(v); }
@@ -1365,10 +1411,11 @@ public:
 };
 
 template <typename T>
-class LocalizerMT : public GraphLocalizer<T> {
+class LocalizerMT : public Localizer<T> {
 public:
     IMPORT_PGSLAM_TYPES(T)
-    using Base = GraphLocalizer<T>;
+    using Base = Localizer<T>;
+    using Ptr = std::shared_ptr<LocalizerMT<T>>;
     explicit LocalizerMT(typename MapManager<T>::Ptr mm, size_t capacity = 3) : Base(mm, capacity) { this->resync_before_update_ = true; }
     ~LocalizerMT() override { Stop(); }
     void AddNewData(unsigned long long, const std::string &, const Matrix &T_world_robot, const Matrix &T_robot_sensor, DPPtr cloud) override
@@ -1496,48 +1543,33 @@ public:
     std::exception_ptr TakeError() { std::lock_guard<std::mutex> l(m_); std::exception_ptr e = error_; error_ = nullptr; return e; }
 };
 
+//! MapManagerMT.h: upstream's lock-carrying map manager.  MapManager<T> here carries the lock in both flavours (it is
+//! uncontended in the single-thread one), so the MT class only has to exist under its name.
 template <typename T>
-class PoseGraphSlamMT {
+class MapManagerMT : public MapManager<T> {
 public:
+    using Ptr = std::shared_ptr<MapManagerMT<T>>;
+};
+
+//! PoseGraphSlamMT.h:17-30: derives from the base with the four MT workers and adds Run()
+template <typename T>
+class PoseGraphSlamMT : public PoseGraphSlamBase<T, MapManagerMT, LocalizerMT, LoopCloserMT, OptimizerMT> {
+public:
+    using Base = PoseGraphSlamBase<T, MapManagerMT, LocalizerMT, LoopCloserMT, OptimizerMT>;
     IMPORT_PGSLAM_TYPES(T)
-    PoseGraphSlamMT()
-        : map_manager_ptr_(std::make_shared<MapManager<T>>()), optimizer_ptr_(std::make_shared<OptimizerMT<T>>(map_manager_ptr_)),
-          loop_closer_ptr_(std::make_shared<LoopCloserMT<T>>(map_manager_ptr_, optimizer_ptr_)),
-          localizer_ptr_(std::make_shared<LocalizerMT<T>>(map_manager_ptr_))
-    {
-        map_manager_ptr_->SetLocalizer(localizer_ptr_);
-        map_manager_ptr_->SetLoopCloser(loop_closer_ptr_);
-    }
+    PoseGraphSlamMT() : Base() {}
     //! PoseGraphSlamMT.h:23-27
     PoseGraphSlamMT(const std::string &localizer_input_filters_config, const std::string &localizer_icp_config,
                     const std::string &loop_closer_icp_config)
-        : PoseGraphSlamMT()
-    {
-        SetIcpConfig(localizer_input_filters_config, localizer_icp_config, loop_closer_icp_config);
-    }
-    ~PoseGraphSlamMT() { localizer_ptr_->Stop(); loop_closer_ptr_->Stop(); optimizer_ptr_->Stop(); }
-    //! PoseGraphSlam.hpp:38-48 (inherited by the MT flavour upstream): three YAML file paths
-    void SetIcpConfig(const std::string &input_filters_path, const std::string &localizer_icp_path, const std::string &loop_closer_icp_path)
-    {
-        SetIcpConfigFromStrings(slurp_config_file(input_filters_path), slurp_config_file(localizer_icp_path), slurp_config_file(loop_closer_icp_path));
-    }
-    void SetIcpConfigFromStrings(const std::string &input_filters_yaml, const std::string &localizer_icp_yaml, const std::string &loop_closer_icp_yaml)
-    {
-        localizer_ptr_->SetInputFiltersConfigFromString(input_filters_yaml);
-        localizer_ptr_->SetIcpConfigFromString(localizer_icp_yaml);
-        loop_closer_ptr_->SetIcpConfigFromString(loop_closer_icp_yaml);
-    }
+        : Base(localizer_input_filters_config, localizer_icp_config, loop_closer_icp_config) {}
+    ~PoseGraphSlamMT() override { this->localizer_ptr_->Stop(); this->loop_closer_ptr_->Stop(); this->optimizer_ptr_->Stop(); }
     //! PoseGraphSlamMT::Run (PoseGraphSlamMT.hpp:21-26)
-    void Run() { localizer_ptr_->Run(); loop_closer_ptr_->Run(); optimizer_ptr_->Run(); }
-    void AddData(unsigned long long timestamp, std::string world_frame_id, Matrix T_world_robot, Matrix T_robot_sensor, DPPtr cloud_ptr)
-    {
-        localizer_ptr_->AddNewData(timestamp, world_frame_id, T_world_robot, T_robot_sensor, cloud_ptr);
-    }
+    void Run() { this->localizer_ptr_->Run(); this->loop_closer_ptr_->Run(); this->optimizer_ptr_->Run(); }
     //! until every queue is empty and every worker rests (the stages feed one another: checked until stable)
     void WaitIdle()
     {
         for (int calm = 0; calm < 3;) {
-            if (localizer_ptr_->Idle() && loop_closer_ptr_->Idle() && optimizer_ptr_->Idle()) calm++;
+            if (this->localizer_ptr_->Idle() && this->loop_closer_ptr_->Idle() && this->optimizer_ptr_->Idle()) calm++;
             else calm = 0;
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
@@ -1547,20 +1579,9 @@ public:
     //! and the first such exception is thrown here, on the caller's thread.
     void RethrowWorkerError()
     {
-        for (std::exception_ptr e : {localizer_ptr_->TakeError(), loop_closer_ptr_->TakeError(), optimizer_ptr_->TakeError()})
+        for (std::exception_ptr e : {this->localizer_ptr_->TakeError(), this->loop_closer_ptr_->TakeError(), this->optimizer_ptr_->TakeError()})
             if (e) std::rethrow_exception(e);
     }
-    void WriteGraphviz(const std::string &path) { auto lock = map_manager_ptr_->GetGraphLock(); map_manager_ptr_->WriteGraphviz(path); }
-    MapManager<T> &map_manager() { return *map_manager_ptr_; }
-    LocalizerMT<T> &localizer() { return *localizer_ptr_; }
-    LoopCloserMT<T> &loop_closer() { return *loop_closer_ptr_; }
-    OptimizerMT<T> &optimizer() { return *optimizer_ptr_; }
-
-protected:
-    typename MapManager<T>::Ptr map_manager_ptr_;
-    std::shared_ptr<OptimizerMT<T>> optimizer_ptr_;
-    std::shared_ptr<LoopCloserMT<T>> loop_closer_ptr_;
-    std::shared_ptr<LocalizerMT<T>> localizer_ptr_;
 };
 
 }  // namespace pgslam

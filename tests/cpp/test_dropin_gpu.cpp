@@ -54,7 +54,7 @@ void run(const char *name)
     CHECK(residual >= 0 && residual < T(1.0));
 
     // --- pgslam::Localizer hot path
-    pgslam::Localizer<T> loc;
+    pgslam::ScanLocalizer<T> loc;
     loc.SetIcpConfigFromString(kIcpYaml);
     loc.SetLocalMap(map, Matrix::Identity(4, 4));
     auto cloud_ptr = std::make_shared<DP>(reading);
@@ -67,7 +67,7 @@ void run(const char *name)
     CHECK(std::fabs((double)ov2 - (double)matched.weightedPointUsedRatio) < 1e-6);
 
     // --- pgslam::LoopCloser hot path
-    pgslam::LoopCloser<T> lc;
+    pgslam::PairLoopCloser<T> lc;
     lc.SetIcpConfigFromString(kIcpYaml);
     auto r = lc.ProcessCandidate(reading, map, guess);
     CHECK(pose_diff(r.T_refkf_kf, T1) == 0.0 && r.accepted && !r.max_iterations_reached);
@@ -109,7 +109,7 @@ void run(const char *name)
     {   // a chain WITH data-point filters gives the batch what the one-at-a-time loop closer gives (both apply them)
         const std::string yaml = std::string("readingDataPointsFilters:\n  - BoundingBoxDataPointsFilter:\n      xMin: -100\n      xMax: 100\n      yMin: -100\n      yMax: 100\n      zMin: -100\n      zMax: 0.9\n      removeInside: 0\n"
                                              "referenceDataPointsFilters:\n  - BoundingBoxDataPointsFilter:\n      xMin: -100\n      xMax: 100\n      yMin: -100\n      yMax: 100\n      zMin: -100\n      zMax: 0.9\n      removeInside: 0\n") + kIcpYamlTail;
-        pgslam::LoopCloser<T> one;
+        pgslam::PairLoopCloser<T> one;
         one.SetIcpConfigFromString(yaml);
         const auto r1 = one.ProcessCandidate(reading, map, guess);
         pgslam::LoopClosureBatch<T> fb;
@@ -130,7 +130,7 @@ void run(const char *name)
         DP turned(reading);
         const int rn = turned.getDescriptorStartingRow("normals");
         for (int j = 0; j < (int)turned.getNbPoints(); j += 7) { const T a = turned.descriptors(rn, j); turned.descriptors(rn, j) = turned.descriptors(rn + 2, j); turned.descriptors(rn + 2, j) = -a; }
-        pgslam::LoopCloser<T> one, plain;
+        pgslam::PairLoopCloser<T> one, plain;
         one.SetIcpConfigFromString(yaml);
         plain.SetIcpConfigFromString(kIcpYaml);
         const auto r1 = one.ProcessCandidate(turned, map, guess), r0 = plain.ProcessCandidate(turned, map, guess);
@@ -146,7 +146,7 @@ void run(const char *name)
         CHECK(pose_diff(pgslam_amd::from_row_major16<T>(en[0].T_from_to), r1.T_refkf_kf) == 0.0 && (T)en[0].overlap == r1.overlap);
         CHECK(std::memcmp(en[0].T_from_to, en[1].T_from_to, sizeof en[0].T_from_to) == 0);
         // the overlap probe of the localizer: the same chain, stage by stage
-        pgslam::Localizer<T> ln, lp;
+        pgslam::ScanLocalizer<T> ln, lp;
         ln.SetIcpConfigFromString(yaml);
         lp.SetIcpConfigFromString(kIcpYaml);
         const T on = ln.ComputeOverlapOf(turned, r1.T_refkf_kf, map), op = lp.ComputeOverlapOf(turned, r1.T_refkf_kf, map);

@@ -40,11 +40,11 @@ int main()
 
     // ---- IsBetterComposition (Localizer.hpp:363-372): a neighbour composition whose overlap beats the current one
     // but stays under the threshold is NOT taken -- in the low-overlap branch the new keyframe must still be created
-    CHECK(!GraphLocalizer<float>::IsBetterOverlap(0.5f, 0.55f, 0.8f));
-    CHECK(GraphLocalizer<float>::IsBetterOverlap(0.5f, 0.85f, 0.8f));
-    CHECK(!GraphLocalizer<float>::IsBetterOverlap(0.9f, 0.85f, 0.8f));
-    CHECK(!GraphLocalizer<double>::IsBetterOverlap(0.85, 0.85, 0.8));
-    CHECK(GraphLocalizer<double>::IsBetterOverlap(0.79, 0.8, 0.8));
+    CHECK(!Localizer<float>::IsBetterOverlap(0.5f, 0.55f, 0.8f));
+    CHECK(Localizer<float>::IsBetterOverlap(0.5f, 0.85f, 0.8f));
+    CHECK(!Localizer<float>::IsBetterOverlap(0.9f, 0.85f, 0.8f));
+    CHECK(!Localizer<double>::IsBetterOverlap(0.85, 0.85, 0.8));
+    CHECK(Localizer<double>::IsBetterOverlap(0.79, 0.8, 0.8));
 
     // ---- graph: a chain 0-1-2-3-4 with unit steps plus a long edge 0-4; Dijkstra settles by distance
     PoseGraph<double> G;
@@ -120,7 +120,7 @@ int main()
     // ---- loop-closure candidate search (LoopCloser.hpp:193-305) on a trajectory that comes back to its start
     auto mm = std::make_shared<MapManager<double>>();
     auto opt = std::make_shared<Optimizer<double>>(mm);
-    GraphLoopCloser<double> lc(mm, opt);
+    LoopCloser<double> lc(mm, opt);
     auto &PG = mm->GetGraph();
     const int L = 14;                                         // an out-and-back line: 0..7 out, 8..13 back next to 5..0
     for (int i = 0; i < L; i++) {

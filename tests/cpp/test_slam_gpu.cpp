@@ -203,7 +203,7 @@ void run_mt_sensor_pose(const char *name)
                 slam.localizer().device_readings_used(), S, pose_diff(slam.localizer().T_world_robot(), st_poses[S - 1]));
 }
 
-// Local maps assembled from keyframe clouds that STAY in device memory (GraphLocalizer::Rebuild, OverlapWith: one upload per
+// Local maps assembled from keyframe clouds that STAY in device memory (Localizer::Rebuild, OverlapWith: one upload per
 // keyframe, pgicp_build_local_map + pgicp_map_create on device pointers) against the host flow (LocalMap.hpp:209-224 through the
 // host at every rebuild): the same kernels on the same values -- poses, keyframes, loop edges and the map itself bit for bit.
 template <typename T>

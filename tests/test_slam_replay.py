@@ -67,7 +67,7 @@ def test_slam_facade_closes_loops_and_replays_through_the_oracle():
 
 @pytest.mark.gpu
 def test_probe_that_keeps_its_indexed_map_changes_nothing():
-    """GraphLocalizer keeps the neighbour composition's world-frame map indexed between scans (the reference assembles and
+    """Localizer keeps the neighbour composition's world-frame map indexed between scans (the reference assembles and
     indexes it for every overlap check, Localizer.hpp:282-348).  With PGSLAM_PROBE_REBUILD set the facade does what the
     reference does: every figure of the run -- keyframes, loops, rebuilds, tracking errors to the printed digit -- is the same."""
     import bench
