@@ -142,6 +142,7 @@ template <> struct Abi<float> {
     static int stats(pgicp_ctx *c, int id, const float *r, int s, int n, const int32_t *ids, const float *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f32(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
     static int map_create_batch(pgicp_ctx *c, int k, const float *const *x, const int *xs, const float *const *n, const int *ns, const int *m, int center, int *ids) { return pgicp_map_create_batch_f32(c, k, x, xs, n, ns, m, PGICP_HOST, center, ids); }
     static int normals(pgicp_ctx *c, const float *x, int xs, int n, int knn, double md, float *out, int os, float *eig) { return pgicp_surface_normals_f32(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, nullptr, nullptr); }
+    static int normals_ids(pgicp_ctx *c, const float *x, int xs, int n, int knn, double md, float *out, int os, float *eig, int32_t *ids) { return pgicp_surface_normals_f32(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, ids, nullptr); }
     static int partial(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
     static int partial_dev(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_DEVICE, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const float *in, int is, float *out, int os, int n, int ro) { return pgicp_transform_f32(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
@@ -168,6 +169,7 @@ template <> struct Abi<double> {
     static int stats(pgicp_ctx *c, int id, const double *r, int s, int n, const int32_t *ids, const double *w, double *ratio, double *res, double *sys) { return pgicp_error_stats_f64(c, id, r, s, n, PGICP_HOST, ids, w, ratio, res, sys); }
     static int map_create_batch(pgicp_ctx *c, int k, const double *const *x, const int *xs, const double *const *n, const int *ns, const int *m, int center, int *ids) { return pgicp_map_create_batch_f64(c, k, x, xs, n, ns, m, PGICP_HOST, center, ids); }
     static int normals(pgicp_ctx *c, const double *x, int xs, int n, int knn, double md, double *out, int os, double *eig) { return pgicp_surface_normals_f64(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, nullptr, nullptr); }
+    static int normals_ids(pgicp_ctx *c, const double *x, int xs, int n, int knn, double md, double *out, int os, double *eig, int32_t *ids) { return pgicp_surface_normals_f64(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, ids, nullptr); }
     static int partial(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
     static int partial_dev(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_DEVICE, Tm, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const double *in, int is, double *out, int os, int n, int ro) { return pgicp_transform_f64(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
@@ -576,21 +578,186 @@ struct PointMatcher {
     //! on request, eigenvalues) of every point from its knn neighbours, computed on the device by
     //! pgicp_surface_normals_*; the descriptors are appended as libpointmatcher appends them.
     struct SurfaceNormalDataPointsFilter : DataPointsFilter {
-        int knn = 5; T maxDist = std::numeric_limits<T>::infinity(); bool keepNormals = true, keepEigenValues = false;
+        int knn = 5; T maxDist = std::numeric_limits<T>::infinity(); bool keepNormals = true, keepEigenValues = false, keepDensities = false;
         pgslam_amd::LazyContext ctx;                 // made when the filter first runs, not when a YAML file is read
-        SurfaceNormalDataPointsFilter(int k, T md, bool kn, bool ke) : knn(k), maxDist(md), keepNormals(kn), keepEigenValues(ke) {}
+        SurfaceNormalDataPointsFilter(int k, T md, bool kn, bool ke, bool kd = false) : knn(k), maxDist(md), keepNormals(kn), keepEigenValues(ke), keepDensities(kd) {}
         SurfaceNormalDataPointsFilter(const SurfaceNormalDataPointsFilter &) = delete;
         SurfaceNormalDataPointsFilter &operator=(const SurfaceNormalDataPointsFilter &) = delete;
         void inPlaceFilter(DataPoints &c) override
         {
             const int n = (int)c.features.cols();
-            if (n == 0 || (!keepNormals && !keepEigenValues)) return;
+            if (n == 0 || (!keepNormals && !keepEigenValues && !keepDensities)) return;
             Matrix nrm(3, n), eig(3, n);
+            std::vector<int32_t> ids(keepDensities ? (size_t)n * knn : 0);
             const double md = std::isfinite((double)maxDist) ? (double)maxDist : 1e300;
-            check(ctx, pgslam_amd::Abi<T>::normals(ctx, c.features.data(), (int)c.features.rows(), n, knn, md, nrm.data(), 3,
-                                                   keepEigenValues ? eig.data() : nullptr));
+            check(ctx, pgslam_amd::Abi<T>::normals_ids(ctx, c.features.data(), (int)c.features.rows(), n, knn, md, nrm.data(), 3,
+                                                       keepEigenValues ? eig.data() : nullptr, keepDensities ? ids.data() : nullptr));
             if (keepNormals) c.addDescriptor("normals", nrm);
+            if (keepDensities) {
+                // [EXT] computeDensity: neighbours found / volume of the sphere that holds them around their MEAN, in T (the oracle's
+                // orc_densities); from the neighbour ids of the device search
+                Matrix dens(1, n);
+                for (int i = 0; i < n; i++) {
+                    const int32_t *nb = ids.data() + (size_t)i * knn;
+                    int cnt = 0;
+                    T sx = 0, sy = 0, sz = 0;
+                    for (int j = 0; j < knn; j++) if (nb[j] >= 0) { sx += c.features(0, nb[j]); sy += c.features(1, nb[j]); sz += c.features(2, nb[j]); cnt++; }
+                    T r2 = 0;
+                    if (cnt > 0) {
+                        const T mx = sx / (T)cnt, my = sy / (T)cnt, mz = sz / (T)cnt;
+                        for (int j = 0; j < knn; j++) if (nb[j] >= 0) {
+                            const T dx = c.features(0, nb[j]) - mx, dy = c.features(1, nb[j]) - my, dz = c.features(2, nb[j]) - mz;
+                            const T q = (dx * dx + dy * dy) + dz * dz;
+                            if (q > r2) r2 = q;
+                        }
+                    }
+                    const T r = std::sqrt(r2);
+                    dens(0, i) = (T)cnt / ((T)((4.0 / 3.0) * 3.14159265358979323846) * ((r * r) * r));
+                }
+                c.addDescriptor("densities", dens);
+            }
             if (keepEigenValues) c.addDescriptor("eigValues", eig);
+        }
+    };
+    //! eigen-decomposition of a symmetric 3x3 (cyclic Jacobi in double): ev[k], columns V[.][k]
+    static void symEigen3(double A[3][3], double V[3][3], double ev[3])
+    {
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = i == j ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 50; sweep++) {
+            const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+            if (off == 0.0) break;
+            for (int p = 0; p < 2; p++)
+                for (int q = p + 1; q < 3; q++) {
+                    if (A[p][q] == 0.0) continue;
+                    const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                    const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                    for (int r = 0; r < 3; r++) { const double a = A[r][p], b = A[r][q]; A[r][p] = cs * a - sn * b; A[r][q] = sn * a + cs * b; }
+                    for (int r = 0; r < 3; r++) { const double a = A[p][r], b = A[q][r]; A[p][r] = cs * a - sn * b; A[q][r] = sn * a + cs * b; }
+                    for (int r = 0; r < 3; r++) { const double a = V[r][p], b = V[r][q]; V[r][p] = cs * a - sn * b; V[r][q] = sn * a + cs * b; }
+                }
+        }
+        for (int i = 0; i < 3; i++) ev[i] = A[i][i];
+    }
+    //! [EXT] SamplingSurfaceNormalDataPointsFilter{ratio, knn, samplingMethod, maxBoxDim, averageExistingDescriptors, keepNormals}
+    //! (DataPointsFilters/SamplingSurfaceNormal.cpp; upstream's setDefault() reference filter): the cloud is cut at the median of
+    //! its widest dimension until a range holds at most knn points; each such box gets ONE normal (PCA of its points) and keeps
+    //! every point with probability `ratio` (samplingMethod 0) or one point moved to its mean, the existing descriptors
+    //! averaged (samplingMethod 1); boxes larger than maxBoxDim or of rank < 2 are dropped; the kept points stay in cloud order.
+    //! The statement is the oracle's (oracle/icp_oracle.c orc_sampling_surface_normal, which says what is upstream's and what
+    //! cannot be: nth_element's arrangement -> a sort on (coordinate, index); rand() -> the seeded draw; EigenSolver -> Jacobi).
+    //! Host side: it runs once per keyframe / map, on the reference (Localizer.hpp:314-315).
+    struct SamplingSurfaceNormalDataPointsFilter : DataPointsFilter {
+        T ratio; int knn, samplingMethod; T maxBoxDim; bool averageExistingDescriptors, keepNormals; unsigned long long seed;
+        SamplingSurfaceNormalDataPointsFilter(T r = T(0.5), int k = 7, int method = 0, T box = std::numeric_limits<T>::infinity(), bool avg = true,
+                                              bool kn = true, unsigned long long sd = 1)
+            : ratio(r), knn(k), samplingMethod(method), maxBoxDim(box), averageExistingDescriptors(avg), keepNormals(kn), seed(sd) {}
+        void inPlaceFilter(DataPoints &c) override
+        {
+            const int n = (int)c.features.cols();
+            if (n == 0) return;
+            const int drows = (int)c.descriptors.rows();
+            std::vector<int> idx(n);
+            for (int i = 0; i < n; i++) idx[i] = i;
+            std::vector<char> keep(n, 0);
+            Matrix nrm(3, n);
+            struct Range { int first, last; T lo[3], hi[3]; };
+            std::vector<Range> stack;
+            Range all{0, n, {c.features(0, 0), c.features(1, 0), c.features(2, 0)}, {c.features(0, 0), c.features(1, 0), c.features(2, 0)}};
+            for (int i = 0; i < n; i++)
+                for (int a = 0; a < 3; a++) { const T v = c.features(a, i); if (v < all.lo[a]) all.lo[a] = v; if (v > all.hi[a]) all.hi[a] = v; }
+            stack.push_back(all);
+            Matrix merged(drows > 0 ? drows : 1, 1);
+            while (!stack.empty()) {
+                const Range R = stack.back();
+                stack.pop_back();
+                const int count = R.last - R.first;
+                if (count > knn) {
+                    int cut = 0;
+                    for (int a = 1; a < 3; a++) if (R.hi[a] - R.lo[a] > R.hi[cut] - R.lo[cut]) cut = a;
+                    std::sort(idx.begin() + R.first, idx.begin() + R.last, [&](int i, int j) {
+                        const T x = c.features(cut, i), y = c.features(cut, j);
+                        return x < y || (x == y && i < j);
+                    });
+                    const int right = count / 2, left = count - right;
+                    const T cv = c.features(cut, idx[R.first + left]);
+                    Range L = R, G = R;
+                    L.last = R.first + left; L.hi[cut] = cv;
+                    G.first = R.first + left; G.lo[cut] = cv;
+                    stack.push_back(G);                  // (the left half is taken first; boxes are independent of one another)
+                    stack.push_back(L);
+                    continue;
+                }
+                // ---- a box
+                T lo[3], hi[3], sum[3] = {0, 0, 0};
+                for (int a = 0; a < 3; a++) { lo[a] = c.features(a, idx[R.first]); hi[a] = lo[a]; }
+                for (int k = R.first; k < R.last; k++)
+                    for (int a = 0; a < 3; a++) { const T v = c.features(a, idx[k]); if (v < lo[a]) lo[a] = v; if (v > hi[a]) hi[a] = v; sum[a] += v; }
+                T box = hi[0] - lo[0];
+                if (hi[1] - lo[1] > box) box = hi[1] - lo[1];
+                if (hi[2] - lo[2] > box) box = hi[2] - lo[2];
+                if (box > maxBoxDim) continue;
+                const T mx = sum[0] / (T)count, my = sum[1] / (T)count, mz = sum[2] / (T)count;
+                T c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+                for (int k = R.first; k < R.last; k++) {
+                    const int i = idx[k];
+                    const T dx = c.features(0, i) - mx, dy = c.features(1, i) - my, dz = c.features(2, i) - mz;
+                    c00 += dx * dx; c01 += dx * dy; c02 += dx * dz; c11 += dy * dy; c12 += dy * dz; c22 += dz * dz;
+                }
+                double A[3][3] = {{(double)c00, (double)c01, (double)c02}, {(double)c01, (double)c11, (double)c12}, {(double)c02, (double)c12, (double)c22}}, V[3][3], ev[3];
+                symEigen3(A, V, ev);
+                int l = 0, h = 0;
+                for (int k = 1; k < 3; k++) { if (ev[k] < ev[l]) l = k; if (ev[k] > ev[h]) h = k; }
+                const int mid = 3 - l - h;
+                if (l == h || !(ev[h] > 0.0) || !(ev[mid] > 3.0 * (double)std::numeric_limits<T>::epsilon() * ev[h])) continue;   // rank < 2
+                if (samplingMethod == 0) {
+                    for (int k = R.first; k < R.last; k++) {
+                        const int i = idx[k];
+                        if (!((double)(RandomSamplingDataPointsFilter::mix(seed * 0x100000001B3ULL + (unsigned long long)i) >> 11) / 9007199254740992.0 < (double)ratio)) continue;
+                        keep[i] = 1;
+                        nrm(0, i) = (T)V[0][l]; nrm(1, i) = (T)V[1][l]; nrm(2, i) = (T)V[2][l];
+                    }
+                } else {
+                    const int i = idx[R.first];
+                    keep[i] = 1;
+                    nrm(0, i) = (T)V[0][l]; nrm(1, i) = (T)V[1][l]; nrm(2, i) = (T)V[2][l];
+                    if (drows > 0 && averageExistingDescriptors) {
+                        for (int r = 0; r < drows; r++) merged(r, 0) = 0;
+                        for (int k = R.first; k < R.last; k++) for (int r = 0; r < drows; r++) merged(r, 0) += c.descriptors(r, idx[k]);
+                        for (int r = 0; r < drows; r++) c.descriptors(r, i) = merged(r, 0) / (T)count;
+                    }
+                    c.features(0, i) = mx; c.features(1, i) = my; c.features(2, i) = mz;
+                    if (c.features.rows() > 3) c.features(3, i) = T(1);
+                }
+            }
+            if (keepNormals) c.addDescriptor("normals", nrm);
+            compactColumns(c, [&](int j) { return keep[j] != 0; });
+        }
+    };
+    //! [EXT] MaxDensityDataPointsFilter{maxDensity} (DataPointsFilters/MaxDensity.cpp): needs the `densities` descriptor
+    //! (SurfaceNormalDataPointsFilter{keepDensities: 1}); keeps a point at or below maxDensity, a denser one with probability
+    //! maxDensity / density -- times (1 - nbSaturatedPts / nbPointsIn) in INTEGER arithmetic for points at the cloud's largest
+    //! density, as upstream writes it.  The draw is the build's seeded one (not rand()-parity, see RandomSampling).
+    struct MaxDensityDataPointsFilter : DataPointsFilter {
+        T maxDensity; unsigned long long seed;
+        explicit MaxDensityDataPointsFilter(T d = T(10), unsigned long long s = 1) : maxDensity(d), seed(s) {}
+        void inPlaceFilter(DataPoints &c) override
+        {
+            if (!c.descriptorExists("densities")) throw std::runtime_error("MaxDensityDataPointsFilter: Error, no densities found in descriptors.");
+            const int n = (int)c.features.cols();
+            if (n == 0) return;
+            const int rd = c.getDescriptorStartingRow("densities");
+            T last = c.descriptors(rd, 0);
+            for (int i = 1; i < n; i++) if (c.descriptors(rd, i) > last) last = c.descriptors(rd, i);
+            int saturated = 0;
+            for (int i = 0; i < n; i++) saturated += c.descriptors(rd, i) == last;
+            compactColumns(c, [&](int j) {
+                const T density = c.descriptors(rd, j);
+                if (!(density > maxDensity)) return true;
+                float accept = (float)(maxDensity / density);
+                if (density == last) accept = accept * (float)(1 - saturated / n);
+                return (double)(RandomSamplingDataPointsFilter::mix(seed * 0x100000001B3ULL + (unsigned long long)j) >> 11) / 9007199254740992.0 < (double)accept;
+            });
         }
     };
     struct DataPointsFilters : std::vector<std::shared_ptr<DataPointsFilter>> {
@@ -617,13 +784,30 @@ struct PointMatcher {
                     auto get = [&](const char *k, const char *def) { return m.params.count(k) ? m.params.at(k) : std::string(def); };
                     // (epsilon > 0 allows an approximate neighbour search upstream; the exact search here meets every allowance)
                     if (!(to_double(get("epsilon", "0"), m.name) >= 0.0)) throw std::runtime_error(m.name + ": epsilon must be >= 0");
-                    for (const char *k : {"keepDensities", "keepEigenVectors", "keepMatchedIds", "keepMeanDist", "smoothNormals"})
+                    for (const char *k : {"keepEigenVectors", "keepMatchedIds", "keepMeanDist", "smoothNormals"})
                         if (to_double(get(k, "0"), m.name) != 0.0) throw std::runtime_error(m.name + ": " + k + " is not supported");
                     const int knn = (int)to_double(get("knn", "5"), m.name);
                     if (knn < 3 || knn > 32) throw std::runtime_error(m.name + ": knn must be in [3, 32]");
                     this->push_back(std::make_shared<SurfaceNormalDataPointsFilter>(knn, (T)to_double(get("maxDist", "inf"), m.name),
                                                                                      to_double(get("keepNormals", "1"), m.name) != 0.0,
-                                                                                     to_double(get("keepEigenValues", "0"), m.name) != 0.0));
+                                                                                     to_double(get("keepEigenValues", "0"), m.name) != 0.0,
+                                                                                     to_double(get("keepDensities", "0"), m.name) != 0.0));
+                } else if (m.name == "SamplingSurfaceNormalDataPointsFilter") {
+                    auto get = [&](const char *k, const char *def) { return m.params.count(k) ? m.params.at(k) : std::string(def); };
+                    for (const char *k : {"keepDensities", "keepEigenValues", "keepEigenVectors"})
+                        if (to_double(get(k, "0"), m.name) != 0.0) throw std::runtime_error(m.name + ": " + k + " is not supported");
+                    const double ratio = to_double(get("ratio", "0.5"), m.name), seed = to_double(get("seed", "1"), m.name);
+                    const int knn = (int)to_double(get("knn", "7"), m.name), method = (int)to_double(get("samplingMethod", "0"), m.name);
+                    if (!(ratio > 0.0 && ratio < 1.0) || knn < 3 || (method != 0 && method != 1) || !(seed >= 0.0 && seed < 9007199254740992.0))
+                        throw std::runtime_error(m.name + ": ratio must be in (0, 1), knn >= 3, samplingMethod 0 or 1, seed in [0, 2^53)");
+                    this->push_back(std::make_shared<SamplingSurfaceNormalDataPointsFilter>((T)ratio, knn, method, (T)to_double(get("maxBoxDim", "inf"), m.name),
+                                                                                             to_double(get("averageExistingDescriptors", "1"), m.name) != 0.0,
+                                                                                             to_double(get("keepNormals", "1"), m.name) != 0.0, (unsigned long long)seed));
+                } else if (m.name == "MaxDensityDataPointsFilter") {
+                    auto get = [&](const char *k, const char *def) { return to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
+                    const double md = get("maxDensity", "10"), seed = get("seed", "1");
+                    if (!(md > 0.0) || !(seed >= 0.0 && seed < 9007199254740992.0)) throw std::runtime_error(m.name + ": maxDensity must be positive, seed in [0, 2^53)");
+                    this->push_back(std::make_shared<MaxDensityDataPointsFilter>((T)md, (unsigned long long)seed));
                 } else if (m.name == "BoundingBoxDataPointsFilter") {
                     auto get = [&](const char *k, const char *def) { return (T)to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
                     const T lo[3] = {get("xMin", "-1"), get("yMin", "-1"), get("zMin", "-1")}, hi[3] = {get("xMax", "1"), get("yMax", "1"), get("zMax", "1")};
@@ -659,7 +843,8 @@ struct PointMatcher {
                 } else
                     throw std::runtime_error("DataPointsFilters: unsupported filter '" + m.name +
                                              "' (supported: Identity, MinDist, MaxDist, BoundingBox, RemoveNaN, SurfaceNormal, "
-                                             "ObservationDirection, OrientNormals, Shadow, FixStepSampling, RandomSampling, MaxPointCount (seeded samplers, not rand()-parity))");
+                                             "SamplingSurfaceNormal, MaxDensity, ObservationDirection, OrientNormals, Shadow, FixStepSampling, RandomSampling, MaxPointCount "
+                                             "(seeded samplers, not rand()-parity))");
             }
         }
         void init() { for (auto &f : *this) f->init(); }
@@ -1049,10 +1234,14 @@ struct PointMatcher {
             transformations.clear(); outlierFilters.clear(); transformationCheckers.clear();
             matcher.reset(); errorMinimizer.reset();
         }
-        //! libpointmatcher defaults: KDTreeMatcher, TrimmedDist 0.85, PointToPlane, Counter(40)+Differential
+        //! libpointmatcher defaults ([EXT] ICP.cpp ICPChaineBase::setDefault): RandomSamplingDataPointsFilter on the
+        //! reading, SamplingSurfaceNormalDataPointsFilter on the reference (where the default point-to-plane minimiser gets its
+        //! normals from), KDTreeMatcher, TrimmedDist 0.85, PointToPlane, Counter(40) + Differential
         virtual void setDefault()
         {
             cleanup();
+            readingDataPointsFilters.push_back(std::make_shared<RandomSamplingDataPointsFilter>(T(0.75), 1ULL));
+            referenceDataPointsFilters.push_back(std::make_shared<SamplingSurfaceNormalDataPointsFilter>());
             transformations.push_back(std::make_shared<RigidTransformation>(&ctx));
             matcher = std::make_shared<Matcher>(this);
             outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));

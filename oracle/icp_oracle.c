@@ -657,6 +657,177 @@ int FN(orc_surface_normals)(const real *xyz, int n, int knn, real max_dist, real
 }
 
 /* --------------------------------------------------------------------------
+ * [EXT] SamplingSurfaceNormalDataPointsFilter{ratio, knn, samplingMethod, maxBoxDim, averageExistingDescriptors,
+ * keepNormals, ...} (libpointmatcher DataPointsFilters/SamplingSurfaceNormal.cpp, version unpinned, restated from its
+ * published source; upstream's ICP::setDefault() installs it with its defaults -- ratio 0.5, knn 7 -- as THE reference filter,
+ * and it is how most point-to-plane configurations get their normals: Localizer.hpp:73-78, 314-315 apply whatever the YAML names).
+ *   buildNew(first, last, min, max): a range of at most knn points is a BOX (fuseRange); otherwise it is cut at the median of
+ *     its widest dimension -- argmax(max - min) over the FEATURE rows, first maximum, the bounds being the cloud's bounding box
+ *     narrowed by the cut values on the way down --: rightCount = count / 2, leftCount = count - rightCount,
+ *     std::nth_element at first + leftCount, cutVal = that element's coordinate; recursion left then right.
+ *   fuseRange: box = max - min of the points; dropped whole when its largest side exceeds maxBoxDim; mean = sum / count and
+ *     C = NN NN^T of the mean-subtracted points, in T; dropped whole when rank(C) + 1 < 3 (a box of collinear or identical
+ *     points: "no noise in data"); normal = eigenvector of the smallest eigenvalue (the solver's sign).
+ *     samplingMethod 0: every point of the box is kept with probability ratio (upstream: rand() / RAND_MAX < ratio) and gets the
+ *       box's normal; samplingMethod 1: ONE point per box -- the first index of the range -- moved to the box's mean.
+ *   The kept indices are sorted and the cloud compacted in that order.
+ * What is NOT upstream's, and cannot be (nothing to be bit-exact against):
+ *   - std::nth_element leaves the order inside the two halves, and which of several points AT the cut value fall left, to the
+ *     C++ library: here a range is cut by a full sort on (coordinate, index) -- one of the arrangements nth_element may produce --
+ *     so a box's members are determined except among equal coordinates, and "the first index of the range" (method 1) is the
+ *     point smallest along the last cut;
+ *   - rand(): the build's counter-based draw (SplitMix64 of the seed and the point's ORIGINAL index), as in RandomSampling;
+ *   - Eigen's EigenSolver: cyclic Jacobi in double on the T-accumulated scatter, rank test as in orc_surface_normals.
+ * keep[i] = 1 / 0 per input point; nrm (3 per input point) is written for kept points; xyz_out (3 per input point, or NULL):
+ * the kept point's coordinates (its own, or the box mean with method 1).  Returns the number of boxes that were fused.
+ * ------------------------------------------------------------------------ */
+typedef struct { const real *xyz; int cut; } FN(ssn_cmp_ctx);
+static _Thread_local FN(ssn_cmp_ctx) FN(ssn_cmp);
+static int FN(ssn_compare)(const void *a, const void *b)
+{
+    const int i = *(const int *)a, j = *(const int *)b;
+    const real x = FN(ssn_cmp).xyz[3 * i + FN(ssn_cmp).cut], y = FN(ssn_cmp).xyz[3 * j + FN(ssn_cmp).cut];
+    if (x < y) return -1;
+    if (x > y) return 1;
+    return (i > j) - (i < j);
+}
+typedef struct {
+    const real *xyz; int *idx; int knn, method; real ratio, max_box; uint64_t seed;
+    int *keep; real *nrm, *xyz_out; int boxes;
+} FN(ssn_state);
+static void FN(ssn_fuse)(FN(ssn_state) *S, int first, int last)
+{
+    const int cnt = last - first;
+    const real *X = S->xyz;
+    real lo[3], hi[3], sum[3] = {0, 0, 0};
+    for (int a = 0; a < 3; a++) { lo[a] = X[3 * S->idx[first] + a]; hi[a] = lo[a]; }
+    for (int k = first; k < last; k++)
+        for (int a = 0; a < 3; a++) {
+            const real v = X[3 * S->idx[k] + a];
+            if (v < lo[a]) lo[a] = v;
+            if (v > hi[a]) hi[a] = v;
+            sum[a] += v;
+        }
+    real box = hi[0] - lo[0];
+    if (hi[1] - lo[1] > box) box = hi[1] - lo[1];
+    if (hi[2] - lo[2] > box) box = hi[2] - lo[2];
+    if (box > S->max_box) return;
+    const real mx = sum[0] / (real)cnt, my = sum[1] / (real)cnt, mz = sum[2] / (real)cnt;
+    real c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    for (int k = first; k < last; k++) {
+        const int i = S->idx[k];
+        const real dx = X[3 * i] - mx, dy = X[3 * i + 1] - my, dz = X[3 * i + 2] - mz;
+        c00 += dx * dx; c01 += dx * dy; c02 += dx * dz; c11 += dy * dy; c12 += dy * dz; c22 += dz * dz;
+    }
+    double A[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}}, V[3][3], ev[3];
+    jacobi3(A, V, ev);
+    int l = 0, h = 0;
+    for (int k = 1; k < 3; k++) { if (ev[k] < ev[l]) l = k; if (ev[k] > ev[h]) h = k; }
+    const int mid = 3 - l - h;
+    const double tol = 3.0 * (double)REAL_EPS;
+    if (l == h || !(ev[h] > 0.0) || !(ev[mid] > tol * ev[h])) return;      /* rank < 2: the box is dropped */
+    S->boxes++;
+    const real n0 = (real)V[0][l], n1 = (real)V[1][l], n2 = (real)V[2][l];
+    if (S->method == 0) {
+        for (int k = first; k < last; k++) {
+            const int i = S->idx[k];
+            const double u = (double)(orc_splitmix(S->seed * 0x100000001B3ULL + (uint64_t)i) >> 11) / 9007199254740992.0;
+            if (!(u < (double)S->ratio)) continue;
+            S->keep[i] = 1;
+            S->nrm[3 * i] = n0; S->nrm[3 * i + 1] = n1; S->nrm[3 * i + 2] = n2;
+            if (S->xyz_out) { S->xyz_out[3 * i] = X[3 * i]; S->xyz_out[3 * i + 1] = X[3 * i + 1]; S->xyz_out[3 * i + 2] = X[3 * i + 2]; }
+        }
+    } else {
+        const int i = S->idx[first];
+        S->keep[i] = 1;
+        S->nrm[3 * i] = n0; S->nrm[3 * i + 1] = n1; S->nrm[3 * i + 2] = n2;
+        if (S->xyz_out) { S->xyz_out[3 * i] = mx; S->xyz_out[3 * i + 1] = my; S->xyz_out[3 * i + 2] = mz; }
+    }
+}
+static void FN(ssn_build)(FN(ssn_state) *S, int first, int last, const real *lo, const real *hi)
+{
+    const int count = last - first;
+    if (count <= S->knn) { FN(ssn_fuse)(S, first, last); return; }
+    int cut = 0;                                            /* argMax(max - min), first maximum */
+    for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[cut] - lo[cut]) cut = a;
+    const int right = count / 2, left = count - right;
+    FN(ssn_cmp).xyz = S->xyz; FN(ssn_cmp).cut = cut;
+    qsort(S->idx + first, (size_t)count, sizeof(int), FN(ssn_compare));
+    const real cut_val = S->xyz[3 * S->idx[first + left] + cut];
+    real lhi[3] = {hi[0], hi[1], hi[2]}, rlo[3] = {lo[0], lo[1], lo[2]};
+    lhi[cut] = cut_val; rlo[cut] = cut_val;
+    FN(ssn_build)(S, first, first + left, lo, lhi);
+    FN(ssn_build)(S, first + left, last, rlo, hi);
+}
+int FN(orc_sampling_surface_normal)(const real *xyz, int n, int knn, real ratio, int sampling_method, real max_box_dim, double seed,
+                                    int *keep, real *nrm, real *xyz_out)
+{
+    if (n <= 0 || knn < 3) return -1;
+    FN(ssn_state) S;
+    S.xyz = xyz; S.knn = knn; S.method = sampling_method; S.ratio = ratio; S.max_box = max_box_dim; S.seed = (uint64_t)seed;
+    S.keep = keep; S.nrm = nrm; S.xyz_out = xyz_out; S.boxes = 0;
+    S.idx = (int *)malloc(sizeof(int) * (size_t)n);
+    real lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
+    for (int i = 0; i < n; i++) {
+        S.idx[i] = i; keep[i] = 0;
+        for (int a = 0; a < 3; a++) { const real v = xyz[3 * i + a]; if (v < lo[a]) lo[a] = v; if (v > hi[a]) hi[a] = v; }
+    }
+    FN(ssn_build)(&S, 0, n, lo, hi);
+    free(S.idx);
+    return S.boxes;
+}
+
+/* --------------------------------------------------------------------------
+ * [EXT] `densities` of SurfaceNormalDataPointsFilter{keepDensities: 1} (computeDensity in DataPointsFilters/utils) and
+ * MaxDensityDataPointsFilter{maxDensity} (DataPointsFilters/MaxDensity.cpp), restated from the published source:
+ *   density(i) = k / ((4 / 3) pi r^3), k = neighbours found (the point itself among them), r = the largest distance of a
+ *     neighbour from the neighbourhood's MEAN -- NN.colwise().norm().maxCoeff() on the mean-subtracted columns -- in T;
+ *   MaxDensity keeps a point whose density is <= maxDensity; a denser one with probability maxDensity / density (upstream:
+ *     rand() / RAND_MAX < acceptRatio -- the build's counter-based draw here); for points AT the cloud's largest density the
+ *     ratio is multiplied by (1 - nbSaturatedPts / nbPointsIn) in INTEGER arithmetic, as upstream writes it: 1 unless every
+ *     point is saturated, then 0.
+ * ------------------------------------------------------------------------ */
+void FN(orc_densities)(const real *xyz, int n, int knn, const int *ids /* n x knn, -1 = none */, real *dens)
+{
+    for (int i = 0; i < n; i++) {
+        const int *nb = ids + (size_t)i * knn;
+        int cnt = 0;
+        real sx = 0, sy = 0, sz = 0;
+        for (int j = 0; j < knn; j++)
+            if (nb[j] >= 0) { sx += xyz[3 * nb[j]]; sy += xyz[3 * nb[j] + 1]; sz += xyz[3 * nb[j] + 2]; cnt++; }
+        real r2 = 0;
+        if (cnt > 0) {
+            const real mx = sx / (real)cnt, my = sy / (real)cnt, mz = sz / (real)cnt;
+            for (int j = 0; j < knn; j++)
+                if (nb[j] >= 0) {
+                    const real dx = xyz[3 * nb[j]] - mx, dy = xyz[3 * nb[j] + 1] - my, dz = xyz[3 * nb[j] + 2] - mz;
+                    const real q = (dx * dx + dy * dy) + dz * dz;
+                    if (q > r2) r2 = q;
+                }
+        }
+        const real r = SQRT_R(r2);
+        const real volume = (real)((4.0 / 3.0) * 3.14159265358979323846) * ((r * r) * r);
+        dens[i] = (real)cnt / volume;
+    }
+}
+void FN(orc_max_density_keep)(const real *dens, int n, real max_density, double seed, int *keep)
+{
+    real last = dens[0];
+    for (int i = 1; i < n; i++) if (dens[i] > last) last = dens[i];
+    int saturated = 0;
+    for (int i = 0; i < n; i++) saturated += dens[i] == last;
+    for (int i = 0; i < n; i++) {
+        keep[i] = 1;
+        if (dens[i] > max_density) {
+            float accept = (float)(max_density / dens[i]);
+            if (dens[i] == last) accept = accept * (float)(1 - saturated / n);
+            const double u = (double)(orc_splitmix((uint64_t)seed * 0x100000001B3ULL + (uint64_t)i) >> 11) / 9007199254740992.0;
+            keep[i] = u < (double)accept;
+        }
+    }
+}
+
+/* --------------------------------------------------------------------------
  * [A.4] TrimmedDistOutlierFilter
  * ------------------------------------------------------------------------ */
 static int cmp_real(const void *a, const void *b)

@@ -171,6 +171,36 @@ class Oracle:
         self._f("orc_shadow_keep")(self._p(xyz), self._p(nrm), C.c_int(len(xyz)), self.real(eps_angle), keep.ctypes.data_as(C.c_void_p))
         return keep.astype(bool)
 
+    def sampling_surface_normal(self, xyz, knn=7, ratio=0.5, sampling_method=0, max_box_dim=np.inf, seed=1):
+        """[EXT] SamplingSurfaceNormalDataPointsFilter (orc_sampling_surface_normal): dict(keep (n,) bool, normals (n,3) -- rows of kept
+        points --, xyz (n,3): the kept points' coordinates (box means with sampling_method 1), boxes: boxes fused)"""
+        xyz = self._a(xyz)
+        n = len(xyz)
+        keep = np.zeros(n, dtype=np.int32)
+        nrm = np.zeros((n, 3), dtype=self.dtype)
+        out = np.zeros((n, 3), dtype=self.dtype)
+        f = self._f("orc_sampling_surface_normal")
+        f.restype = C.c_int
+        boxes = f(self._p(xyz), C.c_int(n), C.c_int(knn), self.real(ratio), C.c_int(sampling_method), self.real(max_box_dim), C.c_double(seed),
+                  keep.ctypes.data_as(C.c_void_p), self._p(nrm), self._p(out))
+        assert boxes >= 0
+        return dict(keep=keep.astype(bool), normals=nrm, xyz=out, boxes=boxes)
+
+    def densities(self, xyz, ids):
+        """[EXT] SurfaceNormalDataPointsFilter{keepDensities}: neighbours / volume of the sphere that holds them around their mean"""
+        xyz = self._a(xyz)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        d = np.empty(len(xyz), dtype=self.dtype)
+        self._f("orc_densities")(self._p(xyz), C.c_int(len(xyz)), C.c_int(ids.shape[1]), self._p(ids), self._p(d))
+        return d
+
+    def max_density_keep(self, dens, max_density=10.0, seed=1):
+        """[EXT] MaxDensityDataPointsFilter{maxDensity}: boolean keep mask"""
+        dens = np.ascontiguousarray(dens, dtype=self.dtype)
+        keep = np.zeros(len(dens), dtype=np.int32)
+        self._f("orc_max_density_keep")(self._p(dens), C.c_int(len(dens)), self.real(max_density), C.c_double(seed), keep.ctypes.data_as(C.c_void_p))
+        return keep.astype(bool)
+
     def robust_weights(self, d2, fct, tuning=1.0, scale=1, approx=0.0):
         """[EXT] RobustOutlierFilter (orc_robust_weights): (weights, squared scale)"""
         d2 = np.ascontiguousarray(d2, dtype=self.dtype)

@@ -177,7 +177,10 @@ void yaml_and_matrix()
     // accepted: the exact search meets it
     { std::istringstream ok("- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: 3.16\n"); PointMatcher<float>::DataPointsFilters g(ok); CHECK(g.size() == 1); }
     // anything outside the supported set is refused at load time, never ignored
-    for (const char *txt : {"- MaxDensityDataPointsFilter:\n    maxDensity: 100\n",
+    for (const char *txt : {"- VoxelGridDataPointsFilter:\n    vSizeX: 0.1\n",
+                            "- MaxDensityDataPointsFilter:\n    maxDensity: -1\n",
+                            "- SamplingSurfaceNormalDataPointsFilter:\n    ratio: 1.5\n",
+                            "- SamplingSurfaceNormalDataPointsFilter:\n    keepDensities: 1\n",
                             "- MaxDistDataPointsFilter:\n    maxDist: 5\n    dim: 3\n",
                             "- SurfaceNormalDataPointsFilter:\n    knn: 10\n    epsilon: -1\n",
                             "- SurfaceNormalDataPointsFilter:\n    knn: 64\n"}) {
@@ -243,6 +246,36 @@ int main()
         threw = false;
         try { icp.loadFromYaml(rob2); } catch (const std::runtime_error &) { threw = true; }
         CHECK(threw);
+    }
+    {   // [EXT] ICPChaineBase::setDefault: the default data-point filters are upstream's -- RandomSampling (prob 0.75) on the reading,
+        // SamplingSurfaceNormal (ratio 0.5, knn 7) on the reference, where the default point-to-plane minimiser gets its normals
+        PointMatcher<float>::ICP icp;
+        icp.setDefault();
+        CHECK(icp.readingDataPointsFilters.size() == 1 && icp.referenceDataPointsFilters.size() == 1 && icp.readingStepDataPointsFilters.empty());
+        CHECK(dynamic_cast<PointMatcher<float>::RandomSamplingDataPointsFilter *>(icp.readingDataPointsFilters[0].get()) != nullptr);
+        auto *ssn = dynamic_cast<PointMatcher<float>::SamplingSurfaceNormalDataPointsFilter *>(icp.referenceDataPointsFilters[0].get());
+        CHECK(ssn != nullptr && ssn->knn == 7 && ssn->ratio == 0.5f && ssn->samplingMethod == 0 && ssn->keepNormals);
+        // a flat patch with a little noise: every kept point carries the patch's normal, +-z
+        std::vector<float> xyz;
+        unsigned lcg = 12345u;
+        for (int i = 0; i < 40; i++) for (int j = 0; j < 40; j++) {
+            lcg = lcg * 1664525u + 1013904223u;
+            xyz.push_back(0.05f * i); xyz.push_back(0.05f * j); xyz.push_back(1.0f + 1e-4f * (float)((lcg >> 8) & 0xFF) / 255.f);
+        }
+        auto ref = PointMatcher<float>::DataPoints::fromXYZ(xyz.data(), 1600, nullptr);
+        icp.referenceDataPointsFilters.apply(ref);
+        CHECK(ref.getNbPoints() > 600 && ref.getNbPoints() < 1000 && ref.descriptorExists("normals"));
+        const int rn = ref.getDescriptorStartingRow("normals");
+        int good = 0;
+        for (size_t j = 0; j < ref.getNbPoints(); j++) good += std::fabs(ref.descriptors(rn + 2, (int)j)) > 0.999f;
+        CHECK(good == (int)ref.getNbPoints());
+        // MaxDensity without the densities descriptor: refused like upstream
+        std::istringstream md("- MaxDensityDataPointsFilter:\n    maxDensity: 100\n");
+        PointMatcher<float>::DataPointsFilters mdf(md);
+        bool refused = false;
+        try { mdf.apply(ref); } catch (const std::runtime_error &) { refused = true; }
+        CHECK(refused);
+        std::puts("setDefault filters ok");
     }
     std::puts("dropin cpu tests ok");
     return 0;

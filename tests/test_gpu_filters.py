@@ -201,3 +201,80 @@ def test_device_memory_calls_refuse_bad_arguments(ctx):
     assert np.array_equal(ctx.device_download(d).ravel(), host)
     ctx.device_free(d)
     assert ctx.lib.pgicp_device_free(None, None) == icp.OK                            # nothing to free, no context: fine
+
+
+# ---------------------------------------------------------------- round 6: densities, MaxDensity, SamplingSurfaceNormal in a chain
+def _write_cloud(path, xyz, dtype):
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("i", len(xyz)))
+        f.write(np.ascontiguousarray(xyz, dtype=dtype).tobytes())
+
+
+def test_densities_and_max_density_filter_through_the_yaml_loader(tmp_path, oracle32):
+    """SurfaceNormalDataPointsFilter{keepDensities: 1} + MaxDensityDataPointsFilter{maxDensity} as a user's input-filter file names
+    them (Localizer.hpp:73-78): the neighbour search runs on the device (pgicp_surface_normals), densities and the thinning on the
+    host.  Against the oracle: the same neighbours, the same densities (in T, bit for bit), the same kept points."""
+    from test_filters_host import apply_filters
+    s = synth.make_two_scans(6000, rings=16)
+    xyz = s["ref_xyz"].astype(np.float32)
+    sn = oracle32.surface_normals(xyz, 10)
+    dens = oracle32.densities(xyz, sn["ids"])
+    md = float(np.median(dens))
+    yaml = ("- SurfaceNormalDataPointsFilter:\n    knn: 10\n    keepDensities: 1\n- MaxDensityDataPointsFilter:\n    maxDensity: %.9g\n    seed: 11\n" % md)
+    pts, nrm = apply_filters(tmp_path, yaml, xyz, np.float32)
+    keep = oracle32.max_density_keep(dens, np.float32(md), seed=11)
+    assert 0.5 * len(xyz) < keep.sum() < 0.95 * len(xyz)
+    assert len(pts) == keep.sum() and np.array_equal(pts, xyz[keep])
+    assert nrm is not None and np.all(np.abs(np.sum(nrm * sn["normals"][keep], axis=1)) > 1 - 1e-4)
+
+
+@pytest.mark.parametrize("chain", ["yaml", "default"])
+def test_icp_whose_reference_filter_is_sampling_surface_normal(tmp_path, oracle32, chain):
+    """A chain that GETS its normals the way upstream's default chain does -- SamplingSurfaceNormalDataPointsFilter on the
+    reference (referenceDataPointsFilters, Localizer.hpp:314-315; ICP::operator(), LoopCloser.hpp:98) -- through loadFromYaml /
+    setDefault of the shim, against the oracle run on the oracle's own filtered reference."""
+    import struct
+    import subprocess
+    from test_cpp_dropin import build
+    s = synth.make_two_scans(8000, rings=16)
+    rd, ref = s["reading_xyz"].astype(np.float32), s["ref_xyz"].astype(np.float32)
+    if chain == "yaml":
+        yaml = ("referenceDataPointsFilters:\n  - SamplingSurfaceNormalDataPointsFilter:\n      ratio: 0.6\n      knn: 10\n      samplingMethod: 1\n"
+                "matcher:\n  KDTreeMatcher:\n    knn: 1\n    maxDist: 2.0\n"
+                "outlierFilters:\n  - TrimmedDistOutlierFilter:\n      ratio: 0.85\n"
+                "errorMinimizer:\n  PointToPlaneWithCovErrorMinimizer:\n    sensorStdDev: 0.01\n"
+                "transformationCheckers:\n  - CounterTransformationChecker:\n      maxIterationCount: 30\n"
+                "  - DifferentialTransformationChecker:\n      minDiffRotErr: 0.001\n      minDiffTransErr: 0.01\n      smoothLength: 3\n")
+        fy = str(tmp_path / "chain.yaml")
+        open(fy, "w").write(yaml)
+        f = oracle32.sampling_surface_normal(ref, knn=10, ratio=0.6, sampling_method=1)
+        oreading, okw = rd, dict(max_dist=2.0, trim_ratio=0.85, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01, smooth_length=3, sensor_std_dev=0.01)
+    else:
+        # upstream's defaults: reading RandomSampling 0.75 (seed 1), reference SamplingSurfaceNormal (0.5, knn 7, method 0, seed 1),
+        # KDTree maxDist inf, TrimmedDist 0.85, PointToPlane, Counter 40, Differential (0.001, 0.001, 3)
+        fy = "default"
+        f = oracle32.sampling_surface_normal(ref, knn=7, ratio=0.5, sampling_method=0, seed=1)
+        kept = oracle32.filter_chain([(6, 0.75, 1)], rd)
+        oreading = rd[kept]
+        okw = dict(max_dist=float("inf"), trim_ratio=0.85, max_iters=40, min_diff_rot=0.001, min_diff_trans=0.001, smooth_length=3, sensor_std_dev=0.01)
+    k = f["keep"]
+    fr, fi, ft, fo = (str(tmp_path / n) for n in ("reading.bin", "ref.bin", "tinit.bin", "out.bin"))
+    _write_cloud(fr, rd, np.float32)
+    _write_cloud(fi, ref, np.float32)
+    open(ft, "wb").write(np.ascontiguousarray(s["T_init"], dtype=np.float64).tobytes())
+    r = subprocess.run([build("icp_apply"), "f32", fy, fr, fi, ft, fo], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    raw = open(fo, "rb").read()
+    T = np.frombuffer(raw, dtype=np.float64, count=16).reshape(4, 4)
+    m, hn = struct.unpack("ii", raw[128:136])
+    assert m == k.sum() and hn == 1
+    o = oracle32.icp(oreading, f["xyz"][k], f["normals"][k], s["T_init"], **okw)
+    assert o["status"] == 0
+    d = np.linalg.inv(o["T"]) @ T
+    dt = np.linalg.norm(d[:3, 3])
+    dr = np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1))
+    # the two sides' box normals agree to float rounding (the same Jacobi on the same sums), not bit for bit: 1e-5 m / 1e-5 rad
+    assert dt < 1e-5 and dr < 1e-5, (dt, dr)
+    truth = np.linalg.inv(s["T_truth"]) @ T
+    assert np.linalg.norm(truth[:3, 3]) < 0.05

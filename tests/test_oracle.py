@@ -576,3 +576,117 @@ def test_shadow_filter_against_numpy(oracle32, oracle64, dtype):
         assert not keep[5]
     assert 0.05 < o.shadow_keep(xyz, nrm, 0.1).mean() < 0.99
 
+
+
+# ---------------------------------------------------------------- round 6: SamplingSurfaceNormal, densities, MaxDensity
+def _splitmix_u(seed, idx):
+    """the build's counter-based uniform draw (SplitMix64 of seed * FNV prime + index, top 53 bits), in Python integers"""
+    M = (1 << 64) - 1
+    z = (int(seed) * 0x100000001B3 + int(idx)) & M
+    z = (z + 0x9E3779B97F4A7C15) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    return (z >> 11) / 9007199254740992.0
+
+
+def _np_sampling_surface_normal(xyz, knn, ratio, method, max_box, seed):
+    """An independent float64 numpy statement of SamplingSurfaceNormalDataPointsFilter: explicit stack instead of recursion,
+    np.lexsort for the median cut, np.linalg.eigh for the PCA (shares no code with icp_oracle.c)."""
+    x = np.asarray(xyz, dtype=np.float64)
+    n = len(x)
+    keep = np.zeros(n, bool)
+    nrm = np.zeros((n, 3))
+    out = np.zeros((n, 3))
+    boxes = []
+    stack = [(np.arange(n), x.min(0), x.max(0))]
+    while stack:
+        idx, lo, hi = stack.pop()
+        if len(idx) <= knn:
+            boxes.append(idx)
+            continue
+        cut = int(np.argmax(hi - lo))
+        order = np.lexsort((idx, x[idx, cut]))
+        idx = idx[order]
+        right = len(idx) // 2
+        left = len(idx) - right
+        cv = x[idx[left], cut]
+        lhi, rlo = hi.copy(), lo.copy()
+        lhi[cut] = cv
+        rlo[cut] = cv
+        stack.append((idx[left:], rlo, hi))          # (popped after the left half: the order of the boxes does not matter)
+        stack.append((idx[:left], lo, lhi))
+    fused = 0
+    for idx in boxes:
+        p = x[idx]
+        if (p.max(0) - p.min(0)).max() > max_box:
+            continue
+        mean = p.mean(0)
+        C = (p - mean).T @ (p - mean)
+        w, v = np.linalg.eigh(C)
+        if not (w[2] > 0 and w[1] > 3 * np.finfo(np.float64).eps * w[2]):
+            continue
+        fused += 1
+        if method == 0:
+            for i in idx:
+                if _splitmix_u(seed, i) < ratio:
+                    keep[i] = True
+                    nrm[i] = v[:, 0]
+                    out[i] = x[i]
+        else:
+            i = idx[0]
+            keep[i] = True
+            nrm[i] = v[:, 0]
+            out[i] = mean
+    return keep, nrm, out, fused
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_sampling_surface_normal_against_numpy(oracle64, method):
+    """[EXT] SamplingSurfaceNormalDataPointsFilter{ratio, knn, samplingMethod, maxBoxDim}: recursive median split of the widest
+    dimension down to boxes of <= knn points, one PCA per box, every point of a box kept with probability `ratio` (method 0) or one
+    point per box moved to the box's mean (method 1), degenerate boxes dropped.  Against an independent numpy float64 statement:
+    the same boxes, the same kept points, the same means, normals equal up to sign."""
+    from pgslam_amd import synth
+    s = synth.make_two_scans(6000, rings=16)
+    xyz = s["ref_xyz"].astype(np.float64)
+    xyz[100:108] = xyz[100]                                  # a box of identical points somewhere: dropped, not fused
+    for knn, ratio, max_box in ((7, 0.5, np.inf), (12, 0.3, 0.4), (3, 0.9, np.inf)):
+        r = oracle64.sampling_surface_normal(xyz, knn=knn, ratio=ratio, sampling_method=method, max_box_dim=max_box, seed=17)
+        keep, nrm, out, fused = _np_sampling_surface_normal(xyz, knn, ratio, method, max_box, 17)
+        assert r["boxes"] == fused and 0 < keep.sum() < len(xyz)
+        assert np.array_equal(r["keep"], keep)
+        np.testing.assert_allclose(r["xyz"][keep], out[keep], rtol=1e-13, atol=1e-13)
+        d = np.abs(np.sum(r["normals"][keep] * nrm[keep], axis=1))
+        # (a box's two small eigenvalues can be close: the normal is then ill-conditioned in BOTH statements -- compared where it is not)
+        assert np.mean(d > 1 - 1e-6) > 0.97 and np.all(np.abs(np.linalg.norm(r["normals"][keep], axis=1) - 1) < 1e-12)
+    if method == 1:
+        assert r["keep"].sum() == r["boxes"]                 # one point per fused box
+
+
+def test_sampling_surface_normal_float_chain_and_density_filters(oracle32, oracle64):
+    """the float instantiation keeps the same boxes as the double one (cuts compare coordinates, which are the same numbers) and
+    about `ratio` of the points; densities = k / ((4/3) pi r^3) around the neighbourhood's mean; MaxDensity keeps every point at or
+    below maxDensity and maxDensity / density of the denser ones"""
+    from pgslam_amd import synth
+    s = synth.make_two_scans(8000, rings=16)
+    xyz = s["ref_xyz"]
+    a = oracle32.sampling_surface_normal(xyz, knn=7, ratio=0.5, sampling_method=1)
+    b = oracle64.sampling_surface_normal(xyz.astype(np.float64), knn=7, ratio=0.5, sampling_method=1)
+    # (which nearly collinear boxes count as degenerate depends on the precision's epsilon: a few boxes differ, no more)
+    assert np.mean(a["keep"] == b["keep"]) > 0.995 and abs(a["boxes"] - b["boxes"]) <= 0.01 * b["boxes"]
+    r0 = oracle32.sampling_surface_normal(xyz, knn=7, ratio=0.5, sampling_method=0, seed=5)
+    assert 0.45 < r0["keep"].mean() < 0.55
+    sn = oracle64.surface_normals(xyz.astype(np.float64), 10)
+    dens = oracle64.densities(xyz.astype(np.float64), sn["ids"])
+    x = xyz.astype(np.float64)
+    for i in (0, 17, 4000, 7999):
+        nb = x[sn["ids"][i]]
+        r = np.linalg.norm(nb - nb.mean(0), axis=1).max()
+        assert dens[i] == pytest.approx(10 / (4.0 / 3.0 * np.pi * r ** 3), rel=1e-12)
+    md = float(np.median(dens))
+    keep = oracle64.max_density_keep(dens, md, seed=3)
+    assert np.all(keep[dens <= md])
+    dense = dens > md
+    expect = np.array([_splitmix_u(3, i) < np.float32(md / dens[i]) for i in np.nonzero(dense)[0]])
+    assert np.array_equal(keep[dense], expect) and 0.2 < keep[dense].mean() < 0.9
