@@ -270,6 +270,16 @@ struct PointMatcher {
             descriptors = nd;
             descriptorLabels.push_back(Label(name, d.rows()));
         }
+        //! what a filter that "allocates" a descriptor does upstream (DataPoints::allocateDescriptors): a descriptor of that name and
+        //! span that already exists is REUSED -- its rows are overwritten --, one of another span is an error, a new one is appended
+        void setDescriptor(const std::string &name, const Matrix &d)
+        {
+            if (!descriptorExists(name)) { addDescriptor(name, d); return; }
+            if (d.cols() != features.cols()) throw std::runtime_error("DataPoints::setDescriptor: wrong number of points");
+            if (getDescriptorDimension(name) != (int)d.rows()) throw std::runtime_error("DataPoints::setDescriptor: " + name + " exists with another dimension");
+            const int r0 = getDescriptorStartingRow(name);
+            for (int j = 0; j < features.cols(); j++) for (int i = 0; i < d.rows(); i++) descriptors(r0 + i, j) = d(i, j);
+        }
         //! append dp; only descriptors present in BOTH clouds (same name and span) are kept
         void concatenate(const DataPoints &dp)
         {
@@ -592,7 +602,7 @@ struct PointMatcher {
             const double md = std::isfinite((double)maxDist) ? (double)maxDist : 1e300;
             check(ctx, pgslam_amd::Abi<T>::normals_ids(ctx, c.features.data(), (int)c.features.rows(), n, knn, md, nrm.data(), 3,
                                                        keepEigenValues ? eig.data() : nullptr, keepDensities ? ids.data() : nullptr));
-            if (keepNormals) c.addDescriptor("normals", nrm);
+            if (keepNormals) c.setDescriptor("normals", nrm);
             if (keepDensities) {
                 // [EXT] computeDensity: neighbours found / volume of the sphere that holds them around their MEAN, in T (the oracle's
                 // orc_densities); from the neighbour ids of the device search
@@ -614,9 +624,9 @@ struct PointMatcher {
                     const T r = std::sqrt(r2);
                     dens(0, i) = (T)cnt / ((T)((4.0 / 3.0) * 3.14159265358979323846) * ((r * r) * r));
                 }
-                c.addDescriptor("densities", dens);
+                c.setDescriptor("densities", dens);
             }
-            if (keepEigenValues) c.addDescriptor("eigValues", eig);
+            if (keepEigenValues) c.setDescriptor("eigValues", eig);
         }
     };
     //! eigen-decomposition of a symmetric 3x3 (cyclic Jacobi in double): ev[k], columns V[.][k]
@@ -730,7 +740,7 @@ struct PointMatcher {
                     if (c.features.rows() > 3) c.features(3, i) = T(1);
                 }
             }
-            if (keepNormals) c.addDescriptor("normals", nrm);
+            if (keepNormals) c.setDescriptor("normals", nrm);
             compactColumns(c, [&](int j) { return keep[j] != 0; });
         }
     };
@@ -1219,7 +1229,10 @@ struct PointMatcher {
         explicit ICPChainBase(int device = 0) : ctx(device)
         {
             std::memset(&lastStats, 0, sizeof lastStats);
-            setDefault();
+            // (upstream's constructor leaves the chain EMPTY -- an ICP object used without setDefault() / loadFromYaml() has no
+            // matcher there; here it starts with the default matcher / outlier filter / minimiser / checkers and no data-point
+            // filters, so that members can be set one by one; setDefault() is upstream's, data-point filters included)
+            setDefaultWithoutDataPointsFilters();
         }
         ICPChainBase(const ICPChainBase &) = delete;
         ICPChainBase &operator=(const ICPChainBase &) = delete;
@@ -1239,9 +1252,13 @@ struct PointMatcher {
         //! normals from), KDTreeMatcher, TrimmedDist 0.85, PointToPlane, Counter(40) + Differential
         virtual void setDefault()
         {
-            cleanup();
+            setDefaultWithoutDataPointsFilters();
             readingDataPointsFilters.push_back(std::make_shared<RandomSamplingDataPointsFilter>(T(0.75), 1ULL));
             referenceDataPointsFilters.push_back(std::make_shared<SamplingSurfaceNormalDataPointsFilter>());
+        }
+        void setDefaultWithoutDataPointsFilters()
+        {
+            cleanup();
             transformations.push_back(std::make_shared<RigidTransformation>(&ctx));
             matcher = std::make_shared<Matcher>(this);
             outlierFilters.push_back(std::make_shared<TrimmedDistOutlierFilter>(this, T(0.85)));
