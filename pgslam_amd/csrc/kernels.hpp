@@ -55,6 +55,7 @@ template <typename T>
 int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m, int knn, T max_dist, T eps_rank, T *out_nrm,
                            int out_stride, T *out_eig, int *out_ids, T *out_d2);
 int reduce_blocks(int max_n);
+void launch_batch_setup(hipStream_t st, int *active, int P, int *z0, long long n0, int *z1, long long n1, int *z2, long long n2);
 void launch_invert_order(hipStream_t st, const ProblemDev *probs, const int *order, int *scan_pos, int P, int max_n);
 template <typename T>
 void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const T *rd_nrm, const int *slot,

@@ -973,8 +973,9 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         HIPC(c, S.nrm_sorted.ensure(sizeof(T) * 3 * (size_t)L.total));
     }
     HIPC(c, S.none_r.ensure(sizeof(T) * (size_t)L.total));
-    HIPC(c, c->probs.ensure(sizeof(ProblemDev) * (size_t)P));
-    HIPC(c, c->src.ensure(sizeof(SrcDesc) * (size_t)P));
+    // (the problem records and the readings' source descriptors share one buffer: one upload -- batch_begin)
+    const size_t src_off = (sizeof(ProblemDev) * (size_t)P + 63) & ~(size_t)63;
+    HIPC(c, c->probs.ensure(src_off + sizeof(SrcDesc) * (size_t)P));
     HIPC(c, c->partials.ensure(sizeof(double) * (size_t)P * reduce_blocks(L.max_pairs()) * kCovTerms));
     HIPC(c, c->sums.ensure(sizeof(double) * (size_t)P * kCovTerms));
     HIPC(c, c->small.ensure(256));
@@ -1013,23 +1014,27 @@ int batch_begin(pgicp_ctx *c, int P, const pgicp_problem *pr, F Tpre_of, BatchLa
         for (int i = 0; i < 12; i++) { D.Tcur[i] = D.T_iter[i]; D.Tcur_f[i] = (float)D.T_iter[i]; }
         checker_init(D.chk);
     }
-    { const int pst = pinned_ensure(c, &c->h_up, &c->h_up_cap, sizeof(ProblemDev) * (size_t)P); if (pst) return pst; }
+    // One upload and one kernel set a batch up (round 6; three copies and three memsets before: six launches a call, twelve per
+    // scan of the facade, which is bound by its launches at sensor size): the problem records and the source descriptors
+    // travel as ONE pinned block into ONE buffer; k_batch_setup writes the identity list of active problems and clears the
+    // small counters, the selection tables and the reading sort's bin counts.
+    { const int pst = pinned_ensure(c, &c->h_up, &c->h_up_cap, src_off + sizeof(SrcDesc) * (size_t)P); if (pst) return pst; }
     std::memcpy(c->h_up, hp.data(), sizeof(ProblemDev) * (size_t)P);
-    HIPC(c, hipMemcpyAsync(c->probs.p, c->h_up, sizeof(ProblemDev) * P, hipMemcpyHostToDevice, c->stream));
-    XFER(c, h2d(c, c->src.p, hs.data(), sizeof(SrcDesc) * P));
+    std::memcpy(c->h_up + src_off, hs.data(), sizeof(SrcDesc) * (size_t)P);
+    HIPC(c, hipMemcpyAsync(c->probs.p, c->h_up, src_off + sizeof(SrcDesc) * (size_t)P, hipMemcpyHostToDevice, c->stream));
+    const SrcDesc *src_dev = (const SrcDesc *)((const char *)c->probs.p + src_off);
     std::vector<int> &ident = c->h_ident;
     ident.resize(P);
     std::iota(ident.begin(), ident.end(), 0);
-    XFER(c, h2d(c, c->active.p, ident.data(), sizeof(int) * P));
-    HIPC(c, hipMemsetAsync(c->small.p, 0, 256, c->stream));
+    launch_batch_setup(c->stream, c->active.as<int>(), P, c->small.as<int>(), 64, c->sel_tables.as<int>(), (long long)(trim_select_table_bytes(P) / sizeof(int)),
+                       c->qcounts.as<int>(), (long long)P * L.max_rows);
     c->counters_clean = 1;
     c->seg_clean = 0;               // a new batch: its first matcher launch clears the segmented counters itself
-    HIPC(c, hipMemsetAsync(c->sel_tables.p, 0, trim_select_table_bytes(P), c->stream));
     {
         ProfScope ps(c, PGICP_PROF_PRETRANSFORM, L.total, P);
         // pre-transform + ordering of each reading by (block of map cells, cell, index), once per scan: waves stay spatially
         // coherent for every iteration
-        launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), c->src.as<SrcDesc>(), S.d_maps.template as<MapDev<T>>(),
+        launch_query_sort<T>(c->stream, c->probs.as<ProblemDev>(), src_dev, S.d_maps.template as<MapDev<T>>(),
                              S.rd_pre.template as<typename Vec4<T>::type>(), S.rd_sorted.template as<T>(), c->qrow.as<int>(), c->qtmp.as<unsigned long long>(),
                              c->order.as<int>(), c->qcounts.as<int>(), c->qblock.as<int>(), c->qstart.as<int>(),
                              P, L.max_n, L.max_rows, L.bin_shift, L.normals ? S.nrm_pre.template as<typename Vec4<T>::type>() : nullptr,
