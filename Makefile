@@ -12,7 +12,7 @@ all: $(LIB) oracle
 
 $(CSRC)/kernels.o: $(CSRC)/kernels.hip $(wildcard $(CSRC)/k_*.inc) $(CSRC)/kernels.hpp $(CSRC)/device_types.hpp $(CSRC)/icp_math.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/pgicp_api.o: $(CSRC)/pgicp_api.cpp $(CSRC)/kernels.hpp $(CSRC)/device_types.hpp $(CSRC)/icp_math.hpp include/pgicp.h
+$(CSRC)/pgicp_api.o: $(CSRC)/pgicp_api.cpp $(wildcard $(CSRC)/api_*.inc) $(CSRC)/kernels.hpp $(CSRC)/device_types.hpp $(CSRC)/icp_math.hpp include/pgicp.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/pgicp_comm.o: $(CSRC)/pgicp_comm.cpp include/pgicp.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
