@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 counter record (GPU box, through gpurun): every rocprofv3 --pmc pass is its own run, no trace domains with it.
+# The round's counter record (GPU box, through gpurun; PGSLAM_COMMIT in the environment is written into every json): every rocprofv3 --pmc pass is its own run, no trace domains with it.
 #   headline: FETCH_SIZE | WRITE_SIZE | GRBM+TA | SQ instruction mix      -> knn_traffic.json, knn_pmc.json
 #   loop closing, streaming, f64: FETCH_SIZE | WRITE_SIZE                    -> knn_traffic_<leg>.json
 OUT=gpurun_out/${1:-r4pmc}; mkdir -p $OUT; rm -f $OUT/passes.log

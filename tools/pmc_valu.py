@@ -5,7 +5,7 @@ cycles), texture-address busy = TA_TA_BUSY_sum / (256 CUs x cycles), with cycles
 over the XCDs).  Writes profiles/knn_pmc.json, which bench.py quotes in roofline.bound_measured_evidence.
 
   pmc_valu.py DIR_GRBM_TA DIR_SQ_INSTS OUT.json QUERIES_PER_LAUNCH [KERNEL [MEAN_ITERATIONS_PER_QUERY]]"""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 d_grbm, d_sq, out, queries = sys.argv[1:5]
 kernel = sys.argv[5] if len(sys.argv) > 5 else "k_knn_grid"
 mean_iters = float(sys.argv[6]) if len(sys.argv) > 6 else None     # iterations a query takes part in on average (the bench line's mean_iterations)
@@ -34,7 +34,7 @@ q = float(queries)
 first = [r for i, r in enumerate(rows) if i == 0 or r["cycles_per_xcd"] > 2.0 * rows[i - 1]["cycles_per_xcd"]]
 rest = [r for r in rows if r not in first]
 tot_valu = sum(r["valu_wave_insts"] for r in rows)
-res = dict(kernel=kernel, bound_measured="valu", launches=n, steps_in_record=len(first),
+res = dict(kernel=kernel, commit=os.environ.get("PGSLAM_COMMIT"), bound_measured="valu", launches=n, steps_in_record=len(first),
            valu_busy_all_launches=busy(rows), valu_busy_unseeded_launches=busy(first), valu_busy_seeded_launches=busy(rest),
            ta_busy_all_launches=sum(r["ta_busy"] * r["cycles_per_xcd"] for r in rows) / sum(r["cycles_per_xcd"] for r in rows),
            valu_lane_ops_per_query_iteration=64.0 * tot_valu / (q * n),

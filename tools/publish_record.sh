@@ -22,6 +22,7 @@ cp $M/bench_loopclosure_shard_proxy_full.json $P/${R}_bench_loopclosure_shard_pr
 cp $M/trace_slam100k_summary.txt $P/${R}_slam100k_trace_summary.txt 2>/dev/null
 cp $M/trace_stream_summary.txt $P/${R}_stream_kernel_totals.txt
 cp $M/stream_timeline_last_scan.txt $P/${R}_stream_timeline_last_scan.txt
-for f in knn_traffic knn_pmc knn_traffic_loopclosure knn_traffic_stream knn_traffic_f64 knn_traffic_slam; do cp $M/pmc/$f.json $P/$f.json; done
+# (the counter records both under their standing names -- bench.py reads profiles/knn_traffic.json / knn_pmc.json -- and under the round's, each with its commit inside)
+for f in knn_traffic knn_pmc knn_traffic_loopclosure knn_traffic_stream knn_traffic_f64 knn_traffic_slam; do cp $M/pmc/$f.json $P/$f.json; cp $M/pmc/$f.json $P/${R}_$f.json; done
 mkdir -p $P/${R}_pmc; cp $M/pmc/*_all_kernels.txt $M/pmc/head_*_per_dispatch.txt $M/pmc/digest.log $P/${R}_pmc/
 python3 tools/measure_digest.py $M > $P/${R}_digest.txt 2>&1
