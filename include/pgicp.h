@@ -322,6 +322,20 @@ int pgicp_partial_chain_f32(pgicp_ctx *ctx, int map_id, const float *reading, in
                             const double *T, double *weighted_point_used_ratio, double *residual);
 int pgicp_partial_chain_f64(pgicp_ctx *ctx, int map_id, const double *reading, int stride, int n, int mem,
                             const double *T, double *weighted_point_used_ratio, double *residual);
+/* (ABI 6) The same chain, its matcher SEEDED from the correspondences another context's last align call ended with -- the
+ * overlap probe of a scan that has just been aligned (Localizer.hpp:210,231 -> 282-348: up to once per scan): the candidate
+ * composition shares keyframes with the map the ICP matched against, so most of the scan's neighbours exist in the candidate
+ * map too, at known index offsets.  `src`: the context that aligned THIS reading (same points, same order) as problem 0 of its
+ * last pgicp_align* call, idle now, on the same device; the two maps as concatenations of keyframe clouds: segment k of
+ * the ICP's reference holds original indices [src_start[k], src_start[k + 1]) and sits at dst_start[k] in this call's map
+ * (-1: not part of it).  A seed is a candidate only -- the matches are exact, the result is pgicp_partial_chain's bit for bit
+ * (tests/test_gpu_parity.py) --; a reading the source context did not align (another size) is searched unseeded. */
+int pgicp_partial_chain_seeded_f32(pgicp_ctx *ctx, int map_id, const float *reading, int stride, int n, int mem, const double *T,
+                                   pgicp_ctx *src, int n_seg, const int32_t *src_start, const int32_t *dst_start,
+                                   double *weighted_point_used_ratio, double *residual);
+int pgicp_partial_chain_seeded_f64(pgicp_ctx *ctx, int map_id, const double *reading, int stride, int n, int mem, const double *T,
+                                   pgicp_ctx *src, int n_seg, const int32_t *src_start, const int32_t *dst_start,
+                                   double *weighted_point_used_ratio, double *residual);
 /* the same chain for a batch of (map, reading, T = problems[p].T_init): the residual check of every
  * loop-closure candidate of a batch (LoopCloser.hpp:340-363) in one device pass.  status[p] is
  * PGICP_OK or PGICP_ERR_NO_MATCH; the call returns the worst status.  Output arrays may be NULL. */

@@ -429,6 +429,12 @@ int pgicp_partial_chain_f64(pgicp_ctx *c, int map_id, const double *rd, int stri
                             double *ratio, double *residual)
 { return partial_chain<double>(c, map_id, rd, stride, n, mem, T, ratio, residual); }
 
+int pgicp_partial_chain_seeded_f32(pgicp_ctx *c, int map_id, const float *rd, int stride, int n, int mem, const double *T, pgicp_ctx *src, int n_seg,
+                                   const int32_t *src_start, const int32_t *dst_start, double *ratio, double *residual)
+{ return partial_chain_seeded<float>(c, map_id, rd, stride, n, mem, T, src, n_seg, src_start, dst_start, ratio, residual); }
+int pgicp_partial_chain_seeded_f64(pgicp_ctx *c, int map_id, const double *rd, int stride, int n, int mem, const double *T, pgicp_ctx *src, int n_seg,
+                                   const int32_t *src_start, const int32_t *dst_start, double *ratio, double *residual)
+{ return partial_chain_seeded<double>(c, map_id, rd, stride, n, mem, T, src, n_seg, src_start, dst_start, ratio, residual); }
 int pgicp_partial_chain_batch_f32(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ratio, double *residual, int *status)
 { return partial_chain_batch<float>(c, P, pr, ratio, residual, status); }
 int pgicp_partial_chain_batch_f64(pgicp_ctx *c, int P, const pgicp_problem *pr, double *ratio, double *residual, int *status)

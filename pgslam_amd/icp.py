@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "pgicp_status_string", "pgicp_upload_f32", "pgicp_upload_f64", "pgicp_host_alloc", "pgicp_host_free",
     "pgicp_ctx_device", "pgicp_comm_unique_id", "pgicp_comm_create", "pgicp_comm_destroy", "pgicp_comm_info",
     "pgicp_comm_last_error", "pgicp_shard_slots", "pgicp_allgather_edges", "pgicp_comm_create_host", "pgicp_profile_process",
-    "pgicp_debug_reading_order",
+    "pgicp_debug_reading_order", "pgicp_partial_chain_seeded_f32", "pgicp_partial_chain_seeded_f64",
 ]
 SUM_ORDER_SORTED, SUM_ORDER_SCAN = 0, 1
 
@@ -581,6 +581,21 @@ class Context:
         fn = getattr(self.lib, "pgicp_partial_chain" + self._sfx(r.dtype))
         self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem),
                        _T16(T) if T is not None else None, C.byref(ratio), C.byref(resid)))
+        return ratio.value, resid.value
+
+    def partial_chain_seeded(self, map_id, reading, T, src: "Context", src_start, dst_start, dtype=None):
+        """pgicp_partial_chain_seeded: the partial chain with its matcher seeded from the correspondences `src`'s last align of THIS
+        reading ended with; the two maps as concatenations of keyframe clouds (src_start: n_seg + 1 index boundaries in the ICP's
+        map; dst_start: where each segment sits in this map, -1 = absent).  Same result as partial_chain, bit for bit."""
+        r = _Buf(reading, dtype)
+        ss = np.ascontiguousarray(src_start, dtype=np.int32)
+        ds = np.ascontiguousarray(dst_start, dtype=np.int32)
+        assert len(ss) == len(ds) + 1
+        ratio, resid = C.c_double(0), C.c_double(0)
+        fn = getattr(self.lib, "pgicp_partial_chain_seeded" + self._sfx(r.dtype))
+        self._check(fn(self.h, C.c_int(map_id), C.c_void_p(r.ptr), C.c_int(r.stride), C.c_int(r.n), C.c_int(r.mem),
+                       _T16(T) if T is not None else None, src.h if src is not None else None, C.c_int(len(ds)),
+                       C.c_void_p(ss.ctypes.data), C.c_void_p(ds.ctypes.data), C.byref(ratio), C.byref(resid)))
         return ratio.value, resid.value
 
     def partial_chain_batch(self, map_ids, readings, Ts, dtype=None, raise_on_error=True):

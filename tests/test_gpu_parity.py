@@ -537,3 +537,58 @@ def test_host_may_look_at_the_iteration_flag_less_often(ctx, small, B):
         assert key == ref, every
     ctx.set_params(**CHAIN, check_every=1)
     ctx.destroy_map(m)
+
+
+# ---------------------------------------------------------------- round 6: the overlap probe seeded from the ICP's correspondences
+def test_seeded_partial_chain_equals_the_unseeded_one(oracle32):
+    """pgicp_partial_chain_seeded (Localizer.hpp:210,231 -> 282-348: the overlap probe of a scan that has just been aligned): context A
+    aligns a scan against the map of keyframes (k0, k1, k2); context B asks for the overlap with the candidate composition
+    (k2, k1, k3) at the result.  The probe's matcher is seeded with A's correspondences moved through the shared keyframes' index
+    offsets.  Seeds are candidates only: ratio and residual are the unseeded chain's doubles, the per-point matches the same --
+    also with segments that lie (wrong offsets), a segment that is absent, and a reading A never aligned."""
+    world = synth.make_world()
+    poses = [synth.se3(x=-6.0 + 1.5 * k, yaw=np.deg2rad(1.5 * (k % 3 - 1))) for k in range(5)]
+    kf = [synth.make_scan(world, poses[k], 12_000, 7100 + k, rings=16) for k in range(4)]
+    ref_pose = poses[2]
+
+    def assemble(order):
+        xs, ns = [], []
+        for k in order:
+            x, n = synth.transform_cloud(synth.se3_inv(ref_pose) @ poses[k], kf[k][0], kf[k][1])
+            xs.append(x); ns.append(n)
+        return np.concatenate(xs).astype(np.float32), np.concatenate(ns).astype(np.float32), [len(x) for x in xs]
+    order_a, order_b = [2, 1, 0], [2, 3, 1]
+    xa, na, sizes_a = assemble(order_a)
+    xb, nb, sizes_b = assemble(order_b)
+    scan, _ = synth.make_scan(world, poses[4] @ synth.se3(x=-2.0), 10_000, 7200, rings=16)
+    scan = scan.astype(np.float32)
+    T0 = synth.se3_inv(ref_pose) @ poses[4] @ synth.se3(x=-2.0) @ synth.perturbation(41)
+    A, B = icp.Context(0, **CHAIN), icp.Context(0, **CHAIN)
+    ma = A.set_map(xa, na, center=True)
+    mb = B.set_map(xb, nb, center=False)
+    T, st = A.align(ma, scan, T0)
+    assert st["status"] == 0
+    plain = B.partial_chain(mb, scan, T=T)
+    ids_plain, d2_plain = B.debug_last_matches(len(scan))
+    start_a = np.concatenate([[0], np.cumsum(sizes_a)])
+    start_b = np.concatenate([[0], np.cumsum(sizes_b)])
+    dst = [int(start_b[order_b.index(k)]) if k in order_b else -1 for k in order_a]
+    assert dst[2] == -1 and dst[0] == 0                       # k0 is not part of the candidate composition; k2 leads both
+    seeded = B.partial_chain_seeded(mb, scan, T, A, start_a, dst)
+    ids_s, d2_s = B.debug_last_matches(len(scan))
+    assert seeded == plain
+    kept = d2_plain <= np.float32(2.0) ** 2
+    assert np.array_equal(ids_s[kept & (ids_plain >= 0)], ids_plain[kept & (ids_plain >= 0)])
+    # the oracle's chain on the same inputs
+    o = oracle32.partial_chain(scan, xb, nb, T, **dict(CHAIN, center_reference=False))
+    assert seeded[0] == pytest.approx(o["overlap"], rel=1e-12)
+    # segments that lie: every seed points at some other point of the map -- candidates only
+    lying = B.partial_chain_seeded(mb, scan, T, A, start_a, [5, 777, 31])
+    assert lying == plain
+    # a reading A did not align (another size): searched unseeded
+    T2, _ = A.align(ma, scan[:5000], T0)
+    other = B.partial_chain_seeded(mb, scan, T, A, start_a, dst)
+    assert other == plain
+    # and the seeds are worth something: fewer candidates are looked at (the fast matcher's launch is shorter) -- asserted as results
+    # only; the timing is bench.py's (slam_100k leg)
+    A.close(); B.close()
