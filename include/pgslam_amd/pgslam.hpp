@@ -315,6 +315,22 @@ public:
                                                                &ratio, &residual));
         return (T)ratio;
     }
+    //! ... with the matcher seeded from the correspondences `icp_ctx`'s last align of this very reading ended with (the two maps as
+    //! concatenations of keyframe clouds: pgicp_partial_chain_seeded); the same result, bit for bit
+    T ComputeOverlapAgainstPrepared(const typename PM::ICPChainBase::DeviceReading &reading, const Matrix &T_world_robot, pgicp_ctx *icp_ctx,
+                                    const std::vector<int32_t> &src_start, const std::vector<int32_t> &dst_start)
+    {
+        if (!temp_icp_) throw std::logic_error("ComputeOverlapAgainstPrepared: no reference prepared");
+        typename PM::ICP &temp_icp = *temp_icp_;
+        if (!reading || !temp_icp.deviceReadingEquivalent() || !icp_ctx || src_start.size() != dst_start.size() + 1)
+            return ComputeOverlapAgainstPrepared(reading, T_world_robot);
+        double Tm[16], ratio = 0, residual = 0;
+        pgslam_amd::to_row_major16(T_world_robot, Tm);
+        temp_icp.pushParams();
+        PM::check(temp_icp.ctx, pgslam_amd::Abi<T>::partial_seeded_dev(temp_icp.ctx, temp_icp.matcher->mapId, reading.dev, reading.xyzStride(), reading.points(), Tm,
+                                                                      icp_ctx, (int)dst_start.size(), src_start.data(), dst_start.data(), &ratio, &residual));
+        return (T)ratio;
+    }
     const Matrix &T_refkf_robot() const { return T_refkf_robot_; }
     const Matrix &T_world_robot() const { return T_world_robot_; }
     ICPSequence &icp() { return icp_sequence_; }

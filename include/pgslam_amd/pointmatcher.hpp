@@ -145,6 +145,7 @@ template <> struct Abi<float> {
     static int normals_ids(pgicp_ctx *c, const float *x, int xs, int n, int knn, double md, float *out, int os, float *eig, int32_t *ids) { return pgicp_surface_normals_f32(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, ids, nullptr); }
     static int partial(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
     static int partial_dev(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f32(c, id, r, s, n, PGICP_DEVICE, Tm, ratio, res); }
+    static int partial_seeded_dev(pgicp_ctx *c, int id, const float *r, int s, int n, const double *Tm, pgicp_ctx *src, int ns, const int32_t *a, const int32_t *b, double *ratio, double *res) { return pgicp_partial_chain_seeded_f32(c, id, r, s, n, PGICP_DEVICE, Tm, src, ns, a, b, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const float *in, int is, float *out, int os, int n, int ro) { return pgicp_transform_f32(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
     static int local_map_dev(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_DEVICE); }
@@ -172,6 +173,7 @@ template <> struct Abi<double> {
     static int normals_ids(pgicp_ctx *c, const double *x, int xs, int n, int knn, double md, double *out, int os, double *eig, int32_t *ids) { return pgicp_surface_normals_f64(c, x, xs, n, PGICP_HOST, knn, md, out, os, eig, ids, nullptr); }
     static int partial(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_HOST, Tm, ratio, res); }
     static int partial_dev(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, double *ratio, double *res) { return pgicp_partial_chain_f64(c, id, r, s, n, PGICP_DEVICE, Tm, ratio, res); }
+    static int partial_seeded_dev(pgicp_ctx *c, int id, const double *r, int s, int n, const double *Tm, pgicp_ctx *src, int ns, const int32_t *a, const int32_t *b, double *ratio, double *res) { return pgicp_partial_chain_seeded_f64(c, id, r, s, n, PGICP_DEVICE, Tm, src, ns, a, b, ratio, res); }
     static int transform(pgicp_ctx *c, const double *Tm, const double *in, int is, double *out, int os, int n, int ro) { return pgicp_transform_f64(c, Tm, in, is, out, os, n, ro, PGICP_HOST); }
     static int local_map(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_HOST); }
     static int local_map_dev(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_DEVICE); }

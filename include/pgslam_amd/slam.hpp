@@ -885,7 +885,10 @@ public:
         if (Prefetched *slot = FindPrefetched(cloud.get())) { ahead = slot->reading; *slot = Prefetched(); }   // (freed even if the ICP throws)
         if (!ahead && direct) ahead = direct;                    // the device copy the input stage left behind (no second upload)
         input_device_ = ahead && ahead.filtered.get() == cloud.get() ? ahead : typename PM::ICPChainBase::DeviceReading();
-        if (ahead) { T_refkf_robot_ = icp_sequence_(ahead, T_refkf_robot_ * d); device_readings_used_++; }
+        // (whichever way the reading travels the ICP aligns the same points in the same order -- a device reading is only taken when
+        //  the chain's reading filters change nothing -- so its correspondences can seed the overlap probe of this scan)
+        last_icp_on_device_reading_ = false;
+        if (ahead) { T_refkf_robot_ = icp_sequence_(ahead, T_refkf_robot_ * d); device_readings_used_++; last_icp_on_device_reading_ = (bool)input_device_; }
         else T_refkf_robot_ = icp_sequence_(*cloud, T_refkf_robot_ * d);
         if (join.on) { join.on = false; host_worker_.wait(); }       // the host cloud is whole again before anything below looks at it
         const auto t2 = clk::now();
@@ -961,6 +964,7 @@ public:
     //! local maps assembled from device-resident keyframe clouds (default) or through the host, as upstream does
     void SetDeviceLocalMap(bool on) { device_local_map_ = on; }
     size_t device_rebuilds() const { return device_rebuilds_; }
+    size_t probes_seeded() const { return probe_seeded_; }
     //! The NEXT scan, already queued (LocalizerMT.hpp:27-40): pre-process it and start its transfer to the device on the ICP
     //! context's copy stream (pgicp_upload_*), so that it travels while the current scan aligns.  Needs a map (the chain
     //! aligns device readings only against one) -- before the first keyframe nothing is prefetched.
@@ -1012,7 +1016,17 @@ protected:
     bool device_input_stage_ = std::getenv("PGSLAM_HOST_INPUT_STAGE") == nullptr;
     bool device_local_map_ = std::getenv("PGSLAM_HOST_LOCAL_MAP") == nullptr;      // keyframe clouds resident, maps assembled in HBM
     pgslam_amd::DeviceCloud<T> map_assembly_, probe_assembly_;                   // assembly buffers (grow-only), one per chain
-    size_t device_rebuilds_ = 0;
+    // the two maps as concatenations of keyframe clouds (identity of a cloud: its device copy; size: its points), in assembly order --
+    // what the overlap probe's seeds are mapped through (pgicp_partial_chain_seeded); empty: that map was not assembled on the device
+    std::vector<std::pair<const void *, int>> map_segs_, probe_segs_;
+    static std::vector<std::pair<const void *, int>> SegmentsOf(const std::vector<Keyframe> &order)
+    {
+        std::vector<std::pair<const void *, int>> out;
+        for (auto &kf : order) out.emplace_back((const void *)kf.device_cloud.get(), kf.device_cloud ? kf.device_cloud->n : 0);
+        return out;
+    }
+    size_t device_rebuilds_ = 0, probe_seeded_ = 0;
+    bool last_icp_on_device_reading_ = false;        // the last ICP aligned input_device_ (same points, same order as the probe's reading)
     bool resync_before_update_ = false;              // the MT flavour re-reads the graph before every update
     unsigned long long synced_version_ = 0;
     void Rebuild()
@@ -1027,8 +1041,10 @@ protected:
             const std::vector<Keyframe> order = lm.AssemblyOrder();
             BuildLocalMapOnDevice<T>(icp_sequence_.ctx, order, map_assembly_);
             icp_sequence_.setMap(map_assembly_, [order]() { return BuildLocalMapCloud<T>(order); });
+            map_segs_ = SegmentsOf(order);
             device_rebuilds_++;
         } else {
+            map_segs_.clear();
             for (size_t v : comp_) lm.PushKeyframe(g[v]);
             lm.BuildCloudFromData();
             icp_sequence_.setMap(lm.Cloud());
@@ -1054,12 +1070,15 @@ protected:
             if (device_local_map_) {                    // (as Rebuild: assembled and moved to the world frame in device memory)
                 for (size_t v : comp) { map_manager_->EnsureKeyframeResident(v, probe_->OverlapContext()); lm.PushKeyframe(g[v]); }
                 const Matrix T_world_ref = g[comp.back()].optimized_T_world_kf;
-                BuildLocalMapOnDevice<T>(probe_->OverlapContext(), lm.AssemblyOrder(), probe_assembly_, &T_world_ref);
+                const std::vector<Keyframe> porder = lm.AssemblyOrder();
+                BuildLocalMapOnDevice<T>(probe_->OverlapContext(), porder, probe_assembly_, &T_world_ref);
                 prepared = probe_->PrepareOverlapReference(probe_assembly_);
+                probe_segs_ = prepared ? SegmentsOf(porder) : std::vector<std::pair<const void *, int>>();
             } else {
                 for (size_t v : comp) lm.PushKeyframe(g[v]);
             }
             if (!prepared) {
+                probe_segs_.clear();
                 lm.BuildCloudFromData();
                 const DP world_map = rigid_->compute(lm.Cloud(), g[comp.back()].optimized_T_world_kf);
                 probe_->PrepareOverlapReference(world_map);
@@ -1068,7 +1087,23 @@ protected:
             probe_version_ = map_manager_->Version();
         }
         // (the scan is on the device already when the input stage ran there: the probe reads that copy)
-        if (input_device_ && input_device_.filtered.get() == input_cloud_.get()) return probe_->ComputeOverlapAgainstPrepared(input_device_, T_world_robot_);
+        if (input_device_ && input_device_.filtered.get() == input_cloud_.get()) {
+            // Seeds for the probe's matcher (round 6): the ICP has just matched this very reading against a map that shares keyframes
+            // with the candidate composition -- the same physical points, at known index offsets in the two assemblies.  Candidates
+            // only: the probe's result is the unseeded one bit for bit (PGSLAM_PROBE_SEEDS=0 turns them off; run_probe_seeds).
+            static const bool seeds_on = !(std::getenv("PGSLAM_PROBE_SEEDS") && std::atoi(std::getenv("PGSLAM_PROBE_SEEDS")) == 0);
+            if (seeds_on && !map_segs_.empty() && !probe_segs_.empty() && map_segs_.size() <= 16 && last_icp_on_device_reading_) {
+                std::vector<int32_t> src_start(map_segs_.size() + 1, 0), dst_start(map_segs_.size(), -1);
+                for (size_t k = 0; k < map_segs_.size(); k++) {
+                    src_start[k + 1] = src_start[k] + map_segs_[k].second;
+                    int at = 0;
+                    for (auto &ps : probe_segs_) { if (ps.first == map_segs_[k].first && ps.second == map_segs_[k].second) { dst_start[k] = at; break; } at += ps.second; }
+                }
+                probe_seeded_++;
+                return probe_->ComputeOverlapAgainstPrepared(input_device_, T_world_robot_, icp_sequence_.ctx, src_start, dst_start);
+            }
+            return probe_->ComputeOverlapAgainstPrepared(input_device_, T_world_robot_);
+        }
         return probe_->ComputeOverlapAgainstPrepared(*input_cloud_, T_world_robot_);
     }
     //! Localizer.hpp:393-483

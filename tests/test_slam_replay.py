@@ -84,3 +84,26 @@ def test_probe_that_keeps_its_indexed_map_changes_nothing():
             "tracking_error_last_m", "keyframe_error_rms_m", "keyframe_error_max_m")
     for k in same:
         assert runs[0][k] == runs[1][k], (k, runs[0][k], runs[1][k])
+
+
+@pytest.mark.gpu
+def test_overlap_probe_seeded_from_the_icp_changes_nothing():
+    """Round 6: the overlap probe's matcher (Localizer.hpp:210,231 -> 282-348, up to once per scan) is seeded with the correspondences
+    the ICP of the same scan ended with, moved through the keyframes the two maps share (pgicp_partial_chain_seeded).  Seeds are
+    candidates only: with PGSLAM_PROBE_SEEDS=0 every figure of the run -- keyframes, loops, rebuilds, tracking errors to the
+    printed digit -- is the same, and the seeded run did seed its probes."""
+    import bench
+    import os
+    seq = bench.build_sequence(300, 20000, 1.2)
+    exe = bench.build_slam_run()
+    runs = []
+    for env in ({}, {"PGSLAM_PROBE_SEEDS": "0"}):
+        out = subprocess.run([exe, seq, "--filters", "sensor"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    same = ("scans", "keyframes", "loop_edges", "loop_candidates_tried", "loops_closed", "optimizer_runs", "optimizer_iterations",
+            "map_rebuilds", "mean_icp_iterations", "scans_not_converged", "tracking_error_rms_m", "tracking_error_max_m",
+            "tracking_error_last_m", "keyframe_error_rms_m", "keyframe_error_max_m")
+    for k in same:
+        assert runs[0][k] == runs[1][k], (k, runs[0][k], runs[1][k])
+    assert runs[0]["overlap_probes_seeded"] > 50 and runs[1]["overlap_probes_seeded"] == 0

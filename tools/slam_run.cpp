@@ -320,7 +320,7 @@ static int run_st(const char *seq_path, int limit, const char *rec_path, int rec
                 "\"tracking_error_max_m\": %.5f, \"tracking_error_last_m\": %.5f, \"odometry_error_last_m\": %.5f, "
                 "\"keyframe_error_rms_m\": %.5f, \"keyframe_error_max_m\": %.5f, \"recorded_calls\": %d, \"recorded_loop_calls\": %d, "
                 "\"localizer_host_s\": {\"filters_and_sensor_transform\": %.4f, \"icp\": %.4f, \"after_icp\": %.4f, \"after_icp_parts\": {\"neighbour_search\": %.4f, \"overlap_probe\": %.4f, \"rebuilds\": %.4f, \"new_keyframes_incl_loop_closing\": %.4f}}, "
-                "\"input_filters\": \"%s\", \"device_input_stages\": %zu, \"device_readings_used\": %zu, \"device_map_rebuilds\": %zu, \"points_after_filters_last_scan\": %u, "
+                "\"input_filters\": \"%s\", \"device_input_stages\": %zu, \"device_readings_used\": %zu, \"device_map_rebuilds\": %zu, \"overlap_probes_seeded\": %zu, \"points_after_filters_last_scan\": %u, "
                 "\"loop_candidates_assembled_on_device\": %zu, \"keyframes_resident\": %zu, \"keyframe_uploads\": %zu, \"keyframe_evictions\": %zu, "
                 "\"keyframes_revisiting_within_3m_by_truth\": %d, \"keyframes_revisiting_within_3m_by_estimate\": %d, "
                 "\"knn_profile\": {\"launches\": %lld, \"total_ms\": %.4f, \"reading_points\": %lld, \"problems\": %lld, \"map_points\": %lld}",
@@ -332,7 +332,7 @@ static int run_st(const char *seq_path, int limit, const char *rec_path, int rec
                 slam.localizer().phase_seconds()[0], slam.localizer().phase_seconds()[1], slam.localizer().phase_seconds()[2],
                 slam.localizer().after_icp_seconds()[0], slam.localizer().after_icp_seconds()[1], slam.localizer().after_icp_seconds()[2], slam.localizer().after_icp_seconds()[3],
                 g_filters == kSensorFilters ? "RemoveNaN, MaxDist 79.9, BoundingBox (vehicle)" : "Identity", slam.localizer().device_input_stages(),
-                slam.localizer().device_readings_used(), slam.localizer().device_rebuilds(), last_cloud_points,
+                slam.localizer().device_readings_used(), slam.localizer().device_rebuilds(), slam.localizer().probes_seeded(), last_cloud_points,
                 slam.loop_closer().device_candidates(), slam.map_manager().resident_keyframes(), slam.map_manager().device_uploads(), slam.map_manager().device_evictions(),
                 count_revisits(std::min(g.NumVertices(), kf_scan.size()), [&](size_t v, int a) { return (double)truth[kf_scan[v]](a, 3); }, 3.0, 4),
                 count_revisits(g.NumVertices(), [&](size_t v, int a) { return (double)g[v].optimized_T_world_kf(a, 3); }, 3.0, 4),
