@@ -328,8 +328,11 @@ int pgicp_partial_chain_f64(pgicp_ctx *ctx, int map_id, const double *reading, i
  * map too, at known index offsets.  `src`: the context that aligned THIS reading (same points, same order) as problem 0 of its
  * last pgicp_align* call, idle now, on the same device; the two maps as concatenations of keyframe clouds: segment k of
  * the ICP's reference holds original indices [src_start[k], src_start[k + 1]) and sits at dst_start[k] in this call's map
- * (-1: not part of it).  A seed is a candidate only -- the matches are exact, the result is pgicp_partial_chain's bit for bit
- * (tests/test_gpu_parity.py) --; a reading the source context did not align (another size) is searched unseeded. */
+ * (-1: not part of it).  A seed is a candidate only: the matches are exact, the ratio is pgicp_partial_chain's double.  The reading
+ * is taken in the order the SOURCE context sorted it in (one set-up kernel instead of a sort of its own), so with
+ * PGICP_SUM_ORDER_SORTED the residual is the same sum in another order (equal to ~1e-16 relative; identical with
+ * PGICP_SUM_ORDER_SCAN) -- tests/test_gpu_parity.py.  A reading the source context did not align (another size), a chain with
+ * knn > 1, the brute matcher or a SurfaceNormalOutlierFilter: searched unseeded, as pgicp_partial_chain. */
 int pgicp_partial_chain_seeded_f32(pgicp_ctx *ctx, int map_id, const float *reading, int stride, int n, int mem, const double *T,
                                    pgicp_ctx *src, int n_seg, const int32_t *src_start, const int32_t *dst_start,
                                    double *weighted_point_used_ratio, double *residual);

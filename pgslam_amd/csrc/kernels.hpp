@@ -57,8 +57,8 @@ int launch_surface_normals(hipStream_t st, const MapDev<T> *maps, int map, int m
 int reduce_blocks(int max_n);
 struct SeedSegs { int n; int src[17]; int dst[16]; };      // pgicp_partial_chain_seeded: the two maps as concatenations of keyframe clouds
 template <typename T>
-void launch_seed_from(hipStream_t st, const int *order_a, const int *slot_a, const typename Vec4<T>::type *pts_a, int n, const SeedSegs &sg,
-                      const int *slot_of_b, int m_b, int *seed_by_point, const int *order_b, int *slot_b);
+void launch_borrow_order(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, const int *order_a, const int *slot_a, const typename Vec4<T>::type *pts_a,
+                         int n, const SeedSegs &sg, const int *slot_of_b, int m_b, T *rd_sorted, int *order_b, int *slot_b);
 void launch_batch_setup(hipStream_t st, int *active, int P, int *z0, long long n0, int *z1, long long n1, int *z2, long long n2);
 void launch_invert_order(hipStream_t st, const ProblemDev *probs, const int *order, int *scan_pos, int P, int max_n);
 template <typename T>
