@@ -582,7 +582,7 @@ def test_seeded_partial_chain_equals_the_unseeded_one(oracle32):
         # call takes the reading in the ICP's sorting order (one set-up kernel instead of a sort), PGICP_SUM_ORDER_SORTED follows it
         return a[0] == b[0] and a[1] == pytest.approx(b[1], rel=1e-12)
     assert same(seeded, plain)
-    kept = d2_plain <= np.float32(2.0) ** 2
+    kept = d2_plain <= np.quantile(d2_plain[np.isfinite(d2_plain)], 0.8)       # (inside the trim threshold: beyond it the capped search is lazy)
     assert np.array_equal(ids_s[kept & (ids_plain >= 0)], ids_plain[kept & (ids_plain >= 0)])
     # the oracle's chain on the same inputs
     o = oracle32.partial_chain(scan, xb, nb, T, **dict(CHAIN, center_reference=False))
@@ -590,6 +590,20 @@ def test_seeded_partial_chain_equals_the_unseeded_one(oracle32):
     # segments that lie: every seed points at some other point of the map -- candidates only
     lying = B.partial_chain_seeded(mb, scan, T, A, start_a, [5, 777, 31])
     assert same(lying, plain)
+    # The seeded probe also starts with a search cap: 1.21 x the threshold the context's previous probe ended with (matcher mode 3:
+    # the capped, lazily exact search of an ICP's later iterations).  A cap that is far too small -- the previous probe sat on the
+    # map, this one is 40 cm off -- and one that is far too large cost time, never a result.
+    T_off = T @ synth.se3(x=0.4, yaw=np.deg2rad(1.0))
+    plain_off = B.partial_chain(mb, scan, T=T_off)
+    assert plain_off[1] > 4.0 * plain[1]                      # (the residual says how far off: the threshold is several times the hint)
+    B.partial_chain(mb, scan, T=T)                            # the hint: the small threshold
+    assert same(B.partial_chain_seeded(mb, scan, T_off, A, start_a, dst), plain_off)
+    ids_o, d2_o = B.debug_last_matches(len(scan))
+    B.partial_chain(mb, scan, T=T_off)
+    ids_po, d2_po = B.debug_last_matches(len(scan))
+    kept_o = d2_po <= np.median(d2_po[np.isfinite(d2_po)])        # (well inside the trim threshold: exact in both calls)
+    assert np.array_equal(ids_o[kept_o & (ids_po >= 0)], ids_po[kept_o & (ids_po >= 0)])
+    assert same(B.partial_chain_seeded(mb, scan, T, A, start_a, dst), plain)       # the hint: the large threshold of T_off
     # a reading A did not align (another size): searched unseeded
     T2, _ = A.align(ma, scan[:5000], T0)
     other = B.partial_chain_seeded(mb, scan, T, A, start_a, dst)

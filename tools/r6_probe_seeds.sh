@@ -6,7 +6,7 @@ OUT=gpurun_out/r6p; mkdir -p $OUT
 SEQ=/tmp/pgslam_amd_seq_600_100000_0.8.bin
 REPO=$(pwd)
 {
-python3 -m pytest tests/test_gpu_parity.py tests/test_slam_replay.py -m gpu -x -q 2>&1 | tail -5
+python3 -m pytest tests/test_gpu_parity.py tests/test_slam_replay.py -m gpu -x -q 2>&1 | grep -v '^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl' | tail -8
 python3 bench.py --workload slam --slam-scans 600 --slam-points 100000 --slam-filters sensor --prepare-only > /dev/null 2>&1
 SEQ=/tmp/pgslam_amd_seq_600_100000_0.8.bin
 python3 -c "import bench; bench.build_slam_run()" > /dev/null 2>&1
