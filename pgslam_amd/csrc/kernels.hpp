@@ -59,7 +59,8 @@ struct SeedSegs { int n; int src[17]; int dst[16]; };      // pgicp_partial_chai
 template <typename T>
 void launch_borrow_order(hipStream_t st, const ProblemDev *probs, const SrcDesc *src, const int *order_a, const int *slot_a, const typename Vec4<T>::type *pts_a,
                          int n, const SeedSegs &sg, const int *slot_of_b, int m_b, T *rd_sorted, int *order_b, int *slot_b);
-void launch_batch_setup(hipStream_t st, int *active, int P, int *z0, long long n0, int *z1, long long n1, int *z2, long long n2);
+void launch_batch_setup(hipStream_t st, int *active, int P, int *z0, long long n0, int *z1, long long n1, int *z2, long long n2, int *z3, long long n3);
+size_t knn_queue_counter_words(int n_problems);      // the segmented queue counters at the head of the matcher's queue buffer
 void launch_invert_order(hipStream_t st, const ProblemDev *probs, const int *order, int *scan_pos, int P, int max_n);
 template <typename T>
 void launch_reduce(hipStream_t st, const ProblemDev *probs, const MapDev<T> *maps, const T *rd_pre, const T *rd_nrm, const int *slot,
