@@ -629,6 +629,9 @@ public:
         std::vector<pgicp_problem> pr(P);
         std::vector<int> maps(P, -1), xs(P), ns(P), ms(P);
         std::vector<const T *> xyz(P), nrm(P);
+        for (int k = 0; k < P; k++)
+            if (queue_[mine[k]].reading && chain_.sensorNoiseApplies(*queue_[mine[k]].reading))
+                throw std::runtime_error("LoopClosureBatch: a reading carries simpleSensorNoise (getOverlap's sensor-noise branch): process the pair with PairLoopCloser");
         bool on_device = DeviceCandidateEquivalent();
         for (int k = 0; k < P && on_device; k++) on_device = queue_[mine[k]].reading_dev && queue_[mine[k]].reference_dev && queue_[mine[k]].reference_dev->hasNormals();
         if (on_device) return RunOnDevice(mine, overlap_threshold, residual_threshold);
@@ -658,6 +661,12 @@ public:
         if (chain_.hasNormalFilter()) for (int k = 0; k < P; k++) with_nrm += reading_of(k).normalsPtr() != nullptr ? 1 : 0;
         if (with_nrm != 0 && with_nrm != P)
             throw std::runtime_error("LoopClosureBatch: a SurfaceNormalOutlierFilter is configured and only some readings carry normals");
+        // getOverlap() of a reading that carries `simpleSensorNoise` is computed from the ICP's LAST error elements; this call's
+        // fused residual pass replaces them: such a candidate goes through PairLoopCloser::ProcessCandidate (the caller's choice --
+        // LoopCloserMT does) instead of getting another overlap silently
+        for (int k = 0; k < P; k++)
+            if (chain_.sensorNoiseApplies(reading_of(k)))
+                throw std::runtime_error("LoopClosureBatch: a reading carries simpleSensorNoise (getOverlap's sensor-noise branch): process the pair with PairLoopCloser");
         chain_.pushParams(with_nrm == P && P > 0 && chain_.hasNormalFilter());
         for (int k = 0; k < P; k++) {
             const Candidate &c = queue_[mine[k]];

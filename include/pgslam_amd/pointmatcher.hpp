@@ -151,6 +151,7 @@ template <> struct Abi<float> {
     static int local_map_dev(pgicp_ctx *c, int k, const float *const *x, const float *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, float *ox, int os, float *on, int ons) { return pgicp_build_local_map_f32(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_DEVICE); }
     static int map_create_dev(pgicp_ctx *c, const float *x, int xs, const float *n, int ns, int m, int center, int *id) { return pgicp_map_create_f32(c, x, xs, n, ns, m, PGICP_DEVICE, center, id); }
     static int transform_dev(pgicp_ctx *c, const double *T16, const float *in, int is, float *out, int os, int n, int rotate_only) { return pgicp_transform_f32(c, T16, in, is, out, os, n, rotate_only, PGICP_DEVICE); }
+    static int last_matches(pgicp_ctx *c, int problem, int32_t *ids, float *d2) { return pgicp_debug_last_matches_f32(c, problem, ids, d2); }
 };
 template <> struct Abi<double> {
     static int map_create(pgicp_ctx *c, const double *x, int xs, const double *n, int ns, int m, int center, int *id) { return pgicp_map_create_f64(c, x, xs, n, ns, m, PGICP_HOST, center, id); }
@@ -179,6 +180,7 @@ template <> struct Abi<double> {
     static int local_map_dev(pgicp_ctx *c, int k, const double *const *x, const double *const *n, const int *sx, const int *sn, const int *cnt, const double *Ts, double *ox, int os, double *on, int ons) { return pgicp_build_local_map_f64(c, k, x, n, sx, sn, cnt, Ts, ox, os, on, ons, PGICP_DEVICE); }
     static int map_create_dev(pgicp_ctx *c, const double *x, int xs, const double *n, int ns, int m, int center, int *id) { return pgicp_map_create_f64(c, x, xs, n, ns, m, PGICP_DEVICE, center, id); }
     static int transform_dev(pgicp_ctx *c, const double *T16, const double *in, int is, double *out, int os, int n, int rotate_only) { return pgicp_transform_f64(c, T16, in, is, out, os, n, rotate_only, PGICP_DEVICE); }
+    static int last_matches(pgicp_ctx *c, int problem, int32_t *ids, double *d2) { return pgicp_debug_last_matches_f64(c, problem, ids, d2); }
 };
 
 }  // namespace pgslam_amd
@@ -772,6 +774,33 @@ struct PointMatcher {
             });
         }
     };
+    //! [EXT] SimpleSensorNoiseDataPointsFilter{sensorType, gain} (DataPointsFilters/SimpleSensorNoise.cpp, restated as recalled):
+    //! adds the one-row descriptor `simpleSensorNoise` = gain * max(minRadius, beamAngle * |p| + beamConst) -- sensorType 0 Sick
+    //! LMS-1xx, 1 Hokuyo URG-04LX, 2 Hokuyo UTM-30LX, 4 Sick Tim3xx -- or gain * |p|^2 * 0.5 * 0.00285 for 3 (Kinect / Xtion);
+    //! ErrorMinimizer::getOverlap() reads it (Localizer.hpp:278, LoopCloser.hpp:331).  oracle: orc_simple_sensor_noise
+    struct SimpleSensorNoiseDataPointsFilter : DataPointsFilter {
+        int sensorType; T gain;
+        explicit SimpleSensorNoiseDataPointsFilter(int t = 0, T g = T(1)) : sensorType(t), gain(g)
+        {
+            if (t < 0 || t > 4) throw std::runtime_error("SimpleSensorNoiseDataPointsFilter: sensorType must be 0 ... 4");
+        }
+        void inPlaceFilter(DataPoints &c) override
+        {
+            static const T prm[5][3] = {{T(0.012), T(0.0068), T(0.0008)}, {T(0.028), T(0.0013), T(0.0001)}, {T(0.018), T(0.0006), T(0.0015)},
+                                        {T(0), T(0), T(0)}, {T(0.004), T(0.0053), T(-0.0092)}};
+            const int n = (int)c.features.cols();
+            Matrix noise(1, n);
+            for (int i = 0; i < n; i++) {
+                const T x = c.features(0, i), y = c.features(1, i), z = c.features(2, i);
+                const T r = std::sqrt((x * x + y * y) + z * z);
+                T v;
+                if (sensorType == 3) v = (r * r) * (T)(0.5 * 0.00285);
+                else { v = prm[sensorType][1] * r + prm[sensorType][2]; if (v < prm[sensorType][0]) v = prm[sensorType][0]; }
+                noise(0, i) = gain * v;
+            }
+            c.setDescriptor("simpleSensorNoise", noise);
+        }
+    };
     struct DataPointsFilters : std::vector<std::shared_ptr<DataPointsFilter>> {
         DataPointsFilters() {}
         //! Localizer.hpp:77 -- a YAML list of filters
@@ -820,6 +849,11 @@ struct PointMatcher {
                     const double md = get("maxDensity", "10"), seed = get("seed", "1");
                     if (!(md > 0.0) || !(seed >= 0.0 && seed < 9007199254740992.0)) throw std::runtime_error(m.name + ": maxDensity must be positive, seed in [0, 2^53)");
                     this->push_back(std::make_shared<MaxDensityDataPointsFilter>((T)md, (unsigned long long)seed));
+                } else if (m.name == "SimpleSensorNoiseDataPointsFilter") {
+                    auto get = [&](const char *k, const char *def) { return to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
+                    const double st = get("sensorType", "0"), gain = get("gain", "1");
+                    if (st != std::floor(st) || st < 0.0 || st > 4.0 || !(gain >= 1.0)) throw std::runtime_error(m.name + ": sensorType must be 0 ... 4, gain >= 1");
+                    this->push_back(std::make_shared<SimpleSensorNoiseDataPointsFilter>((int)st, (T)gain));
                 } else if (m.name == "BoundingBoxDataPointsFilter") {
                     auto get = [&](const char *k, const char *def) { return (T)to_double(m.params.count(k) ? m.params.at(k) : std::string(def), m.name); };
                     const T lo[3] = {get("xMin", "-1"), get("yMin", "-1"), get("zMin", "-1")}, hi[3] = {get("xMax", "1"), get("yMax", "1"), get("zMax", "1")};
@@ -1164,10 +1198,13 @@ struct PointMatcher {
         T lastOverlap = 0; T lastResidual = 0; Matrix lastCov = Matrix::Zero(6, 6);
         explicit ErrorMinimizer(ICPChainBase *c) : chain(c) {}
         virtual ~ErrorMinimizer() {}
-        //! Localizer.hpp:278, LoopCloser.hpp:331: weightedPointUsedRatio of the last error elements (the reading
-        //! carries no simpleSensorNoise descriptor in pgslam's use -- SURVEY.md A.7)
+        //! Localizer.hpp:278, LoopCloser.hpp:331: weightedPointUsedRatio of the last error elements (pgslam's own clouds carry no
+        //! simpleSensorNoise descriptor -- SURVEY.md A.7); for a reading that does (and, with the point-to-plane minimizer, `normals`
+        //! too: ErrorMinimizers/PointToPlane.cpp) the share of the last error elements whose distance lies below mean + noise
+        //! (ICPChainBase::sensorNoiseOverlap; oracle: orc_sensor_noise_overlap)
         T getOverlap() const { return lastOverlap; }
-        T getWeightedPointUsedRatio() const { return lastOverlap; }
+        T getWeightedPointUsedRatio() const { return lastRatio; }
+        T lastRatio = 0;
         //! Localizer.hpp:238, LoopCloser.hpp:108: 6x6 Censi covariance, order [x y z rx ry rz]; zeros without "WithCov"
         Matrix getCovariance() const { return withCov ? lastCov : Matrix::Zero(6, 6); }
         //! LoopCloser.hpp:362: sum w (n.(p-q))^2 -- `reference` must be the cloud given to matcher->init
@@ -1435,10 +1472,52 @@ struct PointMatcher {
         {
             lastStats = s;
             errorMinimizer->lastOverlap = (T)s.overlap;
+            errorMinimizer->lastRatio = (T)s.overlap;
             errorMinimizer->lastResidual = (T)s.residual;
             Matrix cov(6, 6);
             for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) cov(i, j) = (T)s.cov[i * 6 + j];
             errorMinimizer->lastCov = cov;
+        }
+    public:
+        //! does getOverlap() of this chain take the sensor-noise branch for `reading`? (upstream: the reading carries
+        //! `simpleSensorNoise` -- and `normals` when the minimizer is point-to-plane)
+        bool sensorNoiseApplies(const DataPoints &reading) const
+        {
+            return errorMinimizer && reading.descriptorExists("simpleSensorNoise") && (errorMinimizer->pointToPoint || reading.descriptorExists("normals"));
+        }
+    protected:
+        //! getOverlap()'s sensor-noise branch over the last error elements of problem `problem` of the align call that has just
+        //! returned: the pairs the outlier filters kept in its last iteration (exact ids and distances: pgicp_debug_last_matches),
+        //! dists = |reading - reference| in T, mean over the kept pairs, the share below mean + noise(point).  Kept = a neighbour and
+        //! a squared distance within the last threshold (Trimmed / Median / MaxDist filters: what pgicp_stats.trim_limit is);
+        //! a chain whose weights are not that (Robust, SurfaceNormal outlier filters) is refused, not approximated.
+        T sensorNoiseOverlap(const DataPoints &reading, int problem, const pgicp_stats &st) const
+        {
+            for (auto &f : outlierFilters)
+                if (std::dynamic_pointer_cast<RobustOutlierFilter>(f) || std::dynamic_pointer_cast<SurfaceNormalOutlierFilter>(f))
+                    throw std::runtime_error("getOverlap: the sensor-noise overlap (a reading with simpleSensorNoise) is not supported with a Robust / SurfaceNormal outlier filter");
+            const int n = (int)reading.getNbPoints(), knn = std::max(1, matcher ? matcher->knn : 1);
+            std::vector<int32_t> ids((size_t)n * knn);
+            std::vector<T> d2((size_t)n * knn);
+            check(ctx, A::last_matches(ctx, problem, ids.data(), d2.data()));
+            const int rn = reading.getDescriptorStartingRow("simpleSensorNoise");
+            const T limit = (T)st.trim_limit;
+            int nb = 0;
+            T sum = 0;
+            for (int k = 0; k < knn; k++)
+                for (int i = 0; i < n; i++) {
+                    const size_t e = (size_t)i * knn + k;
+                    if (ids[e] >= 0 && d2[e] <= limit) { sum += std::sqrt(d2[e]); nb++; }
+                }
+            if (nb == 0) throw ConvergenceError("PointToPlaneErrorMinimizer: no element to minimize");
+            const T mean = sum / (T)nb;
+            int count = 0;
+            for (int k = 0; k < knn; k++)
+                for (int i = 0; i < n; i++) {
+                    const size_t e = (size_t)i * knn + k;
+                    if (ids[e] >= 0 && d2[e] <= limit && std::sqrt(d2[e]) < mean + reading.descriptors(rn, i)) count++;
+                }
+            return (T)count / (T)nb;
         }
     public:
         //! A reading whose filtered copy is on its way to (or already in) device memory: pgicp_upload_* started the
@@ -1493,6 +1572,7 @@ struct PointMatcher {
             const int rc = A::align_dev(ctx, matcher->mapId, r.dev, r.xyzStride(), r.points(), Ti, To, &st);
             storeStats(st);
             check(ctx, rc);
+            if (r.filtered && sensorNoiseApplies(*r.filtered)) errorMinimizer->lastOverlap = sensorNoiseOverlap(*r.filtered, 0, st);
             const TransformationParameters T_out = pgslam_amd::from_row_major16<T>(To);
             if (onAlign && (currentReference || lazyReference) && (!onAlignWanted || onAlignWanted()))
                 if (const DataPoints *ref = observedReference()) onAlign(*r.filtered, *ref, T_init, T_out, st);
@@ -1523,6 +1603,7 @@ struct PointMatcher {
                                        : A::align(ctx, matcher->mapId, reading.xyzPtr(), reading.xyzStride(), (int)reading.getNbPoints(), Ti, To, &st);
             storeStats(st);
             check(ctx, rc);
+            if (sensorNoiseApplies(reading)) errorMinimizer->lastOverlap = sensorNoiseOverlap(reading, 0, st);
             const TransformationParameters T_out = pgslam_amd::from_row_major16<T>(To);
             if (onAlign && (currentReference || lazyReference) && (!onAlignWanted || onAlignWanted()))
                 if (const DataPoints *ref = observedReference()) onAlign(reading, *ref, T_init, T_out, st);

@@ -1404,6 +1404,22 @@ private:
                 typename Base::PreparedCandidate c;
                 if (this->PrepareCandidate(v, c, dev_ctx)) cands.push_back(c);
             }
+            // a reading with `simpleSensorNoise` takes getOverlap()'s sensor-noise branch, which reads the ICP's LAST error elements:
+            // the batch's fused residual pass replaces them, so such candidates go one at a time (the base class's ProcessCandidate)
+            bool pairwise = false;
+            for (auto &c : cands) pairwise = pairwise || (c.reading && c.reading->descriptorExists("simpleSensorNoise"));
+            if (pairwise) {
+                if (!pairwise_configured_) { this->closer().SetIcpConfigFromString(yaml_); pairwise_configured_ = true; }
+                PairLoopCloser<T> &lc = this->closer();
+                for (auto &c : cands) {
+                    auto r = c.reference_dev && lc.DeviceCandidateEquivalent()
+                                 ? lc.ProcessCandidateOnDevice(c.reading, *c.reading_dev, *c.reference_dev, c.guess, c.host_reference)
+                                 : lc.ProcessCandidate(*c.reading, c.reference ? *c.reference : c.host_reference(), c.guess);
+                    if (r.accepted) { this->loops_closed_++; optimizer_->AddNewData(c.ref_v, c.input_v, r.T_refkf_kf, r.cov); }
+                }
+                batches_++;
+                cands.clear();
+            }
             if (!cands.empty()) {
                 batch.Clear();
                 for (auto &c : cands) {
@@ -1435,7 +1451,7 @@ private:
     std::condition_variable cv_;
     std::deque<size_t> queue_;
     std::thread thread_;
-    bool stop_ = false, busy_ = false, paused_ = false;
+    bool stop_ = false, busy_ = false, paused_ = false, pairwise_configured_ = false;
     size_t max_batch_ = (size_t)1 << 30;
     int batches_ = 0, largest_batch_ = 0;
     size_t device_batches_ = 0;

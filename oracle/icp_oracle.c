@@ -828,6 +828,58 @@ void FN(orc_max_density_keep)(const real *dens, int n, real max_density, double 
 }
 
 /* --------------------------------------------------------------------------
+ * SimpleSensorNoiseDataPointsFilter and the sensor-noise branch of getOverlap() (libpointmatcher 1.3.1,
+ * DataPointsFilters/SimpleSensorNoise.cpp, ErrorMinimizers/PointToPlane.cpp / PointToPoint.cpp: restated from the published
+ * source as recalled; parity unpinned like the rest of this file).  pgslam reads getOverlap() at Localizer.hpp:278 and
+ * LoopCloser.hpp:331; its own clouds carry no such descriptor, a user's input-filter YAML may add it.
+ *   noise(i) = max(minRadius, beamAngle * |p_i| + beamConst), |p_i| the norm of the point's coordinates in T, per sensor
+ *     type: 0 Sick LMS-1xx (0.012, 0.0068, 0.0008), 1 Hokuyo URG-04LX (0.028, 0.0013, 0.0001), 2 Hokuyo UTM-30LX
+ *     (0.018, 0.0006, 0.0015), 4 Sick Tim3xx (0.004, 0.0053, -0.0092); 3 Kinect / Xtion: noise(i) = |p_i|^2 * (0.5 * 0.00285);
+ *     the descriptor holds gain * noise.
+ *   getOverlap(): over the LAST error elements (the pairs the outlier filters kept in the last iteration, nbPoints of them):
+ *     dists(j) = |reading_j - reference_j| in T, mean = sum(dists) / nbPoints, overlap = #{ dists(j) < mean + noise(j) } / nbPoints
+ *     (both in T); without the descriptor -- for the point-to-plane minimizer also without `normals` on the reading --
+ *     weightedPointUsedRatio.
+ * ------------------------------------------------------------------------ */
+int FN(orc_simple_sensor_noise)(const real *xyz, int n, int sensor_type, real gain, real *noise)
+{
+    real min_r = 0, angle = 0, cst = 0;
+    switch (sensor_type) {
+    case 0: min_r = (real)0.012; angle = (real)0.0068; cst = (real)0.0008; break;
+    case 1: min_r = (real)0.028; angle = (real)0.0013; cst = (real)0.0001; break;
+    case 2: min_r = (real)0.018; angle = (real)0.0006; cst = (real)0.0015; break;
+    case 3: break;
+    case 4: min_r = (real)0.004; angle = (real)0.0053; cst = (real)-0.0092; break;
+    default: return -1;
+    }
+    for (int i = 0; i < n; i++) {
+        const real x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const real r2 = (x * x + y * y) + z * z;
+        real v;
+        if (sensor_type == 3) { const real r = SQRT_R(r2); v = (r * r) * (real)(0.5 * 0.00285); }
+        else { v = angle * SQRT_R(r2) + cst; if (v < min_r) v = min_r; }
+        noise[i] = gain * v;
+    }
+    return 0;
+}
+/* d2 / w: the last iteration's squared distances and outlier weights, knn entries per reading point (point-major); noise per point */
+double FN(orc_sensor_noise_overlap)(const real *d2, const real *w, const real *noise, int n, int knn)
+{
+    int nb = 0;
+    real sum = 0;
+    for (int k = 0; k < knn; k++)
+        for (int i = 0; i < n; i++)
+            if (w[(size_t)i * knn + k] != (real)0) { sum += SQRT_R(d2[(size_t)i * knn + k]); nb++; }
+    if (nb == 0) return -1.0;
+    const real mean = sum / (real)nb;
+    int count = 0;
+    for (int k = 0; k < knn; k++)
+        for (int i = 0; i < n; i++)
+            if (w[(size_t)i * knn + k] != (real)0 && SQRT_R(d2[(size_t)i * knn + k]) < mean + noise[i]) count++;
+    return (double)((real)count / (real)nb);
+}
+
+/* --------------------------------------------------------------------------
  * [A.4] TrimmedDistOutlierFilter
  * ------------------------------------------------------------------------ */
 static int cmp_real(const void *a, const void *b)

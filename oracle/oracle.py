@@ -201,6 +201,25 @@ class Oracle:
         self._f("orc_max_density_keep")(self._p(dens), C.c_int(len(dens)), self.real(max_density), C.c_double(seed), keep.ctypes.data_as(C.c_void_p))
         return keep.astype(bool)
 
+    def simple_sensor_noise(self, xyz, sensor_type=0, gain=1.0):
+        """[EXT] SimpleSensorNoiseDataPointsFilter{sensorType, gain}: the `simpleSensorNoise` descriptor (one value per point)"""
+        xyz = self._a(xyz)
+        out = np.empty(len(xyz), dtype=self.dtype)
+        rc = self._f("orc_simple_sensor_noise")(self._p(xyz), C.c_int(len(xyz)), C.c_int(sensor_type), self.real(gain), self._p(out))
+        if rc != 0:
+            raise ValueError("SimpleSensorNoiseDataPointsFilter: sensorType must be 0 ... 4")
+        return out
+
+    def sensor_noise_overlap(self, d2, weights, noise):
+        """[EXT] getOverlap() of a reading that carries `simpleSensorNoise`: d2 / weights (n,) or (n, knn) of the last iteration"""
+        d2 = np.ascontiguousarray(d2, dtype=self.dtype)
+        w = np.ascontiguousarray(weights, dtype=self.dtype)
+        noise = np.ascontiguousarray(noise, dtype=self.dtype)
+        knn = 1 if d2.ndim == 1 else d2.shape[1]
+        f = self._f("orc_sensor_noise_overlap")
+        f.restype = C.c_double
+        return float(f(self._p(d2), self._p(w), self._p(noise), C.c_int(len(noise)), C.c_int(knn)))
+
     def robust_weights(self, d2, fct, tuning=1.0, scale=1, approx=0.0):
         """[EXT] RobustOutlierFilter (orc_robust_weights): (weights, squared scale)"""
         d2 = np.ascontiguousarray(d2, dtype=self.dtype)

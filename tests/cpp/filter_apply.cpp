@@ -1,7 +1,7 @@
 // Applies a DataPointsFilters YAML list of the drop-in's PointMatcher shim to a cloud read from a file and writes the result:
 //   filter_apply f32|f64 FILTERS.yaml IN.bin OUT.bin
 // IN.bin: int32 n, then n x 3 values (T); OUT.bin: int32 n_out, int32 has_normals, int32 has_densities, n_out x 3 points,
-// [n_out x 3 normals], [n_out densities].  The Python tests compare it with the oracle's statement of the same filters
+// [n_out x 3 normals], [n_out densities], int32 has_simpleSensorNoise, [n_out values].  The Python tests compare it with the oracle's statement of the same filters
 // (tests/test_filters_host.py: host-only filters, no device; tests/test_gpu_filters.py: the ones that search neighbours on the device).
 #include <pointmatcher/PointMatcher.h>
 
@@ -32,6 +32,10 @@ static int run(const char *yaml, const char *in, const char *out)
     for (int j = 0; j < m; j++) { const T p[3] = {cloud.features(0, j), cloud.features(1, j), cloud.features(2, j)}; std::fwrite(p, sizeof(T), 3, fo); }
     if (hn) { const int r = cloud.getDescriptorStartingRow("normals"); for (int j = 0; j < m; j++) { const T p[3] = {cloud.descriptors(r, j), cloud.descriptors(r + 1, j), cloud.descriptors(r + 2, j)}; std::fwrite(p, sizeof(T), 3, fo); } }
     if (hd) { const int r = cloud.getDescriptorStartingRow("densities"); for (int j = 0; j < m; j++) { const T v = cloud.descriptors(r, j); std::fwrite(&v, sizeof(T), 1, fo); } }
+    // (appended: int32 has_simpleSensorNoise, then n_out values)
+    const int hs = cloud.descriptorExists("simpleSensorNoise") ? 1 : 0;
+    std::fwrite(&hs, 4, 1, fo);
+    if (hs) { const int r = cloud.getDescriptorStartingRow("simpleSensorNoise"); for (int j = 0; j < m; j++) { const T v = cloud.descriptors(r, j); std::fwrite(&v, sizeof(T), 1, fo); } }
     std::fclose(fo);
     return 0;
 }

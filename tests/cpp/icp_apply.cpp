@@ -2,7 +2,8 @@
 // (icp_.loadFromYaml + icp_(reading, reference, T_init), /root/reference/src/pgslam/LoopCloser.hpp:73, 98):
 //   icp_apply f32|f64 CHAIN.yaml READING.bin REFERENCE.bin TINIT.bin OUT.bin
 // clouds: int32 n, n x 3 values (T); TINIT: 16 doubles row-major; OUT: 16 doubles (T_out row-major), int32 reference points after the
-// reference filters, int32 has_normals.  The reference's `normals` come from the chain's own referenceDataPointsFilters.
+// reference filters, int32 has_normals, 2 doubles: getOverlap(), getWeightedPointUsedRatio().  The reference's `normals` come from
+// the chain's own referenceDataPointsFilters.
 #include <pointmatcher/PointMatcher.h>
 
 #include <cstdio>
@@ -47,6 +48,9 @@ static int run(char **a)
     std::fwrite(out, 8, 16, fo);
     const int m = (int)ref_copy.getNbPoints(), hn = ref_copy.descriptorExists("normals") ? 1 : 0;
     std::fwrite(&m, 4, 1, fo); std::fwrite(&hn, 4, 1, fo);
+    // what pgslam reads after the ICP (Localizer.hpp:278, LoopCloser.hpp:331) and the plain ratio beside it
+    const double ov[2] = {(double)icp.errorMinimizer->getOverlap(), (double)icp.errorMinimizer->getWeightedPointUsedRatio()};
+    std::fwrite(ov, 8, 2, fo);
     std::fclose(fo);
     return 0;
 }

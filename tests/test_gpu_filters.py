@@ -278,3 +278,51 @@ def test_icp_whose_reference_filter_is_sampling_surface_normal(tmp_path, oracle3
     assert dt < 1e-5 and dr < 1e-5, (dt, dr)
     truth = np.linalg.inv(s["T_truth"]) @ T
     assert np.linalg.norm(truth[:3, 3]) < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("minimizer", ["PointToPoint", "PointToPlane"])
+def test_get_overlap_of_a_reading_with_simple_sensor_noise(tmp_path, oracle32, minimizer):
+    """getOverlap() as pgslam reads it (Localizer.hpp:278, LoopCloser.hpp:331) when the user's chain gives the reading a
+    `simpleSensorNoise` descriptor (readingDataPointsFilters: SimpleSensorNoiseDataPointsFilter; the point-to-plane minimizer also wants
+    `normals` on the reading): the share of the LAST error elements whose distance lies below mean + noise, not the weighted ratio.
+    Shim (loadFromYaml -> ICP::operator() -> pgicp_debug_last_matches) against the oracle's ICP, its last correspondences and
+    orc_sensor_noise_overlap."""
+    import struct
+    import subprocess
+    from test_cpp_dropin import build
+    s = synth.make_two_scans(8000, rings=16)
+    rd, ref = s["reading_xyz"].astype(np.float32), s["ref_xyz"].astype(np.float32)
+    p2p = minimizer == "PointToPoint"
+    yaml = ("readingDataPointsFilters:\n"
+            + ("" if p2p else "  - SurfaceNormalDataPointsFilter:\n      knn: 8\n")
+            + "  - SimpleSensorNoiseDataPointsFilter:\n      sensorType: 0\n      gain: 1\n"
+            "referenceDataPointsFilters:\n  - SurfaceNormalDataPointsFilter:\n      knn: 8\n"
+            "matcher:\n  KDTreeMatcher:\n    knn: 1\n    maxDist: 2.0\n"
+            "outlierFilters:\n  - TrimmedDistOutlierFilter:\n      ratio: 0.8\n"
+            "errorMinimizer:\n  %sErrorMinimizer:\n    sensorStdDev: 0.01\n" % minimizer +
+            "transformationCheckers:\n  - CounterTransformationChecker:\n      maxIterationCount: 30\n"
+            "  - DifferentialTransformationChecker:\n      minDiffRotErr: 0.001\n      minDiffTransErr: 0.01\n      smoothLength: 3\n")
+    fy, fr, fi, ft, fo = (str(tmp_path / n) for n in ("chain.yaml", "reading.bin", "ref.bin", "tinit.bin", "out.bin"))
+    open(fy, "w").write(yaml)
+    _write_cloud(fr, rd, np.float32)
+    _write_cloud(fi, ref, np.float32)
+    open(ft, "wb").write(np.ascontiguousarray(s["T_init"], dtype=np.float64).tobytes())
+    r = subprocess.run([build("icp_apply"), "f32", fy, fr, fi, ft, fo], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    raw = open(fo, "rb").read()
+    T = np.frombuffer(raw, dtype=np.float64, count=16).reshape(4, 4)
+    overlap, ratio = struct.unpack("dd", raw[136:152])
+    nrm = oracle32.surface_normals(ref, knn=8)["normals"] if hasattr(oracle32, "surface_normals") else None
+    assert nrm is not None
+    o = oracle32.icp(rd, ref, nrm, s["T_init"], max_dist=2.0, trim_ratio=0.8, max_iters=30, min_diff_rot=0.001, min_diff_trans=0.01,
+                     smooth_length=3, error_minimizer=(1 if p2p else 0))
+    assert o["status"] == 0
+    d = np.linalg.inv(o["T"]) @ T
+    assert np.linalg.norm(d[:3, 3]) < 1e-4
+    noise = oracle32.simple_sensor_noise(rd, 0, 1.0)
+    w = ((o["last_ids"] >= 0) & (o["last_d2"] <= np.float32(o["trim_limit"]))).astype(np.float32)
+    want = oracle32.sensor_noise_overlap(o["last_d2"], w, noise)
+    assert ratio == pytest.approx(0.8, abs=1e-3)
+    assert abs(overlap - ratio) > 0.01                       # the branch was taken: another quantity altogether
+    assert overlap == pytest.approx(want, abs=2e-3)           # (normals and sums agree to float rounding between the two sides: a few pairs near the bound)
