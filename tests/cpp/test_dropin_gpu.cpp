@@ -88,6 +88,24 @@ void run(const char *name)
         CHECK(pose_diff(pgslam_amd::from_row_major16<T>(e.T_from_to), T1) == 0.0);
     }
     CHECK(sizeof(pgicp_edge) == 512 && e1.size() == s1.size());
+    {   // a reading that carries `simpleSensorNoise` (and `normals`): getOverlap() takes its sensor-noise branch over the ICP's last
+        // error elements -- the pair path computes it, the batch (whose fused residual pass replaces those elements) refuses the candidate
+        DP noisy(reading);
+        typename PM::SimpleSensorNoiseDataPointsFilter(0, T(1)).inPlaceFilter(noisy);
+        CHECK(noisy.descriptorExists("simpleSensorNoise") && noisy.descriptorExists("normals"));
+        pgslam::PairLoopCloser<T> pl;
+        pl.SetIcpConfigFromString(kIcpYaml);
+        const auto rn = pl.ProcessCandidate(noisy, map, guess);
+        CHECK(pose_diff(rn.T_refkf_kf, T1) == 0.0);                          // the descriptor changes no pose
+        CHECK(pl.icp().errorMinimizer->getWeightedPointUsedRatio() == r.overlap);
+        CHECK(rn.overlap != r.overlap && rn.overlap > T(0.3) && rn.overlap <= T(1));
+        pgslam::LoopClosureBatch<T> nb2;
+        nb2.SetIcpConfigFromString(kIcpYaml);
+        nb2.Add({7, 8, std::make_shared<DP>(noisy), mp, guess});
+        bool refused_noise = false;
+        try { nb2.Run(nb2.Shard(1, 0)); } catch (const std::runtime_error &) { refused_noise = true; }
+        CHECK(refused_noise);
+    }
     {   // the collective of the C ABI on the real RCCL path, one rank: the gathered list is the queue in order
         char uid[PGICP_UNIQUE_ID_BYTES];
         CHECK(pgicp_comm_unique_id(uid) == PGICP_OK);
