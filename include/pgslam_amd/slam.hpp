@@ -1415,8 +1415,16 @@ private:
                     auto r = c.reference_dev && lc.DeviceCandidateEquivalent()
                                  ? lc.ProcessCandidateOnDevice(c.reading, *c.reading_dev, *c.reference_dev, c.guess, c.host_reference)
                                  : lc.ProcessCandidate(*c.reading, c.reference ? *c.reference : c.host_reference(), c.guess);
+                    pgicp_edge e;
+                    std::memset(&e, 0, sizeof e);
+                    e.from_id = (long long)c.ref_v; e.to_id = (long long)c.input_v; e.max_iter_reached = r.max_iterations_reached ? 1 : 0;
+                    e.overlap = (double)r.overlap; e.residual = (double)r.residual; e.accepted = r.accepted ? 1 : 0;
+                    pgslam_amd::to_row_major16(r.T_refkf_kf, e.T_from_to);
+                    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) e.cov[6 * i + j] = (double)r.cov(i, j);
+                    { std::lock_guard<std::mutex> l(m_); edges_.push_back(e); }
                     if (r.accepted) { this->loops_closed_++; optimizer_->AddNewData(c.ref_v, c.input_v, r.T_refkf_kf, r.cov); }
                 }
+                largest_batch_ = std::max(largest_batch_, 1);
                 batches_++;
                 cands.clear();
             }

@@ -365,8 +365,63 @@ void run_mt_batched_dispatcher(const char *name)
     std::printf("%s: ok  (%zu candidates as ONE device batch == the same %zu one at a time, bit for bit; %d accepted)\n", name, edges[0].size(), edges[1].size(), accepted);
 }
 
+// Clouds that carry `simpleSensorNoise` (the user's input filters add it): getOverlap() takes its sensor-noise branch, which reads
+// the ICP's last error elements -- the MT loop closer sends such candidates one at a time (PairLoopCloser) instead of through the
+// device batch, whose fused residual pass replaces those elements.  Same candidates, same poses; another overlap figure.
+template <typename T>
+void run_mt_sensor_noise(const char *name)
+{
+    IMPORT_PGSLAM_TYPES(T)
+    TransformationPtr rigid = PM::get().REG(Transformation).create("RigidTransformation");
+    const int S = 15;
+    std::vector<Matrix> truth, odom;
+    for (int s = 0; s < S; s++) {
+        const double a = 2 * M_PI * s / (S - 1);
+        truth.push_back(pose<T>(1.5 + 0.5 * std::cos(a), 1.5 + 0.5 * std::sin(a), 0.0, a * 0.2));
+    }
+    odom.push_back(truth[0]);
+    for (int s = 1; s < S; s++) odom.push_back(odom[s - 1] * (truth[s - 1].inverse() * truth[s]) * pose<T>(0.012, -0.009, 0.0, 0.005));
+    std::vector<pgicp_edge> edges[2];
+    for (int noisy = 0; noisy < 2; noisy++) {
+        pgslam::PoseGraphSlamMT<T> slam;
+        slam.SetIcpConfigFromStrings(noisy ? "- SimpleSensorNoiseDataPointsFilter:\n    sensorType: 0\n    gain: 1\n" : "- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
+        slam.localizer().SetOverlapThreshold(T(0.9));
+        slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
+        slam.loop_closer().SetGeometricalDistanceThreshold(T(0.6));
+        slam.loop_closer().SetOverlapThreshold(T(0.3));
+        slam.loop_closer().Pause();
+        slam.optimizer().Pause();
+        slam.Run();
+        for (int s = 0; s < S; s++) {
+            auto cloud = std::make_shared<DP>(rigid->compute(make_corner<T>(2000, 70 + s, 0.004), truth[s].inverse()));
+            slam.AddData((unsigned long long)s, "world", odom[s], Matrix::Identity(4, 4), cloud);
+        }
+        slam.WaitIdle();
+        slam.loop_closer().Resume();
+        while (slam.loop_closer().queued() > 0 || !slam.loop_closer().Idle()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        slam.RethrowWorkerError();
+        edges[noisy] = slam.loop_closer().edges();
+        CHECK(slam.loop_closer().batches() >= 1);
+        CHECK(noisy ? slam.loop_closer().device_batches() == 0 : slam.loop_closer().device_batches() >= 1);
+        slam.optimizer().Resume();
+        slam.WaitIdle();
+    }
+    CHECK(!edges[0].empty());
+    // (the keyframes of the two drives may differ -- the localizer's own getOverlap() decides on new keyframes -- so the candidates are
+    // compared where both drives made the same pair)
+    int same_pairs = 0, other_overlap = 0;
+    for (const pgicp_edge &a : edges[0])
+        for (const pgicp_edge &b : edges[1])
+            if (a.from_id == b.from_id && a.to_id == b.to_id) { same_pairs++; other_overlap += a.overlap != b.overlap; }
+    CHECK(!edges[1].empty());
+    for (const pgicp_edge &b : edges[1]) CHECK(b.overlap > 0.0 && b.overlap <= 1.0);
+    std::printf("%s: ok  (%zu candidates through the device batch, %zu one at a time with the sensor-noise overlap; %d pairs in both, %d with another overlap)\n",
+                name, edges[0].size(), edges[1].size(), same_pairs, other_overlap);
+}
+
 int main()
 {
+    run_mt_sensor_noise<float>("PoseGraphSlamMT<float>, clouds with simpleSensorNoise");
     run_keyframe_residency<float>("keyframe clouds under a device-memory budget, PoseGraphSlam<float>");
     run_deferred_compaction<float>("deferred host compaction, PoseGraphSlam<float>");
     run_deferred_compaction<double>("deferred host compaction, PoseGraphSlam<double>");
