@@ -348,7 +348,7 @@ def test_double_maps_of_one_batch_with_unbounded_max_dist(ctx, oracle64):
 @pytest.mark.parametrize("away", [5.0e3, 2.0e5])
 def test_double_query_far_from_the_map_with_unbounded_max_dist(ctx, oracle64, away):
     """A double reading kilometres from its map (a bad initial pose) with maxDist = inf: the fast matcher's walk is float arithmetic
-    (BK, k_match.inc), whose rounding at such offsets (2^-24 of 5 km is 0.3 mm per operation, of 200 km 12 mm) exceeds the grid's
+    (BK, k_match_common.inc), whose rounding at such offsets (2^-24 of 5 km is 0.3 mm per operation, of 200 km 12 mm) exceeds the grid's
     fixed 2 % margin: bk_margin widens every test by the query's own offset, so no row or window holding the true neighbour is
     pruned.  Part of the reading sits on the map (near queries), the rest far off: ids bit for bit the oracle's."""
     s = synth.make_two_scans(5000, rings=16)
