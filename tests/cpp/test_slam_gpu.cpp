@@ -385,7 +385,7 @@ void run_mt_sensor_noise(const char *name)
     for (int noisy = 0; noisy < 2; noisy++) {
         pgslam::PoseGraphSlamMT<T> slam;
         slam.SetIcpConfigFromStrings(noisy ? "- SimpleSensorNoiseDataPointsFilter:\n    sensorType: 0\n    gain: 1\n" : "- IdentityDataPointsFilter\n", kIcpYaml, kIcpYaml);
-        slam.localizer().SetOverlapThreshold(T(0.9));
+        slam.localizer().SetOverlapThreshold(T(0.9999));             // (every scan a keyframe, whichever overlap figure the drive reads)
         slam.loop_closer().SetTopologicalDistanceThreshold(T(1.0));
         slam.loop_closer().SetGeometricalDistanceThreshold(T(0.6));
         slam.loop_closer().SetOverlapThreshold(T(0.3));
