@@ -1764,7 +1764,11 @@ def main():
                        "headline_host_pageable": [round(host_input["pageable_scans_per_s"], 1), None] if host_input else None,
                        "headline_rotated": [round(rotated["scans_per_s"], 1), None] if rotated else None,
                        "f64": vf(lg.get("f64")), "stream": vf(lg.get("stream")), "slam": vf(lg.get("slam")),
-                       "slam_100k": vf(lg.get("slam_100k")), "loop_closure": vf(lg.get("loop_closure")),
+                       "slam_100k": vf(lg.get("slam_100k")),
+                       # (the three-thread flavour of the same drive -- PoseGraphSlamMT, the reference's production flavour -- free running)
+                       "slam_100k_mt": [round(float(((lg.get("slam_100k") or {}).get("slam_mt") or {}).get("scans_per_s")), 1), None]
+                       if ((lg.get("slam_100k") or {}).get("slam_mt") or {}).get("scans_per_s") else None,
+                       "loop_closure": vf(lg.get("loop_closure")),
                        "loop_closure_predicted_speedup_8": ((lg.get("loop_closure") or {}).get("shard_proxy") or {}).get("predicted_speedup", {}).get("8"),
                        "cpu_port_all_cores": round(cpu["value"], 2) if cpu else None}
         emit(out)
