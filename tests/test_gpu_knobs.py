@@ -24,6 +24,10 @@ SETTINGS = [
     # round 6: every map with the succinct cell table (MapDev::sw: occupancy words + per-occupied-cell starts) instead of the dense ones
     {"PGICP_TABLES": "succinct"},
     {"PGICP_TABLES": "succinct", "PGICP_KX": "1", "PGICP_FAST_LANES": "16"},
+    # round 6: the outlier selection's path is chosen by batch size (band path from four problems on): either path forced for every size,
+    # and the seeded overlap probe's fast pass with one ring
+    {"PGICP_SEL_BAND": "0", "PGICP_PROBE_RINGS": "1"},
+    {"PGICP_SEL_BAND": "1", "PGICP_SEL_SMALL_N": "0"},
 ]
 
 
@@ -31,7 +35,7 @@ SETTINGS = [
 def test_parity_holds_for_every_knob_setting(setting):
     env = dict(os.environ, **setting)
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_edge_cases.py", "tests/test_gpu_matcher_state.py", "tests/test_local_mapper.py", "tests/test_gpu_chain.py",
-                        "tests/test_gpu_bit_exact.py",
+                        "tests/test_gpu_bit_exact.py", "tests/test_gpu_parity.py::test_seeded_partial_chain_equals_the_unseeded_one",
                         "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
