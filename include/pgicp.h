@@ -331,8 +331,8 @@ int pgicp_partial_chain_f64(pgicp_ctx *ctx, int map_id, const double *reading, i
  * (-1: not part of it).  A seed is a candidate only: the matches are exact, the ratio is pgicp_partial_chain's double.  The reading
  * is taken in the order the SOURCE context sorted it in (one set-up kernel instead of a sort of its own), so with
  * PGICP_SUM_ORDER_SORTED the residual is the same sum in another order (equal to ~1e-16 relative; identical with
- * PGICP_SUM_ORDER_SCAN) -- tests/test_gpu_parity.py.  From this context's second probe on the search is also CAPPED at 1.21 x the
- * threshold its previous probe ended with, as an ICP's later iterations are by their previous one's (a query with nothing inside
+ * PGICP_SUM_ORDER_SCAN) -- tests/test_gpu_parity.py.  From this context's second probe on the search is also CAPPED at 1.21 x 3 x the
+ * threshold its previous probe ended with (PGICP_PROBE_CAP_SCALE), as an ICP's later iterations are by their previous one's (a query with nothing inside
  * the cap is resolved lazily, only if the new threshold turns out to need it: a cap that is wrong costs time, never a result --
  * same test).  A reading the source context did not align (another size), a chain with
  * knn > 1, the brute matcher or a SurfaceNormalOutlierFilter: searched unseeded, as pgicp_partial_chain. */
