@@ -497,8 +497,10 @@ int pgicp_debug_counters(pgicp_ctx *ctx, int out[4]);
  * hipHostFree [6,7] calls: their cost is the HOST's (1 ms on some boxes, 45 ms on others; hipFree waits for the whole device),
  * so a caller's slow pass can be told apart from a slow GPU.  No context needed. */
 int pgicp_debug_alloc_stats(long long out[8]);
-/* Diagnostics: the correspondences the LAST iteration of problem `problem` of the last align call
- * ended with, in reading order (host buffers of n entries).  ids: reference index, -1 = no neighbour
+/* The correspondences the LAST iteration of problem `problem` of the last align call ended with (libpointmatcher's
+ * lastErrorElements, before the compaction), in reading order (host buffers of n x knn entries, point-major).  Read by the
+ * tests, and by the C++ shim for getOverlap()'s sensor-noise branch (ErrorMinimizers/PointToPlane.cpp: a reading that
+ * carries `simpleSensorNoise`; Localizer.hpp:278, LoopCloser.hpp:331) -- part of the supported surface despite its name.  ids: reference index, -1 = no neighbour
  * within maxDist, -2 = a neighbour exists but was not located (lazy resolution: its distance is an
  * upper bound and lies beyond the trim threshold).  Kept pairs carry exact ids and distances. */
 int pgicp_debug_last_matches_f32(pgicp_ctx *ctx, int problem, int32_t *ids, float *dist2);
