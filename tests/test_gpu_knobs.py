@@ -28,6 +28,8 @@ SETTINGS = [
     # and the seeded overlap probe's fast pass with one ring
     {"PGICP_SEL_BAND": "0", "PGICP_PROBE_RINGS": "1"},
     {"PGICP_SEL_BAND": "1", "PGICP_SEL_SMALL_N": "0"},
+    # ... without the next iteration's matcher pass enqueued ahead of the convergence flag, small results copied directly
+    {"PGICP_SPECULATE": "0", "PGICP_D2H_DIRECT": "1", "PGICP_PROBE_CAP_SCALE": "0.5"},
 ]
 
 
