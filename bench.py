@@ -46,7 +46,7 @@ LINE_MAX = 6000             # the driver keeps ~8 KB of stdout: the final line s
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
              "dtype", "data", "config")
 LINE_FACTS = ("dry_run", "scans_total", "scans_converged", "mean_iterations", "median_translation_error_m", "set_map_ms", "pairs_ok",
-              "pairs_accepted", "rccl_ranks_seen", "comm_world_size", "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu",
+              "pairs_accepted", "rccl_ranks_seen", "comm_world_size", "edges_transport", "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu",
               "speedup_vs_cpu_baseline", "launched_by", "command_wall_s")
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches",
                  "active_problems_per_launch", "algorithmic_bytes_per_launch", "bound_measured", "traffic_measured_in_this_run",
@@ -463,7 +463,26 @@ def main_loopclosure(args, collect=False):
     uid = [icp.comm_unique_id() if rank == 0 else None]
     if distributed:
         dist.broadcast_object_list(uid, src=0)
-    comm = icp.Comm(ctx, world, rank, uid[0])
+    # (N > 1 has never run on hardware here: if the C ABI's communicator cannot be made on some rank -- all ranks agree on that through
+    #  torch.distributed -- the edge lists travel by torch.distributed's all_gather instead, RCCL as well, and the line says so in
+    #  `edges_transport`; a leg that dies takes the job's line with it)
+    comm, comm_error = None, None
+    try:
+        comm = icp.Comm(ctx, world, rank, uid[0])
+    except Exception as e:
+        comm_error = f"{type(e).__name__}: {e}"
+        if not distributed:
+            raise
+    if distributed:
+        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            errs = [None] * world
+            dist.all_gather_object(errs, comm_error)
+            comm_error = next((e for e in errs if e), "a rank could not make the communicator")
 
     # --lc-contexts C > 1: the shard as C sub-batches on C contexts (C HIP streams, C host threads): one sub-batch's index build
     # and nearly empty last iterations overlap another's full launches (pgicp contexts are fully concurrent, include/pgicp.h)
@@ -495,6 +514,8 @@ def main_loopclosure(args, collect=False):
     def step():
         local = align_shard(mine)
         local["reserved"][:, 1] = rank + 1          # which rank aligned the pair: the line proves the ranks it saw
+        if comm is None:
+            return lc.allgather_edges(local, np.asarray(mine, dtype=np.int64), len(cands), device=dev)
         return lc.allgather_edges_rccl(comm, local, mine, costs)
 
     for _ in range(args.warmup):
@@ -593,7 +614,7 @@ def main_loopclosure(args, collect=False):
                            how="rank r's LPT shard (pgicp_shard_pairs) of a W-rank job aligned alone on this GPU, every r, W in {2, 4, 8}; "
                                "predicted_speedup(W) = T(all pairs) / (max_r T(shard) + world-1 all-gather latency); medians")
     seen = sorted(set(int(v) - 1 for v in np.asarray(edges["reserved"])[:, 1] if v > 0))
-    comm_world, comm_rank = comm.info()
+    comm_world, comm_rank = comm.info() if comm is not None else (world, rank)
     check_all_ranks_reported(seen, comm_world, world)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -631,10 +652,13 @@ def main_loopclosure(args, collect=False):
             "pairs_ok": ok, "pairs_accepted": int(np.sum(edges["accepted"] == 1)),
             "mean_iterations": float(np.mean(edges["iterations"])),
             "rccl_ranks_seen": len(seen), "ranks_that_reported_edges": seen, "comm_world_size": comm_world,
+            "edges_transport": "pgicp_allgather_edges (the C ABI's ncclAllGather over RCCL)" if comm is not None
+                               else f"torch.distributed all_gather (RCCL) -- the C ABI's communicator could not be made: {comm_error}",
             "shard_proxy": shard_proxy,
             "pairs_per_s_one_gpu_same_run": single,
             "speedup_vs_one_gpu": (args.steps * len(cands) / elapsed) / single if single else None})
-    comm.close()
+    if comm is not None:
+        comm.close()
     ctx.close()
     for c_ in extra_ctx:
         c_.close()
@@ -1243,7 +1267,7 @@ def compact_leg(d, wall_s):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "roofline", "cpu_baseline", "dtype",
             "set_map_ms", "median_translation_error_m",
             "mean_iterations", "converged_fraction", "final_position_error_m", "host_input", "new_keyframes_per_vehicle", "map_rebuilds_per_vehicle",
-            "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size",
+            "pairs_ok", "pairs_accepted", "rccl_ranks_seen", "ranks_that_reported_edges", "comm_world_size", "edges_transport",
             "pairs_per_s_one_gpu_same_run", "speedup_vs_one_gpu", "shard_proxy", "slam_mt", "replay_vs_oracle", "scans_per_s_each_pass", "scans_per_s_median_pass", "selection_guess_misses_per_scan")
     out = {k: d[k] for k in keep if k in d}
     if "slam" in d:
@@ -1740,6 +1764,7 @@ def main():
             # the N > 1 evidence of the loop-closure leg, where the driver's parser sees it
             "rccl_ranks_seen": (lc_leg or {}).get("rccl_ranks_seen"),
             "comm_world_size": (lc_leg or {}).get("comm_world_size"),
+            "edges_transport": (lc_leg or {}).get("edges_transport"),
             "pairs_per_s_one_gpu_same_run": (lc_leg or {}).get("pairs_per_s_one_gpu_same_run"),
             "speedup_vs_one_gpu": (lc_leg or {}).get("speedup_vs_one_gpu"),
             "launched_by": ("bench.py itself (launch_ranks)" if os.environ.get("PGSLAM_BENCH_SELF_LAUNCHED") else
